@@ -1,0 +1,278 @@
+/*
+ * raftgpu.h — C-ABI of the MI355X batched multi-Raft decision engine (libraftgpu.so).
+ *
+ * This is the drop-in boundary for ONE path of curioloop/rafting: the per-RaftContext
+ * EventLoop decision logic (io.lubricant.consensus.raft.context.**).  Everything the Java
+ * host would bind through JNI is declared here with plain pointers and sizes; no C++ or
+ * torch types appear in any signature.  Paths below are relative to
+ *   /root/reference/src/main/java/io/lubricant/consensus/raft/
+ *
+ * What each entry point replaces
+ * ------------------------------
+ *   rg_table_create / rg_table_destroy
+ *       ContextManager.buildContext + RaftContext.<init>/initialize
+ *       (context/ContextManager.java:57-106, context/RaftContext.java:62-113): instead of one
+ *       RaftContext object per group, ONE structure-of-arrays table of G groups in HBM.
+ *   rg_load_state / rg_read_state
+ *       StableLock.restore -> switchTo(Follower, term, ballot) (context/RaftContext.java:96-104),
+ *       RaftLog.epoch()/last() (command/storage/RocksLog.java:112-119) and, for leaders,
+ *       Leader.prepareReplication (context/member/Leader.java:30-50).
+ *   rg_submit
+ *       The EventLoop drain itself (support/EventLoopGroup.java:32-46): one row = one task that
+ *       the reference would have run on a ContextLoop thread (or, for responses, on a Netty
+ *       thread), i.e. one call of
+ *         RaftParticipant.appendEntries / preVote / requestVote   (RaftParticipant.java:34-44)
+ *         Leader.replicateLog response callbacks                  (member/Leader.java:174-188,218-237)
+ *         Candidate.startElection / Follower.prepareElection tally callbacks
+ *                                                                (member/Candidate.java:121-134, member/Follower.java:258-270)
+ *         RaftParticipant.onTimeout                               (RaftParticipant.java:24)
+ *         Leader.acceptCommand -> RaftLog.newEntry                (member/Leader.java:128-140, storage/RocksLog.java:82-89)
+ *         RaftLog.flush                                           (storage/RocksLog.java:228-242)
+ *       The reply row is the RaftResponse(term, success) (RaftResponse.java:8-24) plus the
+ *       instructions the host-owned plugins (RaftLog, StableLock, timers) must carry out.
+ *
+ * Ordering contract: rows of one group are applied in (round, row) order — the only ordering
+ * the reference EventLoop guarantees (one context is pinned to one loop thread,
+ * support/EventLoopGroup.java:77-80).  Groups are independent.
+ *
+ * Error convention: functions return 0 on success, <0 on API misuse / HIP failure
+ * (text via rg_last_error).  Reference protocol violations (AssertionError sites) are NOT API
+ * errors: they are reported per row in rg_reply_t.flags status bits, bit-exactly as the
+ * reference would have hit them (the handler dies, no reply is sent, earlier side effects stay).
+ *
+ * Threading: a table is not re-entrant; one host thread + one HIP stream per table.  Different
+ * tables (different GPUs) are fully independent.  No RCCL, no cross-table traffic.
+ */
+#ifndef RAFTGPU_H
+#define RAFTGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_ABI_VERSION      1
+#define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
+#define RG_MAX_CLUSTER      7
+#define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
+#define RG_NO_NODE          (-1)  /* Java null for a RaftCluster.ID */
+
+/* ---- roles: class of RaftContext.participant() (context/RaftContext.java:169) ------------ */
+enum { RG_FOLLOWER = 0, RG_CANDIDATE = 1, RG_LEADER = 2 };
+
+/* ---- event kinds (rg_ev_head_t.hdr bits 0-3) ------------------------------------------------ */
+enum {
+    RG_EV_NONE          = 0,  /* row not addressed this round                                          */
+    RG_EV_AE_REQ        = 1,  /* RaftParticipant.appendEntries       a=term b=prevLogIndex c=prevLogTerm d=leaderCommit
+                                 slot=leaderId n=#entries aux=offset of entry terms in entry_terms[];
+                                 entry k has index prevLogIndex+1+k (what Leader.replicateLog builds, member/Leader.java:192-212) */
+    RG_EV_AE_ACK        = 2,  /* Leader AE response callback         a=result.term b=epoch.index at send c=lastIndex sent
+                                 slot=responder flag=result.success aux=roleEpoch the request was sent under */
+    RG_EV_IS_ACK        = 3,  /* Leader InstallSnapshot callback     a=result.term b=epoch.index at send, slot, flag, aux as AE_ACK */
+    RG_EV_RV_REQ        = 4,  /* RaftParticipant.requestVote        a=term b=lastLogIndex c=lastLogTerm slot=candidateId */
+    RG_EV_PV_REQ        = 5,  /* RaftParticipant.preVote            same fields */
+    RG_EV_RV_REPLY      = 6,  /* Candidate.startElection callback    a=result.term slot=responder flag=result.success aux=roleEpoch */
+    RG_EV_PV_REPLY      = 7,  /* Follower.prepareElection callback   same fields */
+    RG_EV_TIMEOUT       = 8,  /* RaftParticipant.onTimeout (election timer for F/C, heartbeat tick for L) */
+    RG_EV_CLIENT_APPEND = 9,  /* Leader.acceptCommand x n            n=#commands appended at currentTerm */
+    RG_EV_LOG_FLUSH     = 10  /* RaftLog.flush(index, term)          a=index b=term (log compaction / snapshot install moved the epoch) */
+};
+
+#define RG_HDR_KIND(h)        ((uint32_t)(h) & 0xFu)
+#define RG_HDR_SLOT(h)        (((uint32_t)(h) >> 4) & 0xFu)
+#define RG_HDR_FLAG(h)        (((uint32_t)(h) >> 8) & 0x1u)
+#define RG_HDR_HINT(h)        (((uint32_t)(h) >> 9) & 0x1u)
+#define RG_HDR_N(h)           ((uint32_t)(h) >> 12)
+#define RG_HDR_MAKE(kind, slot, flag, n) \
+    (((uint32_t)(kind) & 0xFu) | (((uint32_t)(slot) & 0xFu) << 4) | (((uint32_t)(flag) & 1u) << 8) | ((uint32_t)(n) << 12))
+#define RG_HDR_HINT_BIT       (1u << 9)
+#define RG_MAX_ENTRIES        ((1u << 20) - 1)
+
+/* ---- wire structs: structure-of-small-structs so every lane issues 16-byte accesses -------- */
+typedef struct { uint32_t hdr; uint32_t aux; } rg_ev_head_t;       /*  8 B */
+typedef struct { int64_t  x;   int64_t  y;   } rg_ev_pair_t;       /* 16 B: (a,b) / (c,d) / hints */
+
+/* reply: always written for every row */
+typedef struct {
+    int64_t  resp_term;   /* RaftResponse.term (valid iff RG_F_REPLIED) */
+    uint32_t flags;       /* RG_F_* | status << 16 */
+    uint32_t role_epoch;  /* role epoch AFTER the row: tag the host must attach to RPCs it now emits */
+} rg_reply_t;             /* 16 B */
+
+/* log / commit effects: written iff flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC), or status NEED_HOST */
+typedef struct {
+    int64_t commit_index; /* RaftLog.lastCommitted() after the row (valid iff RG_F_COMMIT)                 */
+    int64_t log_from;     /* first log index the host must (re)write from the request's entries, after
+                             deleting [log_from, oldLast] when RG_F_LOG_TRUNC (RocksLog.truncate+append);
+                             CLIENT_APPEND: index of the first new entry; NEED_HOST: the index whose term is needed */
+} rg_logfx_t;             /* 16 B */
+
+/* durable membership: written iff flags & RG_F_PERSIST — what RaftMember.<init> hands to
+ * StableLock.persist(currentTerm, lastCandidate) BEFORE the reply may leave (member/RaftMember.java:25) */
+typedef struct {
+    int64_t term;
+    int32_t voted_for;    /* peer slot or RG_NO_NODE */
+    int32_t role;
+} rg_persist_t;           /* 16 B */
+
+/* reply.flags bits */
+#define RG_F_SUCCESS      (1u << 0)   /* RaftResponse.success                                             */
+#define RG_F_REPLIED      (1u << 1)   /* a RaftResponse is produced (requests only; absent when an assertion killed the handler) */
+#define RG_F_PERSIST      (1u << 2)   /* >=1 role conversion happened: fsync (term, votedFor) before replying */
+#define RG_F_ROLE_CHANGED (1u << 3)   /* participant object was replaced (RaftRoutine.convertTo)            */
+#define RG_F_RESET_TIMER  (1u << 4)   /* handler re-armed the election timer (ctx.resetTimer / convertTo)   */
+#define RG_F_COMMIT       (1u << 5)   /* markCommitted advanced commitIndex                                 */
+#define RG_F_LOG_TRUNC    (1u << 6)   /* RaftLog.truncate(log_from) must run before the append              */
+#define RG_F_LOG_APPEND   (1u << 7)   /* entries with index >= log_from must be written                     */
+#define RG_F_EMIT_SHIFT   8           /* what the new/refreshed participant broadcasts                      */
+#define RG_F_EMIT_MASK    (3u << 8)
+#define RG_EMIT_NONE      0u
+#define RG_EMIT_PREVOTE   1u          /* preVote(currentTerm+1, self, last|epoch)   member/Follower.java:223-279 */
+#define RG_EMIT_REQVOTE   2u          /* requestVote(currentTerm, self, last|epoch) member/Candidate.java:90-143 */
+#define RG_EMIT_HEARTBEAT 3u          /* Leader.onTimeout -> replicateLog(true)      member/Leader.java:120-126  */
+#define RG_F_ROLE_SHIFT   10          /* role after the row                                                 */
+#define RG_F_ROLE_MASK    (3u << 10)
+#define RG_F_STATUS_SHIFT 16
+#define RG_F_STATUS(f)    (((f) >> RG_F_STATUS_SHIFT) & 0xFFu)
+#define RG_F_EMIT(f)      (((f) & RG_F_EMIT_MASK) >> RG_F_EMIT_SHIFT)
+#define RG_F_ROLE(f)      (((f) & RG_F_ROLE_MASK) >> RG_F_ROLE_SHIFT)
+
+/* per-row status (reply.flags bits 16-23).  A_* = the reference throws at that site: the event
+ * task dies (EventLoopGroup.java:40-44), NO reply is sent, side effects made before the throw stay. */
+enum {
+    RG_OK                       = 0,
+    RG_A_TWO_LEADERS            = 1,   /* member/Follower.java:48-50   */
+    RG_A_PREV_ZERO_MISMATCH     = 2,   /* member/Follower.java:179-181 */
+    RG_A_EPOCH_TERM_MISMATCH    = 3,   /* member/Follower.java:184-186 */
+    RG_A_IMPOSSIBLE_LOG         = 4,   /* member/Follower.java:199-204 */
+    RG_A_COMMIT_ROLLBACK        = 5,   /* storage/RocksLog.java:101-103 (via Follower.java:80, Leader.java:265/269) */
+    RG_A_LOG_NOT_CONTINUOUS     = 6,   /* storage/RocksLog.java:175-177,180-188 */
+    RG_A_LEADER_SELF_AE         = 7,   /* member/Leader.java:71-73     */
+    RG_A_SAME_TERM_LEADER       = 8,   /* member/Leader.java:79-81     */
+    RG_A_LEADER_NOT_SELF_VOTE   = 9,   /* member/Leader.java:101-105   */
+    RG_A_CAND_SELF_RV           = 10,  /* member/Candidate.java:53-55  */
+    RG_A_CAND_NOT_SELF_VOTE     = 11,  /* member/Candidate.java:64-66  */
+    RG_A_LEADER_UNCHANGED       = 12,  /* member/Membership.java:86-90 */
+    RG_A_CAND_BALLOT            = 13,  /* member/Membership.java:103-105 */
+    RG_A_MATCH_ROLLBACK         = 14,  /* member/Leadership.java:76-81 (AbstractMethodError) */
+    RG_A_IMPOSSIBLE_REPLICATION = 15,  /* member/Leader.java:251-253 (unreachable after a sort; kept for completeness) */
+    RG_NPE_MAJOR_NULL           = 16,  /* member/Leader.java:256-257,277-279: log.get(majorIndex)==null, caught+logged, no commit */
+    RG_DROPPED_STALE_ROLE       = 17,  /* response to a fenced participant (transport/rpc/Async.java:157-171) */
+    RG_NOT_LEADER               = 18,  /* command/RaftStub.java:79-91: command submitted to a non-leader */
+    RG_FLUSH_OUT_OF_BOUNDS      = 19,  /* storage/RocksLog.java:230-233 (IndexOutOfBoundsException) */
+    RG_NEED_HOST                = 32,  /* term-run cache miss: row NOT applied; host looks up the term of
+                                          logfx.log_from in its RaftLog and resubmits the row with a hint */
+    RG_SKIPPED_AFTER_NEED_HOST  = 33,  /* later round of a group that hit NEED_HOST in this launch: NOT applied */
+    RG_BAD_EVENT                = 34,  /* malformed row (slot out of range / self, kind unknown, response
+                                          whose epoch matches a role that cannot have sent it): NOT applied */
+    RG_UNSUPPORTED_LOG_STATE    = 35   /* CLIENT_APPEND on an empty log whose epoch.index>0 (RocksLog.newEntry
+                                          would write key 1 below the epoch, storage/RocksLog.java:83-84): NOT applied */
+};
+
+/* ---- batches -------------------------------------------------------------------------------- */
+enum { RG_MEM_HOST = 0, RG_MEM_DEVICE = 1 };
+
+typedef struct {
+    uint32_t            rounds;       /* R >= 1; round r occupies rows [r*count, (r+1)*count)             */
+    uint32_t            count;        /* rows per round. dense: == number of groups                       */
+    const uint32_t     *gid;          /* NULL: dense, row i of every round addresses group i.
+                                         else sparse: row -> group id, strictly ascending, rounds must be 1 */
+    const rg_ev_head_t *head;         /* [rounds*count] */
+    const rg_ev_pair_t *ab;           /* [rounds*count] fields a,b */
+    const rg_ev_pair_t *cd;           /* [rounds*count] fields c,d */
+    const int64_t      *entry_terms;  /* AE_REQ entry terms, addressed by head.aux; may be NULL if no row has n>0 */
+    uint64_t            entry_count;  /* length of entry_terms */
+    const rg_ev_pair_t *hint;         /* optional [rounds*count]; consulted only for rows with RG_HDR_HINT_BIT:
+                                         AE_REQ: x = term of the host log at prevLogIndex (-1 = no such entry),
+                                                 y = RaftLog.conflict(entries).index() (0 = none)
+                                         AE_ACK: x = index, y = term of the host log at that index (-1 = none) */
+} rg_batch_t;
+
+typedef struct {
+    rg_reply_t   *reply;    /* [rounds*count], required */
+    rg_logfx_t   *logfx;    /* [rounds*count], required */
+    rg_persist_t *persist;  /* [rounds*count], required */
+} rg_outcome_t;
+
+/* ---- group state exchange (host SoA, one element per group unless noted) -------------------- */
+typedef struct {
+    int64_t  *current_term;    /* RaftMember.currentTerm                                     */
+    int32_t  *voted_for;       /* RaftMember.lastCandidate as peer slot, RG_NO_NODE = null    */
+    int32_t  *role;            /* RG_FOLLOWER / RG_CANDIDATE / RG_LEADER                      */
+    int32_t  *current_leader;  /* Follower.currentLeader                                      */
+    uint8_t  *timeout_detected;/* Follower.timeoutDetected                                    */
+    uint8_t  *repl_prepared;   /* Leader.followerStatus != null                               */
+    uint32_t *role_epoch;      /* identity of the participant object / its AsyncHead          */
+    int32_t  *votes;           /* AtomicInteger votes of the running (pre-)election           */
+    uint32_t *elected_epoch;   /* role epoch of the Candidate whose election head stayed un-aborted after it won (0 = none) */
+    int64_t  *elected_term;
+    int64_t  *commit_index;    /* RocksLog.commitIndex                                        */
+    int64_t  *epoch_index;     /* RaftLog.epoch()                                             */
+    int64_t  *epoch_term;
+    int64_t  *first_index;     /* smallest key stored (epoch.index or epoch.index+1); ignored when log empty */
+    int64_t  *last_index;      /* RaftLog.last().index(); log empty <=> run_count == 0        */
+    uint32_t *run_count;       /* number of term runs supplied (device keeps the newest RG_TERM_RUNS) */
+    uint32_t *run_offset;      /* start of this group's runs in run_start/run_term            */
+    int64_t  *run_start;       /* [sum run_count] ascending start index of each maximal equal-term run */
+    int64_t  *run_term;
+    /* per (group, follower j) with j = slot<self ? slot : slot-1, array index g*(P-1)+j (Leadership.State) */
+    int64_t  *peer_last_epoch;
+    int64_t  *peer_next_index;
+    int64_t  *peer_match_index;
+    int32_t  *peer_rejection;  /* recentRejection */
+    uint8_t  *peer_pending;    /* pendingInstallation */
+} rg_group_state_t;
+
+typedef struct rg_table rg_table_t;
+
+/* ---- life cycle ----------------------------------------------------------------------------- */
+int         rg_abi_version(void);
+/* device: HIP device ordinal. groups: G. cluster: P (self included). self_slot in [0,P). pre_vote: RaftConfig.preVote(). */
+int         rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self_slot,
+                            int pre_vote, rg_table_t **out);
+int         rg_table_destroy(rg_table_t *t);
+const char *rg_last_error(const rg_table_t *t);      /* t may be NULL for create failures */
+uint32_t    rg_table_groups(const rg_table_t *t);
+uint32_t    rg_table_cluster(const rg_table_t *t);
+
+/* ---- state ---------------------------------------------------------------------------------- */
+/* Load groups [first, first+count). Arrays are indexed from 0 for group `first`. Runs beyond the
+ * newest RG_TERM_RUNS are not cached (lookups into them answer RG_NEED_HOST). */
+int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_state_t *src);
+/* Read groups back. run arrays must hold count*RG_TERM_RUNS elements; run_offset[i] is set to i*RG_TERM_RUNS. */
+int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *dst);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* memspace RG_MEM_HOST: caller-owned host buffers, staged over PCIe and copied back, synchronous.
+ * memspace RG_MEM_DEVICE: all pointers are device pointers (rg_dev_alloc or any hipMalloc memory on
+ * the table's device); the launch is asynchronous on the table's stream — call rg_sync. */
+int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace);
+int rg_sync(rg_table_t *t);
+
+/* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
+int rg_dev_alloc(rg_table_t *t, size_t bytes, void **dptr);
+int rg_dev_free(rg_table_t *t, void *dptr);
+int rg_copy_to_device(rg_table_t *t, void *dst, const void *src, size_t bytes);
+int rg_copy_to_host(rg_table_t *t, void *dst, const void *src, size_t bytes);
+void *rg_stream(rg_table_t *t);   /* the table's hipStream_t */
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* When enabled every rg_submit brackets its step kernel with HIP events on the table's stream. */
+int rg_timing_enable(rg_table_t *t, int on);
+/* Sum and count of step-kernel durations since the last reset (synchronises the stream). */
+int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int reset);
+/* Device-side decision counters accumulated by the step kernel (wave ballot + popcount, one atomic
+ * per wave): [0]=rows with kind!=NONE, [1]=replied, [2]=role conversions, [3]=commit advances,
+ * [4]=assert statuses, [5]=NEED_HOST, [6]=dropped stale, [7]=log appends. */
+#define RG_NUM_COUNTERS 8
+int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int reset);
+/* Plain streaming-copy kernel over `bytes` of scratch on this device: returns achieved GB/s
+ * (read+write) — the measured-copy roofline reported next to the 8 TB/s spec. */
+int rg_copy_bandwidth(rg_table_t *t, size_t bytes, int iters, double *gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAFTGPU_H */

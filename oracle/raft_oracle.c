@@ -1,0 +1,800 @@
+/*
+ * raft_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See raft_oracle.h.
+ *
+ * Every function cites the reference lines it restates.  Paths are relative to
+ *   /root/reference/src/main/java/io/lubricant/consensus/raft/
+ * The reference is read, not copied: the Java keeps one object graph per RaftContext and runs
+ * handlers on an EventLoop thread; here one `group_t` holds the same fields and `step()` plays
+ * one EventLoop task.  Quirks Q1-Q12 of SURVEY.md §8a are reproduced on purpose, plus
+ *   Q13  a Candidate that WON keeps its election AsyncHead un-aborted (Candidate.onFencing skips
+ *        the abort when `elected`, member/Candidate.java:75-79), so late RequestVote replies are
+ *        still processed by the new Leader (and whatever it becomes later);
+ *   Q14  RaftLog.newEntry writes index 1 on an empty log whatever the epoch
+ *        (storage/RocksLog.java:83-84) — reported as RG_UNSUPPORTED_LOG_STATE when epoch.index>0.
+ */
+#include "raft_oracle.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+/* ------------------------------------------------------------------------------------------- */
+/* lossless log: contiguous key window [first,last] as maximal equal-term runs                  */
+
+typedef struct { int64_t start, term; } run_t;
+typedef struct { int64_t first, last; uint32_t n, cap; run_t *r; } olog_t;
+
+typedef struct {                 /* Leadership.State, member/Leadership.java:26-38 */
+    int64_t last_epoch, next_index, match_index;
+    int32_t rejection;
+    uint8_t pending;
+} peer_t;
+
+typedef struct {
+    int64_t  current_term;       /* RaftMember.currentTerm  member/RaftMember.java:17 */
+    int32_t  voted_for;          /* RaftMember.lastCandidate :18 */
+    int32_t  role;
+    int32_t  current_leader;     /* Follower.currentLeader  member/Follower.java:21 */
+    uint8_t  timeout_detected;   /* Follower.timeoutDetected :23 */
+    uint8_t  repl_prepared;      /* Leader.followerStatus != null  member/Leader.java:31 */
+    uint32_t role_epoch;
+    int32_t  votes;
+    uint32_t elected_epoch;
+    int64_t  elected_term;
+    int64_t  commit_index;       /* RocksLog.commitIndex  storage/RocksLog.java:50 */
+    int64_t  epoch_index, epoch_term;
+    olog_t   log;
+    peer_t   peers[RG_MAX_CLUSTER - 1];
+} group_t;
+
+struct orc_table {
+    uint32_t groups, cluster, self, followers;
+    int      pre_vote;
+    int      majority;           /* RaftContext.majority()  context/RaftContext.java:170 */
+    group_t *g;
+};
+
+typedef struct {                 /* what one event task produced */
+    uint32_t flags;
+    uint32_t status;
+    int64_t  resp_term;
+    int64_t  log_from;
+} fx_t;
+
+static inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+static inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+static inline int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+static inline int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+static int log_empty(const olog_t *l) { return l->n == 0; }
+
+static void log_reserve(olog_t *l, uint32_t n)
+{
+    if (n <= l->cap) return;
+    uint32_t c = l->cap ? l->cap * 2 : 4;
+    while (c < n) c *= 2;
+    l->r = (run_t *)realloc(l->r, (size_t)c * sizeof(run_t));
+    if (!l->r) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
+    l->cap = c;
+}
+
+/* RaftLog.get(index).term(): storage/RocksLog.java:122-128. returns 1 and *term when the key exists */
+static int log_get(const olog_t *l, int64_t index, int64_t *term)
+{
+    if (l->n == 0 || index < l->first || index > l->last) return 0;
+    uint32_t j = l->n;
+    while (j > 0 && l->r[j - 1].start > index) j--;
+    if (j == 0) { fprintf(stderr, "oracle: run table corrupt\n"); abort(); }
+    *term = l->r[j - 1].term;
+    return 1;
+}
+
+/* db.put(index, term) for index == last+1, or the first key of an empty log */
+static void log_push(olog_t *l, int64_t index, int64_t term)
+{
+    if (l->n == 0) {
+        log_reserve(l, 1);
+        l->first = l->last = index;
+        l->r[0].start = index; l->r[0].term = term; l->n = 1;
+        return;
+    }
+    if (index != wadd(l->last, 1)) { fprintf(stderr, "oracle: non-contiguous push\n"); abort(); }
+    if (l->r[l->n - 1].term != term) {
+        log_reserve(l, l->n + 1);
+        l->r[l->n].start = index; l->r[l->n].term = term; l->n++;
+    }
+    l->last = index;
+}
+
+/* RaftLog.truncate(index): storage/RocksLog.java:219-225 */
+static void log_truncate(olog_t *l, int64_t index)
+{
+    if (l->n == 0 || l->last < index) return;
+    if (index <= l->first) { l->n = 0; return; }
+    while (l->n > 0 && l->r[l->n - 1].start >= index) l->n--;
+    l->last = index - 1;
+}
+
+/* RaftLog.flush(index, term): storage/RocksLog.java:228-242 — deleteRange [epochIndex, index) */
+static int log_flush(group_t *g, int64_t index, int64_t term)
+{
+    if (index < g->epoch_index) return RG_FLUSH_OUT_OF_BOUNDS;
+    olog_t *l = &g->log;
+    if (l->n != 0) {
+        if (index > l->last) {
+            l->n = 0;
+        } else if (index > l->first) {
+            uint32_t drop = 0;     /* runs that end before `index` */
+            while (drop + 1 < l->n && l->r[drop + 1].start <= index) drop++;
+            if (drop) { memmove(l->r, l->r + drop, (size_t)(l->n - drop) * sizeof(run_t)); l->n -= drop; }
+            l->r[0].start = index;
+            l->first = index;
+        }
+    }
+    g->epoch_index = index;
+    g->epoch_term = term;
+    return RG_OK;
+}
+
+/* RaftLog.conflict(entries): storage/RocksLog.java:199-216. entries k has index e0+k. returns conflict index or 0 */
+static int64_t log_conflict(const olog_t *l, int64_t e0, uint32_t n, const int64_t *terms)
+{
+    for (uint32_t k = 0; k < n; k++) {
+        int64_t idx = wadd(e0, k), t;
+        if (!log_get(l, idx, &t)) return 0;        /* NOT_FOUND: everything before matched */
+        if (t != terms[k]) return idx;
+    }
+    return 0;
+}
+
+/* RaftLog.append(entries): storage/RocksLog.java:169-196 */
+static int log_append(group_t *g, int64_t e0, uint32_t n, const int64_t *terms)
+{
+    olog_t *l = &g->log;
+    int64_t prev_log_index = g->epoch_index;
+    int valid = 0;
+    if (l->n != 0 && l->first <= e0) {             /* iterator.seekForPrev(entries[0].index) */
+        prev_log_index = min64(l->last, e0);
+        valid = 1;
+    }
+    if (!valid && e0 != wadd(prev_log_index, 1)) return RG_A_LOG_NOT_CONTINUOUS;   /* :175-177 */
+    int have_prev = 0; int64_t prev_index = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        int64_t idx = wadd(e0, k);
+        if (idx > prev_log_index) {
+            if (!have_prev || prev_index == prev_log_index) {
+                if (prev_log_index != wsub(idx, 1)) return RG_A_LOG_NOT_CONTINUOUS;  /* :184-188 */
+            }
+            int64_t t;
+            if (log_get(l, idx, &t)) {
+                /* overwrite of an existing key: conflict()+truncate() ran first, so it carries the same term */
+                if (t != terms[k]) { fprintf(stderr, "oracle: append over a different term\n"); abort(); }
+            } else {
+                if (l->n != 0 && idx != wadd(l->last, 1)) { fprintf(stderr, "oracle: append leaves a gap\n"); abort(); }
+                log_push(l, idx, terms[k]);
+            }
+        }
+        have_prev = 1; prev_index = idx;
+    }
+    return RG_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Membership.isBetter: member/Membership.java:74-108                                           */
+
+int orc_is_better(int nr, int64_t nt, int32_t nb, int cr, int64_t ct, int32_t cb)
+{
+    if (nt != ct) return nt > ct;
+    if (nr != cr) {
+        if (nr == RG_LEADER) {
+            if (cr == RG_CANDIDATE) return 1;
+            return -RG_A_LEADER_UNCHANGED;
+        }
+        return nr == RG_FOLLOWER;
+    }
+    if (nr == RG_LEADER) return 0;
+    if (nr == RG_FOLLOWER) return 1;
+    if (nb != cb) return -RG_A_CAND_BALLOT;
+    return 0;
+}
+
+/* RaftContext.switchTo/trySwitchTo -> RaftRoutine.trySwitch + switchTo + convertTo
+ * (context/RaftContext.java:195-215, context/RaftRoutine.java:140-216) and the constructors of the
+ * new participant (member/RaftMember.java:20-26, Follower.java:26-28, Candidate.java:22-25, Leader.java:25-28).
+ * returns 1 converted, 0 not better (participant unchanged), -1 assertion (fx->status set). */
+static int switch_to(const orc_table_t *t, group_t *g, fx_t *fx, int role, int64_t term, int32_t ballot)
+{
+    int b = orc_is_better(role, term, ballot, g->role, g->current_term, g->voted_for);
+    if (b < 0) { fx->status = (uint32_t)(-b); return -1; }
+    if (!b) return 0;
+    g->role = role;
+    g->current_term = term;
+    g->voted_for = ballot;
+    g->role_epoch += 1;                    /* new participant object, old AsyncHead fenced */
+    g->timeout_detected = 0;
+    g->current_leader = RG_NO_NODE;
+    g->votes = 1;
+    g->repl_prepared = 0;
+    fx->flags |= RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER;
+    fx->flags &= ~RG_F_EMIT_MASK;
+    if (role == RG_CANDIDATE) fx->flags |= RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT;   /* startElection */
+    (void)t;
+    return 1;
+}
+
+/* Leader.prepareReplication: member/Leader.java:30-50 */
+static void prepare_replication(const orc_table_t *t, group_t *g)
+{
+    if (g->repl_prepared) return;
+    int64_t last_index = log_empty(&g->log) ? g->epoch_index : g->log.last;
+    for (uint32_t j = 0; j < t->followers; j++) {
+        peer_t *s = &g->peers[j];
+        s->last_epoch = g->epoch_index;
+        s->next_index = wadd(last_index, 1);
+        s->match_index = 0;
+        s->rejection = 0;
+        s->pending = 0;
+    }
+    g->repl_prepared = 1;
+}
+
+/* Math.round(Math.log(Math.E + recentRejection)): member/Leadership.java:105.
+ * Integer thresholds: step >= k  <=>  r >= ceil(exp(k-0.5) - e). (tests/test_oracle_kat.py re-derives them with math.log) */
+int64_t orc_rejection_step(int32_t r)
+{
+    static const int32_t lo[] = { /* smallest r with step == index+2 */
+        2, 10, 31, 88, 242, 663, 1806, 4913, 13358, 36313, 98714, 268335, 729414, 1982757,
+        5389696, 14650717, 39824782, 108254986, 294267564, 799902175 };
+    if (r < 0) return r == -1 ? 1 : 0;     /* ln(e-1)=0.54 -> 1; ln(e-2)<0.5 -> 0; NaN -> 0 */
+    int64_t step = 1;
+    for (unsigned i = 0; i < sizeof(lo) / sizeof(lo[0]); i++) if (r >= lo[i]) step = i + 2;
+    return step;
+}
+
+/* Leadership.State.updateIndex: member/Leadership.java:75-114 */
+static int update_index(peer_t *s, int64_t epoch, int64_t index, int success, int snapshot)
+{
+    if (index < s->match_index) return RG_A_MATCH_ROLLBACK;
+    if (epoch < s->last_epoch) return RG_OK;
+    if (epoch > s->last_epoch) {
+        s->last_epoch = epoch;
+        s->next_index = s->next_index > epoch ? s->next_index : epoch;
+    }
+    if ((s->pending != 0) != (snapshot != 0)) return RG_OK;
+    if (s->pending) {
+        if (success) {
+            s->next_index = max64(s->next_index, wadd(epoch, 1));
+            s->pending = 0;
+        }
+    } else {
+        if (success) {
+            if (index > s->match_index) {
+                s->next_index = wadd(index, 1);
+                s->match_index = index;
+            }
+        } else if (s->match_index == 0) {
+            int64_t step = orc_rejection_step(s->rejection);
+            int64_t next = max64(wsub(s->next_index, step), wadd(epoch, 1));
+            s->next_index = min64(wsub(s->next_index, 1), next);
+        }
+    }
+    if (s->next_index <= epoch && !s->pending) s->pending = 1;
+    return RG_OK;
+}
+
+/* Leadership.State.majorIndices: member/Leadership.java:116-130 */
+void orc_major_indices(const int64_t *match, int n, int64_t out[2])
+{
+    int64_t s[RG_MAX_CLUSTER];
+    for (int i = 0; i < n; i++) s[i] = match[i];
+    for (int i = 1; i < n; i++) {              /* Arrays.sort */
+        int64_t v = s[i]; int j = i;
+        while (j > 0 && s[j - 1] > v) { s[j] = s[j - 1]; j--; }
+        s[j] = v;
+    }
+    out[0] = s[0];
+    out[1] = s[n / 2];
+}
+
+/* RaftLog.markCommitted: storage/RocksLog.java:100-109 (via RaftContext.commitLog :244-255) */
+static int mark_committed(group_t *g, fx_t *fx, int64_t commit_index)
+{
+    if (commit_index < g->commit_index) return RG_A_COMMIT_ROLLBACK;
+    if (commit_index > g->commit_index) {
+        g->commit_index = commit_index;
+        fx->flags |= RG_F_COMMIT;
+    }
+    return RG_OK;
+}
+
+/* Leader.tryCommit: member/Leader.java:247-280 */
+static void try_commit(const orc_table_t *t, group_t *g, fx_t *fx)
+{
+    int64_t m[RG_MAX_CLUSTER], mi[2];
+    for (uint32_t j = 0; j < t->followers; j++) m[j] = g->peers[j].match_index;
+    orc_major_indices(m, (int)t->followers, mi);
+    int64_t full = mi[0], major = mi[1];
+    if (full > major) { fx->status = RG_A_IMPOSSIBLE_REPLICATION; return; }
+    if (major == 0) return;
+    int64_t mt;
+    if (!log_get(&g->log, major, &mt)) { fx->status = RG_NPE_MAJOR_NULL; return; }   /* major.term() on null */
+    int64_t commit = (mt == g->current_term) ? major : full;
+    if (commit != 0 && commit != g->commit_index) {
+        int st = mark_committed(g, fx, commit);
+        if (st) fx->status = (uint32_t)st;
+    }
+}
+
+/* Follower.logContains: member/Follower.java:177-191. returns 1/0, or -1 with fx->status */
+static int log_contains(const group_t *g, fx_t *fx, int64_t index, int64_t term)
+{
+    if (index == 0 && term == 0) return 1;
+    if (index == 0 || term == 0) { fx->status = RG_A_PREV_ZERO_MISMATCH; return -1; }
+    if (index <= g->epoch_index) {
+        if (index == g->epoch_index && term != g->epoch_term) { fx->status = RG_A_EPOCH_TERM_MISMATCH; return -1; }
+        return 1;
+    }
+    int64_t t;
+    return log_get(&g->log, index, &t) && t == term;
+}
+
+/* Follower.logUpToDate: member/Follower.java:193-207 */
+static int log_up_to_date(const group_t *g, fx_t *fx, int64_t index, int64_t term)
+{
+    if (!log_empty(&g->log)) {
+        int64_t last_term = g->log.r[g->log.n - 1].term;
+        return term > last_term || (term == last_term && index >= g->log.last);
+    }
+    if ((index > g->epoch_index && term < g->epoch_term) ||
+        (index == g->epoch_index && term != g->epoch_term)) {
+        fx->status = RG_A_IMPOSSIBLE_LOG;
+        return -1;
+    }
+    return index >= g->epoch_index;
+}
+
+static void reply(fx_t *fx, int64_t term, int success)
+{
+    fx->resp_term = term;
+    fx->flags |= RG_F_REPLIED | (success ? RG_F_SUCCESS : 0);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* RaftParticipant.appendEntries as dispatched on the current role                              */
+
+static void on_append_entries(const orc_table_t *t, group_t *g, fx_t *fx, int64_t term, int32_t leader,
+                              int64_t prev_index, int64_t prev_term, uint32_t n, const int64_t *terms,
+                              int64_t leader_commit)
+{
+    if (g->role == RG_LEADER) {                                   /* Leader.appendEntries member/Leader.java:67-86 */
+        if (leader == (int32_t)t->self) { fx->status = RG_A_LEADER_SELF_AE; return; }
+        if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+        if (term == g->current_term) { fx->status = RG_A_SAME_TERM_LEADER; return; }
+        if (switch_to(t, g, fx, RG_FOLLOWER, g->current_term, g->voted_for) < 0) return;
+    } else if (g->role == RG_CANDIDATE) {                         /* Candidate.appendEntries member/Candidate.java:28-41 */
+        if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+        if (switch_to(t, g, fx, RG_FOLLOWER, term, g->voted_for) < 0) return;
+    }
+    /* Follower.appendEntries member/Follower.java:35-88 (ctx.participant() is a Follower by now) */
+    if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+    fx->flags |= RG_F_RESET_TIMER;                                /* :43 */
+    if (term > g->current_term || g->timeout_detected) {          /* :45-47, re-dispatched on the fresh Follower */
+        if (switch_to(t, g, fx, RG_FOLLOWER, term, g->voted_for) < 0) return;
+    } else if (g->current_leader != RG_NO_NODE && leader != g->current_leader) {
+        fx->status = RG_A_TWO_LEADERS; return;                    /* :48-50 */
+    }
+    g->current_leader = leader;                                   /* :54 */
+    int c = log_contains(g, fx, prev_index, prev_term);           /* :57 */
+    if (c < 0) return;
+    if (!c) { reply(fx, g->current_term, 0); return; }
+    /* purgeEntries :209-221 — entry k has index prev_index+1+k */
+    int64_t e0 = wadd(prev_index, 1);
+    if (n > 0 && e0 <= g->epoch_index) {
+        uint64_t skip = (uint64_t)(g->epoch_index - e0) + 1;
+        if (skip >= n) { n = 0; } else { n -= (uint32_t)skip; terms += skip; e0 = wadd(e0, (int64_t)skip); }
+    }
+    if (n > 0) {                                                  /* :68-74 */
+        int64_t conflict = log_conflict(&g->log, e0, n, terms);
+        if (conflict) {
+            log_truncate(&g->log, conflict);
+            fx->flags |= RG_F_LOG_TRUNC;
+        }
+        int64_t from = log_empty(&g->log) ? e0 : max64(e0, wadd(g->log.last, 1));
+        int st = log_append(g, e0, n, terms);
+        if (conflict || (st == RG_OK && from <= wadd(e0, (int64_t)n - 1))) {
+            fx->log_from = conflict ? conflict : from;
+            if (st == RG_OK) fx->flags |= RG_F_LOG_APPEND;
+        }
+        if (st) { fx->status = (uint32_t)st; return; }
+    }
+    if (leader_commit > g->epoch_index && !log_empty(&g->log)) {  /* :76-82 */
+        int st = mark_committed(g, fx, min64(leader_commit, g->log.last));
+        if (st) { fx->status = (uint32_t)st; return; }
+    }
+    reply(fx, term, 1);                                           /* :87 (Q1: the request term) */
+}
+
+/* RaftParticipant.requestVote / preVote as dispatched on the current role */
+static void on_vote_request(const orc_table_t *t, group_t *g, fx_t *fx, int pre, int64_t term, int32_t cand,
+                            int64_t last_index, int64_t last_term)
+{
+    if (g->role == RG_LEADER) {
+        if (pre) { reply(fx, g->current_term, 0); return; }       /* Leader.preVote member/Leader.java:89-91 */
+        /* Leader.requestVote :94-111 */
+        if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+        if (term == g->current_term) {
+            if (g->voted_for == (int32_t)t->self) { reply(fx, g->current_term, 0); return; }
+            fx->status = RG_A_LEADER_NOT_SELF_VOTE; return;
+        }
+        if (switch_to(t, g, fx, RG_FOLLOWER, g->current_term, cand) < 0) return;
+        pre = 0;                                                  /* re-dispatched as requestVote */
+    } else if (g->role == RG_CANDIDATE) {                         /* Candidate.preVote == requestVote member/Candidate.java:44-72 */
+        if (cand == (int32_t)t->self) { fx->status = RG_A_CAND_SELF_RV; return; }
+        if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+        if (term == g->current_term) {
+            if (cand != g->voted_for) { reply(fx, g->current_term, 0); return; }
+            if (g->voted_for != (int32_t)t->self) { fx->status = RG_A_CAND_NOT_SELF_VOTE; return; }
+        }
+        if (switch_to(t, g, fx, RG_FOLLOWER, term, cand) < 0) return;     /* Q5: no freshness check */
+        pre = 0;                                                  /* ctx.participant().requestVote(...) */
+    }
+    if (pre) {                                                    /* Follower.preVote member/Follower.java:91-105 */
+        if (term <= g->current_term || !g->timeout_detected) { reply(fx, g->current_term, 0); return; }
+        fx->flags |= RG_F_RESET_TIMER;
+        int ok = log_up_to_date(g, fx, last_index, last_term);
+        if (ok < 0) return;
+        reply(fx, g->current_term, ok);
+        return;
+    }
+    /* Follower.requestVote member/Follower.java:108-127 */
+    if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
+    if (term == g->current_term) { reply(fx, g->current_term, cand == g->voted_for); return; }
+    fx->flags |= RG_F_RESET_TIMER;
+    int ok = log_up_to_date(g, fx, last_index, last_term);
+    if (ok < 0) return;
+    if (switch_to(t, g, fx, RG_FOLLOWER, term, ok ? cand : RG_NO_NODE) < 0) return;
+    reply(fx, g->current_term, cand == g->voted_for);             /* re-dispatched: term == currentTerm now */
+}
+
+/* Leader.replicateLog response callbacks: member/Leader.java:174-188 (snapshot) and :218-237 */
+static void on_replicate_ack(const orc_table_t *t, group_t *g, fx_t *fx, int snapshot, uint32_t slot,
+                             int64_t resp_term, int success, int64_t epoch_at_send, int64_t last_sent,
+                             uint32_t sent_epoch)
+{
+    if (sent_epoch != g->role_epoch) { fx->status = RG_DROPPED_STALE_ROLE; return; }
+    if (g->role != RG_LEADER || !g->repl_prepared) { fx->status = RG_BAD_EVENT; return; }
+    uint32_t j = slot < t->self ? slot : slot - 1;
+    if (resp_term > g->current_term) {                            /* Q7: ballot = responder */
+        switch_to(t, g, fx, RG_FOLLOWER, resp_term, (int32_t)slot);
+        return;
+    }
+    peer_t *s = &g->peers[j];
+    if (!success) s->rejection = (int32_t)((uint32_t)s->rejection + 1u);   /* statSuccess member/Leadership.java:53-63 */
+    else if (s->rejection != 0) s->rejection = 0;
+    int st = update_index(s, epoch_at_send, snapshot ? epoch_at_send : last_sent, success, snapshot);
+    if (st) { fx->status = (uint32_t)st; return; }
+    if (!snapshot && success) try_commit(t, g, fx);
+}
+
+/* vote tallies: Candidate.startElection callback member/Candidate.java:121-134,
+ *               Follower.prepareElection callback member/Follower.java:258-270 */
+static void on_vote_reply(const orc_table_t *t, group_t *g, fx_t *fx, int pre, uint32_t slot,
+                          int64_t resp_term, int granted, uint32_t sent_epoch)
+{
+    if (sent_epoch == g->role_epoch) {
+        if (pre ? !(g->role == RG_FOLLOWER && g->timeout_detected) : g->role != RG_CANDIDATE) {
+            fx->status = RG_BAD_EVENT; return;
+        }
+        int64_t T = pre ? wadd(g->current_term, 1) : g->current_term;
+        if (resp_term > T) {
+            switch_to(t, g, fx, RG_FOLLOWER, resp_term, (int32_t)slot);
+        } else if (granted) {
+            g->votes += 1;
+            if (g->votes >= t->majority) {
+                if (pre) {
+                    switch_to(t, g, fx, RG_CANDIDATE, T, (int32_t)t->self);
+                } else {
+                    g->elected_epoch = g->role_epoch;             /* elected = true: head survives the fencing (Q13) */
+                    g->elected_term = g->current_term;
+                    switch_to(t, g, fx, RG_LEADER, T, (int32_t)t->self);
+                }
+            }
+        }
+        return;
+    }
+    if (!pre && g->elected_epoch != 0 && sent_epoch == g->elected_epoch) {   /* Q13: late reply on a winner's head */
+        int64_t T = g->elected_term;
+        if (resp_term > T) {
+            g->elected_epoch = 0;                                 /* head.abortRequests() */
+            switch_to(t, g, fx, RG_FOLLOWER, resp_term, (int32_t)slot);
+        } else if (granted) {
+            switch_to(t, g, fx, RG_LEADER, T, (int32_t)t->self); /* votes already >= majority */
+        }
+        return;
+    }
+    fx->status = RG_DROPPED_STALE_ROLE;
+}
+
+/* RaftParticipant.onTimeout: member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126 */
+static void on_timeout(const orc_table_t *t, group_t *g, fx_t *fx)
+{
+    if (g->role == RG_FOLLOWER) {
+        if (t->pre_vote) {
+            if (switch_to(t, g, fx, RG_FOLLOWER, g->current_term, g->voted_for) < 0) return;
+            g->timeout_detected = 1;                              /* prepareElection :223-279 */
+            g->votes = 1;
+            fx->flags |= RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT;
+        } else {
+            switch_to(t, g, fx, RG_CANDIDATE, wadd(g->current_term, 1), (int32_t)t->self);
+        }
+    } else if (g->role == RG_CANDIDATE) {
+        switch_to(t, g, fx, RG_CANDIDATE, wadd(g->current_term, 1), (int32_t)t->self);
+    } else {
+        fx->flags |= RG_F_RESET_TIMER;                            /* keepAlive context/RaftRoutine.java:53-62 */
+        prepare_replication(t, g);
+        fx->flags |= RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT;
+    }
+}
+
+/* RaftStub.process -> Leader.acceptCommand -> RaftContext.acceptCommand -> RaftLog.newEntry, then replicateLog(false)
+ * command/RaftStub.java:79-91, member/Leader.java:128-140, context/RaftContext.java:223-237, storage/RocksLog.java:82-89 */
+static void on_client_append(const orc_table_t *t, group_t *g, fx_t *fx, uint32_t n)
+{
+    if (g->role != RG_LEADER) { fx->status = RG_NOT_LEADER; return; }
+    if (n == 0) return;
+    if (log_empty(&g->log) && g->epoch_index > 0) { fx->status = RG_UNSUPPORTED_LOG_STATE; return; }   /* Q14 */
+    for (uint32_t k = 0; k < n; k++) {
+        int64_t index = log_empty(&g->log) ? 1 : wadd(g->log.last, 1);
+        if (k == 0) fx->log_from = index;
+        log_push(&g->log, index, g->current_term);
+        prepare_replication(t, g);                                /* replicateLog(false) after every command */
+    }
+    fx->flags |= RG_F_LOG_APPEND | (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+
+static void step(const orc_table_t *t, group_t *g, const rg_batch_t *in, size_t row,
+                 rg_reply_t *rep, rg_logfx_t *lfx, rg_persist_t *per)
+{
+    const uint32_t hdr = in->head[row].hdr, aux = in->head[row].aux;
+    const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), flag = RG_HDR_FLAG(hdr), n = RG_HDR_N(hdr);
+    const int64_t a = in->ab[row].x, b = in->ab[row].y, c = in->cd[row].x, d = in->cd[row].y;
+    fx_t fx = {0, RG_OK, 0, 0};
+
+    switch (kind) {
+    case RG_EV_NONE:
+        break;
+    case RG_EV_AE_REQ:
+        if (slot >= t->cluster || (n > 0 && (in->entry_terms == NULL || (uint64_t)aux + n > in->entry_count))) {
+            fx.status = RG_BAD_EVENT; break;
+        }
+        on_append_entries(t, g, &fx, a, (int32_t)slot, b, c, n, n ? in->entry_terms + aux : NULL, d);
+        break;
+    case RG_EV_AE_ACK:
+    case RG_EV_IS_ACK:
+        if (slot >= t->cluster || slot == t->self) { fx.status = RG_BAD_EVENT; break; }
+        on_replicate_ack(t, g, &fx, kind == RG_EV_IS_ACK, slot, a, (int)flag, b, c, aux);
+        break;
+    case RG_EV_RV_REQ:
+    case RG_EV_PV_REQ:
+        if (slot >= t->cluster) { fx.status = RG_BAD_EVENT; break; }
+        on_vote_request(t, g, &fx, kind == RG_EV_PV_REQ, a, (int32_t)slot, b, c);
+        break;
+    case RG_EV_RV_REPLY:
+    case RG_EV_PV_REPLY:
+        if (slot >= t->cluster || slot == t->self) { fx.status = RG_BAD_EVENT; break; }
+        on_vote_reply(t, g, &fx, kind == RG_EV_PV_REPLY, slot, a, (int)flag, aux);
+        break;
+    case RG_EV_TIMEOUT:
+        on_timeout(t, g, &fx);
+        break;
+    case RG_EV_CLIENT_APPEND:
+        on_client_append(t, g, &fx, n);
+        break;
+    case RG_EV_LOG_FLUSH: {
+        int st = log_flush(g, a, b);
+        if (st) fx.status = (uint32_t)st;
+        break;
+    }
+    default:
+        fx.status = RG_BAD_EVENT;
+        break;
+    }
+
+    rep->resp_term = (fx.flags & RG_F_REPLIED) ? fx.resp_term : 0;
+    rep->flags = fx.flags | ((uint32_t)g->role << RG_F_ROLE_SHIFT) | (fx.status << RG_F_STATUS_SHIFT);
+    rep->role_epoch = g->role_epoch;
+    if (fx.flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) {
+        lfx->commit_index = g->commit_index;
+        lfx->log_from = fx.log_from;
+    }
+    if (fx.flags & RG_F_PERSIST) {
+        per->term = g->current_term;
+        per->voted_for = g->voted_for;
+        per->role = g->role;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+
+orc_table_t *orc_table_create(uint32_t groups, uint32_t cluster, uint32_t self_slot, int pre_vote)
+{
+    if (groups == 0 || cluster < RG_MIN_CLUSTER || cluster > RG_MAX_CLUSTER || self_slot >= cluster) return NULL;
+    orc_table_t *t = (orc_table_t *)calloc(1, sizeof(*t));
+    if (!t) return NULL;
+    t->groups = groups; t->cluster = cluster; t->self = self_slot; t->followers = cluster - 1;
+    t->pre_vote = pre_vote != 0;
+    t->majority = (int)(cluster / 2 + 1);
+    t->g = (group_t *)calloc(groups, sizeof(group_t));
+    if (!t->g) { free(t); return NULL; }
+    for (uint32_t i = 0; i < groups; i++) {
+        t->g[i].voted_for = RG_NO_NODE;
+        t->g[i].current_leader = RG_NO_NODE;
+        t->g[i].role_epoch = 1;
+        t->g[i].votes = 1;
+    }
+    return t;
+}
+
+void orc_table_destroy(orc_table_t *t)
+{
+    if (!t) return;
+    for (uint32_t i = 0; i < t->groups; i++) free(t->g[i].log.r);
+    free(t->g);
+    free(t);
+}
+
+int orc_load_state(orc_table_t *t, uint32_t first, uint32_t count, const rg_group_state_t *s)
+{
+    if (!t || !s || (uint64_t)first + count > t->groups) return -1;
+    const uint32_t F = t->followers;
+    for (uint32_t i = 0; i < count; i++) {
+        group_t *g = &t->g[first + i];
+        g->current_term = s->current_term[i];
+        g->voted_for = s->voted_for[i];
+        g->role = s->role[i];
+        g->current_leader = s->current_leader[i];
+        g->timeout_detected = s->timeout_detected[i] != 0;
+        g->repl_prepared = s->repl_prepared[i] != 0;
+        g->role_epoch = s->role_epoch[i];
+        g->votes = s->votes[i];
+        g->elected_epoch = s->elected_epoch[i];
+        g->elected_term = s->elected_term[i];
+        g->commit_index = s->commit_index[i];
+        g->epoch_index = s->epoch_index[i];
+        g->epoch_term = s->epoch_term[i];
+        uint32_t rc = s->run_count[i], ro = s->run_offset[i];
+        g->log.n = 0;
+        if (rc) {
+            log_reserve(&g->log, rc);
+            for (uint32_t k = 0; k < rc; k++) {
+                g->log.r[k].start = s->run_start[ro + k];
+                g->log.r[k].term = s->run_term[ro + k];
+            }
+            g->log.n = rc;
+            g->log.first = s->first_index[i];
+            g->log.last = s->last_index[i];
+            if (g->log.r[0].start != g->log.first || g->log.last < g->log.r[rc - 1].start) return -2;
+            if (g->log.first != g->epoch_index && g->log.first != g->epoch_index + 1) return -3;
+        }
+        for (uint32_t j = 0; j < F; j++) {
+            peer_t *p = &g->peers[j];
+            p->last_epoch = s->peer_last_epoch[(size_t)i * F + j];
+            p->next_index = s->peer_next_index[(size_t)i * F + j];
+            p->match_index = s->peer_match_index[(size_t)i * F + j];
+            p->rejection = s->peer_rejection[(size_t)i * F + j];
+            p->pending = s->peer_pending[(size_t)i * F + j] != 0;
+        }
+    }
+    return 0;
+}
+
+int orc_read_state(orc_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *d)
+{
+    if (!t || !d || (uint64_t)first + count > t->groups) return -1;
+    const uint32_t F = t->followers;
+    for (uint32_t i = 0; i < count; i++) {
+        const group_t *g = &t->g[first + i];
+        d->current_term[i] = g->current_term;
+        d->voted_for[i] = g->voted_for;
+        d->role[i] = g->role;
+        d->current_leader[i] = g->current_leader;
+        d->timeout_detected[i] = g->timeout_detected;
+        d->repl_prepared[i] = g->repl_prepared;
+        d->role_epoch[i] = g->role_epoch;
+        d->votes[i] = g->votes;
+        d->elected_epoch[i] = g->elected_epoch;
+        d->elected_term[i] = g->elected_term;
+        d->commit_index[i] = g->commit_index;
+        d->epoch_index[i] = g->epoch_index;
+        d->epoch_term[i] = g->epoch_term;
+        uint32_t rc = g->log.n > RG_TERM_RUNS ? RG_TERM_RUNS : g->log.n;
+        d->run_count[i] = rc;
+        d->run_offset[i] = i * RG_TERM_RUNS;
+        d->first_index[i] = g->log.n ? g->log.first : 0;
+        d->last_index[i] = g->log.n ? g->log.last : 0;
+        for (uint32_t k = 0; k < RG_TERM_RUNS; k++) {
+            int have = k < rc;
+            d->run_start[(size_t)i * RG_TERM_RUNS + k] = have ? g->log.r[g->log.n - rc + k].start : 0;
+            d->run_term[(size_t)i * RG_TERM_RUNS + k] = have ? g->log.r[g->log.n - rc + k].term : 0;
+        }
+        for (uint32_t j = 0; j < F; j++) {
+            const peer_t *p = &g->peers[j];
+            d->peer_last_epoch[(size_t)i * F + j] = p->last_epoch;
+            d->peer_next_index[(size_t)i * F + j] = p->next_index;
+            d->peer_match_index[(size_t)i * F + j] = p->match_index;
+            d->peer_rejection[(size_t)i * F + j] = p->rejection;
+            d->peer_pending[(size_t)i * F + j] = p->pending;
+        }
+    }
+    return 0;
+}
+
+static int check_batch(const orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
+{
+    if (!t || !in || !out || !in->head || !in->ab || !in->cd || !out->reply || !out->logfx || !out->persist) return -1;
+    if (in->rounds == 0) return -1;
+    if (in->gid) {
+        if (in->rounds != 1 || in->count > t->groups) return -1;
+        for (uint32_t i = 0; i < in->count; i++) {
+            if (in->gid[i] >= t->groups) return -1;
+            if (i && in->gid[i] <= in->gid[i - 1]) return -1;
+        }
+    } else if (in->count != t->groups) return -1;
+    return 0;
+}
+
+int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
+{
+    if (check_batch(t, in, out)) return -1;
+    for (uint32_t r = 0; r < in->rounds; r++)
+        for (uint32_t i = 0; i < in->count; i++) {
+            size_t row = (size_t)r * in->count + i;
+            uint32_t gid = in->gid ? in->gid[i] : i;
+            step(t, &t->g[gid], in, row, &out->reply[row], &out->logfx[row], &out->persist[row]);
+        }
+    return 0;
+}
+
+/* ---- threaded CPU baseline ------------------------------------------------------------------- */
+
+typedef struct {
+    orc_table_t *t; const rg_batch_t *in; const rg_outcome_t *out;
+    int tid, threads; pthread_barrier_t *bar;
+} job_t;
+
+static void *worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    pthread_barrier_wait(j->bar);
+    for (uint32_t r = 0; r < j->in->rounds; r++)
+        for (uint32_t i = (uint32_t)j->tid; i < j->in->count; i += (uint32_t)j->threads) {
+            size_t row = (size_t)r * j->in->count + i;
+            step(j->t, &j->t->g[i], j->in, row, &j->out->reply[row], &j->out->logfx[row], &j->out->persist[row]);
+        }
+    pthread_barrier_wait(j->bar);
+    return NULL;
+}
+
+double orc_submit_threads(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int threads)
+{
+    if (check_batch(t, in, out) || in->gid || threads < 1 || threads > 256) return -1.0;
+    pthread_t th[256]; job_t jobs[256];
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads + 1);
+    for (int i = 0; i < threads; i++) {
+        jobs[i] = (job_t){t, in, out, i, threads, &bar};
+        pthread_create(&th[i], NULL, worker, &jobs[i]);
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    pthread_barrier_wait(&bar);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    pthread_barrier_destroy(&bar);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -1,0 +1,59 @@
+/*
+ * raft_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the per-RaftContext decision logic of curioloop/rafting
+ * (io.lubricant.consensus.raft.context.**), one event at a time, exactly in the order the
+ * reference EventLoop would run it.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may link or call this; the product path (rafting_amd/, libraftgpu.so) never does.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: the reference (Java 8 + Maven deps) cannot run in this
+ * environment (no JDK) and its own tests hold no golden vector for this path.
+ * The oracle is pinned instead by hand-derived known-answer tests (tests/test_oracle_kat.py), each
+ * citing the reference lines it was derived from, and by the one in-source golden table
+ * (member/Leadership.java:121-126).
+ *
+ * The log model is LOSSLESS: an unbounded run-length encoding of (index -> term) over the contiguous
+ * key window RocksLog keeps (storage/RocksLog.java), so it answers RaftLog.get(i) for every index —
+ * unlike the device, which caches only the newest RG_TERM_RUNS runs.
+ *
+ * It consumes the same wire structs as the C-ABI (include/raftgpu.h) so tests feed both sides the
+ * identical buffers.
+ */
+#ifndef RAFT_ORACLE_H
+#define RAFT_ORACLE_H
+
+#include "../include/raftgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_table orc_table_t;
+
+orc_table_t *orc_table_create(uint32_t groups, uint32_t cluster, uint32_t self_slot, int pre_vote);
+void         orc_table_destroy(orc_table_t *t);
+
+/* same semantics as rg_load_state, but ALL supplied runs are kept (lossless log) */
+int orc_load_state(orc_table_t *t, uint32_t first, uint32_t count, const rg_group_state_t *src);
+/* same semantics as rg_read_state: reports the newest RG_TERM_RUNS runs of each log */
+int orc_read_state(orc_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *dst);
+
+/* same semantics as rg_submit(..., RG_MEM_HOST); never answers RG_NEED_HOST. */
+int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
+
+/* CPU baseline: apply a dense batch with `threads` worker threads, groups assigned round-robin to
+ * threads exactly like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3).
+ * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */
+double orc_submit_threads(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int threads);
+
+/* exposed pieces for known-answer tests */
+int64_t orc_rejection_step(int32_t recent_rejection);                 /* Leadership.java:105 */
+void    orc_major_indices(const int64_t *match, int n, int64_t out[2]); /* Leadership.java:116-130 */
+/* Membership.isBetter (member/Membership.java:74-108): 1 better, 0 not, <0 = -(RG_A_* status) */
+int     orc_is_better(int new_role, int64_t new_term, int32_t new_ballot,
+                      int cur_role, int64_t cur_term, int32_t cur_ballot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

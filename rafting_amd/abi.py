@@ -1,0 +1,247 @@
+"""ctypes/numpy mirror of include/raftgpu.h — wire structs, constants and buffer holders.
+
+Pure layout code (no library is loaded here): both the product binding (rafting_amd.engine) and the
+test-only oracle binding (tests/oracle_lib.py) describe their buffers with these types, so the two
+sides are fed byte-identical inputs.
+"""
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+MIN_CLUSTER, MAX_CLUSTER = 2, 7
+TERM_RUNS = 4
+NO_NODE = -1
+
+FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
+
+EV_NONE, EV_AE_REQ, EV_AE_ACK, EV_IS_ACK, EV_RV_REQ, EV_PV_REQ = 0, 1, 2, 3, 4, 5
+EV_RV_REPLY, EV_PV_REPLY, EV_TIMEOUT, EV_CLIENT_APPEND, EV_LOG_FLUSH = 6, 7, 8, 9, 10
+HDR_HINT_BIT = 1 << 9
+
+F_SUCCESS, F_REPLIED, F_PERSIST, F_ROLE_CHANGED = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+F_RESET_TIMER, F_COMMIT, F_LOG_TRUNC, F_LOG_APPEND = 1 << 4, 1 << 5, 1 << 6, 1 << 7
+F_EMIT_SHIFT, F_EMIT_MASK = 8, 3 << 8
+EMIT_NONE, EMIT_PREVOTE, EMIT_REQVOTE, EMIT_HEARTBEAT = 0, 1, 2, 3
+F_ROLE_SHIFT, F_ROLE_MASK = 10, 3 << 10
+F_STATUS_SHIFT = 16
+
+OK = 0
+A_TWO_LEADERS, A_PREV_ZERO_MISMATCH, A_EPOCH_TERM_MISMATCH, A_IMPOSSIBLE_LOG = 1, 2, 3, 4
+A_COMMIT_ROLLBACK, A_LOG_NOT_CONTINUOUS, A_LEADER_SELF_AE, A_SAME_TERM_LEADER = 5, 6, 7, 8
+A_LEADER_NOT_SELF_VOTE, A_CAND_SELF_RV, A_CAND_NOT_SELF_VOTE, A_LEADER_UNCHANGED = 9, 10, 11, 12
+A_CAND_BALLOT, A_MATCH_ROLLBACK, A_IMPOSSIBLE_REPLICATION, NPE_MAJOR_NULL = 13, 14, 15, 16
+DROPPED_STALE_ROLE, NOT_LEADER, FLUSH_OUT_OF_BOUNDS = 17, 18, 19
+NEED_HOST, SKIPPED_AFTER_NEED_HOST, BAD_EVENT, UNSUPPORTED_LOG_STATE = 32, 33, 34, 35
+
+MEM_HOST, MEM_DEVICE = 0, 1
+NUM_COUNTERS = 8
+
+HEAD_DT = np.dtype([("hdr", "<u4"), ("aux", "<u4")])
+PAIR_DT = np.dtype([("x", "<i8"), ("y", "<i8")])
+REPLY_DT = np.dtype([("resp_term", "<i8"), ("flags", "<u4"), ("role_epoch", "<u4")])
+LOGFX_DT = np.dtype([("commit_index", "<i8"), ("log_from", "<i8")])
+PERSIST_DT = np.dtype([("term", "<i8"), ("voted_for", "<i4"), ("role", "<i4")])
+assert HEAD_DT.itemsize == 8 and PAIR_DT.itemsize == 16 and REPLY_DT.itemsize == 16
+assert LOGFX_DT.itemsize == 16 and PERSIST_DT.itemsize == 16
+
+
+def hdr_make(kind, slot=0, flag=0, n=0):
+    """RG_HDR_MAKE; works on scalars and numpy arrays."""
+    return (
+        (np.uint32(kind) & np.uint32(0xF))
+        | ((np.asarray(slot).astype(np.uint32) & np.uint32(0xF)) << np.uint32(4))
+        | ((np.asarray(flag).astype(np.uint32) & np.uint32(1)) << np.uint32(8))
+        | (np.asarray(n).astype(np.uint32) << np.uint32(12))
+    ).astype(np.uint32)
+
+
+def flags_status(flags):
+    return (np.asarray(flags) >> F_STATUS_SHIFT) & 0xFF
+
+
+def flags_role(flags):
+    return (np.asarray(flags) & F_ROLE_MASK) >> F_ROLE_SHIFT
+
+
+def flags_emit(flags):
+    return (np.asarray(flags) & F_EMIT_MASK) >> F_EMIT_SHIFT
+
+
+class CBatch(C.Structure):
+    _fields_ = [
+        ("rounds", C.c_uint32),
+        ("count", C.c_uint32),
+        ("gid", C.c_void_p),
+        ("head", C.c_void_p),
+        ("ab", C.c_void_p),
+        ("cd", C.c_void_p),
+        ("entry_terms", C.c_void_p),
+        ("entry_count", C.c_uint64),
+        ("hint", C.c_void_p),
+    ]
+
+
+class COutcome(C.Structure):
+    _fields_ = [("reply", C.c_void_p), ("logfx", C.c_void_p), ("persist", C.c_void_p)]
+
+
+_STATE_FIELDS = [
+    ("current_term", np.int64, 1),
+    ("voted_for", np.int32, 1),
+    ("role", np.int32, 1),
+    ("current_leader", np.int32, 1),
+    ("timeout_detected", np.uint8, 1),
+    ("repl_prepared", np.uint8, 1),
+    ("role_epoch", np.uint32, 1),
+    ("votes", np.int32, 1),
+    ("elected_epoch", np.uint32, 1),
+    ("elected_term", np.int64, 1),
+    ("commit_index", np.int64, 1),
+    ("epoch_index", np.int64, 1),
+    ("epoch_term", np.int64, 1),
+    ("first_index", np.int64, 1),
+    ("last_index", np.int64, 1),
+    ("run_count", np.uint32, 1),
+    ("run_offset", np.uint32, 1),
+    ("run_start", np.int64, "runs"),
+    ("run_term", np.int64, "runs"),
+    ("peer_last_epoch", np.int64, "peers"),
+    ("peer_next_index", np.int64, "peers"),
+    ("peer_match_index", np.int64, "peers"),
+    ("peer_rejection", np.int32, "peers"),
+    ("peer_pending", np.uint8, "peers"),
+]
+
+
+class CGroupState(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in _STATE_FIELDS]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class GroupState:
+    """Host SoA image of `count` groups (rg_group_state_t). Fresh groups are what
+    RaftContext.initialize produces: Follower, term 0, no vote, empty log, epoch (0,0)."""
+
+    def __init__(self, count, cluster, runs_total=None):
+        self.count, self.cluster, self.followers = count, cluster, cluster - 1
+        nruns = count * TERM_RUNS if runs_total is None else runs_total
+        for name, dt, shape in _STATE_FIELDS:
+            n = count if shape == 1 else (nruns if shape == "runs" else count * self.followers)
+            setattr(self, name, np.zeros(n, dtype=dt))
+        self.voted_for[:] = NO_NODE
+        self.current_leader[:] = NO_NODE
+        self.role_epoch[:] = 1
+        self.votes[:] = 1
+        self.run_offset[:] = np.arange(count, dtype=np.uint32) * TERM_RUNS if runs_total is None else 0
+
+    def set_log(self, g, first, runs, last):
+        """Give group g the log whose maximal equal-term runs are `runs` = [(start, term), ...]
+        (ascending, runs[0][0] == first) and whose greatest key is `last`. Only valid on the default
+        layout (TERM_RUNS slots per group), so len(runs) <= TERM_RUNS."""
+        assert len(runs) <= TERM_RUNS
+        self.run_count[g] = len(runs)
+        self.first_index[g], self.last_index[g] = (first, last) if runs else (0, 0)
+        for k, (s, t) in enumerate(runs):
+            self.run_start[g * TERM_RUNS + k] = s
+            self.run_term[g * TERM_RUNS + k] = t
+
+    def peers(self, name):
+        return getattr(self, "peer_" + name).reshape(self.count, self.followers)
+
+    def as_struct(self):
+        s = CGroupState()
+        for name, dt, _ in _STATE_FIELDS:
+            a = getattr(self, name)
+            assert a.dtype == dt and a.flags["C_CONTIGUOUS"], name
+            setattr(s, name, _ptr(a))
+        return s
+
+    def fields(self):
+        return [name for name, _, _ in _STATE_FIELDS]
+
+
+class Batch:
+    """Host image of an rg_batch_t: `rounds` x `count` rows."""
+
+    def __init__(self, rounds, count, gid=None, max_entries=0, hints=False):
+        self.rounds, self.count = rounds, count
+        n = rounds * count
+        self.gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
+        self.head = np.zeros(n, dtype=HEAD_DT)
+        self.ab = np.zeros(n, dtype=PAIR_DT)
+        self.cd = np.zeros(n, dtype=PAIR_DT)
+        self.entry_terms = np.zeros(max_entries, dtype=np.int64)
+        self.entry_count = 0
+        self.hint = np.zeros(n, dtype=PAIR_DT) if hints else None
+
+    def row(self, r, i):
+        return r * self.count + i
+
+    def put(self, r, i, kind, slot=0, flag=0, a=0, b=0, c=0, d=0, aux=0, entries=None, n=0):
+        """Write one event row; `entries` (AE_REQ) is the list of entry terms, `n` the command
+        count of a CLIENT_APPEND."""
+        row = self.row(r, i)
+        if entries is not None and len(entries):
+            n = len(entries)
+            if self.entry_count + n > len(self.entry_terms):
+                grown = np.zeros(max(2 * len(self.entry_terms), self.entry_count + n, 64), dtype=np.int64)
+                grown[: self.entry_count] = self.entry_terms[: self.entry_count]
+                self.entry_terms = grown
+            aux = self.entry_count
+            self.entry_terms[self.entry_count : self.entry_count + n] = entries
+            self.entry_count += n
+        self.head[row] = (int(hdr_make(kind, slot, flag, n)), int(aux) & 0xFFFFFFFF)
+        self.ab[row] = (a, b)
+        self.cd[row] = (c, d)
+        return row
+
+    def set_hint(self, row, x, y):
+        assert self.hint is not None
+        self.hint[row] = (x, y)
+        self.head["hdr"][row] |= HDR_HINT_BIT
+
+    def as_struct(self):
+        b = CBatch()
+        b.rounds, b.count = self.rounds, self.count
+        b.gid = _ptr(self.gid)
+        b.head, b.ab, b.cd = _ptr(self.head), _ptr(self.ab), _ptr(self.cd)
+        b.entry_terms = _ptr(self.entry_terms) if self.entry_count else None
+        b.entry_count = self.entry_count
+        b.hint = _ptr(self.hint)
+        return b
+
+
+class Outcome:
+    """Host image of an rg_outcome_t. Buffers are pre-filled with a sentinel so tests can see which
+    conditional fields a side left untouched."""
+
+    def __init__(self, rows, fill=0):
+        self.reply = np.zeros(rows, dtype=REPLY_DT)
+        self.logfx = np.zeros(rows, dtype=LOGFX_DT)
+        self.persist = np.zeros(rows, dtype=PERSIST_DT)
+        if fill:
+            self.reply.view(np.uint8)[:] = fill
+            self.logfx.view(np.uint8)[:] = fill
+            self.persist.view(np.uint8)[:] = fill
+
+    def as_struct(self):
+        o = COutcome()
+        o.reply, o.logfx, o.persist = _ptr(self.reply), _ptr(self.logfx), _ptr(self.persist)
+        return o
+
+    # decoded views -------------------------------------------------------------------------
+    @property
+    def status(self):
+        return flags_status(self.reply["flags"])
+
+    @property
+    def success(self):
+        return (self.reply["flags"] & F_SUCCESS) != 0
+
+    @property
+    def replied(self):
+        return (self.reply["flags"] & F_REPLIED) != 0

@@ -1,0 +1,496 @@
+"""Known-answer scenarios for the hot path, hand-derived from the reference SOURCE (the reference has
+no test that pins this path — SURVEY.md §4/§8c).  Each scenario names the reference lines the
+expected values were read from (paths relative to .../io/lubricant/consensus/raft/).
+
+Scenarios are backend-agnostic: `mk(groups, cluster, self_slot, pre_vote)` returns a table exposing
+load_state/read_state/submit — the CPU oracle in tests/test_oracle_kat.py, the HIP engine through
+the C-ABI in tests/test_gpu_parity.py.
+"""
+from rafting_amd import abi
+from tests.helpers import C, F, L, Sim, simple_log
+
+NO = abi.NO_NODE
+
+
+def _sim(mk, cluster=3, self_slot=0, pre_vote=True, **state):
+    return Sim(mk(1, cluster, self_slot, pre_vote)).load(**state)
+
+
+# --------------------------------------------------------------------------------------------------
+# a1: Follower.appendEntries  member/Follower.java:35-88 (+logContains :177-191, purgeEntries :209-221)
+
+def ae_stale_term(mk):
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5))
+    r = s.append_entries(4, 1, 10, 5, [], 0)                  # :39-41
+    assert (r.status, r.replied, r.success, r.resp_term) == (abi.OK, True, False, 5)
+    assert not r.reset_timer and not r.role_changed
+    assert s.state().leader == NO
+
+
+def ae_heartbeat_commit(mk):
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5), commit=3)
+    r = s.append_entries(5, 1, 10, 5, [], 8)                  # :57 match, :76-82 commit min(8,10)
+    assert (r.status, r.replied, r.success, r.resp_term) == (abi.OK, True, True, 5)
+    assert r.commit_adv and r.commit == 8 and r.reset_timer and not r.role_changed and not r.appended
+    st = s.state()
+    assert (st.commit, st.leader, st.role_epoch) == (8, 1, 1)
+    r = s.append_entries(5, 1, 10, 5, [], 99)                 # commit truncated to last.index (:80)
+    assert r.commit_adv and r.commit == 10
+    r = s.append_entries(5, 1, 10, 5, [], 10)                 # markCommitted(==) -> false, no flag
+    assert r.success and not r.commit_adv
+
+
+def ae_prev_mismatch(mk):
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5))
+    r = s.append_entries(5, 1, 10, 4, [], 0)                  # entry.term()!=term :190
+    assert (r.status, r.replied, r.success, r.resp_term) == (abi.OK, True, False, 5)
+    assert s.state().leader == 1                              # :54 ran before :57
+    r = s.append_entries(5, 1, 11, 5, [], 0)                  # get(11)==null :190
+    assert (r.replied, r.success) == (True, False)
+
+
+def ae_term_bump_keeps_vote(mk):                              # Q1, Q3
+    s = _sim(mk, role=F, term=5, voted_for=2, leader=2)
+    r = s.append_entries(7, 1, 0, 0, [], 0)                   # :45-47 switchTo(Follower, term, lastCandidate)
+    assert (r.status, r.replied, r.success, r.resp_term) == (abi.OK, True, True, 7)
+    assert r.persist and r.role_changed and (r.p_term, r.p_vote, r.p_role) == (7, 2, F)
+    st = s.state()
+    assert (st.term, st.voted_for, st.leader, st.role_epoch) == (7, 2, 1, 2)
+    assert r.role_epoch == 2 and not r.commit_adv
+
+
+def ae_after_own_timeout(mk):                                 # Q2: same-term Follower->Follower refresh
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=2, timeout_detected=1, votes=2)
+    r = s.append_entries(5, 1, 0, 0, [], 0)                   # :45 timeoutDetected branch: no two-leader check
+    assert (r.status, r.success, r.resp_term, r.role_changed, r.persist) == (abi.OK, True, 5, True, True)
+    st = s.state()
+    assert (st.timeout_detected, st.leader, st.role_epoch, st.votes, st.voted_for) == (0, 1, 2, 1, 1)
+
+
+def ae_two_leaders(mk):                                       # Q12
+    s = _sim(mk, role=F, term=5, leader=2)
+    r = s.append_entries(5, 1, 0, 0, [], 0)                   # :48-50
+    assert r.status == abi.A_TWO_LEADERS and not r.replied and r.reset_timer
+    assert s.state().leader == 2
+
+
+def ae_at_candidate(mk):
+    s = _sim(mk, role=C, term=5, voted_for=0, role_epoch=4)
+    r = s.append_entries(4, 1, 0, 0, [], 0)                   # Candidate.java:32-34
+    assert (r.replied, r.success, r.resp_term, r.role) == (True, False, 5, C)
+    r = s.append_entries(5, 1, 0, 0, [], 0)                   # :39 same term: Follower beats Candidate (Membership.java:92)
+    assert (r.status, r.success, r.resp_term, r.role, r.role_epoch) == (abi.OK, True, 5, F, 5)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for, st.leader) == (F, 5, 0, 1)
+
+
+def ae_at_leader(mk):                                         # Q4
+    s = _sim(mk, role=L, term=5, voted_for=0, role_epoch=4)
+    assert s.append_entries(9, 0, 0, 0, [], 0).status == abi.A_LEADER_SELF_AE       # Leader.java:71-73
+    r = s.append_entries(4, 1, 0, 0, [], 0)                                        # :75-77
+    assert (r.replied, r.success, r.resp_term) == (True, False, 5)
+    assert s.append_entries(5, 1, 0, 0, [], 0).status == abi.A_SAME_TERM_LEADER    # :79-81
+    assert s.state().role == L
+    r = s.append_entries(8, 1, 0, 0, [], 0)                   # :84-85 then Follower.java:45-47: two conversions
+    assert (r.status, r.success, r.resp_term, r.role, r.role_epoch) == (abi.OK, True, 8, F, 6)
+    assert (r.p_term, r.p_vote, r.p_role) == (8, 0, F)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for, st.leader, st.role_epoch) == (F, 8, 0, 1, 6)
+
+
+def ae_log_contains_quirks(mk):                               # Q9
+    s = _sim(mk, role=F, term=5, epoch=(5, 3), log=(6, [(6, 3)], 8))
+    assert s.append_entries(5, 1, 0, 0, [], 0).success                              # :178
+    r = s.append_entries(5, 1, 0, 5, [], 0)
+    assert r.status == abi.A_PREV_ZERO_MISMATCH and not r.replied                   # :179-181
+    assert s.append_entries(5, 1, 5, 0, [], 0).status == abi.A_PREV_ZERO_MISMATCH
+    assert s.append_entries(5, 1, 3, 99, [], 0).success                             # index<epoch: term not checked :183-187
+    assert s.append_entries(5, 1, 5, 3, [], 0).success
+    assert s.append_entries(5, 1, 5, 4, [], 0).status == abi.A_EPOCH_TERM_MISMATCH  # :184-186
+    assert s.state().leader == 1
+
+
+def ae_append(mk):
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5), commit=3)
+    r = s.append_entries(5, 1, 10, 5, [5, 5], 11)             # :68-74 append; :80 min(11, 12)
+    assert (r.status, r.success, r.appended, r.truncated, r.log_from) == (abi.OK, True, True, False, 11)
+    assert r.commit_adv and r.commit == 11
+    st = s.state()
+    assert (st.last, st.runs, st.commit) == (12, [(1, 5)], 11)
+    r = s.append_entries(6, 1, 12, 5, [6], 11)                # new term run
+    assert r.success and r.log_from == 13
+    st = s.state()
+    assert (st.last, st.runs, st.term) == (13, [(1, 5), (13, 6)], 6)
+
+
+def ae_append_on_empty_log(mk):
+    s = _sim(mk, role=F, term=1)
+    r = s.append_entries(1, 2, 0, 0, [1, 1, 1], 2)
+    assert (r.success, r.appended, r.log_from, r.commit_adv, r.commit) == (True, True, 1, True, 2)
+    st = s.state()
+    assert (st.first, st.last, st.runs) == (1, 3, [(1, 1)])
+
+
+def ae_conflict_truncates(mk):
+    s = _sim(mk, role=F, term=5, log=(1, [(1, 3), (6, 4)], 10))
+    r = s.append_entries(5, 1, 7, 4, [4, 5, 5], 0)            # idx 8 ok, idx 9: 4 != 5 -> RocksLog.conflict :210-212
+    assert (r.status, r.success, r.truncated, r.appended, r.log_from) == (abi.OK, True, True, True, 9)
+    st = s.state()
+    assert (st.last, st.runs) == (10, [(1, 3), (6, 4), (9, 5)])
+    r = s.append_entries(5, 1, 5, 3, [6], 0)                  # conflict at 6: whole tail goes, shorter log
+    assert (r.truncated, r.log_from) == (True, 6)
+    st = s.state()
+    assert (st.last, st.runs) == (6, [(1, 3), (6, 6)])
+
+
+def ae_stale_duplicate_never_shortens(mk):                    # Q10
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5))
+    r = s.append_entries(5, 1, 5, 5, [5, 5], 0)               # RocksLog.append :183 skips nothing new
+    assert r.success and not r.appended and not r.truncated
+    assert s.state().last == 10
+    r = s.append_entries(5, 1, 9, 5, [5, 5, 5], 0)            # overlap 10, new 11..12
+    assert r.appended and r.log_from == 11 and s.state().last == 12
+
+
+def ae_purge_entries(mk):
+    s = _sim(mk, role=F, term=5, epoch=(5, 3), log=(6, [(6, 3)], 8))
+    r = s.append_entries(5, 1, 3, 2, [2, 3, 3, 3, 4], 0)      # idx 4,5 purged (:209-221); idx 8: 3 != 4 conflict
+    assert (r.status, r.success, r.truncated, r.log_from) == (abi.OK, True, True, 8)
+    assert s.state().runs == [(6, 3), (8, 4)]
+    r = s.append_entries(5, 1, 3, 2, [2, 3], 0)               # everything purged -> entries = null
+    assert r.success and not r.appended and not r.truncated
+
+
+def ae_commit_rollback(mk):                                   # Q8
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5), commit=9)
+    r = s.append_entries(5, 1, 10, 5, [], 7)                  # RocksLog.markCommitted :101-103
+    assert r.status == abi.A_COMMIT_ROLLBACK and not r.replied and not r.commit_adv
+    st = s.state()
+    assert (st.commit, st.leader) == (9, 1)
+    r = s.append_entries(5, 1, 10, 5, [5], 7)                 # entries are appended BEFORE the throw
+    assert r.status == abi.A_COMMIT_ROLLBACK and r.appended and r.log_from == 11 and not r.replied
+    assert s.state().last == 11
+
+
+def ae_commit_guards(mk):
+    s = _sim(mk, role=F, term=5, epoch=(5, 3))               # empty log: last()==null :77-78
+    r = s.append_entries(5, 1, 5, 3, [], 9)
+    assert r.success and not r.commit_adv and s.state().commit == 0
+    s = _sim(mk, role=F, term=5, epoch=(5, 3), log=(6, [(6, 3)], 8))
+    r = s.append_entries(5, 1, 8, 3, [], 5)                   # leaderCommit > epoch.index is false :76
+    assert r.success and not r.commit_adv
+
+
+# --------------------------------------------------------------------------------------------------
+# a5: voter side  Follower.java:91-127,193-207  Candidate.java:44-72  Leader.java:89-111
+
+def rv_follower(mk):                                          # KAT-6
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5))
+    r = s.request_vote(4, 1, 99, 9)
+    assert (r.replied, r.success, r.resp_term) == (True, False, 5)                  # :112-113
+    assert not s.request_vote(5, 1, 99, 9).success                                  # :115 votedFor()==null
+    s.load(role=F, term=5, voted_for=1, log=simple_log(10, 5))
+    r = s.request_vote(5, 1, 0, 0)
+    assert (r.success, r.resp_term, r.role_changed) == (True, 5, False)             # :115 same candidate, no log check
+    assert not s.request_vote(5, 2, 99, 9).success
+    r = s.request_vote(6, 2, 10, 5)                                                 # :122-126 fresh log
+    assert (r.status, r.success, r.resp_term, r.persist, r.reset_timer) == (abi.OK, True, 6, True, True)
+    assert (r.p_term, r.p_vote) == (6, 2)
+    st = s.state()
+    assert (st.term, st.voted_for, st.role_epoch) == (6, 2, 2)
+    r = s.request_vote(7, 1, 9, 5)                                                  # stale log: term still bumps, vote null
+    assert (r.success, r.resp_term, r.p_term, r.p_vote) == (False, 7, 7, NO)
+    st = s.state()
+    assert (st.term, st.voted_for) == (7, NO)
+    assert s.request_vote(8, 1, 3, 6).success                                       # higher last term wins :196
+
+
+def rv_follower_without_last(mk):                             # KAT-3
+    def fresh():
+        return _sim(mk, role=F, term=5, epoch=(5, 3))
+    assert fresh().request_vote(6, 1, 5, 3).success                                 # :205
+    assert fresh().request_vote(6, 1, 9, 3).success
+    r = fresh().request_vote(6, 1, 4, 3)
+    assert (r.status, r.success, r.resp_term) == (abi.OK, False, 6)
+    r = fresh().request_vote(6, 1, 6, 2)                                            # :199
+    assert r.status == abi.A_IMPOSSIBLE_LOG and not r.replied and r.reset_timer and not r.role_changed
+    s = fresh()
+    assert s.request_vote(6, 1, 5, 4).status == abi.A_IMPOSSIBLE_LOG               # :200
+    assert s.state().term == 5
+
+
+def pv_follower(mk):                                          # KAT-10
+    s = _sim(mk, role=F, term=5, log=simple_log(10, 5))
+    r = s.pre_vote(6, 1, 10, 5)                                                     # :94 !timeoutDetected
+    assert (r.replied, r.success, r.resp_term, r.reset_timer) == (True, False, 5, False)
+    s.load(role=F, term=5, log=simple_log(10, 5), timeout_detected=1, role_epoch=3)
+    r = s.pre_vote(6, 1, 10, 5)                                                     # :100-101 replies currentTerm
+    assert (r.status, r.success, r.resp_term, r.reset_timer, r.role_changed) == (abi.OK, True, 5, True, False)
+    st = s.state()
+    assert (st.term, st.role_epoch, st.voted_for, st.timeout_detected) == (5, 3, NO, 1)
+    assert not s.pre_vote(5, 1, 10, 5).success                                      # term <= currentTerm
+    assert not s.pre_vote(6, 1, 9, 5).success                                       # stale
+    assert s.pre_vote(6, 1, 9, 5).resp_term == 5
+
+
+def vote_at_candidate(mk):                                    # KAT-7 / Q5
+    def cand(**kw):
+        return _sim(mk, role=C, term=5, voted_for=0, log=simple_log(10, 5), role_epoch=2, **kw)
+    s = cand()
+    assert s.request_vote(6, 0, 10, 5).status == abi.A_CAND_SELF_RV                 # Candidate.java:53-55
+    r = s.request_vote(4, 1, 10, 5)
+    assert (r.success, r.resp_term) == (False, 5)
+    r = s.request_vote(5, 1, 10, 5)                                                 # :62-63
+    assert (r.success, r.resp_term, r.role) == (False, 5, C)
+    r = s.request_vote(6, 1, 0, 0)                                                  # :70-71 stale log still granted
+    assert (r.status, r.success, r.resp_term, r.role, r.role_epoch) == (abi.OK, True, 6, F, 3)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for) == (F, 6, 1)
+    s = cand()
+    r = s.pre_vote(6, 2, 0, 0)                                                      # :44-46 PreVote == RequestVote here
+    assert (r.success, r.resp_term, r.role) == (True, 6, F)
+    assert (s.state().term, s.state().voted_for) == (6, 2)
+    s = _sim(mk, role=C, term=5, voted_for=1)
+    assert s.request_vote(5, 1, 0, 0).status == abi.A_CAND_NOT_SELF_VOTE            # :64-66
+
+
+def vote_at_leader(mk):
+    def lead(**kw):
+        return _sim(mk, role=L, term=5, voted_for=0, log=simple_log(10, 5), role_epoch=2, **kw)
+    s = lead()
+    r = s.pre_vote(9, 1, 99, 9)                                                     # Leader.java:89-91
+    assert (r.replied, r.success, r.resp_term, r.role) == (True, False, 5, L)
+    assert s.request_vote(4, 1, 99, 9).resp_term == 5
+    r = s.request_vote(5, 1, 99, 9)                                                 # :99-100
+    assert (r.status, r.success, r.resp_term) == (abi.OK, False, 5)
+    r = s.request_vote(6, 1, 10, 5)                                                 # :108 then Follower.java:122-126
+    assert (r.status, r.success, r.resp_term, r.role, r.role_epoch) == (abi.OK, True, 6, F, 4)
+    assert (s.state().term, s.state().voted_for) == (6, 1)
+    s = lead()
+    r = s.request_vote(6, 1, 9, 5)
+    assert (r.success, r.resp_term, r.p_vote) == (False, 6, NO)
+    s = _sim(mk, role=L, term=5, voted_for=1)
+    assert s.request_vote(5, 2, 0, 0).status == abi.A_LEADER_NOT_SELF_VOTE          # :101-105
+    s = _sim(mk, role=L, term=5, voted_for=0, epoch=(5, 3), role_epoch=2)
+    r = s.request_vote(9, 1, 6, 2)                                                  # first conversion sticks, then Follower.java:199 throws
+    assert r.status == abi.A_IMPOSSIBLE_LOG and not r.replied and r.persist and (r.p_term, r.p_vote) == (5, 1)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for, st.role_epoch) == (F, 5, 1, 3)
+
+
+# --------------------------------------------------------------------------------------------------
+# a6/a7: tallies and timeouts  Candidate.java:82-143  Follower.java:156-168,223-279
+
+def election_tally(mk):                                       # Q7, Q13
+    s = _sim(mk, cluster=5, role=C, term=6, voted_for=0, role_epoch=7)
+    r = s.rv_reply(1, 6, True, 7)
+    assert (r.status, r.role, s.state().votes) == (abi.OK, C, 2)
+    assert s.rv_reply(3, 6, False, 7).status == abi.OK and s.state().votes == 2
+    assert s.rv_reply(1, 6, True, 6).status == abi.DROPPED_STALE_ROLE               # fenced head
+    r = s.rv_reply(2, 6, True, 7)                                                   # votes 3 >= majority 3
+    assert (r.status, r.role, r.role_epoch, r.persist, r.emit) == (abi.OK, L, 8, True, abi.EMIT_NONE)
+    assert (r.p_term, r.p_vote, r.p_role) == (6, 0, L)
+    st = s.state()
+    assert (st.role, st.term, st.elected_epoch, st.elected_term, st.repl_prepared) == (L, 6, 7, 6, 0)
+    r = s.rv_reply(3, 6, True, 7)                                                   # Q13 late grant: Leader stays (Membership.java:96)
+    assert (r.status, r.role, r.role_changed) == (abi.OK, L, False)
+    r = s.rv_reply(4, 9, False, 7)                                                  # Q13 late higher term: step down, ballot = responder
+    assert (r.status, r.role, r.p_term, r.p_vote) == (abi.OK, F, 9, 4)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for, st.elected_epoch) == (F, 9, 4, 0)
+    assert s.rv_reply(3, 6, True, 7).status == abi.DROPPED_STALE_ROLE               # head aborted now
+
+
+def election_higher_term_reply(mk):
+    s = _sim(mk, cluster=5, role=C, term=6, voted_for=0, role_epoch=7)
+    r = s.rv_reply(2, 8, False, 7)                                                  # Candidate.java:124-126
+    assert (r.role, r.p_term, r.p_vote, r.role_epoch) == (F, 8, 2, 8)
+    assert s.state().elected_epoch == 0
+    assert s.rv_reply(1, 6, True, 7).status == abi.DROPPED_STALE_ROLE
+
+
+def prevote_round(mk):
+    s = _sim(mk, cluster=5, pre_vote=True, role=F, term=5, voted_for=3, leader=3, log=simple_log(10, 5))
+    r = s.on_timeout()                                                              # Follower.java:158-164
+    assert (r.status, r.role, r.role_epoch, r.emit, r.persist) == (abi.OK, F, 2, abi.EMIT_PREVOTE, True)
+    st = s.state()
+    assert (st.term, st.voted_for, st.leader, st.timeout_detected, st.votes) == (5, 3, NO, 1, 1)
+    assert s.pv_reply(1, 6, False, 2).status == abi.OK                              # result.term == nextTerm: not '>'
+    assert s.state().role_epoch == 2
+    assert s.pv_reply(1, 5, True, 2).role == F
+    r = s.pv_reply(2, 5, True, 2)                                                   # :265-266 -> Candidate(nextTerm)
+    assert (r.status, r.role, r.role_epoch, r.emit, r.p_term, r.p_vote) == (abi.OK, C, 3, abi.EMIT_REQVOTE, 6, 0)
+    st = s.state()
+    assert (st.role, st.term, st.voted_for, st.votes, st.timeout_detected) == (C, 6, 0, 1, 0)
+    assert s.pv_reply(4, 5, True, 2).status == abi.DROPPED_STALE_ROLE
+    s = _sim(mk, cluster=5, pre_vote=True, role=F, term=5, timeout_detected=1, role_epoch=2)
+    r = s.pv_reply(4, 7, False, 2)                                                  # :261-263 result.term > nextTerm
+    assert (r.role, r.p_term, r.p_vote, r.role_epoch) == (F, 7, 4, 3)
+    assert s.state().timeout_detected == 0
+
+
+def timeouts(mk):
+    s = _sim(mk, pre_vote=False, role=F, term=5, voted_for=1)
+    r = s.on_timeout()                                                              # Follower.java:166
+    assert (r.role, r.emit, r.p_term, r.p_vote, r.role_epoch) == (C, abi.EMIT_REQVOTE, 6, 0, 2)
+    r = s.on_timeout()                                                              # Candidate.java:83
+    assert (r.role, r.emit, r.p_term, r.role_epoch) == (C, abi.EMIT_REQVOTE, 7, 3)
+    assert s.state().votes == 1
+    s = _sim(mk, role=L, term=5, voted_for=0, epoch=(2, 1), log=(3, [(3, 4)], 10), role_epoch=4)
+    r = s.on_timeout()                                                              # Leader.java:120-126 -> prepareReplication :30-50
+    assert (r.status, r.role, r.emit, r.role_changed, r.reset_timer) == (abi.OK, L, abi.EMIT_HEARTBEAT, False, True)
+    st = s.state()
+    assert st.repl_prepared == 1 and st.peers == [(2, 11, 0, 0, 0)] * 2
+    s.load(role=L, term=5, voted_for=0, epoch=(2, 1), role_epoch=4, repl_prepared=1,
+           peers=[(2, 7, 5, 1, 0), (2, 3, 0, 0, 1)])
+    s.on_timeout()                                                                  # already prepared: untouched
+    assert s.state().peers == [(2, 7, 5, 1, 0), (2, 3, 0, 0, 1)]
+    s = _sim(mk, role=L, term=5, voted_for=0, epoch=(7, 2))                        # empty log -> epoch.index+1
+    s.on_timeout()
+    assert s.state().peers == [(7, 8, 0, 0, 0)] * 2
+
+
+# --------------------------------------------------------------------------------------------------
+# a3/a4: Leader ack path  Leader.java:174-188,218-280  Leadership.java:53-63,75-130
+
+def _leader(mk, cluster=3, log=(1, [(1, 4), (51, 5)], 100), peers=None, commit=0, epoch=(0, 0)):
+    peers = peers or [(0, 101, 0, 0, 0)] * (cluster - 1)
+    return _sim(mk, cluster=cluster, role=L, term=5, voted_for=0, role_epoch=3, repl_prepared=1,
+                log=log, peers=peers, commit=commit, epoch=epoch)
+
+
+def ack_commit_current_term(mk):
+    s = _leader(mk)
+    r = s.ae_ack(1, 5, True, 0, 100, 3)                       # F=2: sorted[1] = 100, term(100)==5 -> commit major
+    assert (r.status, r.commit_adv, r.commit) == (abi.OK, True, 100)
+    st = s.state()
+    assert st.peers[0] == (0, 101, 100, 0, 0) and st.commit == 100
+    s = _leader(mk, cluster=5)                                # F=4: major = sorted[4/2]
+    assert not s.ae_ack(1, 5, True, 0, 90, 3).commit_adv      # sorted [0,0,0,90] -> major 0
+    r = s.ae_ack(2, 5, True, 0, 80, 3)                        # sorted [0,0,80,90] -> major 80
+    assert (r.commit_adv, r.commit) == (True, 80)             # Leadership.java:121-126 table, N=5
+    r = s.ae_ack(3, 5, True, 0, 85, 3)                        # sorted [0,80,85,90] -> 85
+    assert (r.commit_adv, r.commit) == (True, 85)
+
+
+def ack_commit_old_term_uses_full(mk):                        # KAT-8 / Q6
+    s = _leader(mk, log=simple_log(100, 4))
+    r = s.ae_ack(1, 5, True, 0, 100, 3)                       # major=100, term 4 != 5 -> commit = full = 0 -> nothing
+    assert (r.status, r.commit_adv) == (abi.OK, False)
+    r = s.ae_ack(2, 5, True, 0, 60, 3)                        # full = 60: old-term entry commits once on ALL followers
+    assert (r.commit_adv, r.commit) == (True, 60)
+
+
+def ack_reject_backoff(mk):                                   # KAT-4
+    s = _leader(mk, peers=[(0, 100, 0, 0, 0), (0, 100, 0, 0, 0)])
+    for want_next, want_rej in ((99, 1), (97, 2), (95, 3)):   # step = round(ln(e+r)) = 1, 2, 2
+        r = s.ae_ack(1, 5, False, 0, 99, 3)
+        assert r.status == abi.OK
+        p = s.state().peers[0]
+        assert (p[1], p[3]) == (want_next, want_rej)
+    s.ae_ack(1, 5, True, 0, 94, 3)                            # success: rejection counter resets (Leadership.java:60-62)
+    assert s.state().peers[0] == (0, 95, 94, 0, 0)
+    s.ae_ack(1, 5, False, 0, 94, 3)                           # matchIndex != 0: only the counter moves (:103)
+    assert s.state().peers[0] == (0, 95, 94, 1, 0)
+
+
+def ack_backoff_floor_and_snapshot(mk):
+    s = _leader(mk, epoch=(90, 4), log=(91, [(91, 5)], 100), peers=[(90, 92, 0, 0, 0), (90, 101, 0, 0, 0)])
+    s.ae_ack(1, 5, False, 90, 91, 3)                          # next = max(92-1, 91) = 91
+    assert s.state().peers[0] == (90, 91, 0, 1, 0)
+    s.ae_ack(1, 5, False, 90, 90, 3)                          # next = max(91-2, 91) = 91 ; min(90, 91) = 90 <= epoch -> pending
+    assert s.state().peers[0] == (90, 90, 0, 2, 1)
+    s.ae_ack(1, 5, True, 90, 95, 3)                           # pendingInstallation != snapshot: ignored (:90), counter resets
+    assert s.state().peers[0] == (90, 90, 0, 0, 1)
+    r = s.is_ack(1, 5, False, 90, 3)                          # snapshot refused: stays pending
+    assert r.status == abi.OK and s.state().peers[0] == (90, 90, 0, 1, 1)
+    s.is_ack(1, 5, True, 90, 3)                               # :92-96 nextIndex = max(nextIndex, epoch+1)
+    assert s.state().peers[0] == (90, 91, 0, 0, 0)
+    r = s.is_ack(1, 5, True, 90, 3)                           # not pending any more: ignored
+    assert s.state().peers[0] == (90, 91, 0, 0, 0) and not r.commit_adv
+
+
+def ack_epoch_rules(mk):                                      # Q11
+    s = _leader(mk, epoch=(0, 0), log=(1, [(1, 5)], 200), peers=[(50, 101, 10, 0, 0), (0, 101, 0, 0, 0)])
+    s.ae_ack(1, 5, True, 40, 150, 3)                          # epoch < lastEpoch: ignored (:83)
+    assert s.state().peers[0] == (50, 101, 10, 0, 0)
+    s.ae_ack(1, 5, True, 120, 150, 3)                         # epoch > lastEpoch (:84-88) then success
+    assert s.state().peers[0] == (120, 151, 150, 0, 0)
+    r = s.ae_ack(1, 5, True, 120, 140, 3)                     # index < matchIndex: AbstractMethodError (:76-81)
+    assert r.status == abi.A_MATCH_ROLLBACK
+    assert s.state().peers[0] == (120, 151, 150, 0, 0)
+    r = s.ae_ack(1, 5, False, 120, 140, 3)                    # counter moved BEFORE the throw (Leader.java:229 precedes :230)
+    assert r.status == abi.A_MATCH_ROLLBACK and s.state().peers[0][3] == 1
+
+
+def ack_higher_term_steps_down(mk):                           # Q7
+    s = _leader(mk)
+    r = s.ae_ack(2, 8, False, 0, 100, 3)                      # Leader.java:224-226
+    assert (r.status, r.role, r.p_term, r.p_vote, r.role_epoch) == (abi.OK, F, 8, 2, 4)
+    assert s.ae_ack(1, 5, True, 0, 100, 3).status == abi.DROPPED_STALE_ROLE
+    s = _leader(mk)
+    assert s.is_ack(2, 8, True, 0, 3).role == F               # :178-180
+
+
+def ack_major_null_and_rollback(mk):
+    s = _leader(mk)
+    r = s.ae_ack(1, 5, True, 0, 200, 3)                       # log.get(200)==null -> NPE, caught (:256-257,277-279)
+    assert r.status == abi.NPE_MAJOR_NULL and not r.commit_adv
+    assert s.state().peers[0][2] == 200
+    s = _leader(mk, log=simple_log(100, 4), peers=[(0, 71, 70, 0, 0), (0, 101, 0, 0, 0)], commit=80)
+    r = s.ae_ack(2, 5, True, 0, 60, 3)                        # full=60 < lastCommitted 80 (Q6 + Q8)
+    assert r.status == abi.A_COMMIT_ROLLBACK and s.state().commit == 80
+    s = _leader(mk, peers=[(0, 101, 100, 0, 0), (0, 101, 100, 0, 0)], commit=100)
+    r = s.ae_ack(1, 5, True, 0, 100, 3)                       # commitIndex == lastCommitted: nothing (:262)
+    assert r.status == abi.OK and not r.commit_adv
+
+
+def ack_unprepared_or_wrong_role(mk):
+    s = _sim(mk, role=L, term=5, voted_for=0, role_epoch=3)   # nothing was ever sent under this epoch
+    assert s.ae_ack(1, 5, True, 0, 1, 3).status == abi.BAD_EVENT
+    s = _sim(mk, role=F, term=5, role_epoch=3)
+    assert s.ae_ack(1, 5, True, 0, 1, 3).status == abi.BAD_EVENT
+    assert s.ae_ack(0, 5, True, 0, 1, 3).status == abi.BAD_EVENT                    # responder == self
+
+
+# --------------------------------------------------------------------------------------------------
+# host-driven log changes the device must mirror
+
+def client_append(mk):
+    s = _sim(mk, role=L, term=5, voted_for=0, log=simple_log(10, 4))
+    r = s.client_append(2)                                    # RocksLog.newEntry :82-89; prepareReplication after the FIRST entry
+    assert (r.status, r.appended, r.log_from, r.emit) == (abi.OK, True, 11, abi.EMIT_HEARTBEAT)
+    st = s.state()
+    assert (st.last, st.runs, st.repl_prepared) == (12, [(1, 4), (11, 5)], 1)
+    assert st.peers == [(0, 12, 0, 0, 0)] * 2
+    s = _sim(mk, role=L, term=5, voted_for=0)
+    assert s.client_append(1).log_from == 1 and s.state().runs == [(1, 5)]
+    assert _sim(mk, role=F, term=5).client_append(1).status == abi.NOT_LEADER      # RaftStub.java:83-89
+    assert _sim(mk, role=L, term=5, voted_for=0, epoch=(7, 2)).client_append(1).status == abi.UNSUPPORTED_LOG_STATE
+
+
+def log_flush(mk):
+    s = _sim(mk, role=F, term=5, log=(1, [(1, 3), (6, 4)], 10), commit=8)
+    assert s.log_flush(5, 3).status == abi.OK                 # RocksLog.flush :228-242: key == index survives
+    st = s.state()
+    assert (st.epoch, st.first, st.last, st.runs) == ((5, 3), 5, 10, [(5, 3), (6, 4)])
+    assert s.log_flush(4, 3).status == abi.FLUSH_OUT_OF_BOUNDS
+    assert s.append_entries(5, 1, 5, 9, [], 0).status == abi.A_EPOCH_TERM_MISMATCH
+    s.log_flush(7, 4)
+    st = s.state()
+    assert (st.epoch, st.first, st.runs) == ((7, 4), 7, [(7, 4)])
+    s.log_flush(20, 6)                                        # beyond last: log emptied
+    st = s.state()
+    assert (st.epoch, st.runs, st.last) == ((20, 6), [], 0)
+    r = s.append_entries(6, 1, 20, 6, [6], 0)                 # first key after an install: epoch.index+1
+    assert r.success and r.log_from == 21 and s.state().first == 21
+
+
+def none_rows_do_nothing(mk):
+    s = _sim(mk, role=C, term=5, voted_for=0, role_epoch=9)
+    r = s.event(abi.EV_NONE)
+    assert (r.status, r.replied, r.role, r.role_epoch, r.flags & 0xFF) == (abi.OK, False, C, 9, 0)
+
+
+SCENARIOS = [v for k, v in sorted(globals().items())
+             if callable(v) and getattr(v, "__module__", None) == __name__ and not k.startswith("_")]

@@ -1,0 +1,111 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so) — TEST INFRASTRUCTURE ONLY.
+
+Nothing under rafting_amd/ may import this module; it exists so tests (and bench.py's cpu_baseline
+leg, and __graft_entry__.smoke) can check the HIP path against the restated reference logic.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rafting_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "raft_oracle.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            build()
+        L = C.CDLL(path)
+        L.orc_table_create.restype = C.c_void_p
+        L.orc_table_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_table_destroy.argtypes = [C.c_void_p]
+        L.orc_load_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
+        L.orc_read_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
+        L.orc_submit.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
+        L.orc_submit_threads.restype = C.c_double
+        L.orc_submit_threads.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), C.c_int]
+        L.orc_rejection_step.restype = C.c_int64
+        L.orc_rejection_step.argtypes = [C.c_int32]
+        L.orc_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_is_better.restype = C.c_int
+        L.orc_is_better.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int32]
+        _LIB = L
+    return _LIB
+
+
+class OracleTable:
+    """Same surface as rafting_amd.engine.Table, backed by the CPU oracle."""
+
+    def __init__(self, groups, cluster, self_slot=0, pre_vote=True):
+        self.groups, self.cluster, self.self_slot, self.pre_vote = groups, cluster, self_slot, pre_vote
+        self._h = lib().orc_table_create(groups, cluster, self_slot, int(pre_vote))
+        if not self._h:
+            raise ValueError("orc_table_create rejected the arguments")
+
+    def close(self):
+        if self._h:
+            lib().orc_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def load_state(self, state, first=0):
+        s = state.as_struct()
+        rc = lib().orc_load_state(self._h, first, state.count, C.byref(s))
+        if rc:
+            raise ValueError("orc_load_state failed: %d" % rc)
+
+    def read_state(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        st = abi.GroupState(count, self.cluster)
+        s = st.as_struct()
+        rc = lib().orc_read_state(self._h, first, count, C.byref(s))
+        if rc:
+            raise ValueError("orc_read_state failed: %d" % rc)
+        return st
+
+    def submit(self, batch, out=None, fill=0):
+        out = abi.Outcome(batch.rounds * batch.count, fill) if out is None else out
+        b, o = batch.as_struct(), out.as_struct()
+        rc = lib().orc_submit(self._h, C.byref(b), C.byref(o))
+        if rc:
+            raise ValueError("orc_submit failed: %d" % rc)
+        return out
+
+    def submit_threads(self, batch, threads, out=None):
+        out = abi.Outcome(batch.rounds * batch.count) if out is None else out
+        b, o = batch.as_struct(), out.as_struct()
+        secs = lib().orc_submit_threads(self._h, C.byref(b), C.byref(o), threads)
+        if secs < 0:
+            raise ValueError("orc_submit_threads failed")
+        return secs, out
+
+
+def rejection_step(r):
+    return int(lib().orc_rejection_step(int(r)))
+
+
+def major_indices(match):
+    m = np.ascontiguousarray(match, dtype=np.int64)
+    out = np.zeros(2, dtype=np.int64)
+    lib().orc_major_indices(m.ctypes.data, len(m), out.ctypes.data)
+    return int(out[0]), int(out[1])
+
+
+def is_better(new, cur):
+    """new/cur = (role, term, ballot). Returns True/False or the negative RG_A_* code."""
+    r = lib().orc_is_better(new[0], new[1], new[2], cur[0], cur[1], cur[2])
+    return r if r < 0 else bool(r)
