@@ -759,6 +759,18 @@ int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
     return 0;
 }
 
+int orc_log_term(const orc_table_t *t, uint32_t gid, int64_t index, int64_t *term)
+{
+    if (!t || gid >= t->groups) return 0;
+    return log_get(&t->g[gid].log, index, term);
+}
+
+int64_t orc_log_conflict(const orc_table_t *t, uint32_t gid, int64_t e0, uint32_t n, const int64_t *terms)
+{
+    if (!t || gid >= t->groups) return 0;
+    return log_conflict(&t->g[gid].log, e0, n, terms);
+}
+
 /* ---- threaded CPU baseline ------------------------------------------------------------------- */
 
 typedef struct {

@@ -46,6 +46,12 @@ int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
  * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */
 double orc_submit_threads(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int threads);
 
+/* The lossless log as the host's RaftLog would answer (tests use it to build NEED_HOST hints):
+ * RaftLog.get(index).term() -> returns 1 and *term when the key exists, 0 otherwise. */
+int     orc_log_term(const orc_table_t *t, uint32_t gid, int64_t index, int64_t *term);
+/* RaftLog.conflict over entries with indices e0..e0+n-1 -> conflicting index or 0 */
+int64_t orc_log_conflict(const orc_table_t *t, uint32_t gid, int64_t e0, uint32_t n, const int64_t *terms);
+
 /* exposed pieces for known-answer tests */
 int64_t orc_rejection_step(int32_t recent_rejection);                 /* Leadership.java:105 */
 void    orc_major_indices(const int64_t *match, int n, int64_t out[2]); /* Leadership.java:116-130 */

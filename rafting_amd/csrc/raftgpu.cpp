@@ -1,0 +1,513 @@
+// raftgpu.cpp — host side of libraftgpu.so: the C-ABI of include/raftgpu.h over the gfx950 kernels.
+//
+// Owns, per table: the HBM structure-of-structs state (rg_device.hpp DevTable), one HIP stream, grow-only
+// staging buffers for RG_MEM_HOST submissions, device decision counters and a pool of HIP event pairs for
+// kernel timing.  There is no CPU fallback: every entry point that needs the GPU fails with a HIP error
+// string when no device is present.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rg_device.hpp"
+
+namespace rg {
+hipError_t launch_step(const StepParams &p, int followers, bool sparse, hipStream_t s);
+hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
+}  // namespace rg
+
+using rg::DevTable;
+using rg::I64x2;
+
+struct Staging {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct rg_table {
+    int device = 0;
+    uint32_t G = 0, P = 0, self = 0, F = 0;
+    int pre_vote = 0;
+    hipStream_t stream = nullptr;
+    DevTable dt{};
+    unsigned long long *counters = nullptr;
+    Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    uint64_t t_launches = 0;
+    double t_total_ms = 0.0;
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(rg_table *t, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (t) t->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(t, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess) return fail((t), -2, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+static int bind(rg_table *t)
+{
+    HIP_TRY(t, hipSetDevice(t->device));
+    return 0;
+}
+
+static int reserve(rg_table *t, Staging &s, size_t bytes)
+{
+    if (bytes <= s.cap) return 0;
+    if (s.ptr) HIP_TRY(t, hipFree(s.ptr));
+    s.ptr = nullptr; s.cap = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIP_TRY(t, hipMalloc(&s.ptr, cap));
+    s.cap = cap;
+    return 0;
+}
+
+static int drain_timing(rg_table *t)
+{
+    if (t->ev_used == 0) return 0;
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    for (size_t i = 0; i < t->ev_used; i++) {
+        float ms = 0.f;
+        HIP_TRY(t, hipEventElapsedTime(&ms, t->ev_pool[i].first, t->ev_pool[i].second));
+        t->t_total_ms += ms;
+        t->t_launches += 1;
+    }
+    t->ev_used = 0;
+    return 0;
+}
+
+extern "C" {
+
+int rg_abi_version(void) { return RG_ABI_VERSION; }
+
+const char *rg_last_error(const rg_table_t *t) { return t ? t->err.c_str() : g_create_err.c_str(); }
+uint32_t rg_table_groups(const rg_table_t *t) { return t ? t->G : 0; }
+uint32_t rg_table_cluster(const rg_table_t *t) { return t ? t->P : 0; }
+
+int rg_table_destroy(rg_table_t *t)
+{
+    if (!t) return 0;
+    (void)hipSetDevice(t->device);
+    if (t->stream) (void)hipStreamSynchronize(t->stream);
+    void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
+                    t->dt.peer_en, t->dt.peer_m, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
+                    t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
+                    t->st_persist.ptr};
+    for (void *c : cols) if (c) (void)hipFree(c);
+    for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return 0;
+}
+
+int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self_slot, int pre_vote, rg_table_t **out)
+{
+    if (!out) return fail(nullptr, -1, "rg_table_create: out is NULL");
+    *out = nullptr;
+    if (groups == 0) return fail(nullptr, -1, "rg_table_create: groups must be > 0");
+    if (cluster < RG_MIN_CLUSTER || cluster > RG_MAX_CLUSTER)
+        return fail(nullptr, -1, "rg_table_create: cluster size %u outside [%d, %d]", cluster, RG_MIN_CLUSTER, RG_MAX_CLUSTER);
+    if (self_slot >= cluster) return fail(nullptr, -1, "rg_table_create: self_slot %u >= cluster %u", self_slot, cluster);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, -2, "rg_table_create: no HIP device (%s) — libraftgpu has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, -1, "rg_table_create: device %d of %d", device, ndev);
+
+    rg_table *t = new rg_table();
+    t->device = device; t->G = groups; t->P = cluster; t->self = self_slot; t->F = cluster - 1;
+    t->pre_vote = pre_vote != 0;
+#define CREATE_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e2_ = (expr);                                                           \
+        if (e2_ != hipSuccess) {                                                           \
+            fail(nullptr, -2, "%s failed: %s", #expr, hipGetErrorString(e2_));             \
+            rg_table_destroy(t);                                                           \
+            return -2;                                                                     \
+        }                                                                                  \
+    } while (0)
+    CREATE_TRY(hipSetDevice(device));
+    CREATE_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    const size_t G = groups, F = t->F;
+    CREATE_TRY(hipMalloc((void **)&t->dt.term_commit, G * sizeof(I64x2)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.epoch, G * sizeof(I64x2)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.window, G * sizeof(I64x2)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.ident, G * sizeof(rg::Ident)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.elect, G * sizeof(rg::Elect)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.runs, G * rg::K * sizeof(I64x2)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.peer_en, G * F * sizeof(I64x2)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.peer_m, G * F * sizeof(rg::Match)));
+    CREATE_TRY(hipMalloc((void **)&t->counters, RG_NUM_COUNTERS * sizeof(unsigned long long)));
+    t->dt.groups = groups;
+    CREATE_TRY(hipMemsetAsync(t->dt.term_commit, 0, G * sizeof(I64x2), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.epoch, 0, G * sizeof(I64x2), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.window, 0, G * sizeof(I64x2), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.runs, 0, G * rg::K * sizeof(I64x2), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.peer_en, 0, G * F * sizeof(I64x2), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.peer_m, 0, G * F * sizeof(rg::Match), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->counters, 0, RG_NUM_COUNTERS * sizeof(unsigned long long), t->stream));
+    {   // fresh groups = what RaftContext.initialize leaves: Follower, term 0, no vote, empty log
+        std::vector<rg::Ident> id(G, rg::Ident{RG_NO_NODE, RG_NO_NODE, 1u, 0u});
+        std::vector<rg::Elect> el(G, rg::Elect{0, 0u, 1});
+        CREATE_TRY(hipMemcpyAsync(t->dt.ident, id.data(), G * sizeof(rg::Ident), hipMemcpyHostToDevice, t->stream));
+        CREATE_TRY(hipMemcpyAsync(t->dt.elect, el.data(), G * sizeof(rg::Elect), hipMemcpyHostToDevice, t->stream));
+        CREATE_TRY(hipStreamSynchronize(t->stream));
+    }
+#undef CREATE_TRY
+    *out = t;
+    return 0;
+}
+
+/* ---- state ------------------------------------------------------------------------------------ */
+
+int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_state_t *s)
+{
+    if (!t) return -1;
+    if (!s) return fail(t, -1, "rg_load_state: src is NULL");
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_load_state: range [%u, %u) exceeds %u groups", first, first + count, t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    const size_t n = count, F = t->F, G = t->G;
+    std::vector<I64x2> tc(n), ep(n), win(n), runs(n * rg::K), en(n * F);
+    std::vector<rg::Ident> id(n);
+    std::vector<rg::Elect> el(n);
+    std::vector<rg::Match> pm(n * F);
+    for (size_t i = 0; i < n; i++) {
+        const int32_t role = s->role[i];
+        if (role < RG_FOLLOWER || role > RG_LEADER) return fail(t, -1, "rg_load_state: group %zu role %d", first + i, role);
+        if (s->voted_for[i] < RG_NO_NODE || s->voted_for[i] >= (int32_t)t->P || s->current_leader[i] < RG_NO_NODE ||
+            s->current_leader[i] >= (int32_t)t->P)
+            return fail(t, -1, "rg_load_state: group %zu node slot out of range", first + i);
+        const uint32_t total = s->run_count[i], off = s->run_offset[i];
+        const uint32_t rc = total > (uint32_t)rg::K ? (uint32_t)rg::K : total;
+        int64_t fi = 0, la = 0;
+        if (total) {
+            fi = s->first_index[i]; la = s->last_index[i];
+            if (s->run_start[off] != fi || la < s->run_start[off + total - 1])
+                return fail(t, -1, "rg_load_state: group %zu runs do not span [first,last]", first + i);
+            if (fi != s->epoch_index[i] && fi != s->epoch_index[i] + 1)
+                return fail(t, -1, "rg_load_state: group %zu first index %lld is neither epoch.index nor epoch.index+1",
+                            first + i, (long long)fi);
+            for (uint32_t k = 1; k < total; k++)
+                if (s->run_start[off + k] <= s->run_start[off + k - 1] || s->run_term[off + k] == s->run_term[off + k - 1])
+                    return fail(t, -1, "rg_load_state: group %zu runs are not maximal ascending runs", first + i);
+        }
+        tc[i] = I64x2{s->current_term[i], s->commit_index[i]};
+        ep[i] = I64x2{s->epoch_index[i], s->epoch_term[i]};
+        win[i] = I64x2{fi, la};
+        uint32_t pend = 0;
+        for (size_t j = 0; j < F; j++) {
+            en[j * n + i] = I64x2{s->peer_last_epoch[i * F + j], s->peer_next_index[i * F + j]};
+            pm[j * n + i] = rg::Match{s->peer_match_index[i * F + j], s->peer_rejection[i * F + j], 0};
+            if (s->peer_pending[i * F + j]) pend |= 1u << j;
+        }
+        for (uint32_t k = 0; k < (uint32_t)rg::K; k++) {
+            const bool have = k < rc;
+            runs[(size_t)k * n + i] = have ? I64x2{s->run_start[off + total - rc + k], s->run_term[off + total - rc + k]} : I64x2{0, 0};
+        }
+        const uint32_t meta = (uint32_t)role | (s->timeout_detected[i] ? rg::META_TD : 0u) |
+                              (s->repl_prepared[i] ? rg::META_PREP : 0u) | (rc << rg::META_RC_SHIFT) |
+                              (pend << rg::META_PEND_SHIFT);
+        id[i] = rg::Ident{s->voted_for[i], s->current_leader[i], s->role_epoch[i], meta};
+        el[i] = rg::Elect{s->elected_term[i], s->elected_epoch[i], s->votes[i]};
+    }
+    hipStream_t st = t->stream;
+    HIP_TRY(t, hipMemcpyAsync(t->dt.term_commit + first, tc.data(), n * sizeof(I64x2), hipMemcpyHostToDevice, st));
+    HIP_TRY(t, hipMemcpyAsync(t->dt.epoch + first, ep.data(), n * sizeof(I64x2), hipMemcpyHostToDevice, st));
+    HIP_TRY(t, hipMemcpyAsync(t->dt.window + first, win.data(), n * sizeof(I64x2), hipMemcpyHostToDevice, st));
+    HIP_TRY(t, hipMemcpyAsync(t->dt.ident + first, id.data(), n * sizeof(rg::Ident), hipMemcpyHostToDevice, st));
+    HIP_TRY(t, hipMemcpyAsync(t->dt.elect + first, el.data(), n * sizeof(rg::Elect), hipMemcpyHostToDevice, st));
+    for (size_t k = 0; k < (size_t)rg::K; k++)
+        HIP_TRY(t, hipMemcpyAsync(t->dt.runs + k * G + first, runs.data() + k * n, n * sizeof(I64x2), hipMemcpyHostToDevice, st));
+    for (size_t j = 0; j < F; j++) {
+        HIP_TRY(t, hipMemcpyAsync(t->dt.peer_en + j * G + first, en.data() + j * n, n * sizeof(I64x2), hipMemcpyHostToDevice, st));
+        HIP_TRY(t, hipMemcpyAsync(t->dt.peer_m + j * G + first, pm.data() + j * n, n * sizeof(rg::Match), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(t, hipStreamSynchronize(st));
+    return 0;
+}
+
+int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *d)
+{
+    if (!t) return -1;
+    if (!d) return fail(t, -1, "rg_read_state: dst is NULL");
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_read_state: range exceeds %u groups", t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    const size_t n = count, F = t->F, G = t->G;
+    std::vector<I64x2> tc(n), ep(n), win(n), runs(n * rg::K), en(n * F);
+    std::vector<rg::Ident> id(n);
+    std::vector<rg::Elect> el(n);
+    std::vector<rg::Match> pm(n * F);
+    hipStream_t st = t->stream;
+    HIP_TRY(t, hipMemcpyAsync(tc.data(), t->dt.term_commit + first, n * sizeof(I64x2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(t, hipMemcpyAsync(ep.data(), t->dt.epoch + first, n * sizeof(I64x2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(t, hipMemcpyAsync(win.data(), t->dt.window + first, n * sizeof(I64x2), hipMemcpyDeviceToHost, st));
+    HIP_TRY(t, hipMemcpyAsync(id.data(), t->dt.ident + first, n * sizeof(rg::Ident), hipMemcpyDeviceToHost, st));
+    HIP_TRY(t, hipMemcpyAsync(el.data(), t->dt.elect + first, n * sizeof(rg::Elect), hipMemcpyDeviceToHost, st));
+    for (size_t k = 0; k < (size_t)rg::K; k++)
+        HIP_TRY(t, hipMemcpyAsync(runs.data() + k * n, t->dt.runs + k * G + first, n * sizeof(I64x2), hipMemcpyDeviceToHost, st));
+    for (size_t j = 0; j < F; j++) {
+        HIP_TRY(t, hipMemcpyAsync(en.data() + j * n, t->dt.peer_en + j * G + first, n * sizeof(I64x2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(t, hipMemcpyAsync(pm.data() + j * n, t->dt.peer_m + j * G + first, n * sizeof(rg::Match), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(t, hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t meta = id[i].meta;
+        const uint32_t rc = (meta >> rg::META_RC_SHIFT) & 7u;
+        d->current_term[i] = tc[i].x; d->commit_index[i] = tc[i].y;
+        d->epoch_index[i] = ep[i].x; d->epoch_term[i] = ep[i].y;
+        d->first_index[i] = rc ? win[i].x : 0; d->last_index[i] = rc ? win[i].y : 0;
+        d->voted_for[i] = id[i].voted_for; d->current_leader[i] = id[i].leader; d->role_epoch[i] = id[i].role_epoch;
+        d->role[i] = (int32_t)(meta & rg::META_ROLE);
+        d->timeout_detected[i] = (meta & rg::META_TD) ? 1 : 0;
+        d->repl_prepared[i] = (meta & rg::META_PREP) ? 1 : 0;
+        d->elected_term[i] = el[i].elected_term; d->elected_epoch[i] = el[i].elected_epoch; d->votes[i] = el[i].votes;
+        d->run_count[i] = rc;
+        d->run_offset[i] = (uint32_t)(i * rg::K);
+        for (uint32_t k = 0; k < (uint32_t)rg::K; k++) {
+            d->run_start[i * rg::K + k] = k < rc ? runs[(size_t)k * n + i].x : 0;
+            d->run_term[i * rg::K + k] = k < rc ? runs[(size_t)k * n + i].y : 0;
+        }
+        const uint32_t pend = (meta >> rg::META_PEND_SHIFT) & 0x7Fu;
+        for (size_t j = 0; j < F; j++) {
+            d->peer_last_epoch[i * F + j] = en[j * n + i].x;
+            d->peer_next_index[i * F + j] = en[j * n + i].y;
+            d->peer_match_index[i * F + j] = pm[j * n + i].match_index;
+            d->peer_rejection[i * F + j] = pm[j * n + i].rejection;
+            d->peer_pending[i * F + j] = (pend >> j) & 1u;
+        }
+    }
+    return 0;
+}
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+
+static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (t->timing) {
+        if (t->ev_used == t->ev_pool.size()) {
+            if (t->ev_pool.size() >= 4096) {
+                if (drain_timing(t)) return -2;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(t, hipEventCreate(&a));
+                HIP_TRY(t, hipEventCreate(&b));
+                t->ev_pool.emplace_back(a, b);
+            }
+        }
+        e0 = t->ev_pool[t->ev_used].first; e1 = t->ev_pool[t->ev_used].second;
+        HIP_TRY(t, hipEventRecord(e0, t->stream));
+    }
+    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, t->stream));
+    if (t->timing) {
+        HIP_TRY(t, hipEventRecord(e1, t->stream));
+        t->ev_used += 1;
+    }
+    return 0;
+}
+
+int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace)
+{
+    if (!t) return -1;
+    if (!in || !out) return fail(t, -1, "rg_submit: NULL batch or outcome");
+    if (!in->head || !in->ab || !in->cd || !out->reply || !out->logfx || !out->persist)
+        return fail(t, -1, "rg_submit: head/ab/cd/reply/logfx/persist are required");
+    if (in->rounds == 0) return fail(t, -1, "rg_submit: rounds must be >= 1");
+    const bool sparse = in->gid != nullptr;
+    if (sparse) {
+        if (in->rounds != 1) return fail(t, -1, "rg_submit: sparse batches carry exactly one round");
+        if (in->count > t->G) return fail(t, -1, "rg_submit: %u rows for %u groups", in->count, t->G);
+    } else if (in->count != t->G) {
+        return fail(t, -1, "rg_submit: dense batch has %u rows per round, table has %u groups", in->count, t->G);
+    }
+    if (in->entry_count && !in->entry_terms) return fail(t, -1, "rg_submit: entry_count without entry_terms");
+    if (in->count == 0) return 0;
+    if (bind(t)) return -2;
+
+    const size_t rows = (size_t)in->rounds * in->count;
+    rg::StepParams p{};
+    p.t = t->dt;
+    p.rounds = in->rounds; p.count = in->count;
+    p.entry_count = in->entry_count;
+    p.counters = t->counters;
+    p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
+
+    if (memspace == RG_MEM_DEVICE) {
+        p.gid = in->gid; p.head = in->head;
+        p.ab = (const I64x2 *)in->ab; p.cd = (const I64x2 *)in->cd; p.hint = (const I64x2 *)in->hint;
+        p.entry_terms = in->entry_terms;
+        p.reply = out->reply; p.logfx = (I64x2 *)out->logfx; p.persist = out->persist;
+        return launch(t, p, sparse);
+    }
+    if (memspace != RG_MEM_HOST) return fail(t, -1, "rg_submit: unknown memspace %d", memspace);
+
+    if (sparse) {
+        for (uint32_t i = 0; i < in->count; i++) {
+            if (in->gid[i] >= t->G) return fail(t, -1, "rg_submit: gid[%u]=%u out of range", i, in->gid[i]);
+            if (i && in->gid[i] <= in->gid[i - 1]) return fail(t, -1, "rg_submit: gid must be strictly ascending (row %u)", i);
+        }
+    }
+    hipStream_t s = t->stream;
+    if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_ab, rows * sizeof(I64x2)) ||
+        reserve(t, t->st_cd, rows * sizeof(I64x2)) || reserve(t, t->st_reply, rows * sizeof(rg_reply_t)) ||
+        reserve(t, t->st_logfx, rows * sizeof(I64x2)) || reserve(t, t->st_persist, rows * sizeof(rg_persist_t)))
+        return -2;
+    HIP_TRY(t, hipMemcpyAsync(t->st_head.ptr, in->head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_ab.ptr, in->ab, rows * sizeof(I64x2), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_cd.ptr, in->cd, rows * sizeof(I64x2), hipMemcpyHostToDevice, s));
+    p.head = (const rg_ev_head_t *)t->st_head.ptr;
+    p.ab = (const I64x2 *)t->st_ab.ptr; p.cd = (const I64x2 *)t->st_cd.ptr;
+    if (sparse) {
+        if (reserve(t, t->st_gid, in->count * sizeof(uint32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_gid.ptr, in->gid, in->count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        p.gid = (const uint32_t *)t->st_gid.ptr;
+    }
+    if (in->hint) {
+        if (reserve(t, t->st_hint, rows * sizeof(I64x2))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_hint.ptr, in->hint, rows * sizeof(I64x2), hipMemcpyHostToDevice, s));
+        p.hint = (const I64x2 *)t->st_hint.ptr;
+    }
+    if (in->entry_count) {
+        if (reserve(t, t->st_terms, in->entry_count * sizeof(int64_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_terms.ptr, in->entry_terms, in->entry_count * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        p.entry_terms = (const int64_t *)t->st_terms.ptr;
+    }
+    p.reply = (rg_reply_t *)t->st_reply.ptr; p.logfx = (I64x2 *)t->st_logfx.ptr; p.persist = (rg_persist_t *)t->st_persist.ptr;
+    // conditional outputs keep whatever the caller had in rows the kernel does not write
+    HIP_TRY(t, hipMemcpyAsync(t->st_logfx.ptr, out->logfx, rows * sizeof(I64x2), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_persist.ptr, out->persist, rows * sizeof(rg_persist_t), hipMemcpyHostToDevice, s));
+    if (int rc = launch(t, p, sparse)) return rc;
+    HIP_TRY(t, hipMemcpyAsync(out->reply, t->st_reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(out->logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_sync(rg_table_t *t)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+/* ---- device memory helpers --------------------------------------------------------------------- */
+
+int rg_dev_alloc(rg_table_t *t, size_t bytes, void **dptr)
+{
+    if (!t || !dptr) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+
+int rg_dev_free(rg_table_t *t, void *dptr)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    HIP_TRY(t, hipFree(dptr));
+    return 0;
+}
+
+int rg_copy_to_device(rg_table_t *t, void *dst, const void *src, size_t bytes)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int rg_copy_to_host(rg_table_t *t, void *dst, const void *src, size_t bytes)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+void *rg_stream(rg_table_t *t) { return t ? (void *)t->stream : nullptr; }
+
+/* ---- measurement -------------------------------------------------------------------------------- */
+
+int rg_timing_enable(rg_table_t *t, int on)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    if (drain_timing(t)) return -2;
+    t->timing = on != 0;
+    return 0;
+}
+
+int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int reset)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    if (drain_timing(t)) return -2;
+    if (launches) *launches = t->t_launches;
+    if (total_ms) *total_ms = t->t_total_ms;
+    if (reset) { t->t_launches = 0; t->t_total_ms = 0.0; }
+    return 0;
+}
+
+int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int reset)
+{
+    if (!t || !counters) return -1;
+    if (bind(t)) return -2;
+    unsigned long long host[RG_NUM_COUNTERS];
+    HIP_TRY(t, hipMemcpyAsync(host, t->counters, sizeof host, hipMemcpyDeviceToHost, t->stream));
+    if (reset) HIP_TRY(t, hipMemsetAsync(t->counters, 0, sizeof host, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] = host[i];
+    return 0;
+}
+
+int rg_copy_bandwidth(rg_table_t *t, size_t bytes, int iters, double *gbps)
+{
+    if (!t || !gbps || iters < 1) return -1;
+    if (bind(t)) return -2;
+    bytes &= ~(size_t)15;
+    if (bytes == 0) return fail(t, -1, "rg_copy_bandwidth: bytes must be >= 16");
+    void *src = nullptr, *dst = nullptr;
+    HIP_TRY(t, hipMalloc(&src, bytes));
+    HIP_TRY(t, hipMalloc(&dst, bytes));
+    HIP_TRY(t, hipMemsetAsync(src, 1, bytes, t->stream));
+    hipEvent_t a, b;
+    HIP_TRY(t, hipEventCreate(&a));
+    HIP_TRY(t, hipEventCreate(&b));
+    HIP_TRY(t, rg::launch_copy(src, dst, bytes, t->stream));      /* warm-up */
+    HIP_TRY(t, hipEventRecord(a, t->stream));
+    for (int i = 0; i < iters; i++) HIP_TRY(t, rg::launch_copy(src, dst, bytes, t->stream));
+    HIP_TRY(t, hipEventRecord(b, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    float ms = 0.f;
+    HIP_TRY(t, hipEventElapsedTime(&ms, a, b));
+    *gbps = 2.0 * (double)bytes * iters / ((double)ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(src); (void)hipFree(dst);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,630 @@
+// rg_device.hpp — device-side decision logic of the batched multi-Raft engine (gfx950 / CDNA4).
+//
+// One LANE owns one raft group for the whole launch: the group's scalar state lives in VGPRs, its
+// per-follower replication state (Leadership.State) is staged in LDS as [follower][lane] columns so
+// the responder slot of an ack — a runtime value — indexes LDS instead of forcing the register file
+// through scratch.  Integer work only; no MFMA.
+//
+// What is decided here, and the reference code it stands in for (paths relative to
+// /root/reference/src/main/java/io/lubricant/consensus/raft/):
+//   switch_to            RaftRoutine.trySwitch/switchTo/convertTo  context/RaftRoutine.java:140-216
+//                        Membership.isBetter                       context/member/Membership.java:74-108
+//   on_append_entries    Follower/Candidate/Leader.appendEntries   member/Follower.java:35-88,177-221
+//                                                                  member/Candidate.java:28-41  member/Leader.java:67-86
+//   on_vote_request      requestVote/preVote of the three roles    member/Follower.java:91-127,193-207
+//                                                                  member/Candidate.java:44-72  member/Leader.java:89-111
+//   on_replicate_ack     Leader.replicateLog callbacks             member/Leader.java:174-188,218-237
+//                        State.updateIndex/majorIndices, tryCommit member/Leadership.java:53-63,75-130  member/Leader.java:247-280
+//   on_vote_reply        election / pre-election tallies           member/Candidate.java:121-134  member/Follower.java:258-270
+//   on_timeout           onTimeout of the three roles              member/Follower.java:156-168  member/Candidate.java:82-88  member/Leader.java:120-126
+//   log cache            RaftLog.get/last/conflict/truncate/append/flush/newEntry/markCommitted
+//                                                                  command/storage/RocksLog.java:82-128,169-242
+// The log itself stays with the host (RocksDB); the device keeps the newest RG_TERM_RUNS maximal
+// equal-term runs of it, which answers RaftLog.get(i).term() exactly for every index at or above the
+// oldest cached run.  A lookup below that is a cache miss: the row is left unapplied
+// (RG_NEED_HOST) unless the host attached the answer as a hint.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/raftgpu.h"
+
+namespace rg {
+
+constexpr int K = RG_TERM_RUNS;
+constexpr int BLOCK = 64;          // one wavefront per workgroup: lanes never share LDS columns, no barriers
+
+struct alignas(16) I64x2 { int64_t x, y; };
+struct alignas(16) Ident { int32_t voted_for, leader; uint32_t role_epoch, meta; };
+struct alignas(16) Elect { int64_t elected_term; uint32_t elected_epoch; int32_t votes; };
+struct alignas(16) Match { int64_t match_index; int32_t rejection; int32_t pad; };
+
+// meta word: role[1:0] timeoutDetected[2] replPrepared[3] runCount[6:4] pendingInstallation bit per follower [14:8]
+constexpr uint32_t META_ROLE = 3u, META_TD = 1u << 2, META_PREP = 1u << 3;
+constexpr int META_RC_SHIFT = 4, META_PEND_SHIFT = 8;
+
+// HBM layout of a table: structure of 16-byte structs, one column per struct kind, so every lane
+// moves 16 B per load/store and a wavefront touches 1 KiB of one column at a time.
+struct DevTable {
+    I64x2 *term_commit;   // [G] {currentTerm, commitIndex}
+    I64x2 *epoch;         // [G] {epoch.index, epoch.term}
+    I64x2 *window;        // [G] {firstIndex, lastIndex}
+    Ident *ident;         // [G]
+    Elect *elect;         // [G]
+    I64x2 *runs;          // [K][G] {start, term}
+    I64x2 *peer_en;       // [F][G] {lastEpoch, nextIndex}
+    Match *peer_m;        // [F][G]
+    uint32_t groups;
+};
+
+struct StepParams {
+    DevTable t;
+    uint32_t rounds, count;
+    const uint32_t *gid;            // sparse only
+    const rg_ev_head_t *head;
+    const I64x2 *ab, *cd, *hint;
+    const int64_t *entry_terms;
+    uint64_t entry_count;
+    rg_reply_t *reply;
+    I64x2 *logfx;
+    rg_persist_t *persist;
+    unsigned long long *counters;   // [RG_NUM_COUNTERS]
+    int32_t self, cluster, majority, pre_vote;
+};
+
+__device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+__device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+__device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
+
+// Math.round(Math.log(Math.E + r)) as integer thresholds (member/Leadership.java:105).
+__device__ __forceinline__ int64_t rejection_step(int32_t r)
+{
+    if (r < 0) return r == -1 ? 1 : 0;
+    int64_t s = 1;
+    s += r >= 2; s += r >= 10; s += r >= 31; s += r >= 88; s += r >= 242; s += r >= 663; s += r >= 1806;
+    s += r >= 4913; s += r >= 13358; s += r >= 36313; s += r >= 98714; s += r >= 268335; s += r >= 729414;
+    s += r >= 1982757; s += r >= 5389696; s += r >= 14650717; s += r >= 39824782; s += r >= 108254986;
+    s += r >= 294267564; s += r >= 799902175;
+    return s;
+}
+
+// effects of one row
+struct Fx {
+    uint32_t flags;
+    uint32_t status;
+    int64_t resp_term;
+    int64_t log_from;
+};
+
+template <int F>
+struct Peers {                       // LDS columns of this lane
+    int64_t *last_epoch, *next_index, *match_index;
+    int32_t *rejection;
+    static constexpr int STRIDE = BLOCK;
+};
+
+// Register image of one group.
+struct Group {
+    int64_t term, commit, epoch_index, epoch_term, first, last, elected_term;
+    int64_t rs[K], rt[K];            // cached runs, ascending; valid [0, rc)
+    int32_t voted_for, leader, votes, role, rc;
+    uint32_t role_epoch, elected_epoch, pending;
+    bool td, prepared, log_dirty, peers_dirty;
+
+    __device__ __forceinline__ bool has_log() const { return rc > 0; }
+    __device__ __forceinline__ bool present(int64_t i) const { return rc > 0 && i >= first && i <= last; }
+    __device__ __forceinline__ bool cached(int64_t i) const { return i >= rs[0]; }
+    __device__ __forceinline__ int64_t last_term() const
+    {
+        int64_t t = rt[0];
+#pragma unroll
+        for (int k = 1; k < K; k++) t = (k < rc) ? rt[k] : t;
+        return t;
+    }
+    // term of a PRESENT and CACHED index
+    __device__ __forceinline__ int64_t term_at(int64_t i) const
+    {
+        int64_t t = rt[0];
+#pragma unroll
+        for (int k = 1; k < K; k++) t = (k < rc && rs[k] <= i) ? rt[k] : t;
+        return t;
+    }
+    // db.put(last+1, t) — or the first key of an empty log
+    __device__ __forceinline__ void push(int64_t index, int64_t t)
+    {
+        if (rc == 0) {
+            first = index; rs[0] = index; rt[0] = t; rc = 1;
+        } else if (last_term() != t) {
+            if (rc == K) {           // cache full: forget the oldest run (lookups into it become misses)
+#pragma unroll
+                for (int k = 0; k + 1 < K; k++) { rs[k] = rs[k + 1]; rt[k] = rt[k + 1]; }
+                rc = K - 1;
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) if (k == rc) { rs[k] = index; rt[k] = t; }
+            rc += 1;
+        }
+        last = index;
+        log_dirty = true;
+    }
+    // RaftLog.truncate(index): storage/RocksLog.java:219-225. `keep_term` = term of index-1, used only when
+    // the cut lands below the cached runs (hint-resolved conflict) and the cache must be re-seeded.
+    __device__ __forceinline__ void truncate(int64_t index, int64_t keep_term)
+    {
+        if (rc == 0 || last < index) return;
+        log_dirty = true;
+        if (index <= first) { rc = 0; return; }
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) n += (k < rc && rs[k] < index) ? 1 : 0;
+        if (n == 0) { rs[0] = index - 1; rt[0] = keep_term; n = 1; }
+        rc = n;
+        last = index - 1;
+    }
+    // RaftLog.flush(index, term): storage/RocksLog.java:228-242
+    __device__ __forceinline__ uint32_t flush(int64_t index, int64_t term_)
+    {
+        if (index < epoch_index) return RG_FLUSH_OUT_OF_BOUNDS;
+        if (rc != 0) {
+            if (index > last) {
+                rc = 0; log_dirty = true;
+            } else if (index > first) {
+                int drop = 0;        // runs that end before `index`
+#pragma unroll
+                for (int k = 1; k < K; k++) drop += (k < rc && rs[k] <= index) ? 1 : 0;
+#pragma unroll
+                for (int s = 0; s < K - 1; s++) {
+                    if (s < drop) {
+#pragma unroll
+                        for (int k = 0; k + 1 < K; k++) { rs[k] = rs[k + 1]; rt[k] = rt[k + 1]; }
+                    }
+                }
+                rc -= drop;
+                if (rs[0] < index) rs[0] = index;
+                first = index;
+                log_dirty = true;
+            }
+        }
+        epoch_index = index;
+        epoch_term = term_;
+        return RG_OK;
+    }
+};
+
+template <int F>
+struct Stepper {
+    const StepParams &p;
+    Group &g;
+    Peers<F> pe;
+    Fx fx;
+
+    __device__ __forceinline__ Stepper(const StepParams &p_, Group &g_, const Peers<F> &pe_) : p(p_), g(g_), pe(pe_) {}
+
+    __device__ __forceinline__ void reply(int64_t term, bool success)
+    {
+        fx.resp_term = term;
+        fx.flags |= RG_F_REPLIED | (success ? RG_F_SUCCESS : 0u);
+    }
+
+    // returns 1 converted, 0 not better, -1 assertion
+    __device__ __forceinline__ int switch_to(int role, int64_t term, int32_t ballot)
+    {
+        bool better;
+        if (term != g.term) {
+            better = term > g.term;
+        } else if (role != g.role) {
+            if (role == RG_LEADER) {
+                if (g.role != RG_CANDIDATE) { fx.status = RG_A_LEADER_UNCHANGED; return -1; }
+                better = true;
+            } else {
+                better = role == RG_FOLLOWER;
+            }
+        } else if (role == RG_LEADER) {
+            better = false;
+        } else if (role == RG_FOLLOWER) {
+            better = true;
+        } else {
+            if (ballot != g.voted_for) { fx.status = RG_A_CAND_BALLOT; return -1; }
+            better = false;
+        }
+        if (!better) return 0;
+        g.role = role; g.term = term; g.voted_for = ballot;
+        g.role_epoch += 1u;
+        g.td = false; g.leader = RG_NO_NODE; g.votes = 1; g.prepared = false;
+        fx.flags |= RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER;
+        fx.flags &= ~RG_F_EMIT_MASK;
+        if (role == RG_CANDIDATE) fx.flags |= RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT;
+        return 1;
+    }
+
+    __device__ __forceinline__ void prepare_replication()
+    {
+        if (g.prepared) return;
+        const int64_t next = wadd(g.has_log() ? g.last : g.epoch_index, 1);
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            pe.last_epoch[j * BLOCK] = g.epoch_index;
+            pe.next_index[j * BLOCK] = next;
+            pe.match_index[j * BLOCK] = 0;
+            pe.rejection[j * BLOCK] = 0;
+        }
+        g.pending = 0;
+        g.prepared = true;
+        g.peers_dirty = true;
+    }
+
+    __device__ __forceinline__ uint32_t mark_committed(int64_t index)
+    {
+        if (index < g.commit) return RG_A_COMMIT_ROLLBACK;
+        if (index > g.commit) { g.commit = index; fx.flags |= RG_F_COMMIT; }
+        return RG_OK;
+    }
+
+    // ---- appendEntries --------------------------------------------------------------------------
+    __device__ __forceinline__ void on_append_entries(int64_t term, int32_t leader, int64_t prev_index,
+                                                      int64_t prev_term, uint32_t n, const int64_t *terms,
+                                                      int64_t leader_commit, bool hinted, int64_t hint_prev_term,
+                                                      int64_t hint_conflict)
+    {
+        // --- cache-miss pre-check, BEFORE any mutation, so a NEED_HOST row is a no-op -------------
+        bool use_hint = false;
+        if (term >= g.term && g.has_log()) {
+            int64_t need = INT64_MAX;
+            if (prev_index > g.epoch_index && prev_index <= g.last) need = prev_index;
+            if (n > 0) {
+                const int64_t scan = max64(wadd(prev_index, 1), wadd(g.epoch_index, 1));
+                const int64_t e_last = wadd(prev_index, (int64_t)n);
+                if (scan <= g.last && scan <= e_last) need = min64(need, scan);
+            }
+            if (need != INT64_MAX && !g.cached(need)) {
+                if (!hinted) { fx.status = RG_NEED_HOST; fx.log_from = need; return; }
+                use_hint = true;
+            }
+        }
+
+        if (g.role == RG_LEADER) {
+            if (leader == p.self) { fx.status = RG_A_LEADER_SELF_AE; return; }
+            if (term < g.term) { reply(g.term, false); return; }
+            if (term == g.term) { fx.status = RG_A_SAME_TERM_LEADER; return; }
+            if (switch_to(RG_FOLLOWER, g.term, g.voted_for) < 0) return;
+        } else if (g.role == RG_CANDIDATE) {
+            if (term < g.term) { reply(g.term, false); return; }
+            if (switch_to(RG_FOLLOWER, term, g.voted_for) < 0) return;
+        }
+        if (term < g.term) { reply(g.term, false); return; }
+        fx.flags |= RG_F_RESET_TIMER;
+        if (term > g.term || g.td) {
+            if (switch_to(RG_FOLLOWER, term, g.voted_for) < 0) return;
+        } else if (g.leader != RG_NO_NODE && leader != g.leader) {
+            fx.status = RG_A_TWO_LEADERS; return;
+        }
+        g.leader = leader;
+
+        // logContains
+        bool contains;
+        if (prev_index == 0 && prev_term == 0) {
+            contains = true;
+        } else if (prev_index == 0 || prev_term == 0) {
+            fx.status = RG_A_PREV_ZERO_MISMATCH; return;
+        } else if (prev_index <= g.epoch_index) {
+            if (prev_index == g.epoch_index && prev_term != g.epoch_term) { fx.status = RG_A_EPOCH_TERM_MISMATCH; return; }
+            contains = true;
+        } else if (!g.present(prev_index)) {
+            contains = false;
+        } else {
+            const int64_t t = g.cached(prev_index) ? g.term_at(prev_index) : hint_prev_term;
+            contains = t == prev_term;
+        }
+        if (!contains) { reply(g.term, false); return; }
+
+        // purgeEntries: entry k has index prev_index+1+k
+        int64_t e0 = wadd(prev_index, 1);
+        bool purged = false;
+        if (n > 0 && e0 <= g.epoch_index) {
+            const uint64_t skip = (uint64_t)(g.epoch_index - e0) + 1u;
+            purged = true;
+            if (skip >= n) { n = 0; } else { n -= (uint32_t)skip; terms += skip; e0 = wadd(e0, (int64_t)skip); }
+        }
+        if (n > 0) {
+            const int64_t e_last = wadd(e0, (int64_t)n - 1);
+            // RaftLog.conflict: walk the overlap with the stored keys
+            int64_t conflict = 0;
+            if (use_hint) {
+                conflict = hint_conflict;
+            } else if (g.has_log() && e0 <= g.last) {
+                const int64_t stop = min64(e_last, g.last);
+                for (int64_t idx = e0; idx <= stop; idx++) {
+                    if (g.term_at(idx) != terms[idx - e0]) { conflict = idx; break; }
+                }
+            }
+            if (conflict) {
+                // term of the key just below the cut; only needed when the cut empties the cached runs
+                // (hint-resolved conflict below the cache) while the log itself stays non-empty
+                int64_t keep = 0;
+                if (g.has_log() && conflict > g.first && conflict <= g.rs[0])
+                    keep = (conflict == e0) ? (purged ? g.epoch_term : prev_term) : terms[conflict - 1 - e0];
+                g.truncate(conflict, keep);
+                fx.flags |= RG_F_LOG_TRUNC;
+            }
+            // RaftLog.append: only keys above the greatest stored key <= entries[0].index are written
+            int64_t from;
+            if (!g.has_log()) {
+                if (e0 != wadd(g.epoch_index, 1)) { fx.status = RG_A_LOG_NOT_CONTINUOUS; return; }
+                from = e0;
+            } else {
+                if (g.last < wsub(e0, 1)) { fx.status = RG_A_LOG_NOT_CONTINUOUS; return; }
+                from = max64(e0, wadd(g.last, 1));
+            }
+            if (conflict || from <= e_last) {
+                fx.log_from = conflict ? conflict : from;
+                fx.flags |= RG_F_LOG_APPEND;
+            }
+            for (int64_t idx = from; idx <= e_last; idx++) g.push(idx, terms[idx - e0]);
+        }
+        if (leader_commit > g.epoch_index && g.has_log()) {
+            const uint32_t st = mark_committed(min64(leader_commit, g.last));
+            if (st) { fx.status = st; return; }
+        }
+        reply(term, true);
+    }
+
+    // ---- requestVote / preVote ------------------------------------------------------------------
+    // returns 1/0, -1 on assertion
+    __device__ __forceinline__ int log_up_to_date(int64_t index, int64_t term)
+    {
+        if (g.has_log()) {
+            const int64_t lt = g.last_term();
+            return (term > lt || (term == lt && index >= g.last)) ? 1 : 0;
+        }
+        if ((index > g.epoch_index && term < g.epoch_term) || (index == g.epoch_index && term != g.epoch_term)) {
+            fx.status = RG_A_IMPOSSIBLE_LOG;
+            return -1;
+        }
+        return index >= g.epoch_index ? 1 : 0;
+    }
+
+    __device__ __forceinline__ void on_vote_request(bool pre, int64_t term, int32_t cand, int64_t last_index,
+                                                    int64_t last_term)
+    {
+        if (g.role == RG_LEADER) {
+            if (pre) { reply(g.term, false); return; }
+            if (term < g.term) { reply(g.term, false); return; }
+            if (term == g.term) {
+                if (g.voted_for == p.self) { reply(g.term, false); return; }
+                fx.status = RG_A_LEADER_NOT_SELF_VOTE; return;
+            }
+            if (switch_to(RG_FOLLOWER, g.term, cand) < 0) return;
+            pre = false;
+        } else if (g.role == RG_CANDIDATE) {
+            if (cand == p.self) { fx.status = RG_A_CAND_SELF_RV; return; }
+            if (term < g.term) { reply(g.term, false); return; }
+            if (term == g.term) {
+                if (cand != g.voted_for) { reply(g.term, false); return; }
+                if (g.voted_for != p.self) { fx.status = RG_A_CAND_NOT_SELF_VOTE; return; }
+            }
+            if (switch_to(RG_FOLLOWER, term, cand) < 0) return;
+            pre = false;
+        }
+        if (pre) {
+            if (term <= g.term || !g.td) { reply(g.term, false); return; }
+            fx.flags |= RG_F_RESET_TIMER;
+            const int ok = log_up_to_date(last_index, last_term);
+            if (ok < 0) return;
+            reply(g.term, ok != 0);
+            return;
+        }
+        if (term < g.term) { reply(g.term, false); return; }
+        if (term == g.term) { reply(g.term, cand == g.voted_for); return; }
+        fx.flags |= RG_F_RESET_TIMER;
+        const int ok = log_up_to_date(last_index, last_term);
+        if (ok < 0) return;
+        if (switch_to(RG_FOLLOWER, term, ok ? cand : RG_NO_NODE) < 0) return;
+        reply(g.term, cand == g.voted_for);
+    }
+
+    // ---- Leader ack path ------------------------------------------------------------------------
+    __device__ __forceinline__ void on_replicate_ack(bool snapshot, uint32_t slot, int64_t resp_term, bool success,
+                                                     int64_t epoch_at_send, int64_t last_sent, uint32_t sent_epoch,
+                                                     bool hinted, int64_t hint_index, int64_t hint_term)
+    {
+        if (sent_epoch != g.role_epoch) { fx.status = RG_DROPPED_STALE_ROLE; return; }
+        if (g.role != RG_LEADER || !g.prepared) { fx.status = RG_BAD_EVENT; return; }
+        if (resp_term > g.term) { switch_to(RG_FOLLOWER, resp_term, (int32_t)slot); return; }
+        const int j = (int)(slot < (uint32_t)p.self ? slot : slot - 1u);
+
+        // work on a register copy of this follower's State; committed to LDS only if the row applies
+        int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
+        int32_t s_rej = pe.rejection[j * BLOCK];
+        bool s_pend = (g.pending >> j) & 1u;
+
+        s_rej = success ? 0 : (int32_t)((uint32_t)s_rej + 1u);          // statSuccess runs before updateIndex
+        const int64_t index = snapshot ? epoch_at_send : last_sent;
+        bool rollback = false, matched = false;
+        if (index < s_match) {
+            rollback = true;                                            // AbstractMethodError: only the counter moved
+        } else if (epoch_at_send >= s_epoch) {
+            if (epoch_at_send > s_epoch) { s_epoch = epoch_at_send; s_next = s_next > epoch_at_send ? s_next : epoch_at_send; }
+            if (s_pend == snapshot) {
+                if (s_pend) {
+                    if (success) { s_next = max64(s_next, wadd(epoch_at_send, 1)); s_pend = false; }
+                } else if (success) {
+                    if (index > s_match) { s_next = wadd(index, 1); s_match = index; matched = true; }
+                } else if (s_match == 0) {
+                    const int64_t next = max64(wsub(s_next, rejection_step(s_rej)), wadd(epoch_at_send, 1));
+                    s_next = min64(wsub(s_next, 1), next);
+                }
+                if (s_next <= epoch_at_send && !s_pend) s_pend = true;
+            }
+        }
+
+        // tryCommit on the would-be matchIndex vector
+        int64_t commit_to = 0;
+        uint32_t commit_status = RG_OK;
+        if (!rollback && !snapshot && success) {
+            int64_t m[F];
+#pragma unroll
+            for (int i = 0; i < F; i++) m[i] = (i == j) ? s_match : pe.match_index[i * BLOCK];
+            (void)matched;
+#pragma unroll
+            for (int a = 1; a < F; a++) {                               // insertion network, F <= 6
+#pragma unroll
+                for (int b = a; b > 0; b--) {
+                    const int64_t lo = min64(m[b - 1], m[b]), hi = max64(m[b - 1], m[b]);
+                    m[b - 1] = lo; m[b] = hi;
+                }
+            }
+            const int64_t full = m[0], major = m[F / 2];
+            if (major != 0) {
+                if (!g.present(major)) {
+                    commit_status = RG_NPE_MAJOR_NULL;
+                } else {
+                    int64_t mt;
+                    if (g.cached(major)) {
+                        mt = g.term_at(major);
+                    } else if (hinted && hint_index == major) {
+                        mt = hint_term;
+                    } else {
+                        fx.status = RG_NEED_HOST; fx.log_from = major; return;   // nothing was written yet
+                    }
+                    commit_to = (mt == g.term) ? major : full;
+                }
+            }
+        }
+
+        pe.rejection[j * BLOCK] = s_rej;
+        g.peers_dirty = true;
+        if (rollback) { fx.status = RG_A_MATCH_ROLLBACK; return; }
+        pe.last_epoch[j * BLOCK] = s_epoch;
+        pe.next_index[j * BLOCK] = s_next;
+        pe.match_index[j * BLOCK] = s_match;
+        g.pending = (g.pending & ~(1u << j)) | ((s_pend ? 1u : 0u) << j);
+        if (commit_status) { fx.status = commit_status; return; }
+        if (commit_to != 0 && commit_to != g.commit) {
+            const uint32_t st = mark_committed(commit_to);
+            if (st) fx.status = st;
+        }
+    }
+
+    // ---- tallies --------------------------------------------------------------------------------
+    __device__ __forceinline__ void on_vote_reply(bool pre, uint32_t slot, int64_t resp_term, bool granted,
+                                                  uint32_t sent_epoch)
+    {
+        if (sent_epoch == g.role_epoch) {
+            const bool sender_ok = pre ? (g.role == RG_FOLLOWER && g.td) : (g.role == RG_CANDIDATE);
+            if (!sender_ok) { fx.status = RG_BAD_EVENT; return; }
+            const int64_t T = pre ? wadd(g.term, 1) : g.term;
+            if (resp_term > T) {
+                switch_to(RG_FOLLOWER, resp_term, (int32_t)slot);
+            } else if (granted) {
+                g.votes += 1;
+                if (g.votes >= p.majority) {
+                    if (pre) {
+                        switch_to(RG_CANDIDATE, T, p.self);
+                    } else {
+                        g.elected_epoch = g.role_epoch;       // the winner's AsyncHead is never aborted (Candidate.java:75-79)
+                        g.elected_term = g.term;
+                        switch_to(RG_LEADER, T, p.self);
+                    }
+                }
+            }
+            return;
+        }
+        if (!pre && g.elected_epoch != 0u && sent_epoch == g.elected_epoch) {
+            const int64_t T = g.elected_term;
+            if (resp_term > T) {
+                g.elected_epoch = 0u;
+                switch_to(RG_FOLLOWER, resp_term, (int32_t)slot);
+            } else if (granted) {
+                switch_to(RG_LEADER, T, p.self);
+            }
+            return;
+        }
+        fx.status = RG_DROPPED_STALE_ROLE;
+    }
+
+    __device__ __forceinline__ void on_timeout()
+    {
+        if (g.role == RG_FOLLOWER) {
+            if (p.pre_vote) {
+                if (switch_to(RG_FOLLOWER, g.term, g.voted_for) < 0) return;
+                g.td = true; g.votes = 1;
+                fx.flags |= RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT;
+            } else {
+                switch_to(RG_CANDIDATE, wadd(g.term, 1), p.self);
+            }
+        } else if (g.role == RG_CANDIDATE) {
+            switch_to(RG_CANDIDATE, wadd(g.term, 1), p.self);
+        } else {
+            fx.flags |= RG_F_RESET_TIMER;
+            prepare_replication();
+            fx.flags |= RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT;
+        }
+    }
+
+    __device__ __forceinline__ void on_client_append(uint32_t n)
+    {
+        if (g.role != RG_LEADER) { fx.status = RG_NOT_LEADER; return; }
+        if (n == 0) return;
+        if (!g.has_log() && g.epoch_index > 0) { fx.status = RG_UNSUPPORTED_LOG_STATE; return; }
+        // n x RaftLog.newEntry(currentTerm); replicateLog(false) after each, so prepareReplication sees exactly one new entry
+        const int64_t first_new = g.has_log() ? wadd(g.last, 1) : 1;
+        fx.log_from = first_new;
+        g.push(first_new, g.term);
+        prepare_replication();
+        if (n > 1) { g.last = wadd(g.last, (int64_t)n - 1); }
+        fx.flags |= RG_F_LOG_APPEND | (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT);
+    }
+
+    // ---- one row --------------------------------------------------------------------------------
+    __device__ __forceinline__ void run(uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
+                                        int64_t hx, int64_t hy)
+    {
+        fx = Fx{0u, RG_OK, 0, 0};
+        const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+        const bool flag = RG_HDR_FLAG(hdr) != 0, hinted = RG_HDR_HINT(hdr) != 0;
+        const uint32_t P = (uint32_t)p.cluster;
+        switch (kind) {
+        case RG_EV_NONE:
+            break;
+        case RG_EV_AE_REQ:
+            if (slot >= P || (n > 0 && (p.entry_terms == nullptr || (uint64_t)aux + n > p.entry_count))) {
+                fx.status = RG_BAD_EVENT; break;
+            }
+            on_append_entries(a, (int32_t)slot, b, c, n, p.entry_terms + aux, d, hinted, hx, hy);
+            break;
+        case RG_EV_AE_ACK:
+        case RG_EV_IS_ACK:
+            if (slot >= P || slot == (uint32_t)p.self) { fx.status = RG_BAD_EVENT; break; }
+            on_replicate_ack(kind == RG_EV_IS_ACK, slot, a, flag, b, c, aux, hinted, hx, hy);
+            break;
+        case RG_EV_RV_REQ:
+        case RG_EV_PV_REQ:
+            if (slot >= P) { fx.status = RG_BAD_EVENT; break; }
+            on_vote_request(kind == RG_EV_PV_REQ, a, (int32_t)slot, b, c);
+            break;
+        case RG_EV_RV_REPLY:
+        case RG_EV_PV_REPLY:
+            if (slot >= P || slot == (uint32_t)p.self) { fx.status = RG_BAD_EVENT; break; }
+            on_vote_reply(kind == RG_EV_PV_REPLY, slot, a, flag, aux);
+            break;
+        case RG_EV_TIMEOUT:
+            on_timeout();
+            break;
+        case RG_EV_CLIENT_APPEND:
+            on_client_append(n);
+            break;
+        case RG_EV_LOG_FLUSH: {
+            const uint32_t st = g.flush(a, b);
+            if (st) fx.status = st;
+            break;
+        }
+        default:
+            fx.status = RG_BAD_EVENT;
+            break;
+        }
+    }
+};
+
+}  // namespace rg

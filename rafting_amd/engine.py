@@ -1,0 +1,212 @@
+"""ctypes binding of rafting_amd/libraftgpu.so (include/raftgpu.h) — the product path.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, construction
+raises.  The library is loaded by absolute path from inside the package so the GPU-side tooling can
+see that the in-tree native code is what ran.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libraftgpu.so")
+_LIB = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Every entry point include/raftgpu.h declares."""
+    return [
+        "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_dev_alloc",
+        "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_timing_enable",
+        "rg_timing_read", "rg_counters_read", "rg_copy_bandwidth",
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise EngineError(
+                "%s is missing — build it with `make -C rafting_amd/csrc` (or __graft_entry__.build()); "
+                "there is no CPU fallback for the decision path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+        L.rg_abi_version.restype = i32
+        L.rg_table_create.argtypes = [i32, u32, u32, u32, i32, C.POINTER(vp)]
+        L.rg_table_destroy.argtypes = [vp]
+        L.rg_last_error.restype = C.c_char_p
+        L.rg_last_error.argtypes = [vp]
+        L.rg_table_groups.restype = u32
+        L.rg_table_groups.argtypes = [vp]
+        L.rg_table_cluster.restype = u32
+        L.rg_table_cluster.argtypes = [vp]
+        L.rg_load_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
+        L.rg_read_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
+        L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
+        L.rg_sync.argtypes = [vp]
+        L.rg_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.rg_dev_free.argtypes = [vp, vp]
+        L.rg_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
+        L.rg_copy_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+        L.rg_stream.restype = vp
+        L.rg_stream.argtypes = [vp]
+        L.rg_timing_enable.argtypes = [vp, i32]
+        L.rg_timing_read.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
+        L.rg_counters_read.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+        L.rg_copy_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
+        if L.rg_abi_version() != abi.ABI_VERSION:
+            raise EngineError("libraftgpu.so ABI %d != binding ABI %d" % (L.rg_abi_version(), abi.ABI_VERSION))
+        _LIB = L
+    return _LIB
+
+
+class DeviceBuffer:
+    """A block of HBM owned through rg_dev_alloc."""
+
+    def __init__(self, table, nbytes):
+        self.table, self.nbytes = table, nbytes
+        p = C.c_void_p()
+        table._check(lib().rg_dev_alloc(table._h, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, table, array):
+        a = np.ascontiguousarray(array)
+        buf = cls(table, max(a.nbytes, 16))
+        if a.nbytes:
+            table._check(lib().rg_copy_to_device(table._h, buf.ptr, a.ctypes.data, a.nbytes))
+        return buf
+
+    def to_host(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.table._check(lib().rg_copy_to_host(self.table._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().rg_dev_free(self.table._h, self.ptr)
+            self.ptr = None
+
+
+class DeviceBatch:
+    """An rg_batch_t + rg_outcome_t resident in HBM (RG_MEM_DEVICE): built once, submitted many times."""
+
+    def __init__(self, table, batch):
+        self.table, self.rounds, self.count = table, batch.rounds, batch.count
+        rows = batch.rounds * batch.count
+        self.rows = rows
+        mk = lambda a: DeviceBuffer.from_host(table, a)   # noqa: E731
+        self.gid = None if batch.gid is None else mk(batch.gid)
+        self.head, self.ab, self.cd = mk(batch.head), mk(batch.ab), mk(batch.cd)
+        self.entry_count = batch.entry_count
+        self.entry_terms = mk(batch.entry_terms[: batch.entry_count]) if batch.entry_count else None
+        self.hint = None if batch.hint is None else mk(batch.hint)
+        self.reply = DeviceBuffer(table, rows * abi.REPLY_DT.itemsize)
+        self.logfx = DeviceBuffer(table, rows * abi.LOGFX_DT.itemsize)
+        self.persist = DeviceBuffer(table, rows * abi.PERSIST_DT.itemsize)
+        b = abi.CBatch()
+        b.rounds, b.count = batch.rounds, batch.count
+        b.gid = self.gid.ptr if self.gid else None
+        b.head, b.ab, b.cd = self.head.ptr, self.ab.ptr, self.cd.ptr
+        b.entry_terms = self.entry_terms.ptr if self.entry_terms else None
+        b.entry_count = self.entry_count
+        b.hint = self.hint.ptr if self.hint else None
+        o = abi.COutcome()
+        o.reply, o.logfx, o.persist = self.reply.ptr, self.logfx.ptr, self.persist.ptr
+        self.c_batch, self.c_out = b, o
+
+    def outcome(self, fill_from=None):
+        out = abi.Outcome(self.rows)
+        out.reply = self.reply.to_host(abi.REPLY_DT, self.rows)
+        out.logfx = self.logfx.to_host(abi.LOGFX_DT, self.rows)
+        out.persist = self.persist.to_host(abi.PERSIST_DT, self.rows)
+        return out
+
+    def free(self):
+        for b in (self.gid, self.head, self.ab, self.cd, self.entry_terms, self.hint, self.reply, self.logfx, self.persist):
+            if b is not None:
+                b.free()
+
+
+class Table:
+    """G raft groups resident on one MI355X. Mirrors ContextManager for the decision path: the host
+    keeps RaftLog / StableLock / timers / Netty, this object answers what every RaftParticipant would
+    have decided."""
+
+    def __init__(self, groups, cluster, self_slot=0, pre_vote=True, device=0):
+        self.groups, self.cluster, self.self_slot, self.pre_vote, self.device = groups, cluster, self_slot, pre_vote, device
+        h = C.c_void_p()
+        rc = lib().rg_table_create(device, groups, cluster, self_slot, int(pre_vote), C.byref(h))
+        if rc:
+            raise EngineError("rg_table_create: %s" % lib().rg_last_error(None).decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc:
+            raise EngineError("libraftgpu rc=%d: %s" % (rc, lib().rg_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rg_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # state ---------------------------------------------------------------------------------------
+    def load_state(self, state, first=0):
+        s = state.as_struct()
+        self._check(lib().rg_load_state(self._h, first, state.count, C.byref(s)))
+
+    def read_state(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        st = abi.GroupState(count, self.cluster)
+        s = st.as_struct()
+        self._check(lib().rg_read_state(self._h, first, count, C.byref(s)))
+        return st
+
+    # hot path ------------------------------------------------------------------------------------
+    def submit(self, batch, out=None, fill=0):
+        """Host-buffer submission (RG_MEM_HOST): staged over PCIe, synchronous."""
+        out = abi.Outcome(batch.rounds * batch.count, fill) if out is None else out
+        b, o = batch.as_struct(), out.as_struct()
+        self._check(lib().rg_submit(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
+        return out
+
+    def submit_device(self, dbatch):
+        """HBM-resident submission (RG_MEM_DEVICE): asynchronous on the table's stream."""
+        self._check(lib().rg_submit(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
+
+    def sync(self):
+        self._check(lib().rg_sync(self._h))
+
+    # measurement ---------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._check(lib().rg_timing_enable(self._h, int(on)))
+
+    def timing_read(self, reset=True):
+        n, ms = C.c_uint64(), C.c_double()
+        self._check(lib().rg_timing_read(self._h, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value
+
+    def counters(self, reset=False):
+        arr = (C.c_uint64 * abi.NUM_COUNTERS)()
+        self._check(lib().rg_counters_read(self._h, arr, int(reset)))
+        return list(arr)
+
+    def copy_bandwidth(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        self._check(lib().rg_copy_bandwidth(self._h, nbytes, iters, C.byref(g)))
+        return g.value

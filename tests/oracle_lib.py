@@ -39,6 +39,10 @@ def lib():
         L.orc_rejection_step.restype = C.c_int64
         L.orc_rejection_step.argtypes = [C.c_int32]
         L.orc_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_log_term.restype = C.c_int
+        L.orc_log_term.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(C.c_int64)]
+        L.orc_log_conflict.restype = C.c_int64
+        L.orc_log_conflict.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32, C.c_void_p]
         L.orc_is_better.restype = C.c_int
         L.orc_is_better.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int32]
         _LIB = L
@@ -84,6 +88,15 @@ class OracleTable:
         if rc:
             raise ValueError("orc_submit failed: %d" % rc)
         return out
+
+    def log_term(self, gid, index):
+        """RaftLog.get(index).term() of the lossless log, None when the key does not exist."""
+        t = C.c_int64()
+        return int(t.value) if lib().orc_log_term(self._h, gid, index, C.byref(t)) else None
+
+    def log_conflict(self, gid, e0, terms):
+        a = np.ascontiguousarray(terms, dtype=np.int64)
+        return int(lib().orc_log_conflict(self._h, gid, e0, len(a), a.ctypes.data))
 
     def submit_threads(self, batch, threads, out=None):
         out = abi.Outcome(batch.rounds * batch.count) if out is None else out

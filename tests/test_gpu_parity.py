@@ -1,0 +1,207 @@
+"""Parity of the HIP decision path (through the C-ABI, libraftgpu.so) against the CPU oracle.
+Everything here needs a real MI355X: run with `pytest -m gpu`.
+
+Bar: bit-exact — every reply row, every conditional effect row that is flagged valid, and the final
+state of every group (term, votedFor, role, commitIndex, matchIndex[], log tail ...)."""
+import numpy as np
+import pytest
+
+from rafting_amd import abi, engine
+from tests import fuzz, kat_scenarios, oracle_lib
+from tests.helpers import compare_outcomes, compare_states
+
+pytestmark = pytest.mark.gpu
+
+
+def mk_gpu(groups, cluster, self_slot, pre_vote):
+    return engine.Table(groups, cluster, self_slot, pre_vote)
+
+
+@pytest.mark.parametrize("scenario", kat_scenarios.SCENARIOS, ids=lambda f: f.__name__)
+def test_kat_on_gpu(scenario):
+    """The same hand-derived known answers that pin the oracle, asked of the HIP path."""
+    scenario(mk_gpu)
+
+
+def _subset(b, rows, gids):
+    """sparse single-round batch holding `rows` of dense batch b"""
+    s = abi.Batch(1, len(rows), gid=gids, hints=True)
+    for k, row in enumerate(rows):
+        hdr, aux = int(b.head["hdr"][row]), int(b.head["aux"][row])
+        n = hdr >> 12
+        ents = None
+        if (hdr & 0xF) == abi.EV_AE_REQ and n:
+            ents = b.entry_terms[aux:aux + n]
+        s.put(0, k, hdr & 0xF, slot=(hdr >> 4) & 0xF, flag=(hdr >> 8) & 1, a=int(b.ab["x"][row]), b=int(b.ab["y"][row]),
+              c=int(b.cd["x"][row]), d=int(b.cd["y"][row]), aux=aux, entries=ents, n=n)
+    return s
+
+
+def _resolve_need_host(gpu, orc, b, out, state_before):
+    """The host half of the NEED_HOST protocol: look the missing terms up in the host's log (the oracle's
+    lossless log stands in for RocksLog here) and resubmit those rows, sparse, with hints."""
+    rows = np.flatnonzero(out.status == abi.NEED_HOST)
+    if len(rows) == 0:
+        return 0
+    gids = rows.astype(np.uint32)
+    s = _subset(b, rows, gids)
+    for k, row in enumerate(rows):
+        g = int(row)
+        kind = int(b.head["hdr"][row]) & 0xF
+        if kind == abi.EV_AE_REQ:
+            prev = int(b.ab["y"][row])
+            n = int(b.head["hdr"][row]) >> 12
+            aux = int(b.head["aux"][row])
+            terms = b.entry_terms[aux:aux + n]
+            eidx = int(state_before.epoch_index[g])
+            e0 = prev + 1
+            if n and e0 <= eidx:
+                skip = min(n, eidx - e0 + 1)
+                terms, e0 = terms[skip:], e0 + skip
+            pt = orc.log_term(g, prev)
+            s.set_hint(k, -1 if pt is None else pt, orc.log_conflict(g, e0, terms) if len(terms) else 0)
+        else:
+            idx = int(out.logfx["log_from"][row])
+            t = orc.log_term(g, idx)
+            s.set_hint(k, idx, -1 if t is None else t)
+    o2 = gpu.submit(s, fill=0xAB)
+    assert not np.any(o2.status == abi.NEED_HOST), "hinted rows must apply"
+    out.reply[rows], out.logfx[rows], out.persist[rows] = o2.reply, o2.logfx, o2.persist
+    return len(rows)
+
+
+def _lockstep(groups, cluster, self_slot, pre_vote, rounds, seed, allow_miss):
+    st0 = fuzz.random_initial_state(groups, cluster, self_slot, seed)
+    gpu = engine.Table(groups, cluster, self_slot, pre_vote)
+    orc = oracle_lib.OracleTable(groups, cluster, self_slot, pre_vote)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    fz = fuzz.Fuzzer(groups, cluster, self_slot, seed, allow_miss=allow_miss)
+    batches, outs, hist, misses = [], [], np.zeros(256, dtype=np.int64), 0
+    for r in range(rounds):
+        cur = gpu.read_state()
+        b = abi.Batch(1, groups)
+        fz.round(cur, b, 0)
+        og = gpu.submit(b, fill=0xAB)
+        misses += _resolve_need_host(gpu, orc, b, og, cur)
+        oo = orc.submit(b, fill=0xAB)
+        compare_outcomes(oo, og, "round %d" % r)
+        hist += np.bincount(oo.status, minlength=256)
+        batches.append(b)
+        outs.append(oo)
+    compare_states(orc.read_state(), gpu.read_state(), "final")
+    return st0, batches, outs, hist, misses, gpu
+
+
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (5, 4, False, 13),
+                                                             (2, 1, True, 14), (4, 0, False, 15), (7, 3, True, 16),
+                                                             (6, 5, True, 17)])
+def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
+    """Round-by-round differential replay; cache misses are resolved through the hint protocol."""
+    _, _, _, hist, misses, gpu = _lockstep(384, cluster, self_slot, pre_vote, 120, seed, allow_miss=True)
+    seen = set(np.flatnonzero(hist).tolist())
+    assert {abi.OK, abi.A_COMMIT_ROLLBACK, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER} <= seen
+    c = gpu.counters()
+    assert c[0] > 0 and c[1] > 0 and c[2] > 0
+
+
+def test_fuzz_multi_round_launch():
+    """The same replay as ONE multi-round launch on HBM-resident buffers must equal the row-by-row result."""
+    G, P = 1024, 5
+    st0, batches, outs, _, misses, _ = _lockstep(G, P, 1, True, 64, 21, allow_miss=False)
+    assert misses == 0
+    big = fuzz.concat_batches(batches)
+    ref = fuzz.concat_outcomes(outs)
+    gpu = engine.Table(G, P, 1, True)
+    gpu.load_state(st0)
+    db = engine.DeviceBatch(gpu, big)
+    gpu.timing_enable(True)
+    gpu.submit_device(db)
+    gpu.sync()
+    n, ms = gpu.timing_read()
+    assert n == 1 and ms > 0
+    compare_outcomes(ref, db.outcome(), "multi-round")
+    orc = oracle_lib.OracleTable(G, P, 1, True)
+    orc.load_state(st0)
+    orc.submit(big)
+    compare_states(orc.read_state(), gpu.read_state(), "multi-round final")
+    c = gpu.counters()
+    kinds = big.head["hdr"] & 0xF
+    assert c[0] == int(np.count_nonzero(kinds))
+    assert c[1] == int(np.count_nonzero(ref.reply["flags"] & abi.F_REPLIED))
+    assert c[2] == int(np.count_nonzero(ref.reply["flags"] & abi.F_ROLE_CHANGED))
+    assert c[3] == int(np.count_nonzero(ref.reply["flags"] & abi.F_COMMIT))
+    db.free()
+
+
+def test_need_host_blocks_later_rounds():
+    """A cache miss inside a multi-round launch leaves the row unapplied and skips the group's later rows."""
+    gpu = engine.Table(2, 3, 0, True)
+    st = abi.GroupState(2, 3, runs_total=12)
+    for g in range(2):
+        st.role[g], st.current_term[g] = abi.FOLLOWER, 9
+        st.run_count[g], st.run_offset[g] = 6, 6 * g
+        st.first_index[g], st.last_index[g] = 1, 60
+        for k in range(6):
+            st.run_start[6 * g + k], st.run_term[6 * g + k] = 1 + 10 * k, 1 + k
+    gpu.load_state(st)
+    got = gpu.read_state()
+    assert list(got.run_count) == [4, 4] and int(got.run_start[0]) == 21      # newest 4 runs cached
+    b = abi.Batch(3, 2)
+    b.put(0, 0, abi.EV_AE_REQ, slot=1, a=9, b=15, c=2, d=0)                   # prev in a forgotten run -> miss
+    b.put(1, 0, abi.EV_AE_REQ, slot=1, a=9, b=60, c=6, d=0)
+    b.put(0, 1, abi.EV_AE_REQ, slot=1, a=9, b=25, c=3, d=0)                   # cached: fine
+    b.put(2, 1, abi.EV_AE_REQ, slot=1, a=9, b=60, c=6, d=30)
+    out = gpu.submit(b)
+    stt = out.status.reshape(3, 2)
+    assert stt[0, 0] == abi.NEED_HOST and int(out.logfx["log_from"][0]) == 15
+    assert stt[1, 0] == abi.SKIPPED_AFTER_NEED_HOST and stt[2, 0] == abi.OK   # NONE rows stay OK
+    assert stt[0, 1] == abi.OK and stt[2, 1] == abi.OK and out.success[1] and out.success[5]
+    after = gpu.read_state()
+    assert int(after.current_leader[0]) == abi.NO_NODE and int(after.commit_index[1]) == 30
+    # host answers: term(15) == 2 -> the row applies
+    s = abi.Batch(1, 1, gid=[0], hints=True)
+    row = s.put(0, 0, abi.EV_AE_REQ, slot=1, a=9, b=15, c=2, d=0)
+    s.set_hint(row, 2, 0)
+    o2 = gpu.submit(s)
+    assert o2.status[0] == abi.OK and o2.success[0]
+    assert int(gpu.read_state().current_leader[0]) == 1
+
+
+def test_sparse_rows_only_touch_their_groups():
+    G, P = 300, 3
+    st0 = fuzz.random_initial_state(G, P, 0, 5)
+    gpu, orc = engine.Table(G, P), oracle_lib.OracleTable(G, P)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    gids = np.array([0, 7, 63, 64, 65, 128, 299], dtype=np.uint32)
+    b = abi.Batch(1, len(gids), gid=gids)
+    for k in range(len(gids)):
+        b.put(0, k, abi.EV_TIMEOUT)
+    compare_outcomes(orc.submit(b, fill=0xAB), gpu.submit(b, fill=0xAB), "sparse")
+    compare_states(orc.read_state(), gpu.read_state(), "sparse final")
+    with pytest.raises(engine.EngineError):
+        bad = abi.Batch(1, 2, gid=np.array([5, 5], dtype=np.uint32))
+        gpu.submit(bad)
+
+
+def test_api_misuse_is_reported():
+    gpu = engine.Table(8, 3)
+    with pytest.raises(engine.EngineError):
+        gpu.submit(abi.Batch(1, 7))                                         # dense batch of the wrong width
+    st = abi.GroupState(8, 3)
+    st.role[3] = 7
+    with pytest.raises(engine.EngineError):
+        gpu.load_state(st)
+    st = abi.GroupState(8, 3)
+    st.set_log(0, 5, [(5, 1)], 9)                                           # first index not adjacent to epoch (0,0)
+    with pytest.raises(engine.EngineError):
+        gpu.load_state(st)
+    with pytest.raises(engine.EngineError):
+        engine.Table(8, 9)
+
+
+def test_copy_bandwidth_reports_something_sane():
+    gpu = engine.Table(8, 3)
+    gbps = gpu.copy_bandwidth(1 << 28, 5)
+    assert 500.0 < gbps < 8000.0
