@@ -1,0 +1,206 @@
+#!/usr/bin/env python
+"""bench.py — raft-group decisions/sec of the HIP decision path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One STEP = one launch of the step kernel over one batch of the synthetic RPC replay: `--rounds`
+consecutive rounds x (one event per raft group), inputs and outputs resident in HBM.  The replay is
+BASELINE config 3's mix (65 536 groups x 5 peers per GPU, ~20 % leader view / ~80 % follower view,
+1 % higher-term events, elections to keep the mix stationary); every step consumes FRESH rounds of the
+stream, so no step sees cached or replayed state.  With N > 1 the groups are block-partitioned over the
+ranks (embarrassingly parallel, no collective on the data path — SURVEY.md §8e); per-GPU work is fixed,
+so scaling is "weak".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      algorithmic bytes per launch / average step-kernel duration measured with
+                HIP events on the table's stream, against the 8 TB/s HBM3E peak
+  cpu_baseline  the C restatement of the reference EventLoop path (oracle/, "port") timed on this box's
+                host cores over the same stream (rank 0, N=1 only) — a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rounds", type=int, default=32, help="replay rounds fused into one launch")
+    ap.add_argument("--groups-per-gpu", type=int, default=65536)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batches", type=int, default=4, help="batches of the stream the CPU baseline replays")
+    ap.add_argument("--copy-bw", action="store_true", help="also measure a plain HBM copy kernel")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+
+    import torch                                   # before libraftgpu: both then share one HIP runtime
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        sync_t = torch.zeros(1, device="cuda")
+
+    from rafting_amd import abi, engine, workload
+
+    def barrier():
+        if world > 1:
+            dist.all_reduce(sync_t)
+        torch.cuda.synchronize()
+
+    gpg = args.groups_per_gpu
+    cfg = workload.config(args.config, gpg * world)
+    gen = workload.ReplayGenerator(cfg, first_gid=rank * gpg, count=gpg)
+    F = cfg.cluster - 1
+    table = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=local_rank)
+    st0 = gen.initial_state()
+    table.load_state(st0)
+
+    # ---- stage (warmup + steps) fresh batches of the stream in HBM -------------------------------
+    t_gen = time.time()
+    nb = args.warmup + args.steps
+    dbatches, stats, keep_host = [], [], []
+    for i in range(nb):
+        b = gen.next_batch(args.rounds)
+        stats.append(workload.batch_stats(b, F)[:2])
+        dbatches.append(engine.DeviceBatch(table, b))
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and i < args.cpu_batches:
+            keep_host.append(b)
+    t_gen = time.time() - t_gen
+
+    # ---- warmup, then EXACTLY `steps` timed steps -------------------------------------------------
+    for i in range(args.warmup):
+        table.submit_device(dbatches[i])
+    table.sync()
+    table.timing_enable(True)
+    table.counters(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nb):
+        table.submit_device(dbatches[i])
+    table.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = table.timing_read()
+    table.timing_enable(False)
+    counters = table.counters()
+
+    decisions = sum(s[0] for s in stats[args.warmup:])
+    alg_bytes = sum(s[1] for s in stats[args.warmup:])
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tot = torch.tensor([decisions, alg_bytes], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        decisions_all, alg_all = float(tot[0].item()), float(tot[1].item())
+    else:
+        decisions_all, alg_all = float(decisions), float(alg_bytes)
+
+    copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
+
+    # ---- CPU baseline + result check on the same stream (rank 0, N=1) ------------------------------
+    cpu = None
+    if keep_host:
+        from tests import oracle_lib            # the checker: only this leg touches oracle/
+        from tests.helpers import compare_outcomes
+        cpu_dec = sum(workload.batch_stats(b, F)[0] for b in keep_host)
+        best = {}
+        for threads in (1, 3):
+            orc = oracle_lib.OracleTable(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+            orc.load_state(st0)
+            secs, outs = 0.0, []
+            for b in keep_host:
+                out = abi.Outcome(b.rounds * b.count)
+                out.reply[:] = 0; out.logfx[:] = 0; out.persist[:] = 0      # touch pages outside the timed call
+                s, out = orc.submit_threads(b, threads, out)
+                secs += s
+                outs.append(out)
+            best[threads] = cpu_dec / secs
+            orc.close()
+        for b, db, ref in zip(keep_host, dbatches, outs):
+            compare_outcomes(ref, db.outcome(), "bench stream vs oracle")
+        use = 3 if best[3] >= best[1] else 1
+        cpu = {"value": best[use], "unit": "decisions/s", "cores": use, "kind": "port",
+               "value_1_thread": best[1], "value_3_threads": best[3], "host_cores": os.cpu_count(),
+               "sample": "first %d batches (%d rounds x %d groups = %d decisions) of the same stream; C restatement of "
+                         "the reference EventLoop path (oracle/raft_oracle.c), in-memory log, no fsync/Netty/Kryo; "
+                         "3 threads mirror EventLoopGroup(3); GPU results on this sample verified bit-identical"
+                         % (len(keep_host), args.rounds * len(keep_host), gpg, cpu_dec)}
+
+    if rank == 0:
+        avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
+        alg_per_launch = alg_bytes / max(args.steps, 1)
+        achieved = alg_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        out = {
+            "metric": "raft-group decisions/sec (AppendEntries+vote)",
+            "value": decisions_all / elapsed,
+            "unit": "decisions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": cfg.name if world == 1 else "config%d mix, %d groups x %d peers per GPU (block-sharded, no collective)" % (args.config, gpg, cfg.cluster),
+                "groups_per_gpu": gpg, "groups_total": gpg * world, "peers": cfg.cluster,
+                "rounds_per_step": args.rounds, "decisions_per_step_per_gpu": decisions // max(args.steps, 1),
+                "parallelism": "groups block-partitioned over %d GPU(s), no RCCL on the data path" % world,
+                "inputs": "HBM-resident event/outcome buffers (RG_MEM_DEVICE); every step consumes fresh rounds",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "rg::step_kernel<%d,false>" % F,
+                "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
+                "algorithmic_bytes_per_launch": alg_per_launch,
+                "algorithmic_bytes_per_decision": alg_bytes / max(decisions, 1),
+                "measured_copy_gbps": copy_gbps,
+            },
+            "cpu_baseline": cpu,
+            "counters": dict(zip(["rows", "replied", "role_conversions", "commit_advances", "asserts", "need_host",
+                                  "dropped_stale", "log_appends"], counters)),
+            "stage_seconds": t_gen,
+        }
+        print(json.dumps(out), flush=True)
+
+    for db in dbatches:
+        db.free()
+    table.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,47 +105,74 @@ struct Peers {                       // LDS columns of this lane
     static constexpr int STRIDE = BLOCK;
 };
 
-// Register image of one group.
+// Register image of one group.  The K=4 cached term runs are SCALAR members on purpose: with arrays the
+// optimiser folds the select chains below back into dynamically indexed accesses, which pins the whole
+// struct in scratch memory (measured: 168 B/lane of scratch, every field access a scratch_load).
 struct Group {
     int64_t term, commit, epoch_index, epoch_term, first, last, elected_term;
-    int64_t rs[K], rt[K];            // cached runs, ascending; valid [0, rc)
+    int64_t s0, s1, s2, s3;          // run starts, ascending; valid [0, rc)
+    int64_t t0, t1, t2, t3;          // run terms
     int32_t voted_for, leader, votes, role, rc;
     uint32_t role_epoch, elected_epoch, pending;
     bool td, prepared, log_dirty, peers_dirty;
+    static_assert(K == 4, "run cache is hand-unrolled for 4 runs");
 
+    // NOTE on style: every method first copies the fields it needs into locals, computes with value
+    // selects, and stores back unconditionally.  Member functions are optimised BEFORE they are inlined
+    // into the kernel, while `this` is still an opaque pointer; a load inside a conditional arm there is
+    // folded into "load of a selected address", which later defeats scalar replacement of the struct.
     __device__ __forceinline__ bool has_log() const { return rc > 0; }
-    __device__ __forceinline__ bool present(int64_t i) const { return rc > 0 && i >= first && i <= last; }
-    __device__ __forceinline__ bool cached(int64_t i) const { return i >= rs[0]; }
+    __device__ __forceinline__ bool present(int64_t i) const
+    {
+        const int n = rc; const int64_t f = first, l = last;
+        return n > 0 && i >= f && i <= l;
+    }
+    __device__ __forceinline__ bool cached(int64_t i) const { return i >= s0; }
     __device__ __forceinline__ int64_t last_term() const
     {
-        int64_t t = rt[0];
-#pragma unroll
-        for (int k = 1; k < K; k++) t = (k < rc) ? rt[k] : t;
+        const int n = rc; const int64_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
+        int64_t t = a0;
+        t = n > 1 ? a1 : t;
+        t = n > 2 ? a2 : t;
+        t = n > 3 ? a3 : t;
         return t;
     }
     // term of a PRESENT and CACHED index
     __device__ __forceinline__ int64_t term_at(int64_t i) const
     {
-        int64_t t = rt[0];
-#pragma unroll
-        for (int k = 1; k < K; k++) t = (k < rc && rs[k] <= i) ? rt[k] : t;
+        const int n = rc; const int64_t a0 = t0, a1 = t1, a2 = t2, a3 = t3, b1 = s1, b2 = s2, b3 = s3;
+        int64_t t = a0;
+        t = (n > 1 && b1 <= i) ? a1 : t;
+        t = (n > 2 && b2 <= i) ? a2 : t;
+        t = (n > 3 && b3 <= i) ? a3 : t;
         return t;
     }
     // db.put(last+1, t) — or the first key of an empty log
     __device__ __forceinline__ void push(int64_t index, int64_t t)
     {
-        if (rc == 0) {
-            first = index; rs[0] = index; rt[0] = t; rc = 1;
-        } else if (last_term() != t) {
-            if (rc == K) {           // cache full: forget the oldest run (lookups into it become misses)
-#pragma unroll
-                for (int k = 0; k + 1 < K; k++) { rs[k] = rs[k + 1]; rt[k] = rt[k + 1]; }
-                rc = K - 1;
-            }
-#pragma unroll
-            for (int k = 0; k < K; k++) if (k == rc) { rs[k] = index; rt[k] = t; }
-            rc += 1;
-        }
+        int n = rc;
+        int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
+        const int64_t f = first;
+        int64_t lt = y0;
+        lt = n > 1 ? y1 : lt;
+        lt = n > 2 ? y2 : lt;
+        lt = n > 3 ? y3 : lt;
+        const bool empty = n == 0;
+        const bool newrun = empty || lt != t;
+        const bool shift = newrun && n == K;     // cache full: forget the oldest run (lookups into it become misses)
+        x0 = shift ? x1 : x0; y0 = shift ? y1 : y0;
+        x1 = shift ? x2 : x1; y1 = shift ? y2 : y1;
+        x2 = shift ? x3 : x2; y2 = shift ? y3 : y2;
+        n = shift ? K - 1 : n;
+        const bool w0 = newrun && n == 0, w1 = newrun && n == 1, w2 = newrun && n == 2, w3 = newrun && n == 3;
+        x0 = w0 ? index : x0; y0 = w0 ? t : y0;
+        x1 = w1 ? index : x1; y1 = w1 ? t : y1;
+        x2 = w2 ? index : x2; y2 = w2 ? t : y2;
+        x3 = w3 ? index : x3; y3 = w3 ? t : y3;
+        n += newrun ? 1 : 0;
+        s0 = x0; s1 = x1; s2 = x2; s3 = x3; t0 = y0; t1 = y1; t2 = y2; t3 = y3;
+        rc = n;
+        first = empty ? index : f;
         last = index;
         log_dirty = true;
     }
@@ -153,40 +180,48 @@ struct Group {
     // the cut lands below the cached runs (hint-resolved conflict) and the cache must be re-seeded.
     __device__ __forceinline__ void truncate(int64_t index, int64_t keep_term)
     {
-        if (rc == 0 || last < index) return;
-        log_dirty = true;
-        if (index <= first) { rc = 0; return; }
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < K; k++) n += (k < rc && rs[k] < index) ? 1 : 0;
-        if (n == 0) { rs[0] = index - 1; rt[0] = keep_term; n = 1; }
-        rc = n;
-        last = index - 1;
+        const int n0 = rc;
+        const int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, f = first, l = last;
+        const bool dirty0 = log_dirty;
+        const bool act = n0 != 0 && l >= index;
+        const bool wipe = act && index <= f;
+        int n = (x0 < index ? 1 : 0) + ((n0 > 1 && x1 < index) ? 1 : 0) + ((n0 > 2 && x2 < index) ? 1 : 0) +
+                ((n0 > 3 && x3 < index) ? 1 : 0);
+        const bool reseed = act && !wipe && n == 0;
+        n = reseed ? 1 : n;
+        s0 = reseed ? index - 1 : x0;
+        t0 = reseed ? keep_term : y0;
+        rc = act ? (wipe ? 0 : n) : n0;
+        last = (act && !wipe) ? index - 1 : l;
+        log_dirty = dirty0 || act;
     }
     // RaftLog.flush(index, term): storage/RocksLog.java:228-242
     __device__ __forceinline__ uint32_t flush(int64_t index, int64_t term_)
     {
-        if (index < epoch_index) return RG_FLUSH_OUT_OF_BOUNDS;
-        if (rc != 0) {
-            if (index > last) {
-                rc = 0; log_dirty = true;
-            } else if (index > first) {
-                int drop = 0;        // runs that end before `index`
+        int n = rc;
+        int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
+        const int64_t f = first, l = last, ei = epoch_index;
+        const bool dirty0 = log_dirty;
+        if (index < ei) return RG_FLUSH_OUT_OF_BOUNDS;
+        const bool have = n != 0;
+        const bool wipe = have && index > l;
+        const bool trim = have && !wipe && index > f;
+        // runs that end before `index` (their successor starts at or below it) are gone
+        const int drop = trim ? (((n > 1 && x1 <= index) ? 1 : 0) + ((n > 2 && x2 <= index) ? 1 : 0) +
+                                 ((n > 3 && x3 <= index) ? 1 : 0)) : 0;
 #pragma unroll
-                for (int k = 1; k < K; k++) drop += (k < rc && rs[k] <= index) ? 1 : 0;
-#pragma unroll
-                for (int s = 0; s < K - 1; s++) {
-                    if (s < drop) {
-#pragma unroll
-                        for (int k = 0; k + 1 < K; k++) { rs[k] = rs[k + 1]; rt[k] = rt[k + 1]; }
-                    }
-                }
-                rc -= drop;
-                if (rs[0] < index) rs[0] = index;
-                first = index;
-                log_dirty = true;
-            }
+        for (int s = 0; s < K - 1; s++) {
+            const bool sh = s < drop;
+            x0 = sh ? x1 : x0; y0 = sh ? y1 : y0;
+            x1 = sh ? x2 : x1; y1 = sh ? y2 : y1;
+            x2 = sh ? x3 : x2; y2 = sh ? y3 : y2;
         }
+        n = wipe ? 0 : n - drop;
+        x0 = (trim && x0 < index) ? index : x0;
+        s0 = x0; s1 = x1; s2 = x2; s3 = x3; t0 = y0; t1 = y1; t2 = y2; t3 = y3;
+        rc = n;
+        first = trim ? index : f;
+        log_dirty = dirty0 || wipe || trim;
         epoch_index = index;
         epoch_term = term_;
         return RG_OK;
@@ -242,7 +277,8 @@ struct Stepper {
     __device__ __forceinline__ void prepare_replication()
     {
         if (g.prepared) return;
-        const int64_t next = wadd(g.has_log() ? g.last : g.epoch_index, 1);
+        const int64_t l_ = g.last, e_ = g.epoch_index;
+        const int64_t next = wadd(g.rc > 0 ? l_ : e_, 1);
 #pragma unroll
         for (int j = 0; j < F; j++) {
             pe.last_epoch[j * BLOCK] = g.epoch_index;
@@ -343,7 +379,7 @@ struct Stepper {
                 // term of the key just below the cut; only needed when the cut empties the cached runs
                 // (hint-resolved conflict below the cache) while the log itself stays non-empty
                 int64_t keep = 0;
-                if (g.has_log() && conflict > g.first && conflict <= g.rs[0])
+                if (g.has_log() && conflict > g.first && conflict <= g.s0)
                     keep = (conflict == e0) ? (purged ? g.epoch_term : prev_term) : terms[conflict - 1 - e0];
                 g.truncate(conflict, keep);
                 fx.flags |= RG_F_LOG_TRUNC;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void load_event(const StepParams &p, size_t row, Even
 }
 
 template <int F, bool SPARSE>
-__global__ __launch_bounds__(BLOCK) void step_kernel(const StepParams p)
+__global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 {
     __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
     __shared__ int32_t sh_rej[F * BLOCK];
@@ -56,10 +56,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepParams p)
         g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
         g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
         g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const I64x2 r = p.t.runs[(size_t)k * G + gi];
-            g.rs[k] = r.x; g.rt[k] = r.y;
+        {
+            const I64x2 r0 = p.t.runs[gi], r1 = p.t.runs[(size_t)G + gi], r2 = p.t.runs[(size_t)2 * G + gi],
+                        r3 = p.t.runs[(size_t)3 * G + gi];
+            g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
         }
         g.log_dirty = false; g.peers_dirty = false;
     }
@@ -136,8 +136,10 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(const StepParams p)
         el.elected_term = g.elected_term; el.elected_epoch = g.elected_epoch; el.votes = g.votes;
         p.t.elect[gi] = el;
         if (g.log_dirty) {
-#pragma unroll
-            for (int k = 0; k < K; k++) p.t.runs[(size_t)k * G + gi] = I64x2{g.rs[k], g.rt[k]};
+            p.t.runs[gi] = I64x2{g.s0, g.t0};
+            p.t.runs[(size_t)G + gi] = I64x2{g.s1, g.t1};
+            p.t.runs[(size_t)2 * G + gi] = I64x2{g.s2, g.t2};
+            p.t.runs[(size_t)3 * G + gi] = I64x2{g.s3, g.t3};
         }
         if (g.peers_dirty) {
 #pragma unroll
