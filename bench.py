@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=4, help="batches of the stream the CPU baseline replays")
     ap.add_argument("--copy-bw", action="store_true", help="also measure a plain HBM copy kernel")
+    ap.add_argument("--override", default="", help="experiment only: workload overrides, e.g. leader_frac=0,p_timeout=0")
     return ap.parse_args()
 
 
@@ -76,6 +77,12 @@ def main():
 
     gpg = args.groups_per_gpu
     cfg = workload.config(args.config, gpg * world)
+    if args.override:
+        import ast
+        import dataclasses
+        kv = dict(item.split("=", 1) for item in args.override.split(";"))
+        cfg = dataclasses.replace(cfg, name=cfg.name + " [override %s]" % args.override,
+                                  **{k: ast.literal_eval(v) for k, v in kv.items()})
     gen = workload.ReplayGenerator(cfg, first_gid=rank * gpg, count=gpg)
     F = cfg.cluster - 1
     table = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=local_rank)

@@ -263,7 +263,7 @@ void *rg_stream(rg_table_t *t);   /* the table's hipStream_t */
 int rg_timing_enable(rg_table_t *t, int on);
 /* Sum and count of step-kernel durations since the last reset (synchronises the stream). */
 int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int reset);
-/* Device-side decision counters accumulated by the step kernel (wave ballot + popcount, one atomic
+/* Device-side decision counters accumulated by the step kernel (wave ballot + popcount, one slot
  * per wave): [0]=rows with kind!=NONE, [1]=replied, [2]=role conversions, [3]=commit advances,
  * [4]=assert statuses, [5]=NEED_HOST, [6]=dropped stale, [7]=log appends. */
 #define RG_NUM_COUNTERS 8

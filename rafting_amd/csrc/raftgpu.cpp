@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,7 +16,7 @@
 #include "rg_device.hpp"
 
 namespace rg {
-hipError_t launch_step(const StepParams &p, int followers, bool sparse, hipStream_t s);
+hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s);
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 }  // namespace rg
 
@@ -33,7 +34,10 @@ struct rg_table {
     int pre_vote = 0;
     hipStream_t stream = nullptr;
     DevTable dt{};
-    unsigned long long *counters = nullptr;
+    unsigned long long *counters = nullptr;     // [counter_slots][RG_NUM_COUNTERS], one slot per wave of a dense launch
+    size_t counter_slots = 0;
+    int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
+    int lanes = 64;                             // raft groups per wavefront (RG_LANES env: 8/16/32/64)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -154,7 +158,14 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->dt.runs, G * rg::K * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_en, G * F * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_m, G * F * sizeof(rg::Match)));
-    CREATE_TRY(hipMalloc((void **)&t->counters, RG_NUM_COUNTERS * sizeof(unsigned long long)));
+    t->lanes = 64;
+    if (const char *e = getenv("RG_LANES")) {
+        const int v = atoi(e);
+        if (v == 8 || v == 16 || v == 32 || v == 64) t->lanes = v;
+    }
+    if (const char *e = getenv("RG_FAST")) t->fast_paths = atoi(e) != 0;
+    t->counter_slots = (G + 7) / 8;             // enough for the narrowest wavefronts
+    CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
     t->dt.groups = groups;
     CREATE_TRY(hipMemsetAsync(t->dt.term_commit, 0, G * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.epoch, 0, G * sizeof(I64x2), t->stream));
@@ -162,7 +173,7 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMemsetAsync(t->dt.runs, 0, G * rg::K * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.peer_en, 0, G * F * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.peer_m, 0, G * F * sizeof(rg::Match), t->stream));
-    CREATE_TRY(hipMemsetAsync(t->counters, 0, RG_NUM_COUNTERS * sizeof(unsigned long long), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->counters, 0, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long), t->stream));
     {   // fresh groups = what RaftContext.initialize leaves: Follower, term 0, no vote, empty log
         std::vector<rg::Ident> id(G, rg::Ident{RG_NO_NODE, RG_NO_NODE, 1u, 0u});
         std::vector<rg::Elect> el(G, rg::Elect{0, 0u, 1});
@@ -317,7 +328,7 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
         e0 = t->ev_pool[t->ev_used].first; e1 = t->ev_pool[t->ev_used].second;
         HIP_TRY(t, hipEventRecord(e0, t->stream));
     }
-    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, t->stream));
+    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, t->lanes, t->stream));
     if (t->timing) {
         HIP_TRY(t, hipEventRecord(e1, t->stream));
         t->ev_used += 1;
@@ -350,6 +361,7 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     p.entry_count = in->entry_count;
     p.counters = t->counters;
     p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
+    p.fast_paths = t->fast_paths;
 
     if (memspace == RG_MEM_DEVICE) {
         p.gid = in->gid; p.head = in->head;
@@ -476,11 +488,14 @@ int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int rese
 {
     if (!t || !counters) return -1;
     if (bind(t)) return -2;
-    unsigned long long host[RG_NUM_COUNTERS];
-    HIP_TRY(t, hipMemcpyAsync(host, t->counters, sizeof host, hipMemcpyDeviceToHost, t->stream));
-    if (reset) HIP_TRY(t, hipMemsetAsync(t->counters, 0, sizeof host, t->stream));
+    const size_t n = t->counter_slots * RG_NUM_COUNTERS;
+    std::vector<unsigned long long> host(n);
+    HIP_TRY(t, hipMemcpyAsync(host.data(), t->counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
+    if (reset) HIP_TRY(t, hipMemsetAsync(t->counters, 0, n * sizeof(unsigned long long), t->stream));
     HIP_TRY(t, hipStreamSynchronize(t->stream));
-    for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] = host[i];
+    for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] = 0;
+    for (size_t s = 0; s < t->counter_slots; s++)
+        for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] += host[s * RG_NUM_COUNTERS + i];
     return 0;
 }
 

@@ -71,6 +71,7 @@ struct StepParams {
     rg_persist_t *persist;
     unsigned long long *counters;   // [RG_NUM_COUNTERS]
     int32_t self, cluster, majority, pre_vote;
+    int32_t fast_paths;             // 0: general handlers only
 };
 
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -299,8 +300,22 @@ struct Stepper {
     }
 
     // ---- appendEntries --------------------------------------------------------------------------
+    // entry term k of the request: the first PREFETCHED_ENTRIES arrive in registers with the event
+    // (loaded one round ahead), the rest is read from the entry stream on demand
+    struct Pre { int64_t e0, e1, e2, e3; };          // scalars, not an array: see the note in Group
+    __device__ __forceinline__ int64_t entry_term(const int64_t *terms, const Pre pre, uint64_t k) const
+    {
+        int64_t t = pre.e0;
+        t = k == 1 ? pre.e1 : t;
+        t = k == 2 ? pre.e2 : t;
+        t = k == 3 ? pre.e3 : t;
+        if (k >= 4) t = terms[k];
+        return t;
+    }
+
     __device__ __forceinline__ void on_append_entries(int64_t term, int32_t leader, int64_t prev_index,
                                                       int64_t prev_term, uint32_t n, const int64_t *terms,
+                                                      const Pre pre,
                                                       int64_t leader_commit, bool hinted, int64_t hint_prev_term,
                                                       int64_t hint_conflict)
     {
@@ -357,11 +372,12 @@ struct Stepper {
 
         // purgeEntries: entry k has index prev_index+1+k
         int64_t e0 = wadd(prev_index, 1);
+        const int64_t e_first = e0;                   // index of entry 0 of the request, before the purge
         bool purged = false;
         if (n > 0 && e0 <= g.epoch_index) {
             const uint64_t skip = (uint64_t)(g.epoch_index - e0) + 1u;
             purged = true;
-            if (skip >= n) { n = 0; } else { n -= (uint32_t)skip; terms += skip; e0 = wadd(e0, (int64_t)skip); }
+            if (skip >= n) { n = 0; } else { n -= (uint32_t)skip; e0 = wadd(e0, (int64_t)skip); }
         }
         if (n > 0) {
             const int64_t e_last = wadd(e0, (int64_t)n - 1);
@@ -372,7 +388,7 @@ struct Stepper {
             } else if (g.has_log() && e0 <= g.last) {
                 const int64_t stop = min64(e_last, g.last);
                 for (int64_t idx = e0; idx <= stop; idx++) {
-                    if (g.term_at(idx) != terms[idx - e0]) { conflict = idx; break; }
+                    if (g.term_at(idx) != entry_term(terms, pre, (uint64_t)(idx - e_first))) { conflict = idx; break; }
                 }
             }
             if (conflict) {
@@ -380,7 +396,8 @@ struct Stepper {
                 // (hint-resolved conflict below the cache) while the log itself stays non-empty
                 int64_t keep = 0;
                 if (g.has_log() && conflict > g.first && conflict <= g.s0)
-                    keep = (conflict == e0) ? (purged ? g.epoch_term : prev_term) : terms[conflict - 1 - e0];
+                    keep = (conflict == e0) ? (purged ? g.epoch_term : prev_term)
+                                            : entry_term(terms, pre, (uint64_t)(conflict - 1 - e_first));
                 g.truncate(conflict, keep);
                 fx.flags |= RG_F_LOG_TRUNC;
             }
@@ -397,7 +414,7 @@ struct Stepper {
                 fx.log_from = conflict ? conflict : from;
                 fx.flags |= RG_F_LOG_APPEND;
             }
-            for (int64_t idx = from; idx <= e_last; idx++) g.push(idx, terms[idx - e0]);
+            for (int64_t idx = from; idx <= e_last; idx++) g.push(idx, entry_term(terms, pre, (uint64_t)(idx - e_first)));
         }
         if (leader_commit > g.epoch_index && g.has_log()) {
             const uint32_t st = mark_committed(min64(leader_commit, g.last));
@@ -613,9 +630,105 @@ struct Stepper {
         fx.flags |= RG_F_LOG_APPEND | (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT);
     }
 
-    // ---- one row --------------------------------------------------------------------------------
+    // ---- tier 1: branch-free fast paths -----------------------------------------------------------
+    // A lone wavefront per SIMD pays ~40 cycles for every divergent branch of the general handlers below
+    // (measured: ~3000 cycles for a plain heartbeat), so the three overwhelmingly common rows are decided
+    // here with selects only, under explicit preconditions that make them a strict special case of the
+    // general code (which stays the single source of truth for everything else):
+    //   * AppendEntries at a Follower of the same term, from its known leader, whose prevLog is the log tail
+    //     (member/Follower.java:35-88 with no role switch, no conflict, no purge, entries of the tail's term);
+    //   * AppendEntries ack at a prepared Leader, same role epoch, no term change, no epoch move, not pending
+    //     (member/Leader.java:218-237, member/Leadership.java:75-114, member/Leader.java:247-280);
+    //   * client append at a prepared Leader whose tail is already in its own term (member/Leader.java:128-140).
+    // Any row that misses a precondition is left untouched and goes to run().
+    __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
+                                             int64_t d, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
+    {
+        const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+        const bool flag = RG_HDR_FLAG(hdr) != 0;
+        const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
+        const int64_t g_term = g.term, g_last = g.last, g_commit = g.commit, g_epoch = g.epoch_index, g_first = g.first;
+        const int64_t lt = g.last_term(), g_s0 = g.s0;
+        const int32_t rc = g.rc, role = g.role, g_leader = g.leader;
+        const bool has_log = rc > 0;
+
+        // ---- AppendEntries request at a follower --------------------------------------------------
+        const bool entries_ok = n == 0 || (n <= 4u && p.entry_terms != nullptr && (uint64_t)aux + n <= p.entry_count);
+        const bool same = (n < 2u || pe1 == pe0) && (n < 3u || pe2 == pe0) && (n < 4u || pe3 == pe0);
+        const bool contains = c == lt;                                   // prevLogTerm == term of the tail
+        const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;
+        const bool want_commit = contains && d > g_epoch;
+        const int64_t ae_x = min64(d, ae_last);
+        const bool fa = allow && kind == RG_EV_AE_REQ && slot < P && role == RG_FOLLOWER && a == g_term && !g.td &&
+                        (g_leader == RG_NO_NODE || g_leader == (int32_t)slot) && has_log && b == g_last &&
+                        b > g_epoch && c != 0 && entries_ok &&
+                        (!contains || n == 0 || (same && pe0 == lt)) && !(want_commit && ae_x < g_commit);
+        const bool ae_commit = fa && want_commit && ae_x > g_commit;
+        const bool ae_append = fa && contains && n > 0;
+
+        // ---- AppendEntries ack at a leader ----------------------------------------------------------
+        const bool ack_shape = allow && kind == RG_EV_AE_ACK && slot < P && slot != self;
+        const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
+        const int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
+        const int32_t s_rej = pe.rejection[j * BLOCK];
+        const bool s_pend = ((g.pending >> j) & 1u) != 0;
+        const bool adv = flag && c > s_match;
+        const int64_t n_match = adv ? c : s_match;
+        const int64_t n_next = adv ? wadd(c, 1) : s_next;
+        int64_t m[F];
+#pragma unroll
+        for (int i = 0; i < F; i++) {
+            const int64_t mi = pe.match_index[i * BLOCK];
+            m[i] = ((uint32_t)i == j) ? n_match : mi;
+        }
+#pragma unroll
+        for (int x = 1; x < F; x++) {
+#pragma unroll
+            for (int y = x; y > 0; y--) {
+                const int64_t lo = min64(m[y - 1], m[y]), hi = max64(m[y - 1], m[y]);
+                m[y - 1] = lo; m[y] = hi;
+            }
+        }
+        const int64_t full = m[0], major = m[F / 2];
+        const bool lookup = flag && major != 0;
+        const bool major_ok = has_log && major >= g_first && major <= g_last && major >= g_s0;   // present and cached
+        const int64_t mt = g.term_at(major);
+        const int64_t commit_to = lookup ? (mt == g_term ? major : full) : 0;
+        const bool do_commit = commit_to != 0 && commit_to != g_commit;
+        const bool fk = ack_shape && aux == g.role_epoch && role == RG_LEADER && g.prepared && a <= g_term &&
+                        b == s_epoch && !s_pend && c >= s_match && (flag || s_match != 0) && n_next > b &&
+                        (!lookup || major_ok) && !(do_commit && commit_to < g_commit);
+        const bool ack_commit = fk && do_commit;
+
+        // ---- client append at a leader ----------------------------------------------------------------
+        const bool fc = allow && kind == RG_EV_CLIENT_APPEND && role == RG_LEADER && n >= 1u && has_log && lt == g_term &&
+                        g.prepared;
+
+        const bool fast = fa || fk || fc;
+        if (fk) {
+            pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
+            pe.next_index[j * BLOCK] = n_next;
+            pe.match_index[j * BLOCK] = n_match;
+        }
+        g.peers_dirty = g.peers_dirty || fk;
+        g.leader = fa ? (int32_t)slot : g_leader;
+        g.last = ae_append ? ae_last : (fc ? wadd(g_last, (int64_t)n) : g_last);
+        g.log_dirty = g.log_dirty || ae_append || fc;
+        g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
+        if (fast) {
+            fx.status = RG_OK;
+            fx.resp_term = g_term;                       // == the request term on this path
+            fx.log_from = wadd(g_last, 1);
+            fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
+                       ((ae_append || fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit || ack_commit) ? RG_F_COMMIT : 0u) |
+                       (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
+        }
+        return fast;
+    }
+
+    // ---- one row (tier 2: the general handlers) ---------------------------------------------------
     __device__ __forceinline__ void run(uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
-                                        int64_t hx, int64_t hy)
+                                        int64_t hx, int64_t hy, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
     {
         fx = Fx{0u, RG_OK, 0, 0};
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
@@ -628,7 +741,7 @@ struct Stepper {
             if (slot >= P || (n > 0 && (p.entry_terms == nullptr || (uint64_t)aux + n > p.entry_count))) {
                 fx.status = RG_BAD_EVENT; break;
             }
-            on_append_entries(a, (int32_t)slot, b, c, n, p.entry_terms + aux, d, hinted, hx, hy);
+            on_append_entries(a, (int32_t)slot, b, c, n, p.entry_terms + aux, Pre{pe0, pe1, pe2, pe3}, d, hinted, hx, hy);
             break;
         case RG_EV_AE_ACK:
         case RG_EV_IS_ACK:

@@ -10,8 +10,8 @@
 //     already in flight (software prefetch) — the event/outcome streams are what HBM sees;
 //   * outcomes: the 16-byte reply is always stored; log/commit effects and the durable
 //     (term, votedFor) pair are stored only for rows that have them;
-//   * decision counters are wave-level: ballot + popcount per round into scalar registers, one
-//     atomic per wave per counter at the end.
+//   * decision counters are wave-level: ballot + popcount per round into scalar registers, added to
+//     the wave's own slot of a counter table at the end (no atomics).
 // Workgroup = one wavefront (64 lanes): lanes never share LDS columns, so no barrier exists anywhere.
 #include "rg_device.hpp"
 
@@ -20,27 +20,47 @@ namespace rg {
 struct Event {
     uint32_t hdr, aux;
     int64_t a, b, c, d, hx, hy;
+    int64_t e0, e1, e2, e3;         // first entry terms of an AppendEntries request
 };
 
+// Stage 1 of the event pipeline: the three row-addressed loads (8 + 16 + 16 B per lane). Nothing here
+// depends on loaded data, so the loads are issued two rounds ahead of their use.
 __device__ __forceinline__ void load_event(const StepParams &p, size_t row, Event &e)
 {
     const rg_ev_head_t h = p.head[row];
     const I64x2 ab = p.ab[row], cd = p.cd[row];
     e.hdr = h.hdr; e.aux = h.aux;
     e.a = ab.x; e.b = ab.y; e.c = cd.x; e.d = cd.y;
-    e.hx = 0; e.hy = 0;
-    if (p.hint != nullptr && RG_HDR_HINT(h.hdr)) { const I64x2 hh = p.hint[row]; e.hx = hh.x; e.hy = hh.y; }
+    e.hx = 0; e.hy = 0; e.e0 = 0; e.e1 = 0; e.e2 = 0; e.e3 = 0;
 }
 
-template <int F, bool SPARSE>
+// Stage 2, one round later (the header has landed by now): loads whose ADDRESS comes from the header —
+// the first entry terms of an AppendEntries request and the optional hint. Issued one round ahead of use.
+__device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, Event &e)
+{
+    if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; e.hx = hh.x; e.hy = hh.y; }
+    const uint32_t n = RG_HDR_N(e.hdr);
+    const bool ae = RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ && n > 0 && p.entry_terms != nullptr &&
+                    (uint64_t)e.aux + n <= p.entry_count;
+    const int64_t *t = p.entry_terms + e.aux;
+    e.e0 = ae ? t[0] : 0;
+    e.e1 = (ae && n > 1u) ? t[1] : 0;
+    e.e2 = (ae && n > 2u) ? t[2] : 0;
+    e.e3 = (ae && n > 3u) ? t[3] : 0;
+}
+
+// LANES = raft groups per wavefront.  A lone wavefront per SIMD issues one instruction every ~4.3 cycles
+// (measured), so with only G/64 wavefronts on 1024 SIMDs the chip idles; narrower wavefronts (the upper
+// lanes simply masked off) put several independent instruction streams on every SIMD.
+template <int F, bool SPARSE, int LANES>
 __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 {
     __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
     __shared__ int32_t sh_rej[F * BLOCK];
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * BLOCK + lane;
-    const bool active = i < p.count;
+    const uint32_t i = blockIdx.x * LANES + lane;
+    const bool active = lane < (uint32_t)LANES && i < p.count;
     const uint32_t gi = active ? (SPARSE ? p.gid[i] : i) : 0u;
     const uint32_t G = p.t.groups;
 
@@ -75,52 +95,95 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     }
 
     Stepper<F> st(p, g, pe);
-    unsigned long long cnt[RG_NUM_COUNTERS];
-#pragma unroll
-    for (int c = 0; c < RG_NUM_COUNTERS; c++) cnt[c] = 0ull;
+    const bool FAST = p.fast_paths != 0;                 // RG_FAST=0 forces every row through the general handlers (tests)
+    // decision counters: per-lane 32-bit tallies (no scalar registers tied up across the loop), reduced over the
+    // wavefront once at the end
+    uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
     bool blocked = false;
 
-    Event cur, nxt;
-    if (active) load_event(p, i, cur);
+    // outcome of the previous round, stored one round late (see the drain below)
+    rg_reply_t pend_rep{0, 0u, 0u};
+    I64x2 pend_lfx{0, 0};
+    rg_persist_t pend_per{0, 0, 0};
+    bool pend_w_lfx = false, pend_w_per = false;
+
+    // three-deep event pipeline: `far` = round r+2 (row loads in flight), `near` = round r+1 (header landed,
+    // header-addressed loads in flight), `cur` = round r (complete). Every wait falls at the top of a
+    // round, for memory operations issued a full round earlier, so their latency overlaps decision work.
+    Event cur, near, far;
+    cur = Event{}; near = Event{}; far = Event{};
+    if (active) {
+        load_event(p, i, cur);
+        load_event_tail(p, i, cur);
+        if (p.rounds > 1) load_event(p, (size_t)p.count + i, near);
+    }
     for (uint32_t r = 0; r < p.rounds; r++) {
         const size_t row = (size_t)r * p.count + i;
-        if (active && r + 1 < p.rounds) load_event(p, row + p.count, nxt);
-
-        uint32_t flags = 0, status = RG_OK, kind = 0;
+        // Drain HERE, before issuing anything new: the vm counter retires in order and (on gfx9-class ISAs)
+        // counts stores too, so (a) a wait placed lazily inside the divergent decision code would degrade to
+        // vmcnt(0) and also wait for the loads issued below, and (b) draining right after the outcome stores
+        // would expose the full store latency every round. Hence: loads AND the previous round's stores are
+        // issued right after this point and get a whole round of decision work to complete.
+#ifdef RG_PROFILE
+        const uint64_t tp0 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) expcnt(7) lgkmcnt(15)
+#ifdef RG_PROFILE
+        const uint64_t tp1 = __builtin_amdgcn_s_memtime();
+#endif
         if (active) {
-            kind = RG_HDR_KIND(cur.hdr);
+            if (r > 0) {
+                p.reply[row - p.count] = pend_rep;
+                if (pend_w_lfx) p.logfx[row - p.count] = pend_lfx;
+                if (pend_w_per) p.persist[row - p.count] = pend_per;
+            }
+            if (r + 2 < p.rounds) load_event(p, row + 2 * (size_t)p.count, far);
+            if (r + 1 < p.rounds) load_event_tail(p, row + p.count, near);
+        }
+#ifdef RG_PROFILE
+        const uint64_t tp2 = __builtin_amdgcn_s_memtime();
+#endif
+
+        if (active) {
+            const uint32_t kind = RG_HDR_KIND(cur.hdr);
             if (blocked && kind != RG_EV_NONE) {
                 st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-            } else {
-                st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.hx, cur.hy);
+            } else if (!st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.e0, cur.e1, cur.e2, cur.e3)) {
+                st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.hx, cur.hy, cur.e0, cur.e1, cur.e2, cur.e3);
             }
-            status = st.fx.status;
+            const uint32_t status = st.fx.status, flags = st.fx.flags;
             if (status == RG_NEED_HOST) blocked = true;
-            flags = st.fx.flags;
-            rg_reply_t rep;
-            rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
-            rep.flags = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
-            rep.role_epoch = g.role_epoch;
-            p.reply[row] = rep;
-            if ((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) || status == RG_NEED_HOST)
-                p.logfx[row] = I64x2{g.commit, st.fx.log_from};
-            if (flags & RG_F_PERSIST) {
-                rg_persist_t per;
-                per.term = g.term; per.voted_for = g.voted_for; per.role = g.role;
-                p.persist[row] = per;
-            }
+            pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
+            pend_rep.flags = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+            pend_rep.role_epoch = g.role_epoch;
+            pend_w_lfx = (flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) || status == RG_NEED_HOST;
+            pend_lfx = I64x2{g.commit, st.fx.log_from};
+            pend_w_per = (flags & RG_F_PERSIST) != 0;
+            pend_per.term = g.term; pend_per.voted_for = g.voted_for; pend_per.role = g.role;
+
+            c_rows += kind != RG_EV_NONE ? 1u : 0u;
+            c_replied += (flags >> 1) & 1u;             // RG_F_REPLIED
+            c_conv += (flags >> 3) & 1u;                // RG_F_ROLE_CHANGED
+            c_commit += (flags >> 5) & 1u;              // RG_F_COMMIT
+            c_append += (flags >> 7) & 1u;              // RG_F_LOG_APPEND
+            c_assert += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
+            c_need += status == RG_NEED_HOST ? 1u : 0u;
+            c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
         }
-        // wave-level tallies: one ballot + popcount per counter per round
-        const bool is_assert = status != RG_OK && status < RG_NPE_MAJOR_NULL;
-        cnt[0] += __popcll(__ballot(kind != RG_EV_NONE));
-        cnt[1] += __popcll(__ballot((flags & RG_F_REPLIED) != 0));
-        cnt[2] += __popcll(__ballot((flags & RG_F_ROLE_CHANGED) != 0));
-        cnt[3] += __popcll(__ballot((flags & RG_F_COMMIT) != 0));
-        cnt[4] += __popcll(__ballot(is_assert));
-        cnt[5] += __popcll(__ballot(status == RG_NEED_HOST));
-        cnt[6] += __popcll(__ballot(status == RG_DROPPED_STALE_ROLE));
-        cnt[7] += __popcll(__ballot((flags & RG_F_LOG_APPEND) != 0));
-        cur = nxt;
+#ifdef RG_PROFILE
+        {   // experiment build only: cycles spent draining / issuing / deciding, reported through the tallies
+            const uint64_t tp3 = __builtin_amdgcn_s_memtime();
+            if (lane == 0) { c_need += (uint32_t)(tp1 - tp0); c_stale += (uint32_t)(tp2 - tp1); c_append += (uint32_t)(tp3 - tp2); }
+        }
+#endif
+        cur = near;
+        near = far;
+    }
+    if (active && p.rounds > 0) {
+        const size_t row = (size_t)(p.rounds - 1) * p.count + i;
+        p.reply[row] = pend_rep;
+        if (pend_w_lfx) p.logfx[row] = pend_lfx;
+        if (pend_w_per) p.persist[row] = pend_per;
     }
 
     if (active) {
@@ -151,10 +214,23 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             }
         }
     }
-    if (lane == 0) {
+    // Wavefront reduction of the tallies: butterfly over the 64 lanes, then each wave adds into its own
+    // 64-byte slot of the counter table with a plain read-modify-write (8 atomics per wave onto 8 shared
+    // words cost ~60 us per launch at 1024 waves). rg_counters_read sums the slots.
+    uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
 #pragma unroll
-        for (int c = 0; c < RG_NUM_COUNTERS; c++)
-            if (cnt[c]) atomicAdd(&p.counters[c], cnt[c]);
+    for (int c = 0; c < RG_NUM_COUNTERS; c++) {
+        uint32_t v = active ? tally[c] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        tally[c] = v;
+    }
+    if (lane < RG_NUM_COUNTERS) {
+        uint32_t v = tally[0];
+#pragma unroll
+        for (int c = 1; c < RG_NUM_COUNTERS; c++) v = (lane == (uint32_t)c) ? tally[c] : v;
+        unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
+        *slot += v;
     }
 }
 
@@ -164,25 +240,37 @@ __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 
-template <int F>
-static hipError_t launch_f(const StepParams &p, bool sparse, hipStream_t s)
+template <int F, int LANES>
+static hipError_t launch_fl(const StepParams &p, bool sparse, hipStream_t s)
 {
-    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    const uint32_t blocks = (p.count + LANES - 1) / LANES;
     if (blocks == 0) return hipSuccess;
-    if (sparse) hipLaunchKernelGGL((step_kernel<F, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else        hipLaunchKernelGGL((step_kernel<F, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (sparse) hipLaunchKernelGGL((step_kernel<F, true, LANES>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step_kernel<F, false, LANES>), dim3(blocks), dim3(BLOCK), 0, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_step(const StepParams &p, int followers, bool sparse, hipStream_t s)
+template <int F>
+static hipError_t launch_f(const StepParams &p, bool sparse, int lanes, hipStream_t s)
+{
+    switch (lanes) {
+    case 64: return launch_fl<F, 64>(p, sparse, s);
+    case 32: return launch_fl<F, 32>(p, sparse, s);
+    case 16: return launch_fl<F, 16>(p, sparse, s);
+    case 8:  return launch_fl<F, 8>(p, sparse, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s)
 {
     switch (followers) {
-    case 1: return launch_f<1>(p, sparse, s);
-    case 2: return launch_f<2>(p, sparse, s);
-    case 3: return launch_f<3>(p, sparse, s);
-    case 4: return launch_f<4>(p, sparse, s);
-    case 5: return launch_f<5>(p, sparse, s);
-    case 6: return launch_f<6>(p, sparse, s);
+    case 1: return launch_f<1>(p, sparse, lanes, s);
+    case 2: return launch_f<2>(p, sparse, lanes, s);
+    case 3: return launch_f<3>(p, sparse, lanes, s);
+    case 4: return launch_f<4>(p, sparse, lanes, s);
+    case 5: return launch_f<5>(p, sparse, lanes, s);
+    case 6: return launch_f<6>(p, sparse, lanes, s);
     default: return hipErrorInvalidValue;
     }
 }

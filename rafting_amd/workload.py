@@ -58,6 +58,7 @@ class ReplayConfig:
     grant_prob: float = 0.9
     p_client: float = 0.2         # leader rounds that are client appends rather than acks
     p_reject: float = 0.02
+    ae_entries: tuple = (0, 1, 2, 4)   # entries per AppendEntries request, equiprobable
     self_slot: int = 0
     pre_vote: bool = True
 
@@ -207,7 +208,7 @@ class ReplayGenerator:
         self.term[hi] += 1; self.epoch[hi] += 1; self.leader[hi] = other[hi]
         kind[ae] = abi.EV_AE_REQ
         slot[ae] = self.leader[ae]
-        nn = np.array([0, 1, 2, 4], dtype=np.int64)[self._ri(5, 4)]
+        nn = np.array(cfg.ae_entries, dtype=np.int64)[self._ri(5, len(cfg.ae_entries))]
         nent[ae] = nn[ae]
         a[ae] = self.term[ae]; bb[ae] = self.last[ae]; c[ae] = self.last_term[ae]
         ent_term[ae] = self.term[ae]
