@@ -68,7 +68,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
         sync_t = torch.zeros(1, device="cuda")
 
-    from rafting_amd import abi, engine, workload
+    from rafting_amd import abi, engine, shard, workload
 
     def barrier():
         if world > 1:
@@ -83,7 +83,9 @@ def main():
         kv = dict(item.split("=", 1) for item in args.override.split(";"))
         cfg = dataclasses.replace(cfg, name=cfg.name + " [override %s]" % args.override,
                                   **{k: ast.literal_eval(v) for k, v in kv.items()})
-    gen = workload.ReplayGenerator(cfg, first_gid=rank * gpg, count=gpg)
+    first_gid, count = shard.block_partition(cfg.groups, world, rank)
+    assert count == gpg
+    gen = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
     F = cfg.cluster - 1
     table = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=local_rank)
     st0 = gen.initial_state()
@@ -120,15 +122,7 @@ def main():
 
     decisions = sum(s[0] for s in stats[args.warmup:])
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
-    if world > 1:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        tot = torch.tensor([decisions, alg_bytes], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        decisions_all, alg_all = float(tot[0].item()), float(tot[1].item())
-    else:
-        decisions_all, alg_all = float(decisions), float(alg_bytes)
+    elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device="cuda" if world > 1 else None)
 
     copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
 

@@ -652,27 +652,29 @@ struct Stepper {
         const int32_t rc = g.rc, role = g.role, g_leader = g.leader;
         const bool has_log = rc > 0;
 
+        // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled
+        // back into exec-mask branches, which is exactly what this tier exists to avoid.
         // ---- AppendEntries request at a follower --------------------------------------------------
-        const bool entries_ok = n == 0 || (n <= 4u && p.entry_terms != nullptr && (uint64_t)aux + n <= p.entry_count);
-        const bool same = (n < 2u || pe1 == pe0) && (n < 3u || pe2 == pe0) && (n < 4u || pe3 == pe0);
+        const bool entries_ok = (n == 0) | ((n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)aux + n <= p.entry_count));
+        const bool same = ((n < 2u) | (pe1 == pe0)) & ((n < 3u) | (pe2 == pe0)) & ((n < 4u) | (pe3 == pe0));
         const bool contains = c == lt;                                   // prevLogTerm == term of the tail
         const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;
-        const bool want_commit = contains && d > g_epoch;
+        const bool want_commit = contains & (d > g_epoch);
         const int64_t ae_x = min64(d, ae_last);
-        const bool fa = allow && kind == RG_EV_AE_REQ && slot < P && role == RG_FOLLOWER && a == g_term && !g.td &&
-                        (g_leader == RG_NO_NODE || g_leader == (int32_t)slot) && has_log && b == g_last &&
-                        b > g_epoch && c != 0 && entries_ok &&
-                        (!contains || n == 0 || (same && pe0 == lt)) && !(want_commit && ae_x < g_commit);
-        const bool ae_commit = fa && want_commit && ae_x > g_commit;
-        const bool ae_append = fa && contains && n > 0;
+        const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a == g_term) & !g.td &
+                        ((g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
+                        (b > g_epoch) & (c != 0) & entries_ok &
+                        (!contains | (n == 0) | (same & (pe0 == lt))) & !(want_commit & (ae_x < g_commit));
+        const bool ae_commit = fa & want_commit & (ae_x > g_commit);
+        const bool ae_append = fa & contains & (n > 0);
 
         // ---- AppendEntries ack at a leader ----------------------------------------------------------
-        const bool ack_shape = allow && kind == RG_EV_AE_ACK && slot < P && slot != self;
+        const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & (slot < P) & (slot != self);
         const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
         const int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
         const int32_t s_rej = pe.rejection[j * BLOCK];
         const bool s_pend = ((g.pending >> j) & 1u) != 0;
-        const bool adv = flag && c > s_match;
+        const bool adv = flag & (c > s_match);
         const int64_t n_match = adv ? c : s_match;
         const int64_t n_next = adv ? wadd(c, 1) : s_next;
         int64_t m[F];
@@ -690,37 +692,37 @@ struct Stepper {
             }
         }
         const int64_t full = m[0], major = m[F / 2];
-        const bool lookup = flag && major != 0;
-        const bool major_ok = has_log && major >= g_first && major <= g_last && major >= g_s0;   // present and cached
+        const bool lookup = flag & (major != 0);
+        const bool major_ok = has_log & (major >= g_first) & (major <= g_last) & (major >= g_s0);   // present and cached
         const int64_t mt = g.term_at(major);
         const int64_t commit_to = lookup ? (mt == g_term ? major : full) : 0;
-        const bool do_commit = commit_to != 0 && commit_to != g_commit;
-        const bool fk = ack_shape && aux == g.role_epoch && role == RG_LEADER && g.prepared && a <= g_term &&
-                        b == s_epoch && !s_pend && c >= s_match && (flag || s_match != 0) && n_next > b &&
-                        (!lookup || major_ok) && !(do_commit && commit_to < g_commit);
-        const bool ack_commit = fk && do_commit;
+        const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
+        const bool fk = ack_shape & (aux == g.role_epoch) & (role == RG_LEADER) & g.prepared & (a <= g_term) &
+                        (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
+                        (!lookup | major_ok) & !(do_commit & (commit_to < g_commit));
+        const bool ack_commit = fk & do_commit;
 
         // ---- client append at a leader ----------------------------------------------------------------
-        const bool fc = allow && kind == RG_EV_CLIENT_APPEND && role == RG_LEADER && n >= 1u && has_log && lt == g_term &&
+        const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log & (lt == g_term) &
                         g.prepared;
 
-        const bool fast = fa || fk || fc;
+        const bool fast = fa | fk | fc;
         if (fk) {
             pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
             pe.next_index[j * BLOCK] = n_next;
             pe.match_index[j * BLOCK] = n_match;
         }
-        g.peers_dirty = g.peers_dirty || fk;
+        g.peers_dirty = g.peers_dirty | fk;
         g.leader = fa ? (int32_t)slot : g_leader;
         g.last = ae_append ? ae_last : (fc ? wadd(g_last, (int64_t)n) : g_last);
-        g.log_dirty = g.log_dirty || ae_append || fc;
+        g.log_dirty = g.log_dirty | ae_append | fc;
         g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
         if (fast) {
             fx.status = RG_OK;
             fx.resp_term = g_term;                       // == the request term on this path
             fx.log_from = wadd(g_last, 1);
             fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
-                       ((ae_append || fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit || ack_commit) ? RG_F_COMMIT : 0u) |
+                       ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
                        (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
         }
         return fast;

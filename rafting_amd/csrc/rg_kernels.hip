@@ -39,14 +39,16 @@ __device__ __forceinline__ void load_event(const StepParams &p, size_t row, Even
 __device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, Event &e)
 {
     if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; e.hx = hh.x; e.hy = hh.y; }
+    // four unconditional 8-byte loads: lanes without a k-th entry read a harmless dummy word (the row's own
+    // header) instead of branching around the load
     const uint32_t n = RG_HDR_N(e.hdr);
-    const bool ae = RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ && n > 0 && p.entry_terms != nullptr &&
-                    (uint64_t)e.aux + n <= p.entry_count;
+    const bool ae = (RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ) & (n > 0) & (p.entry_terms != nullptr) &
+                    ((uint64_t)e.aux + n <= p.entry_count);
+    const int64_t *dummy = reinterpret_cast<const int64_t *>(p.head + row);
     const int64_t *t = p.entry_terms + e.aux;
-    e.e0 = ae ? t[0] : 0;
-    e.e1 = (ae && n > 1u) ? t[1] : 0;
-    e.e2 = (ae && n > 2u) ? t[2] : 0;
-    e.e3 = (ae && n > 3u) ? t[3] : 0;
+    const int64_t *q0 = ae ? t : dummy, *q1 = (ae & (n > 1u)) ? t + 1 : dummy, *q2 = (ae & (n > 2u)) ? t + 2 : dummy,
+                  *q3 = (ae & (n > 3u)) ? t + 3 : dummy;
+    e.e0 = *q0; e.e1 = *q1; e.e2 = *q2; e.e3 = *q3;
 }
 
 // LANES = raft groups per wavefront.  A lone wavefront per SIMD issues one instruction every ~4.3 cycles

@@ -30,6 +30,30 @@ def exported_symbols():
     ]
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime. The PyTorch wheel bundles its own libamdhip64.so (same SONAME as
+    /opt/rocm's); if libraftgpu.so pulled in the system copy first and torch its bundled copy later, the second
+    runtime finds no device ("no ROCm-capable device is detected"). Loading torch's copy first — by path,
+    without importing torch — makes both resolve to the same library whatever the import order. A host with no
+    torch installed (the JNI deployment) simply uses the system runtime."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -37,6 +61,7 @@ def lib():
             raise EngineError(
                 "%s is missing — build it with `make -C rafting_amd/csrc` (or __graft_entry__.build()); "
                 "there is no CPU fallback for the decision path" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         L.rg_abi_version.restype = i32

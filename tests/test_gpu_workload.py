@@ -1,0 +1,97 @@
+"""BASELINE.json's configurations at FULL size on one MI355X, bit-exact against the CPU oracle
+(the C oracle replays tens of millions of rows per second, so full size is affordable), plus the
+size-independent properties the sharded deployment relies on. `pytest -m gpu`."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+from rafting_amd import abi, engine, workload
+from tests import oracle_lib
+from tests.helpers import compare_outcomes, compare_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _replay(cfg, rounds, batches=2, first=0, count=None):
+    gen = workload.ReplayGenerator(cfg, first, count)
+    st0 = gen.initial_state()
+    gpu = engine.Table(gen.n, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc = oracle_lib.OracleTable(gen.n, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    hist = np.zeros(256, dtype=np.int64)
+    rows = 0
+    for i in range(batches):
+        b = gen.next_batch(rounds)
+        db = engine.DeviceBatch(gpu, b)
+        gpu.submit_device(db)
+        gpu.sync()
+        ref = orc.submit(b)
+        compare_outcomes(ref, db.outcome(), "%s batch %d" % (cfg.name, i))
+        db.free()
+        hist += np.bincount(ref.status, minlength=256)
+        rows += b.rounds * b.count
+    fin_o, fin_g = orc.read_state(), gpu.read_state()
+    compare_states(fin_o, fin_g, cfg.name)
+    return gen, fin_g, hist, rows
+
+
+@pytest.mark.parametrize("number,rounds", [(2, 64), (3, 48), (4, 6), (5, 6)])
+def test_baseline_config_full_size(number, rounds):
+    """configs[1..4] of BASELINE.json at their full group counts (4 096 / 65 536 / 1 M / 1 M churn)."""
+    cfg = workload.config(number)
+    gen, fin, hist, rows = _replay(cfg, rounds)
+    assert hist[abi.OK] == rows, "the replay model emitted ill-formed / stale / asserting rows: %s" % (
+        {i: int(c) for i, c in enumerate(hist) if c})
+    # the workload model tracks the protocol state on its own: it must agree with the engine's final state
+    assert np.array_equal(fin.current_term, gen.term)
+    assert np.array_equal(fin.role_epoch.astype(np.int64), gen.epoch)
+    assert np.array_equal(fin.commit_index, gen.commit)
+    assert np.array_equal(fin.last_index, gen.last)
+    roles = np.bincount(fin.role, minlength=3)
+    if number in (3, 4):
+        assert 0.1 < roles[abi.LEADER] / cfg.groups < 0.4      # the mix stays mixed
+    if number == 5:
+        assert roles[abi.CANDIDATE] > 0
+
+
+def test_shards_reproduce_the_whole():
+    """1/2/4/8-GPU runs are bit-comparable: any block shard of the group space evolves exactly like the
+    same groups inside the full table (counter-based RNG keyed by global group id, no cross-group state)."""
+    cfg = workload.config(3, 16384)
+    _, whole, _, _ = _replay(cfg, 24)
+    for first, count in ((0, 4096), (4096, 4096), (12288, 4096), (2048, 2048)):
+        _, part, _, _ = _replay(cfg, 24, first=first, count=count)
+        for name in ("current_term", "voted_for", "role", "commit_index", "last_index", "role_epoch"):
+            assert np.array_equal(getattr(part, name), getattr(whole, name)[first:first + count]), (name, first)
+        F = cfg.cluster - 1
+        assert np.array_equal(part.peer_match_index, whole.peer_match_index[first * F:(first + count) * F])
+
+
+def test_general_handlers_alone_give_the_same_answers(monkeypatch):
+    """RG_FAST=0 routes every row through the general handlers: the branch-free fast paths are a strict
+    special case of them."""
+    cfg = workload.config(3, 8192)
+    monkeypatch.setenv("RG_FAST", "0")
+    _, slow, _, _ = _replay(cfg, 32)
+    monkeypatch.delenv("RG_FAST")
+    _, fast, _, _ = _replay(cfg, 32)
+    for name in slow.fields():
+        assert np.array_equal(getattr(slow, name), getattr(fast, name)), name
+
+
+def test_rounds_are_order_preserving_across_launch_shapes():
+    """Splitting the same stream into launches of different round counts cannot change any result."""
+    cfg = workload.config(5, 4096)
+    finals = []
+    for shape in ((48,), (16, 16, 16), (1,) * 8 + (40,)):
+        gen = workload.ReplayGenerator(cfg)
+        gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        gpu.load_state(gen.initial_state())
+        for r in shape:
+            gpu.submit(gen.next_batch(r))
+        finals.append(gpu.read_state())
+    for other in finals[1:]:
+        for name in other.fields():
+            assert np.array_equal(getattr(finals[0], name), getattr(other, name)), name
