@@ -126,6 +126,16 @@ def main():
 
     copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
 
+    # ---- the same step with caller-owned HOST buffers (PCIe staging both ways): reported, never `value` ------
+    pcie = None
+    if rank == 0 and world == 1:
+        hb = gen.next_batch(args.rounds)
+        hout = abi.Outcome(hb.rounds * hb.count)
+        hout.reply[:] = 0; hout.logfx[:] = 0; hout.persist[:] = 0
+        t1 = time.perf_counter()
+        table.submit(hb, hout)
+        pcie = workload.batch_stats(hb, F)[0] / (time.perf_counter() - t1)
+
     # ---- CPU baseline + result check on the same stream (rank 0, N=1) ------------------------------
     cpu = None
     if keep_host:
@@ -189,6 +199,7 @@ def main():
                 "measured_copy_gbps": copy_gbps,
             },
             "cpu_baseline": cpu,
+            "pcie_inclusive_value": pcie,
             "counters": dict(zip(["rows", "replied", "role_conversions", "commit_advances", "asserts", "need_host",
                                   "dropped_stale", "log_appends"], counters)),
             "stage_seconds": t_gen,

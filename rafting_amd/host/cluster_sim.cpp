@@ -1,0 +1,294 @@
+// cluster_sim.cpp — BASELINE.json configs[0] on the GPU path: the reference's own demo
+// (src/test/java/.../cluster/TestNode1-3.java + cmd/FileMachine.java: three nodes, context "root", a client
+// appending lines through the leader, humans killing / restarting nodes and diffing the three output files)
+// as ONE deterministic in-process simulation.  Each node is a raftgpu::host::ContextManager (its own
+// rg_table on the GPU) holding `groups` RaftContexts; RPCs travel through an in-memory network with one tick
+// of delay; election / heartbeat timers are logical (tick 1 = raft1.xml's 300 ms tick: heartbeat x1,
+// election x3 randomised in [E, 2E]).  Every decision — vote, append, commit, role change — is taken by the
+// HIP kernels; the host only moves messages, keeps the RaftLog and the FileMachine.
+//
+// What is asserted (the reference checks "eventual file equality by eye", README.md:28-33; we check more):
+//   * election safety: never two leaders in one term of one group;
+//   * state-machine safety: the FileMachine files of all nodes agree line by line on their common prefix,
+//     at every tick;
+//   * liveness: commands keep committing, also after the leader is partitioned away and after it rejoins;
+//   * convergence: once traffic stops, all three files are identical.
+// usage: cluster_sim [groups=1] [ticks=400] [seed=1]   exit code 0 = all invariants held
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <map>
+#include <random>
+#include <set>
+#include <string>
+
+#include "raft_host.hpp"
+
+using namespace raftgpu::host;
+
+enum MsgType { AE, AE_RESP, PV, PV_RESP, RV, RV_RESP, IS, IS_RESP };
+struct Msg {
+    int from = -1, to = -1;
+    uint32_t gid;
+    MsgType type;
+    int64_t term = 0, x = 0, y = 0, z = 0;      // AE: prevIndex, prevTerm, leaderCommit; votes: lastIndex, lastTerm
+    std::vector<Entry> entries;
+    bool success = false;
+    uint32_t epoch = 0;                           // role epoch of the requester when it sent the request
+    int64_t epochAtSend = 0, lastSent = 0;        // Leader.replicateLog closure state echoed by the response
+};
+
+static const int P = 3, HEARTBEAT = 1, ELECTION = 3, FETCH = 50;   // raft1.xml:10-13, Leadership.java:10
+
+struct Group {
+    RaftContext *ctx = nullptr;
+    std::deque<Msg> inbox;
+    int64_t deadline = 0;                         // election deadline (F/C) or next heartbeat (L)
+    std::vector<std::string> file;                // FileMachine: "<index>:<line>"
+    int64_t applied = 0;
+    int inflight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // State.requestInFlight per peer
+};
+
+struct Node {
+    int id;
+    std::unique_ptr<ContextManager> mgr;
+    std::vector<Group> g;
+    bool connected = true;
+};
+
+static std::mt19937_64 rng;
+static int64_t now_tick = 0;
+static std::vector<Msg> wire, wire_next;
+static std::map<std::pair<uint32_t, int64_t>, int> leader_of_term;
+static int violations = 0;
+
+static int64_t election_timeout() { return now_tick + ELECTION + (int64_t)(rng() % (ELECTION + 1)); }
+static void fail(const char *what, uint32_t gid) { fprintf(stderr, "INVARIANT VIOLATED (tick %lld, group %u): %s\n", (long long)now_tick, gid, what); violations++; }
+static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term) + "-cmd" + std::to_string(e.index); }
+
+static void send(Node &n, Msg m) { m.from = n.id; if (n.connected) wire_next.push_back(std::move(m)); }
+
+// Leader.replicateLog (member/Leader.java:142-245): one AppendEntries per follower from its nextIndex
+static void replicate(Node &n, Group &g)
+{
+    RaftContext &c = *g.ctx;
+    RaftLog &log = c.replicatedLog();
+    auto prog = n.mgr->progress(c);
+    const Entry epoch = log.epoch();
+    for (int peer = 0; peer < P; peer++) {
+        if (peer == n.id) continue;
+        const PeerProgress &s = prog[peer < n.id ? peer : peer - 1];
+        if (s.pendingInstallation) {                               // Leader.java:168-190: InstallSnapshot(epoch) instead of entries
+            Msg m; m.to = peer; m.gid = c.gid(); m.type = IS; m.term = c.currentTerm(); m.epoch = c.roleEpoch();
+            m.x = epoch.index; m.y = epoch.term; m.epochAtSend = epoch.index;
+            send(n, std::move(m));
+            continue;
+        }
+        if (g.inflight[peer] > 20 / 10) continue;                  // IN_FLIGHT_LIMIT / 10 for heartbeats (Leader.java:162-166)
+        g.inflight[peer]++;
+        Msg m; m.to = peer; m.gid = c.gid(); m.type = AE; m.term = c.currentTerm(); m.epoch = c.roleEpoch();
+        int64_t prevIndex = epoch.index, prevTerm = epoch.term;
+        int64_t next = std::max(s.nextIndex - 1, epoch.index);
+        if (auto pe = log.get(next); pe && next > epoch.index) { prevIndex = pe->index; prevTerm = pe->term; }
+        for (int64_t i = prevIndex + 1; (int)m.entries.size() < FETCH; i++) {
+            auto e = log.get(i);
+            if (!e) break;
+            m.entries.push_back(*e);
+        }
+        m.x = prevIndex; m.y = prevTerm; m.z = log.lastCommitted();
+        m.epochAtSend = epoch.index;
+        m.lastSent = m.entries.empty() ? prevIndex : m.entries.back().index;
+        send(n, std::move(m));
+    }
+}
+
+static void broadcast_vote(Node &n, Group &g, bool pre, uint32_t epoch)
+{
+    RaftContext &c = *g.ctx;
+    auto last = c.replicatedLog().last();
+    const Entry l = last ? *last : c.replicatedLog().epoch();
+    for (int peer = 0; peer < P; peer++) {
+        if (peer == n.id) continue;
+        Msg m; m.to = peer; m.gid = c.gid(); m.type = pre ? PV : RV; m.epoch = epoch;
+        m.term = pre ? c.currentTerm() + 1 : c.currentTerm(); m.x = l.index; m.y = l.term;
+        send(n, std::move(m));
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const uint32_t groups = argc > 1 ? (uint32_t)atoi(argv[1]) : 1;
+    const int64_t ticks = argc > 2 ? atoll(argv[2]) : 400;
+    rng.seed(argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
+    std::vector<Node> nodes(P);
+    for (int k = 0; k < P; k++) {
+        nodes[k].id = k;
+        nodes[k].mgr.reset(new ContextManager(0, groups, P, k, true));
+        nodes[k].g.resize(groups);
+        for (uint32_t i = 0; i < groups; i++) {
+            Group &g = nodes[k].g[i];
+            g.ctx = &nodes[k].mgr->createContext(groups == 1 ? "root" : "ctx-" + std::to_string(i));
+            g.deadline = election_timeout();
+        }
+        nodes[k].mgr->onCommit([&nodes, k](RaftContext &c, int64_t upTo) {     // FileMachine.apply (cmd/FileMachine.java:62-84)
+            Group &g = nodes[k].g[c.gid()];
+            for (; g.applied < upTo; g.applied++) {
+                auto e = c.replicatedLog().get(g.applied + 1);
+                if (!e) { fail("commit beyond the stored log", c.gid()); return; }
+                g.file.push_back(std::to_string(e->index) + ":" + line_of(*e));
+            }
+        });
+    }
+    const int64_t cut_at = ticks / 3, heal_at = 2 * ticks / 3, quiet_at = ticks - 60;
+    int cut_node = -1;
+    uint64_t commands = 0, elections = 0, rollbacks = 0;
+
+    for (now_tick = 0; now_tick < ticks; now_tick++) {
+        for (Msg &m : wire) if (nodes[m.to].connected && nodes[m.from].connected) nodes[m.to].g[m.gid].inbox.push_back(std::move(m));
+        wire.clear();
+        if (now_tick == cut_at) {                       // "a human kills the leader's process"
+            for (Node &n : nodes) if (n.g[0].ctx->role() == RG_LEADER) cut_node = n.id;
+            if (cut_node >= 0) nodes[cut_node].connected = false;
+        }
+        if (now_tick == heal_at && cut_node >= 0) nodes[cut_node].connected = true;
+
+        for (Node &n : nodes) {
+          std::vector<char> commanded(groups, 0);
+          // broadcast timeout = 0.5 tick (raft1.xml:13): every request still unanswered a tick later has
+          // completed with a timeout error, which releases its in-flight slot (Leader.java:221,235)
+          for (Group &g : n.g) for (int &x : g.inflight) x = 0;
+          for (int sub = 0; sub < 8; sub++) {             // several EventLoop drains per tick: one row per context each
+            struct Src { Group *g; Msg msg; int what; };   // what: 0 message, 1 timer, 2 client command
+            std::vector<Src> src;
+            for (Group &g : n.g) {
+                RaftContext &c = *g.ctx;
+                if (now_tick >= g.deadline) {                       // timers are urgent (EventLoop.execute(evt, true))
+                    c.onTimeout();
+                    g.deadline = INT64_MAX;                         // re-armed by the outcome
+                    src.push_back({&g, Msg{}, 1});
+                } else if (!g.inbox.empty()) {
+                    Msg m = std::move(g.inbox.front()); g.inbox.pop_front();
+                    if (m.type == IS) {
+                        // Follower.installSnapshot (member/Follower.java:130-153) is host-side work (download + RaftLog.flush);
+                        // no compaction happens in this demo, so the snapshot at epoch (0,0) is empty: answer from the mirror
+                        Msg r; r.to = m.from; r.gid = m.gid; r.type = IS_RESP; r.term = c.currentTerm();
+                        r.success = m.term >= c.currentTerm(); r.epoch = m.epoch; r.epochAtSend = m.epochAtSend;
+                        send(n, std::move(r));
+                        continue;
+                    }
+                    switch (m.type) {
+                    case AE: c.appendEntries(m.term, m.from, m.x, m.y, m.entries, m.z); break;
+                    case PV: c.preVote(m.term, m.from, m.x, m.y); break;
+                    case RV: c.requestVote(m.term, m.from, m.x, m.y); break;
+                    case AE_RESP:
+                        if (g.inflight[m.from] > 0) g.inflight[m.from]--;
+                        c.onAppendEntriesResponse(m.from, {m.term, m.success}, m.epochAtSend, m.lastSent, m.epoch);
+                        break;
+                    case PV_RESP: c.onVoteResponse(true, m.from, {m.term, m.success}, m.epoch); break;
+                    case RV_RESP: c.onVoteResponse(false, m.from, {m.term, m.success}, m.epoch); break;
+                    case IS_RESP: c.onInstallSnapshotResponse(m.from, {m.term, m.success}, m.epochAtSend, m.epoch); break;
+                    case IS: break;
+                    }
+                    src.push_back({&g, std::move(m), 0});
+                } else if (c.role() == RG_LEADER && now_tick < quiet_at && !commanded[c.gid()] && (now_tick + c.gid()) % 2 == 0) {
+                    c.acceptCommand(1);                             // TestNode: submit(AppendCommand(...))
+                    commanded[c.gid()] = 1;
+                    src.push_back({&g, Msg{}, 2});
+                }
+            }
+            if (src.empty()) break;
+            std::vector<Outcome> out = n.mgr->flush();
+            for (size_t i = 0; i < out.size(); i++) {
+                Group &g = *src[i].g;
+                RaftContext &c = *g.ctx;
+                const Outcome &o = out[i];
+                if (o.status == RG_A_MATCH_ROLLBACK) {
+                    // reachable in the reference too: pipelined AppendEntries whose 50-entry window moved DOWN after a
+                    // late rejection are acknowledged after a longer one (Leadership.java:76-81 throws, the callback dies)
+                    rollbacks++;
+                } else if (o.status != RG_OK && o.status != RG_DROPPED_STALE_ROLE && o.status != RG_NOT_LEADER) {
+                    fprintf(stderr, "tick %lld node %d group %u: status %u\n", (long long)now_tick, n.id, c.gid(), o.status);
+                    if (o.status < RG_NPE_MAJOR_NULL) fail("an AssertionError site of the reference was reached", c.gid());
+                }
+                if (src[i].what == 0 && o.response) {
+                    const Msg &q = src[i].msg;
+                    Msg r; r.to = q.from; r.gid = q.gid; r.term = o.response->term; r.success = o.response->success;
+                    r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent;
+                    r.type = q.type == AE ? AE_RESP : q.type == PV ? PV_RESP : RV_RESP;
+                    send(n, std::move(r));
+                }
+                if (src[i].what == 2 && o.status == RG_OK) commands++;
+                if (o.roleChanged()) for (int &x : g.inflight) x = 0;          // AsyncHead.abortRequests
+                if (o.roleChanged() && o.role == RG_LEADER) {
+                    elections++;
+                    auto key = std::make_pair(c.gid(), c.currentTerm());
+                    if (leader_of_term.count(key) && leader_of_term[key] != n.id) fail("two leaders in one term", c.gid());
+                    leader_of_term[key] = n.id;
+                }
+                if (o.resetTimer()) g.deadline = o.role == RG_LEADER ? (o.roleChanged() ? now_tick + 1 : now_tick + HEARTBEAT) : election_timeout();
+                else if (g.deadline == INT64_MAX) g.deadline = o.role == RG_LEADER ? now_tick + HEARTBEAT : election_timeout();
+                if (o.emit() == RG_EMIT_PREVOTE) broadcast_vote(n, g, true, o.roleEpoch);
+                else if (o.emit() == RG_EMIT_REQVOTE) broadcast_vote(n, g, false, o.roleEpoch);
+                else if (o.emit() == RG_EMIT_HEARTBEAT) replicate(n, g);
+            }
+          }
+        }
+        // state-machine safety, every tick
+        for (uint32_t i = 0; i < groups; i++)
+            for (int a = 0; a < P; a++)
+                for (int b = a + 1; b < P; b++) {
+                    const auto &fa = nodes[a].g[i].file, &fb = nodes[b].g[i].file;
+                    for (size_t k = 0; k < std::min(fa.size(), fb.size()); k++)
+                        if (fa[k] != fb[k]) { fail("FileMachine files diverge", i); k = fa.size(); }
+                }
+        wire.swap(wire_next);
+    }
+
+    // Safety held at every tick for every group (checked above). Liveness is statistical: the reference can
+    // livelock a group for a while (a Candidate grants ANY higher-term vote — Candidate.java:69-71 — so a node
+    // with a short log can keep disrupting), hence convergence is required of >= 99 % of the groups.
+    size_t min_lines = SIZE_MAX, max_lines = 0, converged = 0;
+    std::vector<size_t> per_group;
+    for (uint32_t i = 0; i < groups; i++) {
+        bool same = true;
+        size_t lo = SIZE_MAX;
+        for (int k = 0; k < P; k++) {
+            lo = std::min(lo, nodes[k].g[i].file.size());
+            max_lines = std::max(max_lines, nodes[k].g[i].file.size());
+            same = same && nodes[k].g[i].file == nodes[0].g[i].file;
+        }
+        converged += same;
+        min_lines = std::min(min_lines, lo);
+        per_group.push_back(lo);
+    }
+    std::sort(per_group.begin(), per_group.end());
+    const size_t median_lines = per_group[per_group.size() / 2];
+    const bool identical = converged == groups;
+    uint64_t rows = 0, hints = 0;
+    for (Node &n : nodes) { rows += n.mgr->rowsDecided(); hints += n.mgr->hintsServed(); }
+    for (uint32_t i = 0; i < groups && !identical && i < 4096; i++) {
+        bool same = true;
+        for (int k = 1; k < P; k++) same = same && nodes[k].g[i].file == nodes[0].g[i].file;
+        if (!same) {
+            fprintf(stderr, "group %u:", i);
+            for (int k = 0; k < P; k++) {
+                RaftContext &c = *nodes[k].g[i].ctx;
+                auto l = c.replicatedLog().last();
+                fprintf(stderr, "  node%d role=%d term=%lld last=%lld commit=%lld lines=%zu inbox=%zu", k, c.role(), (long long)c.currentTerm(),
+                        (long long)(l ? l->index : -1), (long long)c.replicatedLog().lastCommitted(), nodes[k].g[i].file.size(), nodes[k].g[i].inbox.size());
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+    printf("groups=%u ticks=%lld commands_accepted=%llu elections=%llu partitioned_node=%d lines(min,max)=(%zu,%zu) "
+           "files_identical=%d gpu_rows=%llu hints=%llu match_rollbacks=%llu violations=%d converged=%zu median_lines=%zu\n",
+           groups, (long long)ticks, (unsigned long long)commands, (unsigned long long)elections, cut_node, min_lines, max_lines,
+           (int)identical, (unsigned long long)rows, (unsigned long long)hints, (unsigned long long)rollbacks, violations, converged,
+           median_lines);
+    if (converged * 100 < (size_t)groups * 99) fail("files did not converge after traffic stopped", 0);
+    if (median_lines < (size_t)(ticks / 8)) fail("too little progress", 0);
+    if (elections < (groups == 1 ? 2u : groups)) fail("no (re-)election happened", 0);
+    return violations ? 1 : 0;
+}

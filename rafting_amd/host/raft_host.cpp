@@ -1,0 +1,333 @@
+// raft_host.cpp — see raft_host.hpp.
+#include "raft_host.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+namespace raftgpu {
+namespace host {
+
+// ---- MemoryLog: the observable behaviour of command/storage/RocksLog.java --------------------------
+
+std::optional<Entry> MemoryLog::last() const
+{
+    if (terms_.empty()) return std::nullopt;
+    return Entry{first_ + (int64_t)terms_.size() - 1, terms_.back()};
+}
+
+std::optional<Entry> MemoryLog::get(int64_t index) const          // RocksLog.java:122-128
+{
+    if (terms_.empty() || index < first_ || index >= first_ + (int64_t)terms_.size()) return std::nullopt;
+    return Entry{index, terms_[(size_t)(index - first_)]};
+}
+
+std::optional<Entry> MemoryLog::conflict(const std::vector<Entry> &entries) const   // RocksLog.java:199-216
+{
+    for (const Entry &e : entries) {
+        auto g = get(e.index);
+        if (!g) return std::nullopt;
+        if (g->term != e.term) return Entry{e.index, g->term};
+    }
+    return std::nullopt;
+}
+
+void MemoryLog::truncate(int64_t index)                            // RocksLog.java:219-225
+{
+    auto l = last();
+    if (!l || l->index < index) return;
+    if (index <= first_) { terms_.clear(); return; }
+    terms_.resize((size_t)(index - first_));
+}
+
+void MemoryLog::append(const std::vector<Entry> &entries)          // RocksLog.java:169-196
+{
+    if (entries.empty()) return;
+    int64_t prevLogIndex = epoch_.index;
+    bool valid = false;
+    if (!terms_.empty() && first_ <= entries[0].index) {           // seekForPrev
+        prevLogIndex = std::min(last()->index, entries[0].index);
+        valid = true;
+    }
+    if (!valid && entries[0].index != prevLogIndex + 1) throw std::logic_error("log index should follow epoch closely");
+    const Entry *prev = nullptr;
+    for (const Entry &e : entries) {
+        if (prev && prev->index != e.index - 1) throw std::logic_error("log index is not continuous");
+        if (e.index > prevLogIndex) {
+            if (!prev || prev->index == prevLogIndex)
+                if (prevLogIndex != e.index - 1) throw std::logic_error("log index is not continuous");
+            if (terms_.empty()) { first_ = e.index; terms_.push_back(e.term); }
+            else if (e.index <= last()->index) terms_[(size_t)(e.index - first_)] = e.term;
+            else terms_.push_back(e.term);
+        }
+        prev = &e;
+    }
+}
+
+Entry MemoryLog::newEntry(int64_t term)                            // RocksLog.java:82-89
+{
+    auto l = last();
+    const int64_t index = l ? l->index + 1 : 1;
+    if (terms_.empty()) first_ = index;
+    terms_.push_back(term);
+    return Entry{index, term};
+}
+
+bool MemoryLog::markCommitted(int64_t commitIndex)                 // RocksLog.java:100-109
+{
+    if (commitIndex < commit_) throw std::logic_error("rollback is not allowed");
+    if (commitIndex > commit_) { commit_ = commitIndex; return true; }
+    return false;
+}
+
+void MemoryLog::flush(int64_t index, int64_t term)                 // RocksLog.java:228-242
+{
+    if (index < epoch_.index) throw std::out_of_range("flush below the epoch");
+    if (!terms_.empty()) {
+        if (index > last()->index) terms_.clear();
+        else if (index > first_) { terms_.erase(terms_.begin(), terms_.begin() + (index - first_)); first_ = index; }
+    }
+    epoch_ = Entry{index, term};
+}
+
+std::vector<Entry> MemoryLog::runs() const
+{
+    std::vector<Entry> r;
+    for (size_t i = 0; i < terms_.size(); i++)
+        if (i == 0 || terms_[i] != terms_[i - 1]) r.push_back(Entry{first_ + (int64_t)i, terms_[i]});
+    return r;
+}
+
+// ---- one-group state image for rg_load_state / rg_read_state -------------------------------------
+
+namespace {
+struct StateBuf {
+    int64_t current_term = 0, elected_term = 0, commit_index = 0, epoch_index = 0, epoch_term = 0, first_index = 0, last_index = 0;
+    int32_t voted_for = RG_NO_NODE, role = RG_FOLLOWER, current_leader = RG_NO_NODE, votes = 1;
+    uint8_t timeout_detected = 0, repl_prepared = 0;
+    uint32_t role_epoch = 1, elected_epoch = 0, run_count = 0, run_offset = 0;
+    std::vector<int64_t> run_start, run_term, pe, pn, pm;
+    std::vector<int32_t> pr;
+    std::vector<uint8_t> pp;
+    explicit StateBuf(uint32_t followers, size_t runs = RG_TERM_RUNS)
+        : run_start(runs), run_term(runs), pe(followers), pn(followers), pm(followers), pr(followers), pp(followers) {}
+    rg_group_state_t view()
+    {
+        rg_group_state_t s{};
+        s.current_term = &current_term; s.voted_for = &voted_for; s.role = &role; s.current_leader = &current_leader;
+        s.timeout_detected = &timeout_detected; s.repl_prepared = &repl_prepared; s.role_epoch = &role_epoch;
+        s.votes = &votes; s.elected_epoch = &elected_epoch; s.elected_term = &elected_term; s.commit_index = &commit_index;
+        s.epoch_index = &epoch_index; s.epoch_term = &epoch_term; s.first_index = &first_index; s.last_index = &last_index;
+        s.run_count = &run_count; s.run_offset = &run_offset; s.run_start = run_start.data(); s.run_term = run_term.data();
+        s.peer_last_epoch = pe.data(); s.peer_next_index = pn.data(); s.peer_match_index = pm.data();
+        s.peer_rejection = pr.data(); s.peer_pending = pp.data();
+        return s;
+    }
+};
+}  // namespace
+
+// ---- RaftContext: every call queues one row -----------------------------------------------------------
+
+Ticket RaftContext::appendEntries(int64_t term, ID leaderId, int64_t prevLogIndex, int64_t prevLogTerm,
+                                  const std::vector<Entry> &entries, int64_t leaderCommit)
+{
+    // the wire carries entry terms only: indices are prevLogIndex+1+k, as Leader.replicateLog builds them
+    // (member/Leader.java:192-212); anything else is what RocksLog would reject as "not continuous"
+    for (size_t k = 0; k < entries.size(); k++)
+        if (entries[k].index != prevLogIndex + 1 + (int64_t)k) throw std::logic_error("log index is not continuous");
+    if (entries.size() > RG_MAX_ENTRIES) throw std::length_error("too many entries in one AppendEntries");
+    ContextManager::Row r{this, RG_HDR_MAKE(RG_EV_AE_REQ, leaderId, 0, entries.size()), 0, term, prevLogIndex, prevLogTerm,
+                          leaderCommit, entries};
+    return mgr_->enqueue(*this, std::move(r));
+}
+Ticket RaftContext::preVote(int64_t term, ID cand, int64_t lastLogIndex, int64_t lastLogTerm)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_PV_REQ, cand, 0, 0), 0, term, lastLogIndex, lastLogTerm, 0, {}});
+}
+Ticket RaftContext::requestVote(int64_t term, ID cand, int64_t lastLogIndex, int64_t lastLogTerm)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_RV_REQ, cand, 0, 0), 0, term, lastLogIndex, lastLogTerm, 0, {}});
+}
+Ticket RaftContext::onTimeout() { return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_TIMEOUT, 0, 0, 0), 0, 0, 0, 0, 0, {}}); }
+Ticket RaftContext::onAppendEntriesResponse(ID peer, RaftResponse res, int64_t epochAtSend, int64_t lastIndexSent, uint32_t sentEpoch)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_AE_ACK, peer, res.success, 0), sentEpoch, res.term, epochAtSend, lastIndexSent, 0, {}});
+}
+Ticket RaftContext::onInstallSnapshotResponse(ID peer, RaftResponse res, int64_t epochAtSend, uint32_t sentEpoch)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_IS_ACK, peer, res.success, 0), sentEpoch, res.term, epochAtSend, 0, 0, {}});
+}
+Ticket RaftContext::onVoteResponse(bool pre, ID peer, RaftResponse res, uint32_t sentEpoch)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(pre ? RG_EV_PV_REPLY : RG_EV_RV_REPLY, peer, res.success, 0), sentEpoch, res.term, 0, 0, 0, {}});
+}
+Ticket RaftContext::acceptCommand(uint32_t commands)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_CLIENT_APPEND, 0, 0, commands), 0, 0, 0, 0, 0, {}});
+}
+Ticket RaftContext::compactLog(int64_t index, int64_t term)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_LOG_FLUSH, 0, 0, 0), 0, index, term, 0, 0, {}});
+}
+
+// ---- ContextManager ----------------------------------------------------------------------------------
+
+ContextManager::ContextManager(int device, uint32_t maxContexts, uint32_t clusterSize, ID self, bool preVote)
+    : cluster_(clusterSize), self_(self), capacity_(maxContexts), queued_(maxContexts, 0)
+{
+    if (rg_table_create(device, maxContexts, clusterSize, (uint32_t)self, preVote ? 1 : 0, &table_) != 0)
+        throw std::runtime_error(std::string("rg_table_create: ") + rg_last_error(nullptr));
+}
+
+ContextManager::~ContextManager() { rg_table_destroy(table_); }
+
+RaftContext &ContextManager::createContext(const std::string &id, int64_t restoreTerm, ID restoreBallot)
+{
+    if (by_id_.count(id)) return *by_id_[id];
+    if (contexts_.size() >= capacity_) throw std::length_error("context table is full");
+    const uint32_t gid = (uint32_t)contexts_.size();
+    contexts_.emplace_back(new RaftContext(this, id, gid, std::make_unique<MemoryLog>()));
+    RaftContext &c = *contexts_.back();
+    c.term_ = restoreTerm; c.voted_for_ = restoreBallot;
+    StateBuf sb(cluster_ - 1);                                    // RaftContext.initialize: switchTo(Follower, term, ballot)
+    sb.current_term = restoreTerm; sb.voted_for = restoreBallot;
+    rg_group_state_t v = sb.view();
+    if (rg_load_state(table_, gid, 1, &v) != 0) throw std::runtime_error(rg_last_error(table_));
+    by_id_[id] = &c;
+    return c;
+}
+
+RaftContext *ContextManager::getContext(const std::string &id)
+{
+    auto it = by_id_.find(id);
+    return it == by_id_.end() ? nullptr : it->second;
+}
+
+bool ContextManager::pending(const RaftContext &c) const { return queued_[c.gid()] != 0; }
+
+Ticket ContextManager::enqueue(RaftContext &c, Row row)
+{
+    if (queued_[c.gid()]) throw std::logic_error("one event per context per flush: call flush() first");
+    queued_[c.gid()] = 1;
+    queue_.push_back(std::move(row));
+    return queue_.size() - 1;
+}
+
+// one sparse single-round rg_submit over queue_ rows `which` (ascending gid); results land at the rows' queue positions
+void ContextManager::submit(std::vector<size_t> &which, bool hinted, std::vector<rg_reply_t> &rep,
+                            std::vector<rg_logfx_t> &lfx, std::vector<rg_persist_t> &per)
+{
+    std::sort(which.begin(), which.end(), [&](size_t x, size_t y) { return queue_[x].ctx->gid() < queue_[y].ctx->gid(); });
+    const size_t n = which.size();
+    std::vector<uint32_t> gid(n);
+    std::vector<rg_ev_head_t> head(n);
+    std::vector<rg_ev_pair_t> ab(n), cd(n), hint(hinted ? n : 0);
+    std::vector<int64_t> terms;
+    for (size_t k = 0; k < n; k++) {
+        const Row &r = queue_[which[k]];
+        gid[k] = r.ctx->gid();
+        head[k] = {r.hdr, r.aux};
+        if (RG_HDR_KIND(r.hdr) == RG_EV_AE_REQ) {
+            head[k].aux = (uint32_t)terms.size();
+            for (const Entry &e : r.entries) terms.push_back(e.term);
+        }
+        ab[k] = {r.a, r.b};
+        cd[k] = {r.c, r.d};
+        if (hinted) {
+            // the host half of the NEED_HOST protocol: answer from the RaftLog this side owns
+            RaftLog &log = r.ctx->replicatedLog();
+            head[k].hdr |= RG_HDR_HINT_BIT;
+            if (RG_HDR_KIND(r.hdr) == RG_EV_AE_REQ) {
+                auto pt = log.get(r.b);
+                std::vector<Entry> rest;                            // Follower.purgeEntries
+                for (const Entry &e : r.entries) if (e.index > log.epoch().index) rest.push_back(e);
+                auto cf = rest.empty() ? std::nullopt : log.conflict(rest);
+                hint[k] = {pt ? pt->term : -1, cf ? cf->index : 0};
+            } else {
+                const int64_t idx = lfx[which[k]].log_from;
+                auto t = log.get(idx);
+                hint[k] = {idx, t ? t->term : -1};
+            }
+            hints_served_++;
+        }
+    }
+    std::vector<rg_reply_t> o_rep(n);
+    std::vector<rg_logfx_t> o_lfx(n);
+    std::vector<rg_persist_t> o_per(n);
+    rg_batch_t in{};
+    in.rounds = 1; in.count = (uint32_t)n; in.gid = gid.data(); in.head = head.data(); in.ab = ab.data(); in.cd = cd.data();
+    in.entry_terms = terms.empty() ? nullptr : terms.data(); in.entry_count = terms.size();
+    in.hint = hinted ? hint.data() : nullptr;
+    rg_outcome_t out{o_rep.data(), o_lfx.data(), o_per.data()};
+    if (rg_submit(table_, &in, &out, RG_MEM_HOST) != 0) throw std::runtime_error(rg_last_error(table_));
+    for (size_t k = 0; k < n; k++) { rep[which[k]] = o_rep[k]; lfx[which[k]] = o_lfx[k]; per[which[k]] = o_per[k]; }
+    rows_decided_ += n;
+}
+
+std::vector<Outcome> ContextManager::flush()
+{
+    const size_t n = queue_.size();
+    std::vector<Outcome> result(n);
+    if (n == 0) return result;
+    std::vector<rg_reply_t> rep(n);
+    std::vector<rg_logfx_t> lfx(n);
+    std::vector<rg_persist_t> per(n);
+    std::vector<size_t> which(n);
+    std::iota(which.begin(), which.end(), 0);
+    submit(which, false, rep, lfx, per);
+    for (int attempt = 0; attempt < 2; attempt++) {                 // term-run cache misses: look up, resubmit with hints
+        std::vector<size_t> miss;
+        for (size_t i = 0; i < n; i++) if (RG_F_STATUS(rep[i].flags) == RG_NEED_HOST) miss.push_back(i);
+        if (miss.empty()) break;
+        submit(miss, true, rep, lfx, per);
+    }
+    for (size_t i = 0; i < n; i++) {
+        Row &r = queue_[i];
+        RaftContext &c = *r.ctx;
+        const uint32_t f = rep[i].flags, kind = RG_HDR_KIND(r.hdr);
+        RaftLog &log = c.replicatedLog();
+        // 1. log mutations, in handler order (truncate -> append / newEntry / flush)
+        if (kind == RG_EV_AE_REQ) {
+            if (f & RG_F_LOG_TRUNC) log.truncate(lfx[i].log_from);
+            if (f & RG_F_LOG_APPEND) {
+                std::vector<Entry> sub;
+                for (const Entry &e : r.entries) if (e.index >= lfx[i].log_from) sub.push_back(e);
+                log.append(sub);
+            }
+        } else if (kind == RG_EV_CLIENT_APPEND && (f & RG_F_LOG_APPEND)) {
+            for (uint32_t k = 0; k < RG_HDR_N(r.hdr); k++) log.newEntry(c.term_);
+        } else if (kind == RG_EV_LOG_FLUSH && RG_F_STATUS(f) == RG_OK) {
+            log.flush(r.a, r.b);
+        }
+        // 2. durable (term, votedFor) BEFORE the response may leave (RaftMember.java:25)
+        if (f & RG_F_PERSIST) {
+            c.term_ = per[i].term; c.voted_for_ = per[i].voted_for;
+            if (persist_) persist_(c, per[i].term, per[i].voted_for);
+        }
+        c.role_ = (int)RG_F_ROLE(f);
+        c.role_epoch_ = rep[i].role_epoch;
+        // 3. commit (RaftContext.commitLog -> RaftLog.markCommitted -> RaftRoutine.commitState)
+        if (f & RG_F_COMMIT) {
+            log.markCommitted(lfx[i].commit_index);
+            if (commit_) commit_(c, lfx[i].commit_index);
+        }
+        Outcome &o = result[i];
+        o.status = RG_F_STATUS(f); o.flags = f; o.roleEpoch = rep[i].role_epoch; o.role = c.role_;
+        if (f & RG_F_REPLIED) o.response = RaftResponse{rep[i].resp_term, (f & RG_F_SUCCESS) != 0};
+        queued_[c.gid()] = 0;
+    }
+    queue_.clear();
+    return result;
+}
+
+std::vector<PeerProgress> ContextManager::progress(const RaftContext &c)
+{
+    StateBuf sb(cluster_ - 1);
+    rg_group_state_t v = sb.view();
+    if (rg_read_state(table_, c.gid(), 1, &v) != 0) throw std::runtime_error(rg_last_error(table_));
+    std::vector<PeerProgress> p(cluster_ - 1);
+    for (uint32_t j = 0; j + 1 < cluster_; j++) p[j] = {sb.pe[j], sb.pn[j], sb.pm[j], sb.pp[j] != 0};
+    return p;
+}
+
+}  // namespace host
+}  // namespace raftgpu

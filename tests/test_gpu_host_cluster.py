@@ -1,0 +1,40 @@
+"""BASELINE.json configs[0] — the reference's 3-node file-append demo (TestNode1-3 + FileMachine) — driven
+through the C++ host mirror (rafting_amd/host) with every decision taken by the HIP kernels. `pytest -m gpu`."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "build", "cluster_sim")
+
+
+def _run(groups, ticks, seed):
+    if not os.path.exists(SIM):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rafting_amd", "host")], check=True)
+    p = subprocess.run([SIM, str(groups), str(ticks), str(seed)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    m = re.search(r"commands_accepted=(\d+) elections=(\d+) partitioned_node=(-?\d+) lines\(min,max\)=\((\d+),(\d+)\) "
+                  r"files_identical=(\d) gpu_rows=(\d+) hints=(\d+) match_rollbacks=(\d+) violations=(\d+) converged=(\d+) "
+                  r"median_lines=(\d+)", p.stdout)
+    assert m, p.stdout
+    return [int(x) for x in m.groups()]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_three_node_file_append_cluster(seed):
+    """one context "root" on three nodes; the leader is partitioned away a third of the way in and rejoins later"""
+    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(1, 400, seed)
+    assert violations == 0 and identical == 1
+    assert cut >= 0 and elections >= 2                 # a leader existed, was cut off, and a new one was elected
+    assert lo == hi and lo >= 50                       # the three FileMachine files are equal and grew
+    assert rows > 1000
+
+
+def test_many_contexts_per_node():
+    """the same cluster with 256 contexts per node: one rg_submit per node per tick decides all of them"""
+    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(256, 240, 7)
+    assert violations == 0                       # election safety + state-machine safety held for every group at every tick
+    assert converged >= 254 and median >= 30 and elections >= 256
