@@ -632,15 +632,22 @@ struct Stepper {
 
     // ---- tier 1: branch-free fast paths -----------------------------------------------------------
     // A lone wavefront per SIMD pays ~40 cycles for every divergent branch of the general handlers below
-    // (measured: ~3000 cycles for a plain heartbeat), so the three overwhelmingly common rows are decided
-    // here with selects only, under explicit preconditions that make them a strict special case of the
-    // general code (which stays the single source of truth for everything else):
-    //   * AppendEntries at a Follower of the same term, from its known leader, whose prevLog is the log tail
-    //     (member/Follower.java:35-88 with no role switch, no conflict, no purge, entries of the tail's term);
-    //   * AppendEntries ack at a prepared Leader, same role epoch, no term change, no epoch move, not pending
+    // (measured: ~3000 cycles for a plain heartbeat), so the common rows are decided here with selects only,
+    // under explicit preconditions that make them a strict special case of the general code (which stays the
+    // single source of truth for everything else):
+    //   * AppendEntries at a Follower (term >= currentTerm; a higher term or a pending pre-vote refreshes the
+    //     Follower first, member/Follower.java:45-47) whose prevLog is the log tail: no conflict, no purge,
+    //     entries of one term (member/Follower.java:35-88);
+    //   * AppendEntries ack at a prepared Leader: same role epoch, no term change, no epoch move, not pending
     //     (member/Leader.java:218-237, member/Leadership.java:75-114, member/Leader.java:247-280);
-    //   * client append at a prepared Leader whose tail is already in its own term (member/Leader.java:128-140).
-    // Any row that misses a precondition is left untouched and goes to run().
+    //   * client append at a Leader with a non-empty log (member/Leader.java:128-140);
+    //   * vote replies that only count (member/Candidate.java:127-128, member/Follower.java:264-265), late
+    //     replies to a won election that change nothing (Q13), and responses to a fenced participant.
+    // The two rare sub-cases that need more than selects (a new term run at the log tail, the first
+    // prepareReplication of a new Leader) sit behind ONE wave-level branch. Any row that misses a precondition
+    // is left untouched and goes to run().
+    // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
+    // into exec-mask branches, which is exactly what this tier exists to avoid.
     __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
                                              int64_t d, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
     {
@@ -648,28 +655,32 @@ struct Stepper {
         const bool flag = RG_HDR_FLAG(hdr) != 0;
         const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
         const int64_t g_term = g.term, g_last = g.last, g_commit = g.commit, g_epoch = g.epoch_index, g_first = g.first;
-        const int64_t lt = g.last_term(), g_s0 = g.s0;
-        const int32_t rc = g.rc, role = g.role, g_leader = g.leader;
-        const bool has_log = rc > 0;
+        const int64_t lt = g.last_term(), g_s0 = g.s0, el_term = g.elected_term;
+        const int32_t rc = g.rc, role = g.role, g_leader = g.leader, g_votes = g.votes;
+        const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
+        const bool has_log = rc > 0, g_td = g.td, g_prep = g.prepared;
+        const bool peer_ok = (slot < P) & (slot != self);
 
-        // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled
-        // back into exec-mask branches, which is exactly what this tier exists to avoid.
         // ---- AppendEntries request at a follower --------------------------------------------------
         const bool entries_ok = (n == 0) | ((n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)aux + n <= p.entry_count));
         const bool same = ((n < 2u) | (pe1 == pe0)) & ((n < 3u) | (pe2 == pe0)) & ((n < 4u) | (pe3 == pe0));
         const bool contains = c == lt;                                   // prevLogTerm == term of the tail
+        const bool refresh = (a > g_term) | g_td;                        // switchTo(Follower, term, lastCandidate)
         const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;
         const bool want_commit = contains & (d > g_epoch);
         const int64_t ae_x = min64(d, ae_last);
-        const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a == g_term) & !g.td &
-                        ((g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
-                        (b > g_epoch) & (c != 0) & entries_ok &
-                        (!contains | (n == 0) | (same & (pe0 == lt))) & !(want_commit & (ae_x < g_commit));
+        const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a >= g_term) &
+                        (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
+                        (b > g_epoch) & (c != 0) & entries_ok & (!contains | (n == 0) | same) &
+                        !(want_commit & (ae_x < g_commit));
+        const bool ae_refresh = fa & refresh;
         const bool ae_commit = fa & want_commit & (ae_x > g_commit);
         const bool ae_append = fa & contains & (n > 0);
+        const bool ae_newrun = ae_append & (pe0 != lt);
 
         // ---- AppendEntries ack at a leader ----------------------------------------------------------
-        const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & (slot < P) & (slot != self);
+        const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
+        const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
         const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
         const int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
         const int32_t s_rej = pe.rejection[j * BLOCK];
@@ -697,31 +708,64 @@ struct Stepper {
         const int64_t mt = g.term_at(major);
         const int64_t commit_to = lookup ? (mt == g_term ? major : full) : 0;
         const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
-        const bool fk = ack_shape & (aux == g.role_epoch) & (role == RG_LEADER) & g.prepared & (a <= g_term) &
+        const bool fk = ack_shape & (aux == g_repoch) & (role == RG_LEADER) & g_prep & (a <= g_term) &
                         (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
                         (!lookup | major_ok) & !(do_commit & (commit_to < g_commit));
         const bool ack_commit = fk & do_commit;
+        const bool ack_drop = allow & ack_kind & peer_ok & (aux != g_repoch);       // AsyncHead aborted: response dropped
 
         // ---- client append at a leader ----------------------------------------------------------------
-        const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log & (lt == g_term) &
-                        g.prepared;
+        const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
+        const bool fc_newrun = fc & (lt != g_term);
+        const bool fc_prepare = fc & !g_prep;
 
-        const bool fast = fa | fk | fc;
+        // ---- vote replies that only count, change nothing, or reach a fenced participant --------------
+        const bool is_pv = kind == RG_EV_PV_REPLY;
+        const bool vr_shape = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
+        const bool cur_epoch = aux == g_repoch;
+        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
+        const int64_t T = is_pv ? wadd(g_term, 1) : g_term;
+        const bool count_only = vr_shape & cur_epoch & sender_ok & (a <= T) & (!flag | (g_votes + 1 < p.majority));
+        const bool late = !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
+        const bool late_noop = vr_shape & late & (a <= el_term) &
+                               (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
+        const bool vote_drop = vr_shape & !cur_epoch & !late;
+        const bool fv = count_only | late_noop | vote_drop;
+
+        const bool fast = fa | fk | fc | fv | ack_drop;
         if (fk) {
             pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
             pe.next_index[j * BLOCK] = n_next;
             pe.match_index[j * BLOCK] = n_match;
         }
-        g.peers_dirty = g.peers_dirty | fk;
+        if (ae_newrun | fc_newrun | fc_prepare) {          // rare: one wave-level branch for both
+            if (ae_newrun | fc_newrun) g.push(wadd(g_last, 1), ae_newrun ? pe0 : g_term);
+            if (fc_prepare) {                             // Leader.prepareReplication after the FIRST new entry
+                const int64_t next = wadd(g_last, 2);
+#pragma unroll
+                for (int i = 0; i < F; i++) {
+                    pe.last_epoch[i * BLOCK] = g_epoch; pe.next_index[i * BLOCK] = next;
+                    pe.match_index[i * BLOCK] = 0; pe.rejection[i * BLOCK] = 0;
+                }
+                g.pending = 0;
+            }
+        }
+        g.prepared = g_prep | fc_prepare;
+        g.peers_dirty = g.peers_dirty | fk | fc_prepare;
+        g.term = ae_refresh ? a : g_term;
+        g.role_epoch = g_repoch + (ae_refresh ? 1u : 0u);
+        g.td = g_td & !ae_refresh;
+        g.votes = ae_refresh ? 1 : (g_votes + ((count_only & flag) ? 1 : 0));
         g.leader = fa ? (int32_t)slot : g_leader;
-        g.last = ae_append ? ae_last : (fc ? wadd(g_last, (int64_t)n) : g_last);
+        g.last = ae_append ? ae_last : (fc ? wadd(g_last, (int64_t)n) : g.last);
         g.log_dirty = g.log_dirty | ae_append | fc;
         g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
         if (fast) {
-            fx.status = RG_OK;
-            fx.resp_term = g_term;                       // == the request term on this path
+            fx.status = (ack_drop | vote_drop) ? RG_DROPPED_STALE_ROLE : RG_OK;
+            fx.resp_term = a;                            // only read for AppendEntries: the request term (== currentTerm by now)
             fx.log_from = wadd(g_last, 1);
             fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
+                       (ae_refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) |
                        ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
                        (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
         }
