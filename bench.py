@@ -166,6 +166,15 @@ def main():
                          % (len(keep_host), args.rounds * len(keep_host), gpg, cpu_dec)}
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 x2 fetch correction applied; profiles/r01_traffic.json) — only quoted when the workload matches
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if (tr["config"], tr["groups_per_gpu"], tr["rounds"]) == (args.config, gpg, args.rounds) and not args.override:
+                traffic = tr["traffic_bytes_per_launch"] / 1e9
+        except (OSError, KeyError, ValueError):
+            pass
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
         alg_per_launch = alg_bytes / max(args.steps, 1)
         achieved = alg_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -191,7 +200,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
                 "kernel": "rg::step_kernel<%d,false>" % F,
                 "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_per_launch,
