@@ -13,8 +13,9 @@ ranks (embarrassingly parallel, no collective on the data path — SURVEY.md §8
 so scaling is "weak".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      algorithmic bytes per launch / average step-kernel duration measured with
-                HIP events on the table's stream, against the 8 TB/s HBM3E peak
+  roofline      algorithmic bytes per launch / average step-kernel launch duration, measured with a
+                HIP event pair on the table's stream around the K timed launches (inter-launch gaps included),
+                against the 8 TB/s HBM3E peak
   cpu_baseline  the C restatement of the reference EventLoop path (oracle/, "port") timed on this box's
                 host cores over the same stream (rank 0, N=1 only) — a reported baseline, not the target.
 """
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rounds", type=int, default=32, help="replay rounds fused into one launch")
+    ap.add_argument("--rounds", type=int, default=64, help="replay rounds fused into one launch")
     ap.add_argument("--groups-per-gpu", type=int, default=65536)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,17 +108,17 @@ def main():
     for i in range(args.warmup):
         table.submit_device(dbatches[i])
     table.sync()
-    table.timing_enable(True)
     table.counters(reset=True)
     barrier()
     t0 = time.perf_counter()
+    table.timing_begin()                 # one HIP event pair on the table's stream around the K launches
     for i in range(args.warmup, nb):
         table.submit_device(dbatches[i])
+    kernel_ms = table.timing_end()       # records the stop event and waits for it
     table.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kernel_ms = table.timing_read()
-    table.timing_enable(False)
+    launches = args.steps
     counters = table.counters()
 
     decisions = sum(s[0] for s in stats[args.warmup:])

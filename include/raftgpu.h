@@ -263,6 +263,11 @@ void *rg_stream(rg_table_t *t);   /* the table's hipStream_t */
 int rg_timing_enable(rg_table_t *t, int on);
 /* Sum and count of step-kernel durations since the last reset (synchronises the stream). */
 int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int reset);
+/* One event pair around a whole REGION of submissions on the table's stream (cheaper than per-launch pairs, which
+ * put two timestamp packets between consecutive kernels): rg_timing_begin records the start event,
+ * rg_timing_end records the stop event, synchronises, and returns the elapsed milliseconds. */
+int rg_timing_begin(rg_table_t *t);
+int rg_timing_end(rg_table_t *t, double *elapsed_ms);
 /* Device-side decision counters accumulated by the step kernel (wave ballot + popcount, one slot
  * per wave): [0]=rows with kind!=NONE, [1]=replied, [2]=role conversions, [3]=commit advances,
  * [4]=assert statuses, [5]=NEED_HOST, [6]=dropped stale, [7]=log appends. */

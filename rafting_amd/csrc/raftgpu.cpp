@@ -44,6 +44,7 @@ struct rg_table {
     size_t ev_used = 0;
     uint64_t t_launches = 0;
     double t_total_ms = 0.0;
+    hipEvent_t region0 = nullptr, region1 = nullptr;
     std::string err;
 };
 
@@ -116,6 +117,7 @@ int rg_table_destroy(rg_table_t *t)
                     t->st_persist.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
     for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (t->region0) { (void)hipEventDestroy(t->region0); (void)hipEventDestroy(t->region1); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return 0;
@@ -481,6 +483,28 @@ int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int rese
     if (launches) *launches = t->t_launches;
     if (total_ms) *total_ms = t->t_total_ms;
     if (reset) { t->t_launches = 0; t->t_total_ms = 0.0; }
+    return 0;
+}
+
+int rg_timing_begin(rg_table_t *t)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    if (!t->region0) { HIP_TRY(t, hipEventCreate(&t->region0)); HIP_TRY(t, hipEventCreate(&t->region1)); }
+    HIP_TRY(t, hipEventRecord(t->region0, t->stream));
+    return 0;
+}
+
+int rg_timing_end(rg_table_t *t, double *elapsed_ms)
+{
+    if (!t || !elapsed_ms) return -1;
+    if (bind(t)) return -2;
+    if (!t->region0) return fail(t, -1, "rg_timing_end without rg_timing_begin");
+    HIP_TRY(t, hipEventRecord(t->region1, t->stream));
+    HIP_TRY(t, hipEventSynchronize(t->region1));
+    float ms = 0.f;
+    HIP_TRY(t, hipEventElapsedTime(&ms, t->region0, t->region1));
+    *elapsed_ms = ms;
     return 0;
 }
 

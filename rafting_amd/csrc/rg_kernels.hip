@@ -85,6 +85,13 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         }
         g.log_dirty = false; g.peers_dirty = false;
     }
+    // start the event pipeline before anything that has to wait for the state loads above
+    Event cur, near, far;
+    cur = Event{}; near = Event{}; far = Event{};
+    if (active) {
+        load_event(p, i, cur);
+        if (p.rounds > 1) load_event(p, (size_t)p.count + i, near);
+    }
     Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
     if (active && g.prepared) {
 #pragma unroll
@@ -112,13 +119,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // three-deep event pipeline: `far` = round r+2 (row loads in flight), `near` = round r+1 (header landed,
     // header-addressed loads in flight), `cur` = round r (complete). Every wait falls at the top of a
     // round, for memory operations issued a full round earlier, so their latency overlaps decision work.
-    Event cur, near, far;
-    cur = Event{}; near = Event{}; far = Event{};
-    if (active) {
-        load_event(p, i, cur);
-        load_event_tail(p, i, cur);
-        if (p.rounds > 1) load_event(p, (size_t)p.count + i, near);
-    }
+    if (active) load_event_tail(p, i, cur);
     for (uint32_t r = 0; r < p.rounds; r++) {
         const size_t row = (size_t)r * p.count + i;
         // Drain HERE, before issuing anything new: the vm counter retires in order and (on gfx9-class ISAs)

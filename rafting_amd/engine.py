@@ -26,7 +26,7 @@ def exported_symbols():
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
         "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_timing_enable",
-        "rg_timing_read", "rg_counters_read", "rg_copy_bandwidth",
+        "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
 
 
@@ -85,6 +85,8 @@ def lib():
         L.rg_stream.argtypes = [vp]
         L.rg_timing_enable.argtypes = [vp, i32]
         L.rg_timing_read.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
+        L.rg_timing_begin.argtypes = [vp]
+        L.rg_timing_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.rg_counters_read.argtypes = [vp, C.POINTER(C.c_uint64), i32]
         L.rg_copy_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
         if L.rg_abi_version() != abi.ABI_VERSION:
@@ -225,6 +227,14 @@ class Table:
         n, ms = C.c_uint64(), C.c_double()
         self._check(lib().rg_timing_read(self._h, C.byref(n), C.byref(ms), int(reset)))
         return n.value, ms.value
+
+    def timing_begin(self):
+        self._check(lib().rg_timing_begin(self._h))
+
+    def timing_end(self):
+        ms = C.c_double()
+        self._check(lib().rg_timing_end(self._h, C.byref(ms)))
+        return ms.value
 
     def counters(self, reset=False):
         arr = (C.c_uint64 * abi.NUM_COUNTERS)()
