@@ -43,8 +43,10 @@ def parse():
     ap.add_argument("--groups-per-gpu", type=int, default=65536)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batches", type=int, default=4, help="batches of the stream the CPU baseline replays")
+    ap.add_argument("--cpu-batches", type=int, default=6, help="batches of the stream the CPU baseline replays")
     ap.add_argument("--copy-bw", action="store_true", help="also measure a plain HBM copy kernel")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (single-GPU test of the N>1 path)")
+    ap.add_argument("--device", type=int, default=None, help="test only: HIP device for every rank (default LOCAL_RANK)")
     ap.add_argument("--override", default="", help="experiment only: workload overrides, e.g. leader_frac=0,p_timeout=0")
     return ap.parse_args()
 
@@ -63,11 +65,13 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
-    torch.cuda.set_device(local_rank)
+    dev = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev)
+    red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-        sync_t = torch.zeros(1, device="cuda")
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        sync_t = torch.zeros(1, device=red_dev)
 
     from rafting_amd import abi, engine, shard, workload
 
@@ -88,7 +92,7 @@ def main():
     assert count == gpg
     gen = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
     F = cfg.cluster - 1
-    table = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=local_rank)
+    table = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
     st0 = gen.initial_state()
     table.load_state(st0)
 
@@ -123,7 +127,7 @@ def main():
 
     decisions = sum(s[0] for s in stats[args.warmup:])
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
-    elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device="cuda" if world > 1 else None)
+    elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device=red_dev if world > 1 else None)
 
     copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
 

@@ -251,6 +251,46 @@ int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_
 int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace);
 int rg_sync(rg_table_t *t);
 
+/* ---- N1: the leader's send side ---------------------------------------------------------------- */
+/* Leader.replicateLog (member/Leader.java:142-245) for many leader groups at once: WHAT to send to each follower —
+ * heartbeat / entries range / InstallSnapshot — decided from nextIndex, pendingInstallation, the log window and the
+ * in-flight gate. The host then reads the payload range [prev_index+1, prev_index+count] from its RaftLog, ships the
+ * RPC tagged with head.role_epoch, and keeps (head.epoch_index, send.last_index) for the response row (AE_ACK b, c).
+ * Runs Leader.prepareReplication first for a leader that has not sent anything yet (the only state change). */
+enum {
+    RG_SEND_NONE      = 0,   /* the group is not a Leader: nothing to send                                   */
+    RG_SEND_APPEND    = 1,   /* appendEntries(term, self, prev_index, prev_term, entries[count], leaderCommit) */
+    RG_SEND_SNAPSHOT  = 2,   /* installSnapshot(term, self, epoch.index, epoch.term)  (Leader.java:168-190)   */
+    RG_SEND_GATED     = 3,   /* requestInFlight > IN_FLIGHT_LIMIT / (heartbeat ? 10 : 1)  (Leader.java:162-166) */
+    RG_SEND_NEED_HOST = 4    /* term of prev_index is below the cached runs: host reads it from its RaftLog    */
+};
+#define RG_REPLICATE_LIMIT 50    /* member/Leadership.java:10 */
+#define RG_IN_FLIGHT_LIMIT 20    /* member/Leadership.java:11 */
+
+typedef struct {                 /* one per row */
+    int64_t  term;               /* currentTerm                                    */
+    int64_t  leader_commit;      /* RaftLog.lastCommitted()                        */
+    int64_t  epoch_index;        /* RaftLog.epoch() at send time (closure state of the callback) */
+    int64_t  epoch_term;
+    uint32_t role_epoch;         /* tag for the response rows                      */
+    uint32_t is_leader;          /* 0: every send of this row is RG_SEND_NONE      */
+} rg_send_head_t;                /* 40 B */
+
+typedef struct {                 /* one per (row, follower j); j = slot<self ? slot : slot-1 */
+    int64_t  prev_index;
+    int64_t  prev_term;
+    int64_t  last_index;         /* lastIndex of Leader.replicateLog: what the success ack will claim */
+    uint32_t count;              /* entries to ship: indices prev_index+1 .. prev_index+count         */
+    uint32_t kind;               /* RG_SEND_* */
+} rg_send_t;                     /* 32 B */
+
+/* rows: `count` groups; gid NULL = groups 0..count-1 (count == table groups), else strictly ascending group ids.
+ * heartbeat[i] != 0: Leader.onTimeout path (fetch limit 25, in-flight limit 2); else the acceptCommand path (50, 20).
+ * in_flight: [count * (cluster-1)] State.requestInFlight per follower, NULL = all zero.
+ * head: [count], send: [count * (cluster-1)]. memspace as rg_submit (RG_MEM_DEVICE is asynchronous). */
+int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
+                 rg_send_head_t *head, rg_send_t *send, int memspace);
+
 /* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
 int rg_dev_alloc(rg_table_t *t, size_t bytes, void **dptr);
 int rg_dev_free(rg_table_t *t, void *dptr);

@@ -759,6 +759,56 @@ int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
     return 0;
 }
 
+/* Leader.replicateLog: member/Leader.java:142-245, with RaftLog.batch: storage/RocksLog.java:131-166 */
+int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
+                  rg_send_head_t *head, rg_send_t *send)
+{
+    if (!t || !head || !send) return -1;
+    if (gid ? count > t->groups : count != t->groups) return -1;
+    const uint32_t F = t->followers;
+    for (uint32_t i = 0; i < count; i++) {
+        if (gid && (gid[i] >= t->groups || (i && gid[i] <= gid[i - 1]))) return -1;
+        group_t *g = &t->g[gid ? gid[i] : i];
+        rg_send_head_t *h = &head[i];
+        rg_send_t *out = send + (size_t)i * F;
+        h->term = g->current_term; h->leader_commit = g->commit_index;
+        h->epoch_index = g->epoch_index; h->epoch_term = g->epoch_term;
+        h->role_epoch = g->role_epoch; h->is_leader = g->role == RG_LEADER;
+        if (g->role != RG_LEADER) {
+            for (uint32_t j = 0; j < F; j++) out[j] = (rg_send_t){0, 0, 0, 0, RG_SEND_NONE};
+            continue;
+        }
+        prepare_replication(t, g);                                               /* :146 */
+        const int hb = heartbeat && heartbeat[i];
+        const uint32_t limit = (uint32_t)(RG_IN_FLIGHT_LIMIT / (hb ? 10 : 1));      /* :162 */
+        const int64_t fetch = RG_REPLICATE_LIMIT >> (hb ? 1 : 0);                  /* :194 */
+        for (uint32_t j = 0; j < F; j++) {
+            const peer_t *s = &g->peers[j];
+            rg_send_t o = {g->epoch_index, g->epoch_term, g->epoch_index, 0, RG_SEND_APPEND};
+            const uint32_t fl = in_flight ? in_flight[(size_t)i * F + j] : 0;
+            if (fl > limit) { o.kind = RG_SEND_GATED; out[j] = o; continue; }     /* :163-166 */
+            if (s->pending) { o.kind = RG_SEND_SNAPSHOT; out[j] = o; continue; }  /* :168-190 */
+            const int64_t next = max64(wsub(s->next_index, 1), g->epoch_index);    /* :193 */
+            /* entries = log.batch(next, fetch + 1) */
+            int64_t idx = next, len = fetch + 1;
+            if (idx == g->epoch_index) { idx = wadd(idx, 1); len -= 1; }
+            int64_t got = 0, first_term = 0, t_;
+            while (got < len && log_get(&g->log, wadd(idx, got), &t_)) { if (got == 0) first_term = t_; got++; }
+            if (got > 0) {
+                if (idx == next) {                                                /* prevEntry.index() == nextIndex :197-200 */
+                    o.prev_index = next; o.prev_term = first_term;
+                    o.count = (uint32_t)(got - 1);
+                } else {
+                    o.count = (uint32_t)got;                                      /* prevEntry.index() == epoch.index()+1 :201-203 */
+                }
+                o.last_index = o.count == 0 ? o.prev_index : wadd(o.prev_index, o.count);   /* :204-208 */
+            }
+            out[j] = o;
+        }
+    }
+    return 0;
+}
+
 int orc_log_term(const orc_table_t *t, uint32_t gid, int64_t index, int64_t *term)
 {
     if (!t || gid >= t->groups) return 0;

@@ -41,6 +41,10 @@ int orc_read_state(orc_table_t *t, uint32_t first, uint32_t count, rg_group_stat
 /* same semantics as rg_submit(..., RG_MEM_HOST); never answers RG_NEED_HOST. */
 int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
 
+/* same semantics as rg_replicate(..., RG_MEM_HOST); never answers RG_SEND_NEED_HOST */
+int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
+                  rg_send_head_t *head, rg_send_t *send);
+
 /* CPU baseline: apply a dense batch with `threads` worker threads, groups assigned round-robin to
  * threads exactly like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3).
  * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */

@@ -42,6 +42,12 @@ PAIR_DT = np.dtype([("x", "<i8"), ("y", "<i8")])
 REPLY_DT = np.dtype([("resp_term", "<i8"), ("flags", "<u4"), ("role_epoch", "<u4")])
 LOGFX_DT = np.dtype([("commit_index", "<i8"), ("log_from", "<i8")])
 PERSIST_DT = np.dtype([("term", "<i8"), ("voted_for", "<i4"), ("role", "<i4")])
+SEND_HEAD_DT = np.dtype([("term", "<i8"), ("leader_commit", "<i8"), ("epoch_index", "<i8"), ("epoch_term", "<i8"),
+                         ("role_epoch", "<u4"), ("is_leader", "<u4")])
+SEND_DT = np.dtype([("prev_index", "<i8"), ("prev_term", "<i8"), ("last_index", "<i8"), ("count", "<u4"), ("kind", "<u4")])
+SEND_NONE, SEND_APPEND, SEND_SNAPSHOT, SEND_GATED, SEND_NEED_HOST = 0, 1, 2, 3, 4
+REPLICATE_LIMIT, IN_FLIGHT_LIMIT = 50, 20
+assert SEND_HEAD_DT.itemsize == 40 and SEND_DT.itemsize == 32
 assert HEAD_DT.itemsize == 8 and PAIR_DT.itemsize == 16 and REPLY_DT.itemsize == 16
 assert LOGFX_DT.itemsize == 16 and PERSIST_DT.itemsize == 16
 

@@ -18,6 +18,7 @@
 namespace rg {
 hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s);
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
+hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s);
 }  // namespace rg
 
 using rg::DevTable;
@@ -38,7 +39,7 @@ struct rg_table {
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
     int lanes = 64;                             // raft groups per wavefront (RG_LANES env: 8/16/32/64)
-    Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist;
+    Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
@@ -114,7 +115,7 @@ int rg_table_destroy(rg_table_t *t)
     void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
                     t->dt.peer_en, t->dt.peer_m, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
-                    t->st_persist.ptr};
+                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
     for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (t->region0) { (void)hipEventDestroy(t->region0); (void)hipEventDestroy(t->region1); }
@@ -413,6 +414,53 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     HIP_TRY(t, hipMemcpyAsync(out->reply, t->st_reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipMemcpyAsync(out->logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
+                 rg_send_head_t *head, rg_send_t *send, int memspace)
+{
+    if (!t) return -1;
+    if (!head || !send) return fail(t, -1, "rg_replicate: head and send are required");
+    if (gid ? count > t->G : count != t->G) return fail(t, -1, "rg_replicate: %u rows for %u groups", count, t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    rg::ReplicateParams p{};
+    p.t = t->dt; p.count = count;
+    if (memspace == RG_MEM_DEVICE) {
+        p.gid = gid; p.heartbeat = heartbeat; p.in_flight = in_flight; p.head = head; p.send = send;
+        HIP_TRY(t, rg::launch_replicate(p, (int)t->F, t->stream));
+        return 0;
+    }
+    if (memspace != RG_MEM_HOST) return fail(t, -1, "rg_replicate: unknown memspace %d", memspace);
+    if (gid)
+        for (uint32_t i = 0; i < count; i++) {
+            if (gid[i] >= t->G) return fail(t, -1, "rg_replicate: gid[%u]=%u out of range", i, gid[i]);
+            if (i && gid[i] <= gid[i - 1]) return fail(t, -1, "rg_replicate: gid must be strictly ascending (row %u)", i);
+        }
+    hipStream_t s = t->stream;
+    const size_t F = t->F;
+    if (reserve(t, t->st_sh, count * sizeof(rg_send_head_t)) || reserve(t, t->st_ss, count * F * sizeof(rg_send_t))) return -2;
+    if (gid) {
+        if (reserve(t, t->st_gid, count * sizeof(uint32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_gid.ptr, gid, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        p.gid = (const uint32_t *)t->st_gid.ptr;
+    }
+    if (heartbeat) {
+        if (reserve(t, t->st_hb, count)) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_hb.ptr, heartbeat, count, hipMemcpyHostToDevice, s));
+        p.heartbeat = (const uint8_t *)t->st_hb.ptr;
+    }
+    if (in_flight) {
+        if (reserve(t, t->st_fl, count * F * sizeof(uint16_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_fl.ptr, in_flight, count * F * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+        p.in_flight = (const uint16_t *)t->st_fl.ptr;
+    }
+    p.head = (rg_send_head_t *)t->st_sh.ptr; p.send = (rg_send_t *)t->st_ss.ptr;
+    HIP_TRY(t, rg::launch_replicate(p, (int)t->F, s));
+    HIP_TRY(t, hipMemcpyAsync(head, t->st_sh.ptr, count * sizeof(rg_send_head_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(send, t->st_ss.ptr, count * F * sizeof(rg_send_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
     return 0;
 }

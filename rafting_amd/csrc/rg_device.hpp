@@ -74,6 +74,16 @@ struct StepParams {
     int32_t fast_paths;             // 0: general handlers only
 };
 
+struct ReplicateParams {             // N1: Leader.replicateLog for many groups (rg_kernels.hip: replicate_kernel)
+    DevTable t;
+    uint32_t count;
+    const uint32_t *gid;
+    const uint8_t *heartbeat;
+    const uint16_t *in_flight;
+    rg_send_head_t *head;
+    rg_send_t *send;
+};
+
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }

@@ -237,6 +237,104 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     }
 }
 
+// N1 — Leader.replicateLog (member/Leader.java:142-245) for many groups: one lane per row, F sends per lane.
+// HBM-bound integer scan: reads the group's scalar columns + the F {lastEpoch,nextIndex} pairs, writes 40 + 32 F bytes.
+template <int F>
+__global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.count) return;
+    const uint32_t gi = p.gid ? p.gid[i] : i;
+    const uint32_t G = p.t.groups;
+    const I64x2 tc = p.t.term_commit[gi], ep = p.t.epoch[gi], w = p.t.window[gi];
+    Ident id = p.t.ident[gi];
+    const bool leader = (id.meta & META_ROLE) == RG_LEADER;
+    rg_send_head_t h;
+    h.term = tc.x; h.leader_commit = tc.y; h.epoch_index = ep.x; h.epoch_term = ep.y;
+    h.role_epoch = id.role_epoch; h.is_leader = leader ? 1u : 0u;
+    p.head[i] = h;
+    rg_send_t *out = p.send + (size_t)i * F;
+    if (!leader) {
+#pragma unroll
+        for (int j = 0; j < F; j++) out[j] = rg_send_t{0, 0, 0, 0u, RG_SEND_NONE};
+        return;
+    }
+    const int rc = (int)((id.meta >> META_RC_SHIFT) & 7u);
+    const bool has_log = rc > 0;
+    const int64_t first = w.x, last = w.y;
+    const bool hb = p.heartbeat != nullptr && p.heartbeat[i] != 0;
+    const uint32_t limit = hb ? RG_IN_FLIGHT_LIMIT / 10 : RG_IN_FLIGHT_LIMIT;
+    const int64_t fetch = hb ? RG_REPLICATE_LIMIT / 2 : RG_REPLICATE_LIMIT;
+    uint32_t pend = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+    const bool prepared = (id.meta & META_PREP) != 0;
+    if (!prepared) {                                  // Leader.prepareReplication :30-50
+        const int64_t next0 = wadd(has_log ? last : ep.x, 1);
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            p.t.peer_en[(size_t)j * G + gi] = I64x2{ep.x, next0};
+            p.t.peer_m[(size_t)j * G + gi] = Match{0, 0, 0};
+        }
+        pend = 0;
+        id.meta = (id.meta & ~(0x7Fu << META_PEND_SHIFT)) | META_PREP;
+        p.t.ident[gi] = id;
+    }
+    // cached runs (only needed for the term of prev_index)
+    const I64x2 r0 = p.t.runs[gi], r1 = p.t.runs[(size_t)G + gi], r2 = p.t.runs[(size_t)2 * G + gi], r3 = p.t.runs[(size_t)3 * G + gi];
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const uint32_t fl = p.in_flight ? p.in_flight[(size_t)i * F + j] : 0u;
+        rg_send_t s{ep.x, ep.y, ep.x, 0u, RG_SEND_APPEND};
+        if (fl > limit) {
+            s.kind = RG_SEND_GATED;
+        } else if ((pend >> j) & 1u) {
+            s.kind = RG_SEND_SNAPSHOT;
+        } else {
+            const int64_t next_index = prepared ? p.t.peer_en[(size_t)j * G + gi].y : wadd(has_log ? last : ep.x, 1);
+            const int64_t next = max64(wsub(next_index, 1), ep.x);
+            int64_t idx = next, len = fetch + 1;                  // RaftLog.batch(next, fetch + 1)  storage/RocksLog.java:131-166
+            if (idx == ep.x) { idx = wadd(idx, 1); len -= 1; }
+            int64_t avail = 0;
+            if (has_log && idx >= first && idx <= last) avail = min64(len, wsub(last, idx) + 1);
+            if (avail > 0) {
+                if (idx == next) {                                // entries[0] is the prevLog entry
+                    s.prev_index = next;
+                    if (next >= r0.x) {
+                        int64_t t = r0.y;
+                        t = (rc > 1 && r1.x <= next) ? r1.y : t;
+                        t = (rc > 2 && r2.x <= next) ? r2.y : t;
+                        t = (rc > 3 && r3.x <= next) ? r3.y : t;
+                        s.prev_term = t;
+                    } else {
+                        s.prev_term = 0;
+                        s.kind = RG_SEND_NEED_HOST;
+                    }
+                    s.count = (uint32_t)(avail - 1);
+                } else {
+                    s.count = (uint32_t)avail;
+                }
+                s.last_index = s.count == 0 ? s.prev_index : wadd(s.prev_index, (int64_t)s.count);
+            }
+        }
+        out[j] = s;
+    }
+}
+
+hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + 255) / 256;
+    if (blocks == 0) return hipSuccess;
+    switch (followers) {
+    case 1: hipLaunchKernelGGL(replicate_kernel<1>, dim3(blocks), dim3(256), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(replicate_kernel<2>, dim3(blocks), dim3(256), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(replicate_kernel<3>, dim3(blocks), dim3(256), 0, s, p); break;
+    case 4: hipLaunchKernelGGL(replicate_kernel<4>, dim3(blocks), dim3(256), 0, s, p); break;
+    case 5: hipLaunchKernelGGL(replicate_kernel<5>, dim3(blocks), dim3(256), 0, s, p); break;
+    case 6: hipLaunchKernelGGL(replicate_kernel<6>, dim3(blocks), dim3(256), 0, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

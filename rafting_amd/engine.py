@@ -25,7 +25,7 @@ def exported_symbols():
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
         "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_dev_alloc",
-        "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_timing_enable",
+        "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timing_enable",
         "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
 
@@ -77,6 +77,7 @@ def lib():
         L.rg_read_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_sync.argtypes = [vp]
+        L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.rg_dev_free.argtypes = [vp, vp]
         L.rg_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
@@ -93,6 +94,19 @@ def lib():
             raise EngineError("libraftgpu.so ABI %d != binding ABI %d" % (L.rg_abi_version(), abi.ABI_VERSION))
         _LIB = L
     return _LIB
+
+
+def _replicate(call, groups, cluster, gid, heartbeat, in_flight):
+    F = cluster - 1
+    gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
+    count = groups if gid is None else len(gid)
+    hb = None if heartbeat is None else np.ascontiguousarray(np.broadcast_to(heartbeat, (count,)), dtype=np.uint8)
+    fl = None if in_flight is None else np.ascontiguousarray(in_flight, dtype=np.uint16).reshape(count * F)
+    head = np.zeros(count, dtype=abi.SEND_HEAD_DT)
+    send = np.zeros(count * F, dtype=abi.SEND_DT)
+    ptr = lambda a: None if a is None else a.ctypes.data   # noqa: E731
+    call(count, ptr(gid), ptr(hb), ptr(fl), head.ctypes.data, send.ctypes.data)
+    return head, send.reshape(count, F)
 
 
 class DeviceBuffer:
@@ -218,6 +232,11 @@ class Table:
 
     def sync(self):
         self._check(lib().rg_sync(self._h))
+
+    def replicate(self, gid=None, heartbeat=None, in_flight=None):
+        """Leader.replicateLog for `gid` (None = every group): returns (head[count], send[count, F])."""
+        return _replicate(lambda *a: self._check(lib().rg_replicate(self._h, *a, abi.MEM_HOST)), self.groups, self.cluster,
+                          gid, heartbeat, in_flight)
 
     # measurement ---------------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -70,37 +70,39 @@ static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term)
 
 static void send(Node &n, Msg m) { m.from = n.id; if (n.connected) wire_next.push_back(std::move(m)); }
 
-// Leader.replicateLog (member/Leader.java:142-245): one AppendEntries per follower from its nextIndex
-static void replicate(Node &n, Group &g)
+// Leader.replicateLog (member/Leader.java:142-245): WHAT to send is decided on the GPU (rg_replicate, one launch for
+// all leader contexts of the node that emitted a heartbeat this drain); the host only reads the payload range
+static void replicate(Node &n, std::vector<Group *> &leaders)
 {
-    RaftContext &c = *g.ctx;
-    RaftLog &log = c.replicatedLog();
-    auto prog = n.mgr->progress(c);
-    const Entry epoch = log.epoch();
-    for (int peer = 0; peer < P; peer++) {
-        if (peer == n.id) continue;
-        const PeerProgress &s = prog[peer < n.id ? peer : peer - 1];
-        if (s.pendingInstallation) {                               // Leader.java:168-190: InstallSnapshot(epoch) instead of entries
-            Msg m; m.to = peer; m.gid = c.gid(); m.type = IS; m.term = c.currentTerm(); m.epoch = c.roleEpoch();
-            m.x = epoch.index; m.y = epoch.term; m.epochAtSend = epoch.index;
+    if (leaders.empty()) return;
+    const size_t F = P - 1;
+    std::vector<RaftContext *> ctxs;
+    std::vector<uint8_t> hb(leaders.size(), 1);
+    std::vector<uint16_t> fl;
+    for (Group *g : leaders) {
+        ctxs.push_back(g->ctx);
+        for (int peer = 0; peer < P; peer++) if (peer != n.id) fl.push_back((uint16_t)g->inflight[peer]);
+    }
+    std::vector<SendPlan> plans = n.mgr->replicateLog(ctxs, hb, fl);
+    for (size_t i = 0; i < leaders.size(); i++) {
+        Group &g = *leaders[i];
+        RaftContext &c = *g.ctx;
+        const SendPlan &pl = plans[i];
+        if (!pl.head.is_leader) continue;
+        for (size_t j = 0; j < F; j++) {
+            const rg_send_t &s = pl.to[j];
+            const int peer = (int)j < n.id ? (int)j : (int)j + 1;
+            if (s.kind == RG_SEND_GATED || s.kind == RG_SEND_NONE) continue;
+            Msg m; m.to = peer; m.gid = c.gid(); m.term = pl.head.term; m.epoch = pl.head.role_epoch; m.epochAtSend = pl.head.epoch_index;
+            if (s.kind == RG_SEND_SNAPSHOT) {
+                m.type = IS; m.x = pl.head.epoch_index; m.y = pl.head.epoch_term;
+            } else {
+                m.type = AE; m.x = s.prev_index; m.y = s.prev_term; m.z = pl.head.leader_commit; m.lastSent = s.last_index;
+                for (uint32_t k = 1; k <= s.count; k++) m.entries.push_back(*c.replicatedLog().get(s.prev_index + k));
+                g.inflight[peer]++;
+            }
             send(n, std::move(m));
-            continue;
         }
-        if (g.inflight[peer] > 20 / 10) continue;                  // IN_FLIGHT_LIMIT / 10 for heartbeats (Leader.java:162-166)
-        g.inflight[peer]++;
-        Msg m; m.to = peer; m.gid = c.gid(); m.type = AE; m.term = c.currentTerm(); m.epoch = c.roleEpoch();
-        int64_t prevIndex = epoch.index, prevTerm = epoch.term;
-        int64_t next = std::max(s.nextIndex - 1, epoch.index);
-        if (auto pe = log.get(next); pe && next > epoch.index) { prevIndex = pe->index; prevTerm = pe->term; }
-        for (int64_t i = prevIndex + 1; (int)m.entries.size() < FETCH; i++) {
-            auto e = log.get(i);
-            if (!e) break;
-            m.entries.push_back(*e);
-        }
-        m.x = prevIndex; m.y = prevTerm; m.z = log.lastCommitted();
-        m.epochAtSend = epoch.index;
-        m.lastSent = m.entries.empty() ? prevIndex : m.entries.back().index;
-        send(n, std::move(m));
     }
 }
 
@@ -200,6 +202,7 @@ int main(int argc, char **argv)
             }
             if (src.empty()) break;
             std::vector<Outcome> out = n.mgr->flush();
+            std::vector<Group *> to_replicate;
             for (size_t i = 0; i < out.size(); i++) {
                 Group &g = *src[i].g;
                 RaftContext &c = *g.ctx;
@@ -231,8 +234,9 @@ int main(int argc, char **argv)
                 else if (g.deadline == INT64_MAX) g.deadline = o.role == RG_LEADER ? now_tick + HEARTBEAT : election_timeout();
                 if (o.emit() == RG_EMIT_PREVOTE) broadcast_vote(n, g, true, o.roleEpoch);
                 else if (o.emit() == RG_EMIT_REQVOTE) broadcast_vote(n, g, false, o.roleEpoch);
-                else if (o.emit() == RG_EMIT_HEARTBEAT) replicate(n, g);
+                else if (o.emit() == RG_EMIT_HEARTBEAT) to_replicate.push_back(&g);
             }
+            replicate(n, to_replicate);
           }
         }
         // state-machine safety, every tick

@@ -319,6 +319,43 @@ std::vector<Outcome> ContextManager::flush()
     return result;
 }
 
+std::vector<SendPlan> ContextManager::replicateLog(const std::vector<RaftContext *> &ctxs, const std::vector<uint8_t> &heartbeat,
+                                                   const std::vector<uint16_t> &inFlight)
+{
+    const size_t n = ctxs.size(), F = cluster_ - 1;
+    std::vector<SendPlan> plans(n);
+    if (n == 0) return plans;
+    if (heartbeat.size() != n || (!inFlight.empty() && inFlight.size() != n * F)) throw std::invalid_argument("replicateLog: array sizes");
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return ctxs[x]->gid() < ctxs[y]->gid(); });
+    std::vector<uint32_t> gid(n);
+    std::vector<uint8_t> hb(n);
+    std::vector<uint16_t> fl(inFlight.empty() ? 0 : n * F);
+    for (size_t k = 0; k < n; k++) {
+        gid[k] = ctxs[order[k]]->gid();
+        hb[k] = heartbeat[order[k]];
+        for (size_t j = 0; j < F && !fl.empty(); j++) fl[k * F + j] = inFlight[order[k] * F + j];
+    }
+    std::vector<rg_send_head_t> head(n);
+    std::vector<rg_send_t> send(n * F);
+    if (rg_replicate(table_, (uint32_t)n, gid.data(), hb.data(), fl.empty() ? nullptr : fl.data(), head.data(), send.data(), RG_MEM_HOST) != 0)
+        throw std::runtime_error(rg_last_error(table_));
+    for (size_t k = 0; k < n; k++) {
+        SendPlan &pl = plans[order[k]];
+        pl.head = head[k];
+        pl.to.assign(send.begin() + k * F, send.begin() + (k + 1) * F);
+        for (rg_send_t &s : pl.to)
+            if (s.kind == RG_SEND_NEED_HOST) {                       // prevLogTerm straight from the log this side owns
+                auto e = ctxs[order[k]]->replicatedLog().get(s.prev_index);
+                s.prev_term = e ? e->term : 0;
+                s.kind = RG_SEND_APPEND;
+                hints_served_++;
+            }
+    }
+    return plans;
+}
+
 std::vector<PeerProgress> ContextManager::progress(const RaftContext &c)
 {
     StateBuf sb(cluster_ - 1);

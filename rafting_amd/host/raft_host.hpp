@@ -151,6 +151,11 @@ class RaftContext {
     uint32_t role_epoch_ = 1;
 };
 
+struct SendPlan {                          // what Leader.replicateLog decided for one leader context
+    rg_send_head_t head;
+    std::vector<rg_send_t> to;             // one per follower j (j = slot < self ? slot : slot - 1)
+};
+
 struct PeerProgress {                      // Leadership.State as the send side needs it
     int64_t lastEpoch, nextIndex, matchIndex;
     bool pendingInstallation;
@@ -178,6 +183,12 @@ class ContextManager {
     // The EventLoop drain: decide every queued row on the GPU, apply effects, complete tickets.
     // Outcome i answers ticket i of this flush; tickets restart at 0 afterwards.
     std::vector<Outcome> flush();
+    // Leader.replicateLog (member/Leader.java:142-245) for a set of contexts in one rg_replicate launch: which range to
+    // ship to every follower, heartbeat[i] selects the onTimeout limits; inFlight holds State.requestInFlight per
+    // (context, follower) or is empty. A send whose prevLogTerm is below the device's cached runs comes back
+    // RG_SEND_NEED_HOST and is completed here from the context's RaftLog.
+    std::vector<SendPlan> replicateLog(const std::vector<RaftContext *> &ctxs, const std::vector<uint8_t> &heartbeat,
+                                       const std::vector<uint16_t> &inFlight = {});
     // replication progress of a leader context (read back from the device)
     std::vector<PeerProgress> progress(const RaftContext &c);
 

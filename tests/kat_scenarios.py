@@ -486,6 +486,61 @@ def log_flush(mk):
     assert r.success and r.log_from == 21 and s.state().first == 21
 
 
+# --------------------------------------------------------------------------------------------------
+# N1: the leader's send side  Leader.replicateLog member/Leader.java:142-245, RaftLog.batch storage/RocksLog.java:131-166
+
+def _send(s, heartbeat, in_flight=None):
+    head, send = s.t.replicate(heartbeat=heartbeat, in_flight=in_flight)
+    rows = [(int(x["prev_index"]), int(x["prev_term"]), int(x["last_index"]), int(x["count"]), int(x["kind"])) for x in send[0]]
+    h = head[0]
+    return (int(h["term"]), int(h["leader_commit"]), int(h["epoch_index"]), int(h["epoch_term"]), int(h["role_epoch"]),
+            int(h["is_leader"])), rows
+
+
+def replicate_ranges(mk):
+    s = _sim(mk, role=L, term=5, voted_for=0, role_epoch=4, epoch=(2, 1), log=(3, [(3, 4), (8, 5)], 10), commit=6,
+             repl_prepared=1, peers=[(2, 11, 0, 0, 0), (2, 5, 4, 0, 0)])
+    head, rows = _send(s, heartbeat=1)
+    assert head == (5, 6, 2, 1, 4, 1)
+    # follower 0: nextIndex 11 -> prev = entry 10 (term 5), nothing to ship, lastIndex = prevIndex (:204-206)
+    assert rows[0] == (10, 5, 10, 0, abi.SEND_APPEND)
+    # follower 1: nextIndex 5 -> batch(4, 26): entry 4 is prevLog (term 4), entries 5..10
+    assert rows[1] == (4, 4, 10, 6, abi.SEND_APPEND)
+    s.load(role=L, term=5, voted_for=0, epoch=(2, 1), log=(3, [(3, 4)], 100), repl_prepared=1,
+           peers=[(2, 3, 0, 0, 0), (2, 40, 0, 0, 0)])
+    _, rows = _send(s, heartbeat=1)
+    # nextIndex-1 == epoch.index: batch skips the epoch key, prevLog stays the epoch, fetchLimit 25 entries (:193-203)
+    assert rows[0] == (2, 1, 27, 25, abi.SEND_APPEND)
+    assert rows[1] == (39, 4, 64, 25, abi.SEND_APPEND)
+    _, rows = _send(s, heartbeat=0)                            # acceptCommand path: REPLICATE_LIMIT 50
+    assert rows[0] == (2, 1, 52, 50, abi.SEND_APPEND) and rows[1] == (39, 4, 89, 50, abi.SEND_APPEND)
+
+
+def replicate_gates_and_snapshot(mk):
+    s = _sim(mk, role=L, term=5, voted_for=0, epoch=(20, 3), log=(21, [(21, 5)], 30), repl_prepared=1,
+             peers=[(20, 31, 30, 0, 0), (20, 20, 0, 3, 1)])
+    _, rows = _send(s, heartbeat=1, in_flight=[[3, 0]])        # 3 > IN_FLIGHT_LIMIT/10 (:162-166)
+    assert rows[0][4] == abi.SEND_GATED
+    assert rows[1] == (20, 3, 20, 0, abi.SEND_SNAPSHOT)        # pendingInstallation -> installSnapshot(epoch) (:168-190)
+    _, rows = _send(s, heartbeat=0, in_flight=[[3, 21]])       # limit 20 on the acceptCommand path
+    assert rows[0] == (30, 5, 30, 0, abi.SEND_APPEND) and rows[1][4] == abi.SEND_GATED
+    s.load(role=L, term=5, voted_for=0, epoch=(20, 3), repl_prepared=1, peers=[(20, 21, 0, 0, 0)] * 2)
+    _, rows = _send(s, heartbeat=1)                            # empty log: heartbeat on the epoch, lastIndex = epoch.index (:209-211)
+    assert rows[0] == (20, 3, 20, 0, abi.SEND_APPEND)
+
+
+def replicate_prepares_and_skips_non_leaders(mk):
+    s = _sim(mk, role=L, term=5, voted_for=0, epoch=(0, 0), log=simple_log(7, 5), role_epoch=9)
+    head, rows = _send(s, heartbeat=1)                         # first send of a new leader: prepareReplication (:146, :30-50)
+    assert head[4:] == (9, 1) and rows == [(7, 5, 7, 0, abi.SEND_APPEND)] * 2
+    st = s.state()
+    assert st.repl_prepared == 1 and st.peers == [(0, 8, 0, 0, 0)] * 2
+    s = _sim(mk, role=F, term=5)
+    head, rows = _send(s, heartbeat=1)
+    assert head[5] == 0 and all(r[4] == abi.SEND_NONE for r in rows)
+    assert s.state().repl_prepared == 0
+
+
 def none_rows_do_nothing(mk):
     s = _sim(mk, role=C, term=5, voted_for=0, role_epoch=9)
     r = s.event(abi.EV_NONE)

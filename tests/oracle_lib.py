@@ -39,6 +39,7 @@ def lib():
         L.orc_rejection_step.restype = C.c_int64
         L.orc_rejection_step.argtypes = [C.c_int32]
         L.orc_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_replicate.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
         L.orc_log_term.restype = C.c_int
         L.orc_log_term.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_log_conflict.restype = C.c_int64
@@ -88,6 +89,14 @@ class OracleTable:
         if rc:
             raise ValueError("orc_submit failed: %d" % rc)
         return out
+
+    def replicate(self, gid=None, heartbeat=None, in_flight=None):
+        from rafting_amd.engine import _replicate
+
+        def call(*a):
+            if lib().orc_replicate(self._h, *a):
+                raise ValueError("orc_replicate failed")
+        return _replicate(call, self.groups, self.cluster, gid, heartbeat, in_flight)
 
     def log_term(self, gid, index):
         """RaftLog.get(index).term() of the lossless log, None when the key does not exist."""

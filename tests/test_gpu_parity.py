@@ -205,3 +205,35 @@ def test_copy_bandwidth_reports_something_sane():
     gpu = engine.Table(8, 3)
     gbps = gpu.copy_bandwidth(1 << 28, 5)
     assert 500.0 < gbps < 8000.0
+
+
+def test_replicate_matches_oracle_on_fuzzed_state():
+    """N1: the send-side kernel against the oracle's Leader.replicateLog on states reached by random traffic."""
+    G, P = 2048, 5
+    st0 = fuzz.random_initial_state(G, P, 1, 31)
+    gpu, orc = engine.Table(G, P, 1, True), oracle_lib.OracleTable(G, P, 1, True)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    fz = fuzz.Fuzzer(G, P, 1, 31, allow_miss=False)
+    rng = np.random.default_rng(5)
+    seen = np.zeros(5, dtype=np.int64)
+    for r in range(40):
+        b = abi.Batch(1, G)
+        fz.round(gpu.read_state(), b, 0)
+        compare_outcomes(orc.submit(b, fill=0xAB), gpu.submit(b, fill=0xAB), "round %d" % r)
+        if r % 4 == 3:
+            hb = rng.integers(0, 2, G).astype(np.uint8)
+            fl = rng.choice([0, 1, 2, 3, 20, 21], size=(G, P - 1)).astype(np.uint16)
+            gids = None if r % 8 == 3 else np.flatnonzero(rng.random(G) < 0.3).astype(np.uint32)
+            sel = slice(None) if gids is None else gids
+            hg, sg = gpu.replicate(gids, hb[sel], fl[sel])
+            ho, so = orc.replicate(gids, hb[sel], fl[sel])
+            need = sg["kind"] == abi.SEND_NEED_HOST                # cache miss: the host would look prevLogTerm up itself
+            assert np.array_equal(hg, ho)
+            for f in ("prev_index", "last_index", "count"):
+                assert np.array_equal(sg[f], so[f]), f
+            assert np.array_equal(sg["kind"][~need], so["kind"][~need]) and np.array_equal(sg["prev_term"][~need], so["prev_term"][~need])
+            assert np.all(so["kind"][need] == abi.SEND_APPEND)
+            seen += np.bincount(so["kind"].reshape(-1), minlength=5)[:5]
+            compare_states(orc.read_state(), gpu.read_state(), "after replicate %d" % r)
+    assert seen[abi.SEND_NONE] and seen[abi.SEND_APPEND] and seen[abi.SEND_GATED] and seen[abi.SEND_SNAPSHOT]

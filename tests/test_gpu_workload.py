@@ -95,3 +95,25 @@ def test_rounds_are_order_preserving_across_launch_shapes():
     for other in finals[1:]:
         for name in other.fields():
             assert np.array_equal(getattr(finals[0], name), getattr(other, name)), name
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The N>1 code path of bench.py (rank-sharded streams, barrier, MAX/SUM aggregation, one JSON line from rank 0)
+    exercised with two gloo ranks sharing the only GPU of the test box; the real run uses RCCL, one GPU per rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--rounds", "8", "--groups-per-gpu", "8192", "--dist-backend", "gloo", "--device", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["groups_total"] == 16384
+    assert d["value"] > 0 and d["cpu_baseline"] is None
+    # both ranks' decisions are in the aggregate: about twice one rank's share
+    assert 1.8 < d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["decisions_per_step_per_gpu"] < 2.2
