@@ -282,12 +282,13 @@ typedef struct {                 /* one per (row, follower j); j = slot<self ? s
     int64_t  last_index;         /* lastIndex of Leader.replicateLog: what the success ack will claim */
     uint32_t count;              /* entries to ship: indices prev_index+1 .. prev_index+count         */
     uint32_t kind;               /* RG_SEND_* */
-} rg_send_t;                     /* 32 B */
+} rg_send_t;                     /* 32 B; stored follower-major: send[j * count + row], so a wavefront writes 2 KiB runs */
 
 /* rows: `count` groups; gid NULL = groups 0..count-1 (count == table groups), else strictly ascending group ids.
  * heartbeat[i] != 0: Leader.onTimeout path (fetch limit 25, in-flight limit 2); else the acceptCommand path (50, 20).
- * in_flight: [count * (cluster-1)] State.requestInFlight per follower, NULL = all zero.
- * head: [count], send: [count * (cluster-1)]. memspace as rg_submit (RG_MEM_DEVICE is asynchronous). */
+ * in_flight: [(cluster-1) * count] State.requestInFlight, follower-major like `send`; NULL = all zero.
+ * head: [count]; send: [(cluster-1) * count], element (j, row) at j * count + row.
+ * memspace as rg_submit (RG_MEM_DEVICE is asynchronous). */
 int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
                  rg_send_head_t *head, rg_send_t *send, int memspace);
 

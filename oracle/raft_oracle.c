@@ -770,12 +770,13 @@ int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uin
         if (gid && (gid[i] >= t->groups || (i && gid[i] <= gid[i - 1]))) return -1;
         group_t *g = &t->g[gid ? gid[i] : i];
         rg_send_head_t *h = &head[i];
-        rg_send_t *out = send + (size_t)i * F;
+        rg_send_t *out = send + i;                       /* follower-major: (j, row) at j * count + row */
+        const size_t os = count;
         h->term = g->current_term; h->leader_commit = g->commit_index;
         h->epoch_index = g->epoch_index; h->epoch_term = g->epoch_term;
         h->role_epoch = g->role_epoch; h->is_leader = g->role == RG_LEADER;
         if (g->role != RG_LEADER) {
-            for (uint32_t j = 0; j < F; j++) out[j] = (rg_send_t){0, 0, 0, 0, RG_SEND_NONE};
+            for (uint32_t j = 0; j < F; j++) out[j * os] = (rg_send_t){0, 0, 0, 0, RG_SEND_NONE};
             continue;
         }
         prepare_replication(t, g);                                               /* :146 */
@@ -785,9 +786,9 @@ int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uin
         for (uint32_t j = 0; j < F; j++) {
             const peer_t *s = &g->peers[j];
             rg_send_t o = {g->epoch_index, g->epoch_term, g->epoch_index, 0, RG_SEND_APPEND};
-            const uint32_t fl = in_flight ? in_flight[(size_t)i * F + j] : 0;
-            if (fl > limit) { o.kind = RG_SEND_GATED; out[j] = o; continue; }     /* :163-166 */
-            if (s->pending) { o.kind = RG_SEND_SNAPSHOT; out[j] = o; continue; }  /* :168-190 */
+            const uint32_t fl = in_flight ? in_flight[(size_t)j * os + i] : 0;
+            if (fl > limit) { o.kind = RG_SEND_GATED; out[j * os] = o; continue; }     /* :163-166 */
+            if (s->pending) { o.kind = RG_SEND_SNAPSHOT; out[j * os] = o; continue; }  /* :168-190 */
             const int64_t next = max64(wsub(s->next_index, 1), g->epoch_index);    /* :193 */
             /* entries = log.batch(next, fetch + 1) */
             int64_t idx = next, len = fetch + 1;
@@ -803,7 +804,7 @@ int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uin
                 }
                 o.last_index = o.count == 0 ? o.prev_index : wadd(o.prev_index, o.count);   /* :204-208 */
             }
-            out[j] = o;
+            out[j * os] = o;
         }
     }
     return 0;

@@ -253,10 +253,11 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
     h.term = tc.x; h.leader_commit = tc.y; h.epoch_index = ep.x; h.epoch_term = ep.y;
     h.role_epoch = id.role_epoch; h.is_leader = leader ? 1u : 0u;
     p.head[i] = h;
-    rg_send_t *out = p.send + (size_t)i * F;
+    rg_send_t *out = p.send + i;                          // follower-major: element (j, row) at j * count + row
+    const size_t ostride = p.count;
     if (!leader) {
 #pragma unroll
-        for (int j = 0; j < F; j++) out[j] = rg_send_t{0, 0, 0, 0u, RG_SEND_NONE};
+        for (int j = 0; j < F; j++) out[j * ostride] = rg_send_t{0, 0, 0, 0u, RG_SEND_NONE};
         return;
     }
     const int rc = (int)((id.meta >> META_RC_SHIFT) & 7u);
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
     const I64x2 r0 = p.t.runs[gi], r1 = p.t.runs[(size_t)G + gi], r2 = p.t.runs[(size_t)2 * G + gi], r3 = p.t.runs[(size_t)3 * G + gi];
 #pragma unroll
     for (int j = 0; j < F; j++) {
-        const uint32_t fl = p.in_flight ? p.in_flight[(size_t)i * F + j] : 0u;
+        const uint32_t fl = p.in_flight ? p.in_flight[(size_t)j * ostride + i] : 0u;
         rg_send_t s{ep.x, ep.y, ep.x, 0u, RG_SEND_APPEND};
         if (fl > limit) {
             s.kind = RG_SEND_GATED;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
                 s.last_index = s.count == 0 ? s.prev_index : wadd(s.prev_index, (int64_t)s.count);
             }
         }
-        out[j] = s;
+        out[j * ostride] = s;
     }
 }
 

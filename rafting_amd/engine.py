@@ -101,12 +101,13 @@ def _replicate(call, groups, cluster, gid, heartbeat, in_flight):
     gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
     count = groups if gid is None else len(gid)
     hb = None if heartbeat is None else np.ascontiguousarray(np.broadcast_to(heartbeat, (count,)), dtype=np.uint8)
-    fl = None if in_flight is None else np.ascontiguousarray(in_flight, dtype=np.uint16).reshape(count * F)
+    # callers pass [count, F]; the wire is follower-major [F, count]
+    fl = None if in_flight is None else np.ascontiguousarray(np.asarray(in_flight, dtype=np.uint16).reshape(count, F).T).reshape(count * F)
     head = np.zeros(count, dtype=abi.SEND_HEAD_DT)
     send = np.zeros(count * F, dtype=abi.SEND_DT)
     ptr = lambda a: None if a is None else a.ctypes.data   # noqa: E731
     call(count, ptr(gid), ptr(hb), ptr(fl), head.ctypes.data, send.ctypes.data)
-    return head, send.reshape(count, F)
+    return head, np.ascontiguousarray(send.reshape(F, count).T)
 
 
 class DeviceBuffer:

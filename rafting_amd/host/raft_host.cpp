@@ -335,7 +335,7 @@ std::vector<SendPlan> ContextManager::replicateLog(const std::vector<RaftContext
     for (size_t k = 0; k < n; k++) {
         gid[k] = ctxs[order[k]]->gid();
         hb[k] = heartbeat[order[k]];
-        for (size_t j = 0; j < F && !fl.empty(); j++) fl[k * F + j] = inFlight[order[k] * F + j];
+        for (size_t j = 0; j < F && !fl.empty(); j++) fl[j * n + k] = inFlight[order[k] * F + j];   // wire is follower-major
     }
     std::vector<rg_send_head_t> head(n);
     std::vector<rg_send_t> send(n * F);
@@ -344,7 +344,8 @@ std::vector<SendPlan> ContextManager::replicateLog(const std::vector<RaftContext
     for (size_t k = 0; k < n; k++) {
         SendPlan &pl = plans[order[k]];
         pl.head = head[k];
-        pl.to.assign(send.begin() + k * F, send.begin() + (k + 1) * F);
+        pl.to.resize(F);
+        for (size_t j = 0; j < F; j++) pl.to[j] = send[j * n + k];
         for (rg_send_t &s : pl.to)
             if (s.kind == RG_SEND_NEED_HOST) {                       // prevLogTerm straight from the log this side owns
                 auto e = ctxs[order[k]]->replicatedLog().get(s.prev_index);
