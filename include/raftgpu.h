@@ -293,6 +293,10 @@ int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8
                  rg_send_head_t *head, rg_send_t *send, int memspace);
 
 /* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
+/* Page-locked host memory for RG_MEM_HOST batches (JNI: wrap it with NewDirectByteBuffer): staging then runs at PCIe
+ * speed instead of through the driver's pageable bounce buffers. */
+int rg_host_alloc(rg_table_t *t, size_t bytes, void **hptr);
+int rg_host_free(rg_table_t *t, void *hptr);
 int rg_dev_alloc(rg_table_t *t, size_t bytes, void **dptr);
 int rg_dev_free(rg_table_t *t, void *dptr);
 int rg_copy_to_device(rg_table_t *t, void *dst, const void *src, size_t bytes);

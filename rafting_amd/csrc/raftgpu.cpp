@@ -475,6 +475,23 @@ int rg_sync(rg_table_t *t)
 
 /* ---- device memory helpers --------------------------------------------------------------------- */
 
+int rg_host_alloc(rg_table_t *t, size_t bytes, void **hptr)
+{
+    if (!t || !hptr) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+
+int rg_host_free(rg_table_t *t, void *hptr)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    HIP_TRY(t, hipHostFree(hptr));
+    return 0;
+}
+
 int rg_dev_alloc(rg_table_t *t, size_t bytes, void **dptr)
 {
     if (!t || !dptr) return -1;

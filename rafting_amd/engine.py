@@ -24,7 +24,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timing_enable",
         "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
@@ -78,6 +78,8 @@ def lib():
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_sync.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
+        L.rg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.rg_host_free.argtypes = [vp, vp]
         L.rg_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.rg_dev_free.argtypes = [vp, vp]
         L.rg_copy_to_device.argtypes = [vp, vp, vp, C.c_size_t]
@@ -108,6 +110,25 @@ def _replicate(call, groups, cluster, gid, heartbeat, in_flight):
     ptr = lambda a: None if a is None else a.ctypes.data   # noqa: E731
     call(count, ptr(gid), ptr(hb), ptr(fl), head.ctypes.data, send.ctypes.data)
     return head, np.ascontiguousarray(send.reshape(F, count).T)
+
+
+def pinned_like(table, array):
+    """A page-locked copy of `array` (rg_host_alloc) as a numpy view; keep the returned owner alive, free with .free()."""
+    a = np.ascontiguousarray(array)
+    p = C.c_void_p()
+    table._check(lib().rg_host_alloc(table._h, max(a.nbytes, 16), C.byref(p)))
+    buf = (C.c_char * max(a.nbytes, 16)).from_address(p.value)
+    view = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+    view[...] = a
+
+    class _Owner:
+        ptr = p.value
+
+        def free(self):
+            if self.ptr:
+                lib().rg_host_free(table._h, self.ptr)
+                self.ptr = None
+    return view, _Owner()
 
 
 class DeviceBuffer:

@@ -14,6 +14,8 @@
 //   * liveness: commands keep committing, also after the leader is partitioned away and after it rejoins;
 //   * convergence: once traffic stops, all three files are identical.
 // usage: cluster_sim [groups=1] [ticks=400] [seed=1]   exit code 0 = all invariants held
+#include <unistd.h>
+
 #include <algorithm>
 #include <climits>
 #include <cstdio>
@@ -53,6 +55,7 @@ struct Group {
 
 struct Node {
     int id;
+    std::unique_ptr<StableStore> store;           // N3: one journal per node instead of one StableLock file per context
     std::unique_ptr<ContextManager> mgr;
     std::vector<Group> g;
     bool connected = true;
@@ -127,7 +130,11 @@ int main(int argc, char **argv)
     std::vector<Node> nodes(P);
     for (int k = 0; k < P; k++) {
         nodes[k].id = k;
+        const std::string journal = "/tmp/rg_cluster_sim_" + std::to_string((long)getpid()) + "_node" + std::to_string(k) + ".journal";
+        ::unlink(journal.c_str());
+        nodes[k].store.reset(new StableStore(journal));
         nodes[k].mgr.reset(new ContextManager(0, groups, P, k, true));
+        nodes[k].mgr->attachStableStore(nodes[k].store.get());
         nodes[k].g.resize(groups);
         for (uint32_t i = 0; i < groups; i++) {
             Group &g = nodes[k].g[i];
@@ -270,8 +277,18 @@ int main(int argc, char **argv)
     std::sort(per_group.begin(), per_group.end());
     const size_t median_lines = per_group[per_group.size() / 2];
     const bool identical = converged == groups;
-    uint64_t rows = 0, hints = 0;
-    for (Node &n : nodes) { rows += n.mgr->rowsDecided(); hints += n.mgr->hintsServed(); }
+    uint64_t rows = 0, hints = 0, syncs = 0, persisted = 0;
+    for (Node &n : nodes) {
+        rows += n.mgr->rowsDecided(); hints += n.mgr->hintsServed();
+        syncs += n.store->syncs(); persisted += n.store->records();
+        for (Group &g : n.g) {                           // what a restart would restore == what the participant believes
+            int64_t t = 0; int32_t v = RG_NO_NODE;
+            const bool have = n.store->restore(g.ctx->gid(), &t, &v);
+            if (have ? (t != g.ctx->currentTerm() || v != g.ctx->votedFor()) : g.ctx->currentTerm() != 0)
+                fail("journal does not hold the participant's (term, votedFor)", g.ctx->gid());
+        }
+    }
+    fprintf(stderr, "durability: %llu (term, votedFor) records in %llu fdatasyncs\n", (unsigned long long)persisted, (unsigned long long)syncs);
     for (uint32_t i = 0; i < groups && !identical && i < 4096; i++) {
         bool same = true;
         for (int k = 1; k < P; k++) same = same && nodes[k].g[i].file == nodes[0].g[i].file;
@@ -291,6 +308,7 @@ int main(int argc, char **argv)
            groups, (long long)ticks, (unsigned long long)commands, (unsigned long long)elections, cut_node, min_lines, max_lines,
            (int)identical, (unsigned long long)rows, (unsigned long long)hints, (unsigned long long)rollbacks, violations, converged,
            median_lines);
+    for (int k = 0; k < P; k++) ::unlink(("/tmp/rg_cluster_sim_" + std::to_string((long)getpid()) + "_node" + std::to_string(k) + ".journal").c_str());
     if (converged * 100 < (size_t)groups * 99) fail("files did not converge after traffic stopped", 0);
     if (median_lines < (size_t)(ticks / 8)) fail("too little progress", 0);
     if (elections < (groups == 1 ? 2u : groups)) fail("no (re-)election happened", 0);

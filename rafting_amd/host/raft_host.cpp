@@ -187,6 +187,7 @@ RaftContext &ContextManager::createContext(const std::string &id, int64_t restor
     const uint32_t gid = (uint32_t)contexts_.size();
     contexts_.emplace_back(new RaftContext(this, id, gid, std::make_unique<MemoryLog>()));
     RaftContext &c = *contexts_.back();
+    if (store_) store_->restore(gid, &restoreTerm, &restoreBallot);            // StableLock.restore
     c.term_ = restoreTerm; c.voted_for_ = restoreBallot;
     StateBuf sb(cluster_ - 1);                                    // RaftContext.initialize: switchTo(Follower, term, ballot)
     sb.current_term = restoreTerm; sb.voted_for = restoreBallot;
@@ -279,6 +280,12 @@ std::vector<Outcome> ContextManager::flush()
         for (size_t i = 0; i < n; i++) if (RG_F_STATUS(rep[i].flags) == RG_NEED_HOST) miss.push_back(i);
         if (miss.empty()) break;
         submit(miss, true, rep, lfx, per);
+    }
+    if (store_) {                                                     // the durability barrier of the whole flush
+        std::vector<StableStore::Record> dirty;
+        for (size_t i = 0; i < n; i++)
+            if (rep[i].flags & RG_F_PERSIST) dirty.push_back({queue_[i].ctx->gid(), per[i].term, per[i].voted_for});
+        store_->persist(dirty);
     }
     for (size_t i = 0; i < n; i++) {
         Row &r = queue_[i];

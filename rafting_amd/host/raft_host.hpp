@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/raftgpu.h"
+#include "stable_store.hpp"
 
 namespace raftgpu {
 namespace host {
@@ -177,6 +178,9 @@ class ContextManager {
     RaftContext &createContext(const std::string &id, int64_t restoreTerm = 0, ID restoreBallot = RG_NO_NODE);
     RaftContext *getContext(const std::string &id);
     void onPersist(PersistHook h) { persist_ = std::move(h); }
+    // N3: every (term, votedFor) a flush marks RG_F_PERSIST goes to this journal with ONE write + ONE fdatasync,
+    // before any response of that flush is released; createContext restores from it.
+    void attachStableStore(StableStore *s) { store_ = s; }
     void onCommit(CommitHook h) { commit_ = std::move(h); }
 
     bool pending(const RaftContext &c) const;  // a row for this context is already queued (one per context per flush)
@@ -218,6 +222,7 @@ class ContextManager {
     std::vector<Row> queue_;
     std::vector<char> queued_;             // by gid
     PersistHook persist_;
+    StableStore *store_ = nullptr;
     CommitHook commit_;
     uint64_t rows_decided_ = 0, hints_served_ = 0;
 };
