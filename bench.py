@@ -153,7 +153,8 @@ def main():
             hb.entry_count = n2
             t1 = time.perf_counter()
             table.submit(hb, hout)
-            pcie = workload.batch_stats(hb2, F)[0] / (time.perf_counter() - t1)
+            dt = time.perf_counter() - t1
+            pcie = workload.batch_stats(hb2, F)[0] / dt
         for own in owners:
             own.free()
 

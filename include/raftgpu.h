@@ -245,9 +245,11 @@ int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_
 int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *dst);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
-/* memspace RG_MEM_HOST: caller-owned host buffers, staged over PCIe and copied back, synchronous.
+/* memspace RG_MEM_HOST: caller-owned host buffers (ideally from rg_host_alloc), staged over PCIe and copied back,
+ * synchronous; logfx/persist rows that are not flagged valid come back zeroed. Sparse gid lists are validated.
  * memspace RG_MEM_DEVICE: all pointers are device pointers (rg_dev_alloc or any hipMalloc memory on
- * the table's device); the launch is asynchronous on the table's stream — call rg_sync. */
+ * the table's device); the launch is asynchronous on the table's stream — call rg_sync. Unflagged logfx/persist
+ * rows keep their previous content; a sparse gid list is trusted (it cannot be inspected from the host). */
 int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace);
 int rg_sync(rg_table_t *t);
 

@@ -407,9 +407,9 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
         p.entry_terms = (const int64_t *)t->st_terms.ptr;
     }
     p.reply = (rg_reply_t *)t->st_reply.ptr; p.logfx = (I64x2 *)t->st_logfx.ptr; p.persist = (rg_persist_t *)t->st_persist.ptr;
-    // conditional outputs keep whatever the caller had in rows the kernel does not write
-    HIP_TRY(t, hipMemcpyAsync(t->st_logfx.ptr, out->logfx, rows * sizeof(I64x2), hipMemcpyHostToDevice, s));
-    HIP_TRY(t, hipMemcpyAsync(t->st_persist.ptr, out->persist, rows * sizeof(rg_persist_t), hipMemcpyHostToDevice, s));
+    // conditional outputs: rows the kernel does not write come back zeroed (they are only valid when flagged)
+    HIP_TRY(t, hipMemsetAsync(t->st_logfx.ptr, 0, rows * sizeof(I64x2), s));
+    HIP_TRY(t, hipMemsetAsync(t->st_persist.ptr, 0, rows * sizeof(rg_persist_t), s));
     if (int rc = launch(t, p, sparse)) return rc;
     HIP_TRY(t, hipMemcpyAsync(out->reply, t->st_reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipMemcpyAsync(out->logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
