@@ -40,6 +40,9 @@
  * errors: they are reported per row in rg_reply_t.flags status bits, bit-exactly as the
  * reference would have hit them (the handler dies, no reply is sent, earlier side effects stay).
  *
+ * Environment knobs read by rg_table_create (experiments / tests only): RG_FAST=0 routes every row through the
+ * general handlers (no fast-path tier); RG_LANES=8|16|32|64 sets the raft groups per wavefront (default 64).
+ *
  * Threading: a table is not re-entrant; one host thread + one HIP stream per table.  Different
  * tables (different GPUs) are fully independent.  No RCCL, no cross-table traffic.
  */

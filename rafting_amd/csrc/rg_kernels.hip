@@ -51,9 +51,10 @@ __device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row,
     e.e0 = *q0; e.e1 = *q1; e.e2 = *q2; e.e3 = *q3;
 }
 
-// LANES = raft groups per wavefront.  A lone wavefront per SIMD issues one instruction every ~4.3 cycles
-// (measured), so with only G/64 wavefronts on 1024 SIMDs the chip idles; narrower wavefronts (the upper
-// lanes simply masked off) put several independent instruction streams on every SIMD.
+// LANES = raft groups per wavefront (the upper lanes are simply masked off). Measured at 64 / 32 / 16 / 8 on
+// 65 536 groups: 0.193 / 0.204 / 0.358 / 0.527 ms — a half-masked wavefront still costs both passes of a wave64
+// instruction, so narrower wavefronts buy more instruction streams per SIMD but no throughput. 64 is the default;
+// the knob (RG_LANES) stays for experiments.
 template <int F, bool SPARSE, int LANES>
 __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 {
