@@ -541,6 +541,30 @@ def replicate_prepares_and_skips_non_leaders(mk):
     assert s.state().repl_prepared == 0
 
 
+def extreme_values(mk):
+    """Java longs near their limits: nothing on the path may truncate to 32 bits or misorder signed values."""
+    big = (1 << 62) + 12345
+    top = (1 << 63) - 1000
+    s = _sim(mk, role=F, term=big, voted_for=1, epoch=(top - 50, big - 3), log=(top - 49, [(top - 49, big - 2), (top - 20, big - 1)], top))
+    r = s.append_entries(big, 1, top, big - 1, [big, big], top + 1)          # append at the very end of the index space
+    assert (r.status, r.success, r.resp_term, r.log_from, r.commit) == (abi.OK, True, big, top + 1, top + 1)
+    st = s.state()
+    assert (st.last, st.last_term, st.commit) == (top + 2, big, top + 1)
+    r = s.append_entries(big + (1 << 40), 2, top - 30, big - 2, [big - 2], 0)  # higher term far away, prevLog deep in the first run
+    assert (r.success, r.resp_term, r.p_term) == (True, big + (1 << 40), big + (1 << 40))
+    assert not s.append_entries(big, 1, top, big - 1, [], 0).success          # now stale: (cur, false)
+    assert s.request_vote(big + (1 << 41), 2, top + 2, big).success
+    s = _sim(mk, cluster=5, role=L, term=big, voted_for=0, role_epoch=0xFFFFFFF0, repl_prepared=1,
+             log=(1, [(1, big)], top), peers=[(0, top - 5, top - 6, 0, 0)] * 4)
+    s.ae_ack(1, big, True, 0, top - 1, 0xFFFFFFF0)
+    r = s.ae_ack(2, big, True, 0, top - 2, 0xFFFFFFF0)
+    assert (r.status, r.commit_adv, r.commit) == (abi.OK, True, top - 2)
+    _, rows = _send(s, heartbeat=0)
+    assert rows[0] == (top - 1, big, top, 1, abi.SEND_APPEND) and rows[2] == (top - 6, big, top, 6, abi.SEND_APPEND)
+    r = s.ae_ack(3, big + 1, False, 0, 0, 0xFFFFFFF0)                          # role epoch wraps around 2^32 on the step-down
+    assert (r.role, r.role_epoch) == (F, 0xFFFFFFF1)
+
+
 def none_rows_do_nothing(mk):
     s = _sim(mk, role=C, term=5, voted_for=0, role_epoch=9)
     r = s.event(abi.EV_NONE)

@@ -105,6 +105,23 @@ def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
     assert c[0] > 0 and c[1] > 0 and c[2] > 0
 
 
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(5, 0, True, 41), (3, 2, False, 42)])
+def test_fuzz_lockstep_general_handlers_only(monkeypatch, cluster, self_slot, pre_vote, seed):
+    """Same differential replay with RG_FAST=0: with the fast-path tier on, most rows never reach the general
+    handlers, so they get their own dirty-traffic coverage here."""
+    monkeypatch.setenv("RG_FAST", "0")
+    _, _, _, hist, _, _ = _lockstep(384, cluster, self_slot, pre_vote, 100, seed, allow_miss=True)
+    assert hist[abi.OK] > 0 and hist[abi.DROPPED_STALE_ROLE] > 0
+
+
+def test_fuzz_lockstep_large():
+    """a longer run on the most common shape (5 peers): more rare-path interleavings through both tiers"""
+    _, _, _, hist, misses, _ = _lockstep(4096, 5, 3, True, 160, 43, allow_miss=True)
+    seen = set(np.flatnonzero(hist).tolist())
+    assert {abi.OK, abi.A_TWO_LEADERS, abi.A_COMMIT_ROLLBACK, abi.NPE_MAJOR_NULL, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER,
+            abi.BAD_EVENT} <= seen, seen
+
+
 def test_fuzz_multi_round_launch():
     """The same replay as ONE multi-round launch on HBM-resident buffers must equal the row-by-row result."""
     G, P = 1024, 5
