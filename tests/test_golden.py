@@ -1,0 +1,28 @@
+"""Committed fixtures (tests/golden/replay_digests.json, made by tools/make_golden.py): the oracle must still produce
+them (CPU), and the HIP path must produce them WITHOUT the oracle in the loop (GPU)."""
+import json
+import os
+
+import pytest
+
+from tools import make_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.json")))["cases"]
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_oracle_reproduces_committed_digests(name):
+    from tests import oracle_lib
+    c = GOLDEN[name]
+    got = make_golden.replay(lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_gpu_reproduces_committed_digests(name):
+    from rafting_amd import engine
+    c = GOLDEN[name]
+    got = make_golden.replay(lambda g, p, s, v: engine.Table(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""Regenerate tests/golden/replay_digests.json: SHA-256 digests of the canonical outcomes and final state of small
+replays, computed with the CPU oracle. The reference (Java) cannot run here and ships no vectors for this path, so
+these fixtures do not pin the oracle to the REFERENCE — they pin it to ITSELF across rounds (any change of restated
+semantics must be deliberate and show up as a fixture diff), and they let the GPU path be checked against committed
+vectors without the oracle in the loop.  usage: python tools/make_golden.py"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rafting_amd import abi, workload  # noqa: E402
+
+CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048, 32)]
+
+
+def canonical_outcome_digest(out):
+    """digest of an Outcome with every field that is not flagged valid forced to zero"""
+    f = out.reply["flags"]
+    rep = out.reply.copy()
+    rep["resp_term"][(f & abi.F_REPLIED) == 0] = 0
+    lfx = out.logfx.copy()
+    lfx["commit_index"][(f & (abi.F_COMMIT | abi.F_LOG_APPEND | abi.F_LOG_TRUNC)) == 0] = 0
+    lfx["log_from"][(f & (abi.F_LOG_APPEND | abi.F_LOG_TRUNC)) == 0] = 0
+    per = out.persist.copy()
+    per[(f & abi.F_PERSIST) == 0] = (0, 0, 0)
+    h = hashlib.sha256()
+    for a in (rep, lfx, per):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def state_digest(st):
+    h = hashlib.sha256()
+    for n in ("current_term", "voted_for", "role", "current_leader", "timeout_detected", "repl_prepared", "role_epoch", "votes",
+              "elected_epoch", "elected_term", "commit_index", "epoch_index", "epoch_term", "first_index", "last_index",
+              "peer_last_epoch", "peer_next_index", "peer_match_index", "peer_rejection", "peer_pending"):
+        h.update(np.ascontiguousarray(getattr(st, n)).tobytes())
+    return h.hexdigest()
+
+
+def replay(make_table, number, groups, rounds):
+    cfg = workload.config(number, groups)
+    gen = workload.ReplayGenerator(cfg)
+    t = make_table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    t.load_state(gen.initial_state())
+    b = gen.next_batch(rounds)
+    inputs = hashlib.sha256(b.head.tobytes() + b.ab.tobytes() + b.cd.tobytes() + b.entry_terms[: b.entry_count].tobytes()).hexdigest()
+    out = t.submit(b)
+    return {"inputs": inputs, "outcomes": canonical_outcome_digest(out), "state": state_digest(t.read_state())}
+
+
+def main():
+    from tests import oracle_lib
+    mk = lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v)   # noqa: E731
+    doc = {"generator": "tools/make_golden.py (CPU oracle)", "cases": {}}
+    for name, number, groups, rounds in CASES:
+        doc["cases"][name] = dict(number=number, groups=groups, rounds=rounds, **replay(mk, number, groups, rounds))
+    path = os.path.join(ROOT, "tests", "golden", "replay_digests.json")
+    json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()
