@@ -297,6 +297,29 @@ typedef struct {                 /* one per (row, follower j); j = slot<self ? s
 int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
                  rg_send_head_t *head, rg_send_t *send, int memspace);
 
+/* ---- N4: election / heartbeat timers on the device ------------------------------------------------ */
+/* RaftRoutine.resetTimer / electionTimeout / keepAlive (context/RaftRoutine.java:53-130) for all groups: instead of two
+ * ScheduledFuture operations per AppendEntries on the host, one deadline per group lives in HBM.
+ *   rg_timers_update  folds the RG_F_RESET_TIMER / RG_F_ROLE_CHANGED flags of a finished batch into the deadlines:
+ *                     Follower/Candidate -> now + election timeout drawn uniformly from [E, 2E] (RaftConfig.java:187-190;
+ *                     the draw is splitmix64(seed, gid, role_epoch, now), not Java's ThreadLocalRandom), a new Leader ->
+ *                     now (first heartbeat at once), a Leader's tick -> now + H. A ticket that already fired is only
+ *                     replaced by a new participant (TimerTicket.TIMEOUT makes resetTimer return false).
+ *   rg_timers_expired lists, in ascending group order, every group whose deadline has passed (wavefront ballot +
+ *                     popcount compaction) and marks its ticket fired: the host turns each into one RG_EV_TIMEOUT row.
+ * now / deadlines are milliseconds on any monotonic clock of the host's choosing; deadline 0 = no ticket yet. */
+int rg_timers_configure(rg_table_t *t, int64_t election_ms, int64_t heartbeat_ms, uint64_t seed);
+/* reply: the rg_reply_t rows of the batch just submitted ([rounds*count], same gid convention as rg_submit);
+ * now: [rounds] timestamp of every round. memspace applies to reply and gid (now is always a host array). */
+int rg_timers_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_reply_t *reply,
+                     const int64_t *now, int memspace);
+/* out_gid: caller buffer for up to `capacity` group ids (host or device per memspace); *out_count receives the number of
+ * expired groups (may exceed capacity: then only the first `capacity` were written AND marked fired). Synchronous. */
+int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count, int memspace);
+/* arm every group that has no ticket yet (after rg_load_state): role from the table, as rg_timers_update would */
+int rg_timers_arm(rg_table_t *t, int64_t now);
+int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
+
 /* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
 /* Page-locked host memory for RG_MEM_HOST batches (JNI: wrap it with NewDirectByteBuffer): staging then runs at PCIe
  * speed instead of through the driver's pageable bounce buffers. */

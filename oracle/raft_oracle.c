@@ -50,6 +50,9 @@ typedef struct {
 } group_t;
 
 struct orc_table {
+    int64_t *deadline;           /* N4: per-group timer ticket: 0 none, -1 fired (TimerTicket.TIMEOUT), >0 armed */
+    int64_t election_ms, heartbeat_ms;
+    uint64_t timer_seed;
     uint32_t groups, cluster, self, followers;
     int      pre_vote;
     int      majority;           /* RaftContext.majority()  context/RaftContext.java:170 */
@@ -629,7 +632,9 @@ orc_table_t *orc_table_create(uint32_t groups, uint32_t cluster, uint32_t self_s
     t->pre_vote = pre_vote != 0;
     t->majority = (int)(cluster / 2 + 1);
     t->g = (group_t *)calloc(groups, sizeof(group_t));
-    if (!t->g) { free(t); return NULL; }
+    t->deadline = (int64_t *)calloc(groups, sizeof(int64_t));
+    t->election_ms = 900; t->heartbeat_ms = 300;
+    if (!t->g || !t->deadline) { free(t->g); free(t->deadline); free(t); return NULL; }
     for (uint32_t i = 0; i < groups; i++) {
         t->g[i].voted_for = RG_NO_NODE;
         t->g[i].current_leader = RG_NO_NODE;
@@ -644,6 +649,7 @@ void orc_table_destroy(orc_table_t *t)
     if (!t) return;
     for (uint32_t i = 0; i < t->groups; i++) free(t->g[i].log.r);
     free(t->g);
+    free(t->deadline);
     free(t);
 }
 
@@ -653,6 +659,7 @@ int orc_load_state(orc_table_t *t, uint32_t first, uint32_t count, const rg_grou
     const uint32_t F = t->followers;
     for (uint32_t i = 0; i < count; i++) {
         group_t *g = &t->g[first + i];
+        t->deadline[first + i] = 0;
         g->current_term = s->current_term[i];
         g->voted_for = s->voted_for[i];
         g->role = s->role[i];
@@ -807,6 +814,89 @@ int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uin
             out[j * os] = o;
         }
     }
+    return 0;
+}
+
+/* ---- N4 timers: RaftRoutine.resetTimer / electionTimeout / keepAlive  context/RaftRoutine.java:53-130 ---------- */
+
+static uint64_t timer_mix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+/* RaftConfig.electionTimeout: uniform in [E, 2E] (support/RaftConfig.java:187-190); the draw itself is ours */
+static int64_t election_timeout(uint64_t seed, uint32_t gid, uint32_t role_epoch, int64_t now, int64_t E)
+{
+    uint64_t h = timer_mix(seed ^ timer_mix((uint64_t)gid * 0xD1342543DE82EF95ull ^ ((uint64_t)role_epoch << 32) ^ (uint64_t)now));
+    return E + (int64_t)(h % (uint64_t)(E + 1));
+}
+
+/* the deadline resetTimer leaves behind: a handler mutes (deadline MAX) and un-mutes, so the un-muted reset sees
+ * moment == MAX and lands on now + timeout (:105-107); a Leader is re-scheduled heartbeatInterval ahead, at once
+ * when the ticket is new (:117-118); a ticket that already fired (moment < 0) is not replaced (:96-98) */
+static int64_t rearm(const orc_table_t *t, int64_t d, uint32_t gid, int role, int fresh, uint32_t role_epoch, int64_t now)
+{
+    if (fresh) d = 0;                                            /* convertTo: ticketHolder.set(null) :198 */
+    if (role == RG_LEADER) return d == 0 ? now : wadd(now, t->heartbeat_ms);
+    if (d < 0) return d;
+    return wadd(now, election_timeout(t->timer_seed, gid, role_epoch, now, t->election_ms));
+}
+
+int orc_timers_configure(orc_table_t *t, int64_t election_ms, int64_t heartbeat_ms, uint64_t seed)
+{
+    if (!t || election_ms <= 0 || heartbeat_ms <= 0) return -1;
+    t->election_ms = election_ms; t->heartbeat_ms = heartbeat_ms; t->timer_seed = seed;
+    return 0;
+}
+
+int orc_timers_update(orc_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_reply_t *reply, const int64_t *now)
+{
+    if (!t || !reply || !now || rounds == 0) return -1;
+    if (gid ? (rounds != 1 || count > t->groups) : count != t->groups) return -1;
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t g = gid ? gid[i] : i;
+        if (g >= t->groups) return -1;
+        int64_t d = t->deadline[g];
+        for (uint32_t r = 0; r < rounds; r++) {
+            const rg_reply_t *rep = &reply[(size_t)r * count + i];
+            if (rep->flags & RG_F_RESET_TIMER)
+                d = rearm(t, d, g, (int)RG_F_ROLE(rep->flags), (rep->flags & RG_F_ROLE_CHANGED) != 0, rep->role_epoch, now[r]);
+        }
+        t->deadline[g] = d;
+    }
+    return 0;
+}
+
+int orc_timers_arm(orc_table_t *t, int64_t now)
+{
+    if (!t) return -1;
+    for (uint32_t g = 0; g < t->groups; g++)
+        if (t->deadline[g] == 0) t->deadline[g] = rearm(t, 0, g, t->g[g].role, 1, t->g[g].role_epoch, now);
+    return 0;
+}
+
+/* electionTimeout / keepAlive firing: deadline reached -> CAS to TimerTicket.TIMEOUT, onTimeout gets queued (:53-77) */
+int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count)
+{
+    if (!t || !out_count) return -1;
+    uint32_t n = 0;
+    for (uint32_t g = 0; g < t->groups; g++) {
+        if (t->deadline[g] > 0 && t->deadline[g] <= now) {
+            if (n < capacity) { out_gid[n] = g; t->deadline[g] = -1; }
+            n++;
+        }
+    }
+    *out_count = n;
+    return 0;
+}
+
+int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline)
+{
+    if (!t || !deadline || (uint64_t)first + count > t->groups) return -1;
+    memcpy(deadline, t->deadline + first, (size_t)count * sizeof(int64_t));
     return 0;
 }
 

@@ -45,6 +45,13 @@ int orc_submit(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
 int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
                   rg_send_head_t *head, rg_send_t *send);
 
+/* N4 timers: same semantics as rg_timers_configure / _update / _arm / _expired / _read (host memory) */
+int orc_timers_configure(orc_table_t *t, int64_t election_ms, int64_t heartbeat_ms, uint64_t seed);
+int orc_timers_update(orc_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_reply_t *reply, const int64_t *now);
+int orc_timers_arm(orc_table_t *t, int64_t now);
+int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count);
+int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
+
 /* CPU baseline: apply a dense batch with `threads` worker threads, groups assigned round-robin to
  * threads exactly like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3).
  * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */

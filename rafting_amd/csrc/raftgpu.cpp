@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,10 @@ namespace rg {
 hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s);
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s);
+hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
+hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
+hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+                                 uint32_t *out_gid, uint32_t capacity, hipStream_t s);
 }  // namespace rg
 
 using rg::DevTable;
@@ -46,6 +51,11 @@ struct rg_table {
     uint64_t t_launches = 0;
     double t_total_ms = 0.0;
     hipEvent_t region0 = nullptr, region1 = nullptr;
+    int64_t *timer_deadline = nullptr;          // [G] N4
+    uint32_t *timer_counts = nullptr;           // [waves + 1]: per-wave counts / offsets, last = total
+    int64_t election_ms = 900, heartbeat_ms = 300;   // raft1.xml:10-13
+    uint64_t timer_seed = 0;
+    Staging st_tgid;
     std::string err;
 };
 
@@ -115,7 +125,8 @@ int rg_table_destroy(rg_table_t *t)
     void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
                     t->dt.peer_en, t->dt.peer_m, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
-                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr};
+                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline,
+                    t->timer_counts, t->st_tgid.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
     for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (t->region0) { (void)hipEventDestroy(t->region0); (void)hipEventDestroy(t->region1); }
@@ -170,6 +181,9 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     t->counter_slots = (G + 7) / 8;             // enough for the narrowest wavefronts
     CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
     t->dt.groups = groups;
+    CREATE_TRY(hipMalloc((void **)&t->timer_deadline, G * sizeof(int64_t)));
+    CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 63) / 64 + 1) * sizeof(uint32_t)));
+    CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.term_commit, 0, G * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.epoch, 0, G * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.window, 0, G * sizeof(I64x2), t->stream));
@@ -254,6 +268,7 @@ int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_
         HIP_TRY(t, hipMemcpyAsync(t->dt.peer_en + j * G + first, en.data() + j * n, n * sizeof(I64x2), hipMemcpyHostToDevice, st));
         HIP_TRY(t, hipMemcpyAsync(t->dt.peer_m + j * G + first, pm.data() + j * n, n * sizeof(rg::Match), hipMemcpyHostToDevice, st));
     }
+    HIP_TRY(t, hipMemsetAsync(t->timer_deadline + first, 0, n * sizeof(int64_t), st));   // loaded groups hold no timer ticket yet
     HIP_TRY(t, hipStreamSynchronize(st));
     return 0;
 }
@@ -462,6 +477,109 @@ int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8
     HIP_TRY(t, hipMemcpyAsync(head, t->st_sh.ptr, count * sizeof(rg_send_head_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipMemcpyAsync(send, t->st_ss.ptr, count * F * sizeof(rg_send_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+/* ---- N4: timers --------------------------------------------------------------------------------------- */
+
+int rg_timers_configure(rg_table_t *t, int64_t election_ms, int64_t heartbeat_ms, uint64_t seed)
+{
+    if (!t) return -1;
+    if (election_ms <= 0 || heartbeat_ms <= 0 || election_ms > (INT64_MAX >> 2)) return fail(t, -1, "rg_timers_configure: bad intervals");
+    t->election_ms = election_ms; t->heartbeat_ms = heartbeat_ms; t->timer_seed = seed;
+    return 0;
+}
+
+static rg::TimerParams timer_params(rg_table *t)
+{
+    rg::TimerParams p{};
+    p.deadline = t->timer_deadline; p.ident = t->dt.ident; p.groups = t->G;
+    p.election_ms = t->election_ms; p.heartbeat_ms = t->heartbeat_ms; p.seed = t->timer_seed;
+    return p;
+}
+
+int rg_timers_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_reply_t *reply,
+                     const int64_t *now, int memspace)
+{
+    if (!t) return -1;
+    if (!reply || !now || rounds == 0) return fail(t, -1, "rg_timers_update: reply, now and rounds are required");
+    if (gid ? (rounds != 1 || count > t->G) : count != t->G) return fail(t, -1, "rg_timers_update: %u rows for %u groups", count, t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    const size_t rows = (size_t)rounds * count;
+    const rg_reply_t *d_reply = reply;
+    const uint32_t *d_gid = gid;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_reply, rows * sizeof(rg_reply_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_reply.ptr, reply, rows * sizeof(rg_reply_t), hipMemcpyHostToDevice, s));
+        d_reply = (const rg_reply_t *)t->st_reply.ptr;
+        if (gid) {
+            for (uint32_t i = 0; i < count; i++)
+                if (gid[i] >= t->G || (i && gid[i] <= gid[i - 1])) return fail(t, -1, "rg_timers_update: bad gid list at row %u", i);
+            if (reserve(t, t->st_gid, count * sizeof(uint32_t))) return -2;
+            HIP_TRY(t, hipMemcpyAsync(t->st_gid.ptr, gid, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            d_gid = (const uint32_t *)t->st_gid.ptr;
+        }
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_timers_update: unknown memspace %d", memspace);
+    }
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 64) {               // <= 64 timestamps travel in the kernel arguments
+        rg::TimerParams p = timer_params(t);
+        p.rounds = rounds - r0 < 64 ? rounds - r0 : 64; p.count = count; p.gid = d_gid;
+        p.reply = d_reply + (size_t)r0 * count;
+        for (uint32_t k = 0; k < p.rounds; k++) p.now[k] = now[r0 + k];
+        HIP_TRY(t, rg::launch_timers_update(p, s));
+    }
+    if (memspace == RG_MEM_HOST) HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_timers_arm(rg_table_t *t, int64_t now)
+{
+    if (!t) return -1;
+    if (bind(t)) return -2;
+    rg::TimerParams p = timer_params(t);
+    p.now[0] = now;
+    HIP_TRY(t, rg::launch_timers_arm(p, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count, int memspace)
+{
+    if (!t) return -1;
+    if (!out_count || (capacity && !out_gid)) return fail(t, -1, "rg_timers_expired: out_gid/out_count are required");
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    uint32_t *d_out = out_gid;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_tgid, (size_t)(capacity ? capacity : 1) * sizeof(uint32_t))) return -2;
+        d_out = (uint32_t *)t->st_tgid.ptr;
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_timers_expired: unknown memspace %d", memspace);
+    }
+    const uint32_t waves = (t->G + 63) / 64;
+    HIP_TRY(t, rg::launch_timers_expired(t->timer_deadline, t->G, now, t->timer_counts, t->timer_counts + waves, d_out, capacity, s));
+    uint32_t total = 0;
+    HIP_TRY(t, hipMemcpyAsync(&total, t->timer_counts + waves, sizeof total, hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    *out_count = total;
+    const uint32_t n = total < capacity ? total : capacity;
+    if (memspace == RG_MEM_HOST && n) {
+        HIP_TRY(t, hipMemcpyAsync(out_gid, d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(t, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline)
+{
+    if (!t || !deadline) return -1;
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_timers_read: range exceeds %u groups", t->G);
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(deadline, t->timer_deadline + first, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
     return 0;
 }
 

@@ -84,6 +84,17 @@ struct ReplicateParams {             // N1: Leader.replicateLog for many groups 
     rg_send_t *send;
 };
 
+struct TimerParams {                 // N4: RaftRoutine.resetTimer / electionTimeout for many groups (rg_kernels.hip)
+    int64_t *deadline;               // [G] 0 = no ticket, -1 = fired (TimerTicket.TIMEOUT), >0 = armed
+    const Ident *ident;              // role / role epoch of the table (arm only)
+    uint32_t groups, rounds, count;
+    const uint32_t *gid;
+    const rg_reply_t *reply;
+    int64_t now[64];                 // per-round timestamps of one update launch (<= 64 rounds per launch)
+    int64_t election_ms, heartbeat_ms;
+    uint64_t seed;
+};
+
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }

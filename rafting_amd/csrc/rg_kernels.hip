@@ -337,6 +337,119 @@ hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t
     return hipGetLastError();
 }
 
+// ---- N4: timers ------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t timer_mix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// RaftConfig.electionTimeout(): uniform in [E, 2E] (support/RaftConfig.java:187-190)
+__host__ __device__ __forceinline__ int64_t election_timeout(uint64_t seed, uint32_t gid, uint32_t role_epoch, int64_t now, int64_t E)
+{
+    const uint64_t h = timer_mix(seed ^ timer_mix((uint64_t)gid * 0xD1342543DE82EF95ull ^ ((uint64_t)role_epoch << 32) ^ (uint64_t)now));
+    return E + (int64_t)(h % (uint64_t)(E + 1));
+}
+// what RaftRoutine.resetTimer leaves behind for a participant of `role` (context/RaftRoutine.java:86-130)
+__device__ __forceinline__ int64_t rearm(const TimerParams &p, int64_t d, uint32_t g, int role, bool fresh, uint32_t role_epoch, int64_t now)
+{
+    if (fresh) d = 0;                                            // convertTo: ticketHolder.set(null)
+    if (role == RG_LEADER) return d == 0 ? now : wadd(now, p.heartbeat_ms);   // keepAlive: schedule(exist == null ? 0 : timeout)
+    if (d < 0) return d;                                         // moment < 0: the fired ticket stays
+    return wadd(now, election_timeout(p.seed, g, role_epoch, now, p.election_ms));
+}
+
+__global__ __launch_bounds__(256) void timers_update_kernel(const TimerParams p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.count) return;
+    const uint32_t g = p.gid ? p.gid[i] : i;
+    int64_t d = p.deadline[g];
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const rg_reply_t rep = p.reply[(size_t)r * p.count + i];
+        if (rep.flags & RG_F_RESET_TIMER)
+            d = rearm(p, d, g, (int)RG_F_ROLE(rep.flags), (rep.flags & RG_F_ROLE_CHANGED) != 0, rep.role_epoch, p.now[r]);
+    }
+    p.deadline[g] = d;
+}
+
+__global__ __launch_bounds__(256) void timers_arm_kernel(const TimerParams p)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.groups) return;
+    if (p.deadline[g] != 0) return;
+    const Ident id = p.ident[g];
+    p.deadline[g] = rearm(p, 0, g, (int)(id.meta & META_ROLE), true, id.role_epoch, p.now[0]);
+}
+
+// Expired groups in ascending order, three passes so the list is deterministic:
+//  1. per wavefront: ballot of (0 < deadline <= now), popcount -> counts[wave]
+//  2. one block: exclusive prefix sum over the wavefront counts
+//  3. per wavefront: every expired lane writes its gid at offset[wave] + popcount(ballot below its lane) and marks
+//     the ticket fired (electionTimeout's CAS deadline -> TimerTicket.TIMEOUT)
+__global__ __launch_bounds__(256) void timers_count_kernel(const int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t d = g < groups ? deadline[g] : 0;
+    const unsigned long long m = __ballot(d > 0 && d <= now);
+    if ((threadIdx.x & 63u) == 0) counts[g >> 6] = (uint32_t)__popcll(m);
+}
+
+__global__ __launch_bounds__(1024) void timers_scan_kernel(uint32_t *counts, uint32_t waves, uint32_t *total)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (waves + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = lo + per < waves ? lo + per : waves;
+    uint32_t s = 0;
+    for (uint32_t k = lo; k < hi; k++) s += counts[k];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {              // Hillis-Steele inclusive scan of the 1024 partial sums
+        const uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t k = lo; k < hi; k++) { const uint32_t c = counts[k]; counts[k] = run; run += c; }
+    if (tid == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, uint32_t groups, int64_t now, const uint32_t *offsets,
+                                                          uint32_t *out_gid, uint32_t capacity)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t d = g < groups ? deadline[g] : 0;
+    const bool exp = d > 0 && d <= now;
+    const unsigned long long m = __ballot(exp);
+    if (!exp) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t pos = offsets[g >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (pos < capacity) { out_gid[pos] = g; deadline[g] = -1; }
+}
+
+hipError_t launch_timers_update(const TimerParams &p, hipStream_t s)
+{
+    if (p.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(timers_update_kernel, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(timers_arm_kernel, dim3((p.groups + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+                                 uint32_t *out_gid, uint32_t capacity, hipStream_t s)
+{
+    const uint32_t blocks = (groups + 255) / 256, waves = (groups + 63) / 64;
+    hipLaunchKernelGGL(timers_count_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, counts);
+    hipLaunchKernelGGL(timers_scan_kernel, dim3(1), dim3(1024), 0, s, counts, waves, total);
+    hipLaunchKernelGGL(timers_emit_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, counts, out_gid, capacity);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -25,7 +25,8 @@ def exported_symbols():
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
         "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
-        "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timing_enable",
+        "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
+        "rg_timers_expired", "rg_timers_arm", "rg_timers_read", "rg_timing_enable",
         "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
 
@@ -78,6 +79,11 @@ def lib():
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_sync.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
+        L.rg_timers_configure.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64]
+        L.rg_timers_update.argtypes = [vp, u32, u32, vp, vp, vp, i32]
+        L.rg_timers_expired.argtypes = [vp, C.c_int64, vp, u32, C.POINTER(u32), i32]
+        L.rg_timers_arm.argtypes = [vp, C.c_int64]
+        L.rg_timers_read.argtypes = [vp, u32, u32, vp]
         L.rg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.rg_host_free.argtypes = [vp, vp]
         L.rg_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -254,6 +260,34 @@ class Table:
 
     def sync(self):
         self._check(lib().rg_sync(self._h))
+
+    # N4 timers ------------------------------------------------------------------------------------
+    def timers_configure(self, election_ms, heartbeat_ms, seed=0):
+        self._check(lib().rg_timers_configure(self._h, election_ms, heartbeat_ms, seed))
+
+    def timers_update(self, batch_rounds, batch_count, reply, now, gid=None):
+        now = np.ascontiguousarray(now, dtype=np.int64)
+        gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
+        reply = np.ascontiguousarray(reply)
+        assert len(now) == batch_rounds and len(reply) == batch_rounds * batch_count
+        self._check(lib().rg_timers_update(self._h, batch_rounds, batch_count, None if gid is None else gid.ctypes.data,
+                                           reply.ctypes.data, now.ctypes.data, abi.MEM_HOST))
+
+    def timers_arm(self, now):
+        self._check(lib().rg_timers_arm(self._h, now))
+
+    def timers_expired(self, now, capacity=None):
+        capacity = self.groups if capacity is None else capacity
+        out = np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        self._check(lib().rg_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n), abi.MEM_HOST))
+        return out[: min(n.value, capacity)], n.value
+
+    def timers_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        out = np.zeros(count, dtype=np.int64)
+        self._check(lib().rg_timers_read(self._h, first, count, out.ctypes.data))
+        return out
 
     def replicate(self, gid=None, heartbeat=None, in_flight=None):
         """Leader.replicateLog for `gid` (None = every group): returns (head[count], send[count, F])."""

@@ -541,6 +541,57 @@ def replicate_prepares_and_skips_non_leaders(mk):
     assert s.state().repl_prepared == 0
 
 
+# --------------------------------------------------------------------------------------------------
+# N4: timers  RaftRoutine.resetTimer / electionTimeout / keepAlive  context/RaftRoutine.java:53-130
+
+def timers_follow_reset_timer(mk):
+    E, H = 900, 300                                            # raft1.xml:10-13 through RaftConfig.java:187-198
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=1, log=simple_log(10, 5))
+    t = s.t
+    t.timers_configure(E, H, 11)
+    assert t.timers_read()[0] == 0                             # no ticket yet
+    t.timers_arm(1000)
+    d0 = int(t.timers_read()[0])
+    assert 1000 + E <= d0 <= 1000 + 2 * E                      # election timeout in [E, 2E]
+    assert t.timers_expired(d0 - 1)[1] == 0
+
+    def step(now, **ev):
+        b = abi.Batch(1, 1)
+        b.put(0, 0, **ev)
+        out = t.submit(b)
+        t.timers_update(1, 1, out.reply, [now])
+        return out
+
+    step(1500, kind=abi.EV_AE_REQ, slot=1, a=5, b=10, c=5, d=0)   # heartbeat: Follower.java:43,84 re-arm the timer
+    d1 = int(t.timers_read()[0])
+    assert 1500 + E <= d1 <= 1500 + 2 * E
+    step(1600, kind=abi.EV_AE_REQ, slot=1, a=4, b=10, c=5, d=0)   # stale term: no resetTimer (Follower.java:39-41)
+    assert int(t.timers_read()[0]) == d1
+    gids, n = t.timers_expired(d1)                              # electionTimeout: CAS deadline -> TIMEOUT (:68)
+    assert (gids.tolist(), n) == ([0], 1) and int(t.timers_read()[0]) == -1
+    assert t.timers_expired(d1 + 10 ** 6)[1] == 0              # fires once
+    step(d1 + 1, kind=abi.EV_AE_REQ, slot=1, a=5, b=10, c=5, d=0)  # same participant, ticket already fired: moment < 0 (:96-98)
+    assert int(t.timers_read()[0]) == -1
+    out = step(d1 + 2, kind=abi.EV_TIMEOUT)                     # onTimeout -> new participant -> fresh ticket
+    assert out.reply["flags"][0] & abi.F_ROLE_CHANGED
+    d2 = int(t.timers_read()[0])
+    assert d1 + 2 + E <= d2 <= d1 + 2 + 2 * E
+    s = _sim(mk, cluster=3, role=C, term=6, voted_for=0, role_epoch=3)
+    t = s.t
+    t.timers_configure(E, H, 11)
+    b = abi.Batch(1, 1)
+    b.put(0, 0, abi.EV_RV_REPLY, slot=1, flag=1, a=6, aux=3)    # majority of 3 -> Leader
+    out = t.submit(b)
+    t.timers_update(1, 1, out.reply, [7000])
+    assert int(t.timers_read()[0]) == 7000                      # first keepAlive at once (:117-118 exist == null ? 0)
+    assert t.timers_expired(7000)[0].tolist() == [0]
+    b = abi.Batch(1, 1)
+    b.put(0, 0, abi.EV_TIMEOUT)                                 # the heartbeat tick itself
+    out = t.submit(b)
+    t.timers_update(1, 1, out.reply, [7001])
+    assert int(t.timers_read()[0]) == 7001 + H
+
+
 def extreme_values(mk):
     """Java longs near their limits: nothing on the path may truncate to 32 bits or misorder signed values."""
     big = (1 << 62) + 12345

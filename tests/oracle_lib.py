@@ -40,6 +40,11 @@ def lib():
         L.orc_rejection_step.argtypes = [C.c_int32]
         L.orc_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.orc_replicate.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+        L.orc_timers_configure.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]
+        L.orc_timers_update.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_timers_arm.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_timers_expired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_timers_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_log_term.restype = C.c_int
         L.orc_log_term.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_log_conflict.restype = C.c_int64
@@ -88,6 +93,32 @@ class OracleTable:
         rc = lib().orc_submit(self._h, C.byref(b), C.byref(o))
         if rc:
             raise ValueError("orc_submit failed: %d" % rc)
+        return out
+
+    def timers_configure(self, election_ms, heartbeat_ms, seed=0):
+        assert lib().orc_timers_configure(self._h, election_ms, heartbeat_ms, seed) == 0
+
+    def timers_update(self, batch_rounds, batch_count, reply, now, gid=None):
+        now = np.ascontiguousarray(now, dtype=np.int64)
+        gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
+        reply = np.ascontiguousarray(reply)
+        assert lib().orc_timers_update(self._h, batch_rounds, batch_count, None if gid is None else gid.ctypes.data,
+                                       reply.ctypes.data, now.ctypes.data) == 0
+
+    def timers_arm(self, now):
+        assert lib().orc_timers_arm(self._h, now) == 0
+
+    def timers_expired(self, now, capacity=None):
+        capacity = self.groups if capacity is None else capacity
+        out = np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        assert lib().orc_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n)) == 0
+        return out[: min(n.value, capacity)], n.value
+
+    def timers_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        out = np.zeros(count, dtype=np.int64)
+        assert lib().orc_timers_read(self._h, first, count, out.ctypes.data) == 0
         return out
 
     def replicate(self, gid=None, heartbeat=None, in_flight=None):

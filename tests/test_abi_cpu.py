@@ -34,7 +34,8 @@ def test_python_mirror_matches_header_constants():
     assert (define("RG_MIN_CLUSTER"), define("RG_MAX_CLUSTER")) == (abi.MIN_CLUSTER, abi.MAX_CLUSTER)
     for flag in ("SUCCESS", "REPLIED", "PERSIST", "ROLE_CHANGED", "RESET_TIMER", "COMMIT", "LOG_TRUNC", "LOG_APPEND"):
         assert define("RG_F_" + flag) == getattr(abi, "F_" + flag), flag
-    enums = dict(re.findall(r"\b(RG_[A-Z_]+)\s*=\s*(\d+)", HEADER))
+    enums = dict(re.findall(r"^\s*(RG_[A-Z_0-9]+)\s*=\s*(\d+)\s*,?\s*(?:/\*.*)?$", HEADER, re.M))
+    assert len(enums) >= 35
     for name, val in enums.items():
         short = name[3:]
         py = getattr(abi, short, None)

@@ -236,8 +236,11 @@ def test_replicate_matches_oracle_on_fuzzed_state():
     seen = np.zeros(5, dtype=np.int64)
     for r in range(40):
         b = abi.Batch(1, G)
-        fz.round(gpu.read_state(), b, 0)
-        compare_outcomes(orc.submit(b, fill=0xAB), gpu.submit(b, fill=0xAB), "round %d" % r)
+        cur = gpu.read_state()
+        fz.round(cur, b, 0)
+        og = gpu.submit(b, fill=0xAB)
+        _resolve_need_host(gpu, orc, b, og, cur)
+        compare_outcomes(orc.submit(b, fill=0xAB), og, "round %d" % r)
         if r % 4 == 3:
             hb = rng.integers(0, 2, G).astype(np.uint8)
             fl = rng.choice([0, 1, 2, 3, 20, 21], size=(G, P - 1)).astype(np.uint16)
@@ -254,3 +257,48 @@ def test_replicate_matches_oracle_on_fuzzed_state():
             seen += np.bincount(so["kind"].reshape(-1), minlength=5)[:5]
             compare_states(orc.read_state(), gpu.read_state(), "after replicate %d" % r)
     assert seen[abi.SEND_NONE] and seen[abi.SEND_APPEND] and seen[abi.SEND_GATED] and seen[abi.SEND_SNAPSHOT]
+
+
+def test_timer_driven_replay_matches_oracle():
+    """N4 in a closed loop: expired timers (ballot-compacted on the device) become TIMEOUT rows, every batch's replies
+    re-arm the deadlines; lists, outcomes and deadlines must equal the oracle's round after round."""
+    G, P = 4096, 5
+    st0 = fuzz.random_initial_state(G, P, 2, 77)
+    gpu, orc = engine.Table(G, P, 2, True), oracle_lib.OracleTable(G, P, 2, True)
+    fz = fuzz.Fuzzer(G, P, 2, 77, allow_miss=False)
+    for t in (gpu, orc):
+        t.load_state(st0)
+        t.timers_configure(900, 300, 1234)
+        t.timers_arm(10_000)
+    assert np.array_equal(gpu.timers_read(), orc.timers_read())
+    fired = 0
+    for r in range(60):
+        now = 10_000 + 150 * r
+        eg, ng = gpu.timers_expired(now, capacity=G if r % 7 else 97)     # a short buffer now and then
+        eo, no = orc.timers_expired(now, capacity=G if r % 7 else 97)
+        assert ng == no and np.array_equal(eg, eo) and np.all(np.diff(eg.astype(np.int64)) > 0)
+        fired += len(eg)
+        b = abi.Batch(1, G)
+        cur = gpu.read_state()
+        fz.round(cur, b, 0)
+        for g in eg:                                                       # the expired groups get their onTimeout instead
+            b.head[int(g)] = (int(abi.hdr_make(abi.EV_TIMEOUT)), 0)
+        og = gpu.submit(b, fill=0xAB)
+        _resolve_need_host(gpu, orc, b, og, cur)                           # an ack's quorum index may lie below the cached runs
+        oo = orc.submit(b, fill=0xAB)
+        compare_outcomes(oo, og, "round %d" % r)
+        gpu.timers_update(1, G, og.reply, [now])
+        orc.timers_update(1, G, oo.reply, [now])
+        assert np.array_equal(gpu.timers_read(), orc.timers_read()), r
+    assert fired > G // 4
+    # multi-round update in one call == round by round
+    big = abi.Batch(3, G)
+    for k in range(3):
+        big.put(k, 5 + k, abi.EV_TIMEOUT)
+        big.put(k, 900, abi.EV_TIMEOUT)
+    og, oo = gpu.submit(big), orc.submit(big)
+    compare_outcomes(oo, og, "multi-round")
+    nows = [30_000, 30_100, 30_250]
+    gpu.timers_update(3, G, og.reply, nows)
+    orc.timers_update(3, G, oo.reply, nows)
+    assert np.array_equal(gpu.timers_read(), orc.timers_read())
