@@ -3,9 +3,10 @@
 // appending lines through the leader, humans killing / restarting nodes and diffing the three output files)
 // as ONE deterministic in-process simulation.  Each node is a raftgpu::host::ContextManager (its own
 // rg_table on the GPU) holding `groups` RaftContexts; RPCs travel through an in-memory network with one tick
-// of delay; election / heartbeat timers are logical (tick 1 = raft1.xml's 300 ms tick: heartbeat x1,
-// election x3 randomised in [E, 2E]).  Every decision — vote, append, commit, role change — is taken by the
-// HIP kernels; the host only moves messages, keeps the RaftLog and the FileMachine.
+// (50 ms) of delay; heartbeat 300 ms and election timeout 900 ms randomised in [E, 2E] as in raft1.xml, and the timers
+// themselves live on the device (rg_timers_*, N4): the host only asks which tickets have fired.  Every decision —
+// vote, append, commit, role change, what to replicate, when to time out — is taken by the HIP kernels; the host
+// moves messages, keeps the RaftLog, the durability journal and the FileMachine.
 //
 // What is asserted (the reference checks "eventual file equality by eye", README.md:28-33; we check more):
 //   * election safety: never two leaders in one term of one group;
@@ -13,7 +14,7 @@
 //     at every tick;
 //   * liveness: commands keep committing, also after the leader is partitioned away and after it rejoins;
 //   * convergence: once traffic stops, all three files are identical.
-// usage: cluster_sim [groups=1] [ticks=400] [seed=1]   exit code 0 = all invariants held
+// usage: cluster_sim [groups=1] [ticks=2400 (50 ms each)] [seed=1]   exit code 0 = all invariants held
 #include <unistd.h>
 
 #include <algorithm>
@@ -42,12 +43,13 @@ struct Msg {
     int64_t epochAtSend = 0, lastSent = 0;        // Leader.replicateLog closure state echoed by the response
 };
 
-static const int P = 3, HEARTBEAT = 1, ELECTION = 3, FETCH = 50;   // raft1.xml:10-13, Leadership.java:10
+static const int P = 3;
+static const int64_t HEARTBEAT_MS = 300, ELECTION_MS = 900;     // raft1.xml:10-13: tick 300 ms, heartbeat x1, election x3
 
 struct Group {
     RaftContext *ctx = nullptr;
     std::deque<Msg> inbox;
-    int64_t deadline = 0;                         // election deadline (F/C) or next heartbeat (L)
+    bool timer_due = false;                       // the device reported this context's ticket as fired
     std::vector<std::string> file;                // FileMachine: "<index>:<line>"
     int64_t applied = 0;
     int inflight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // State.requestInFlight per peer
@@ -67,7 +69,7 @@ static std::vector<Msg> wire, wire_next;
 static std::map<std::pair<uint32_t, int64_t>, int> leader_of_term;
 static int violations = 0;
 
-static int64_t election_timeout() { return now_tick + ELECTION + (int64_t)(rng() % (ELECTION + 1)); }
+static const int64_t TICK_MS = 50;                // simulation step = network delay; timers keep millisecond deadlines
 static void fail(const char *what, uint32_t gid) { fprintf(stderr, "INVARIANT VIOLATED (tick %lld, group %u): %s\n", (long long)now_tick, gid, what); violations++; }
 static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term) + "-cmd" + std::to_string(e.index); }
 
@@ -125,8 +127,9 @@ static void broadcast_vote(Node &n, Group &g, bool pre, uint32_t epoch)
 int main(int argc, char **argv)
 {
     const uint32_t groups = argc > 1 ? (uint32_t)atoi(argv[1]) : 1;
-    const int64_t ticks = argc > 2 ? atoll(argv[2]) : 400;
+    const int64_t ticks = argc > 2 ? atoll(argv[2]) : 2400;
     rng.seed(argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
+    const int trace_group = getenv("SIM_TRACE_GROUP") ? atoi(getenv("SIM_TRACE_GROUP")) : -1;
     std::vector<Node> nodes(P);
     for (int k = 0; k < P; k++) {
         nodes[k].id = k;
@@ -139,8 +142,9 @@ int main(int argc, char **argv)
         for (uint32_t i = 0; i < groups; i++) {
             Group &g = nodes[k].g[i];
             g.ctx = &nodes[k].mgr->createContext(groups == 1 ? "root" : "ctx-" + std::to_string(i));
-            g.deadline = election_timeout();
         }
+        nodes[k].mgr->configureTimers(ELECTION_MS, HEARTBEAT_MS, rng());
+        nodes[k].mgr->armTimers(0);
         nodes[k].mgr->onCommit([&nodes, k](RaftContext &c, int64_t upTo) {     // FileMachine.apply (cmd/FileMachine.java:62-84)
             Group &g = nodes[k].g[c.gid()];
             for (; g.applied < upTo; g.applied++) {
@@ -150,7 +154,7 @@ int main(int argc, char **argv)
             }
         });
     }
-    const int64_t cut_at = ticks / 3, heal_at = 2 * ticks / 3, quiet_at = ticks - 60;
+    const int64_t cut_at = ticks / 3, heal_at = 2 * ticks / 3, quiet_at = ticks - 200;
     int cut_node = -1;
     uint64_t commands = 0, elections = 0, rollbacks = 0;
 
@@ -168,14 +172,16 @@ int main(int argc, char **argv)
           // broadcast timeout = 0.5 tick (raft1.xml:13): every request still unanswered a tick later has
           // completed with a timeout error, which releases its in-flight slot (Leader.java:221,235)
           for (Group &g : n.g) for (int &x : g.inflight) x = 0;
+          const int64_t now_ms = now_tick * TICK_MS;
+          for (RaftContext *c : n.mgr->expiredTimers(now_ms)) n.g[c->gid()].timer_due = true;   // electionTimeout / keepAlive fired
           for (int sub = 0; sub < 8; sub++) {             // several EventLoop drains per tick: one row per context each
             struct Src { Group *g; Msg msg; int what; };   // what: 0 message, 1 timer, 2 client command
             std::vector<Src> src;
             for (Group &g : n.g) {
                 RaftContext &c = *g.ctx;
-                if (now_tick >= g.deadline) {                       // timers are urgent (EventLoop.execute(evt, true))
+                if (g.timer_due) {                                  // timers are urgent (EventLoop.execute(evt, true))
                     c.onTimeout();
-                    g.deadline = INT64_MAX;                         // re-armed by the outcome
+                    g.timer_due = false;
                     src.push_back({&g, Msg{}, 1});
                 } else if (!g.inbox.empty()) {
                     Msg m = std::move(g.inbox.front()); g.inbox.pop_front();
@@ -201,14 +207,14 @@ int main(int argc, char **argv)
                     case IS: break;
                     }
                     src.push_back({&g, std::move(m), 0});
-                } else if (c.role() == RG_LEADER && now_tick < quiet_at && !commanded[c.gid()] && (now_tick + c.gid()) % 2 == 0) {
+                } else if (c.role() == RG_LEADER && now_tick < quiet_at && !commanded[c.gid()] && (now_tick + c.gid()) % 4 == 0) {
                     c.acceptCommand(1);                             // TestNode: submit(AppendCommand(...))
                     commanded[c.gid()] = 1;
                     src.push_back({&g, Msg{}, 2});
                 }
             }
             if (src.empty()) break;
-            std::vector<Outcome> out = n.mgr->flush();
+            std::vector<Outcome> out = n.mgr->flush(now_ms);    // also folds RESET_TIMER / ROLE_CHANGED into the device timers
             std::vector<Group *> to_replicate;
             for (size_t i = 0; i < out.size(); i++) {
                 Group &g = *src[i].g;
@@ -230,6 +236,12 @@ int main(int argc, char **argv)
                     send(n, std::move(r));
                 }
                 if (src[i].what == 2 && o.status == RG_OK) commands++;
+                if (trace_group >= 0 && (int)c.gid() == trace_group && (o.roleChanged() || o.status != RG_OK || src[i].what != 0 || (src[i].msg.type != AE && src[i].msg.type != AE_RESP)))
+                    fprintf(stderr, "trace tick %lld node %d: src=%d msgtype=%d from=%d mterm=%lld -> role=%d term=%lld epoch=%u status=%u flags=%x resp=%d/%lld last=%lld commit=%lld\n",
+                            (long long)now_tick, n.id, src[i].what, (int)src[i].msg.type, src[i].msg.from, (long long)src[i].msg.term, o.role,
+                            (long long)c.currentTerm(), o.roleEpoch, o.status, o.flags, o.response ? (int)o.response->success : -1,
+                            (long long)(o.response ? o.response->term : -1), (long long)(c.replicatedLog().last() ? c.replicatedLog().last()->index : -1),
+                            (long long)c.replicatedLog().lastCommitted());
                 if (o.roleChanged()) for (int &x : g.inflight) x = 0;          // AsyncHead.abortRequests
                 if (o.roleChanged() && o.role == RG_LEADER) {
                     elections++;
@@ -237,8 +249,6 @@ int main(int argc, char **argv)
                     if (leader_of_term.count(key) && leader_of_term[key] != n.id) fail("two leaders in one term", c.gid());
                     leader_of_term[key] = n.id;
                 }
-                if (o.resetTimer()) g.deadline = o.role == RG_LEADER ? (o.roleChanged() ? now_tick + 1 : now_tick + HEARTBEAT) : election_timeout();
-                else if (g.deadline == INT64_MAX) g.deadline = o.role == RG_LEADER ? now_tick + HEARTBEAT : election_timeout();
                 if (o.emit() == RG_EMIT_PREVOTE) broadcast_vote(n, g, true, o.roleEpoch);
                 else if (o.emit() == RG_EMIT_REQVOTE) broadcast_vote(n, g, false, o.roleEpoch);
                 else if (o.emit() == RG_EMIT_HEARTBEAT) to_replicate.push_back(&g);
@@ -310,7 +320,7 @@ int main(int argc, char **argv)
            median_lines);
     for (int k = 0; k < P; k++) ::unlink(("/tmp/rg_cluster_sim_" + std::to_string((long)getpid()) + "_node" + std::to_string(k) + ".journal").c_str());
     if (converged * 100 < (size_t)groups * 99) fail("files did not converge after traffic stopped", 0);
-    if (median_lines < (size_t)(ticks / 8)) fail("too little progress", 0);
+    if (median_lines < (size_t)(ticks / 16)) fail("too little progress", 0);
     if (elections < (groups == 1 ? 2u : groups)) fail("no (re-)election happened", 0);
     return violations ? 1 : 0;
 }

@@ -214,8 +214,30 @@ Ticket ContextManager::enqueue(RaftContext &c, Row row)
 }
 
 // one sparse single-round rg_submit over queue_ rows `which` (ascending gid); results land at the rows' queue positions
+void ContextManager::configureTimers(int64_t electionMs, int64_t heartbeatMs, uint64_t seed)
+{
+    if (rg_timers_configure(table_, electionMs, heartbeatMs, seed) != 0) throw std::runtime_error(rg_last_error(table_));
+}
+
+void ContextManager::armTimers(int64_t now)
+{
+    if (rg_timers_arm(table_, now) != 0) throw std::runtime_error(rg_last_error(table_));
+}
+
+std::vector<RaftContext *> ContextManager::expiredTimers(int64_t now)
+{
+    std::vector<uint32_t> gids(contexts_.size() ? contexts_.size() : 1);
+    uint32_t n = 0;
+    if (rg_timers_expired(table_, now, gids.data(), (uint32_t)contexts_.size(), &n, RG_MEM_HOST) != 0)
+        throw std::runtime_error(rg_last_error(table_));
+    std::vector<RaftContext *> out;
+    for (uint32_t i = 0; i < n && i < contexts_.size(); i++)
+        if (gids[i] < contexts_.size()) out.push_back(contexts_[gids[i]].get());
+    return out;
+}
+
 void ContextManager::submit(std::vector<size_t> &which, bool hinted, std::vector<rg_reply_t> &rep,
-                            std::vector<rg_logfx_t> &lfx, std::vector<rg_persist_t> &per)
+                            std::vector<rg_logfx_t> &lfx, std::vector<rg_persist_t> &per, int64_t now)
 {
     std::sort(which.begin(), which.end(), [&](size_t x, size_t y) { return queue_[x].ctx->gid() < queue_[y].ctx->gid(); });
     const size_t n = which.size();
@@ -260,11 +282,13 @@ void ContextManager::submit(std::vector<size_t> &which, bool hinted, std::vector
     in.hint = hinted ? hint.data() : nullptr;
     rg_outcome_t out{o_rep.data(), o_lfx.data(), o_per.data()};
     if (rg_submit(table_, &in, &out, RG_MEM_HOST) != 0) throw std::runtime_error(rg_last_error(table_));
+    if (now >= 0 && rg_timers_update(table_, 1, (uint32_t)n, gid.data(), o_rep.data(), &now, RG_MEM_HOST) != 0)
+        throw std::runtime_error(rg_last_error(table_));
     for (size_t k = 0; k < n; k++) { rep[which[k]] = o_rep[k]; lfx[which[k]] = o_lfx[k]; per[which[k]] = o_per[k]; }
     rows_decided_ += n;
 }
 
-std::vector<Outcome> ContextManager::flush()
+std::vector<Outcome> ContextManager::flush(int64_t now)
 {
     const size_t n = queue_.size();
     std::vector<Outcome> result(n);
@@ -274,12 +298,12 @@ std::vector<Outcome> ContextManager::flush()
     std::vector<rg_persist_t> per(n);
     std::vector<size_t> which(n);
     std::iota(which.begin(), which.end(), 0);
-    submit(which, false, rep, lfx, per);
+    submit(which, false, rep, lfx, per, now);
     for (int attempt = 0; attempt < 2; attempt++) {                 // term-run cache misses: look up, resubmit with hints
         std::vector<size_t> miss;
         for (size_t i = 0; i < n; i++) if (RG_F_STATUS(rep[i].flags) == RG_NEED_HOST) miss.push_back(i);
         if (miss.empty()) break;
-        submit(miss, true, rep, lfx, per);
+        submit(miss, true, rep, lfx, per, now);
     }
     if (store_) {                                                     // the durability barrier of the whole flush
         std::vector<StableStore::Record> dirty;

@@ -183,10 +183,17 @@ class ContextManager {
     void attachStableStore(StableStore *s) { store_ = s; }
     void onCommit(CommitHook h) { commit_ = std::move(h); }
 
+    // N4: timers live on the device. configureTimers = RaftConfig's election / heartbeat intervals; every flush(now) folds
+    // the RESET_TIMER / ROLE_CHANGED flags of its rows into the deadlines (RaftRoutine.resetTimer); expiredTimers(now) is
+    // what electionTimeout / keepAlive would have fired by `now`: the caller answers each with ctx.onTimeout().
+    void configureTimers(int64_t electionMs, int64_t heartbeatMs, uint64_t seed);
+    void armTimers(int64_t now);
+    std::vector<RaftContext *> expiredTimers(int64_t now);
+
     bool pending(const RaftContext &c) const;  // a row for this context is already queued (one per context per flush)
     // The EventLoop drain: decide every queued row on the GPU, apply effects, complete tickets.
     // Outcome i answers ticket i of this flush; tickets restart at 0 afterwards.
-    std::vector<Outcome> flush();
+    std::vector<Outcome> flush(int64_t now = -1);          // now >= 0: also maintain the device timers
     // Leader.replicateLog (member/Leader.java:142-245) for a set of contexts in one rg_replicate launch: which range to
     // ship to every follower, heartbeat[i] selects the onTimeout limits; inFlight holds State.requestInFlight per
     // (context, follower) or is empty. A send whose prevLogTerm is below the device's cached runs comes back
@@ -211,7 +218,7 @@ class ContextManager {
     };
     Ticket enqueue(RaftContext &c, Row row);
     void submit(std::vector<size_t> &which, bool hinted, std::vector<rg_reply_t> &rep, std::vector<rg_logfx_t> &lfx,
-                std::vector<rg_persist_t> &per);
+                std::vector<rg_persist_t> &per, int64_t now);
 
     rg_table_t *table_ = nullptr;
     uint32_t cluster_;

@@ -25,8 +25,9 @@ def _run(groups, ticks, seed):
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_three_node_file_append_cluster(seed):
-    """one context "root" on three nodes; the leader is partitioned away a third of the way in and rejoins later"""
-    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(1, 400, seed)
+    """one context "root" on three nodes, 120 s of simulated time in 50 ms steps; the leader is partitioned away a third
+    of the way in and rejoins later; timers, replication plans and every decision come from the GPU"""
+    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(1, 2400, seed)
     assert violations == 0 and identical == 1
     assert cut >= 0 and elections >= 2                 # a leader existed, was cut off, and a new one was elected
     assert lo == hi and lo >= 50                       # the three FileMachine files are equal and grew
@@ -35,6 +36,6 @@ def test_three_node_file_append_cluster(seed):
 
 def test_many_contexts_per_node():
     """the same cluster with 256 contexts per node: one rg_submit per node per tick decides all of them"""
-    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(256, 240, 7)
+    commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(256, 1200, 7)
     assert violations == 0                       # election safety + state-machine safety held for every group at every tick
-    assert converged >= 254 and median >= 30 and elections >= 256
+    assert converged >= 254 and median >= 100 and elections >= 256
