@@ -124,7 +124,6 @@ template <int F>
 struct Peers {                       // LDS columns of this lane
     int64_t *last_epoch, *next_index, *match_index;
     int32_t *rejection;
-    static constexpr int STRIDE = BLOCK;
 };
 
 // Register image of one group.  The K=4 cached term runs are SCALAR members on purpose: with arrays the
@@ -515,7 +514,7 @@ struct Stepper {
 
         s_rej = success ? 0 : (int32_t)((uint32_t)s_rej + 1u);          // statSuccess runs before updateIndex
         const int64_t index = snapshot ? epoch_at_send : last_sent;
-        bool rollback = false, matched = false;
+        bool rollback = false;
         if (index < s_match) {
             rollback = true;                                            // AbstractMethodError: only the counter moved
         } else if (epoch_at_send >= s_epoch) {
@@ -524,7 +523,7 @@ struct Stepper {
                 if (s_pend) {
                     if (success) { s_next = max64(s_next, wadd(epoch_at_send, 1)); s_pend = false; }
                 } else if (success) {
-                    if (index > s_match) { s_next = wadd(index, 1); s_match = index; matched = true; }
+                    if (index > s_match) { s_next = wadd(index, 1); s_match = index; }
                 } else if (s_match == 0) {
                     const int64_t next = max64(wsub(s_next, rejection_step(s_rej)), wadd(epoch_at_send, 1));
                     s_next = min64(wsub(s_next, 1), next);
@@ -540,7 +539,6 @@ struct Stepper {
             int64_t m[F];
 #pragma unroll
             for (int i = 0; i < F; i++) m[i] = (i == j) ? s_match : pe.match_index[i * BLOCK];
-            (void)matched;
 #pragma unroll
             for (int a = 1; a < F; a++) {                               // insertion network, F <= 6
 #pragma unroll

@@ -17,7 +17,6 @@ import numpy as np
 
 from . import abi
 
-M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 FOLLOW, LEAD, PV, RV = 0, 1, 2, 3
 
 # algorithmic bytes per decision, SURVEY.md §8(d) (state fields at natural width, each touched once)
