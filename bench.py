@@ -165,7 +165,8 @@ def main():
         from tests.helpers import compare_outcomes
         cpu_dec = sum(workload.batch_stats(b, F)[0] for b in keep_host)
         best = {}
-        for threads in (1, 3):
+        many = max(4, min(os.cpu_count() or 4, 64))
+        for threads in (1, 3, many):
             orc = oracle_lib.OracleTable(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote)
             orc.load_state(st0)
             secs, outs = 0.0, []
@@ -179,12 +180,13 @@ def main():
             orc.close()
         for b, db, ref in zip(keep_host, dbatches, outs):
             compare_outcomes(ref, db.outcome(), "bench stream vs oracle")
-        use = 3 if best[3] >= best[1] else 1
+        use = max(best, key=best.get)
         cpu = {"value": best[use], "unit": "decisions/s", "cores": use, "kind": "port",
-               "value_1_thread": best[1], "value_3_threads": best[3], "host_cores": os.cpu_count(),
+               "value_1_thread": best[1], "value_3_threads": best[3], "value_%d_threads" % many: best[many],
+               "host_cores": os.cpu_count(),
                "sample": "first %d batches (%d rounds x %d groups = %d decisions) of the same stream; C restatement of "
                          "the reference EventLoop path (oracle/raft_oracle.c), in-memory log, no fsync/Netty/Kryo; "
-                         "3 threads mirror EventLoopGroup(3); GPU results on this sample verified bit-identical"
+                         "3 threads mirror EventLoopGroup(3), the widest run uses up to 64 host cores; GPU results on this sample verified bit-identical"
                          % (len(keep_host), args.rounds * len(keep_host), gpg, cpu_dec)}
 
     if rank == 0:

@@ -923,11 +923,15 @@ static void *worker(void *arg)
 {
     job_t *j = (job_t *)arg;
     pthread_barrier_wait(j->bar);
+    /* contexts are dealt round-robin to the loops (EventLoopGroup.next), here in chunks of 64 so that two threads
+     * never write the same cache line of the packed outcome arrays (an artefact of the batch format, not of the path) */
+    const uint32_t chunk = 64, stride = chunk * (uint32_t)j->threads;
     for (uint32_t r = 0; r < j->in->rounds; r++)
-        for (uint32_t i = (uint32_t)j->tid; i < j->in->count; i += (uint32_t)j->threads) {
-            size_t row = (size_t)r * j->in->count + i;
-            step(j->t, &j->t->g[i], j->in, row, &j->out->reply[row], &j->out->logfx[row], &j->out->persist[row]);
-        }
+        for (uint32_t base = (uint32_t)j->tid * chunk; base < j->in->count; base += stride)
+            for (uint32_t i = base; i < base + chunk && i < j->in->count; i++) {
+                size_t row = (size_t)r * j->in->count + i;
+                step(j->t, &j->t->g[i], j->in, row, &j->out->reply[row], &j->out->logfx[row], &j->out->persist[row]);
+            }
     pthread_barrier_wait(j->bar);
     return NULL;
 }

@@ -52,8 +52,8 @@ int orc_timers_arm(orc_table_t *t, int64_t now);
 int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count);
 int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
 
-/* CPU baseline: apply a dense batch with `threads` worker threads, groups assigned round-robin to
- * threads exactly like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3).
+/* CPU baseline: apply a dense batch with `threads` worker threads, groups dealt round-robin to the threads
+ * like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3), in chunks of 64 groups.
  * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */
 double orc_submit_threads(orc_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int threads);
 
