@@ -205,10 +205,18 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
 
 /* ---- state ------------------------------------------------------------------------------------ */
 
+static bool state_complete(const rg_group_state_t *s)
+{
+    return s->current_term && s->voted_for && s->role && s->current_leader && s->timeout_detected && s->repl_prepared &&
+           s->role_epoch && s->votes && s->elected_epoch && s->elected_term && s->commit_index && s->epoch_index &&
+           s->epoch_term && s->first_index && s->last_index && s->run_count && s->run_offset && s->run_start && s->run_term &&
+           s->peer_last_epoch && s->peer_next_index && s->peer_match_index && s->peer_rejection && s->peer_pending;
+}
+
 int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_state_t *s)
 {
     if (!t) return -1;
-    if (!s) return fail(t, -1, "rg_load_state: src is NULL");
+    if (!s || !state_complete(s)) return fail(t, -1, "rg_load_state: src or one of its columns is NULL");
     if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_load_state: range [%u, %u) exceeds %u groups", first, first + count, t->G);
     if (count == 0) return 0;
     if (bind(t)) return -2;
@@ -276,7 +284,7 @@ int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_
 int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_t *d)
 {
     if (!t) return -1;
-    if (!d) return fail(t, -1, "rg_read_state: dst is NULL");
+    if (!d || !state_complete(d)) return fail(t, -1, "rg_read_state: dst or one of its columns is NULL");
     if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_read_state: range exceeds %u groups", t->G);
     if (count == 0) return 0;
     if (bind(t)) return -2;
