@@ -320,6 +320,25 @@ int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t ca
 int rg_timers_arm(rg_table_t *t, int64_t now);
 int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
 
+/* ---- N4 (second half): follower health and the leader's readiness gate ------------------------------ */
+/* Leadership.State.{requestSuccess, requestFailure, recentFailure} with statSuccess / statFailure / isUnhealthy / isReady
+ * (member/Leadership.java:28-73) and Leader.isReady (member/Leader.java:52-64), the gate RaftStub.process puts in front of
+ * client commands (command/RaftStub.java:83-87). Wall-clock inputs arrive as `now`; nothing here feeds back into decisions.
+ *   rg_health_update   fold a finished batch: every AE_ACK / IS_ACK row that reached statSuccess (not fenced, no higher
+ *                      term, row applied) sets requestSuccess = max(.., now) and clears recentFailure; a group that
+ *                      became Leader gets fresh State objects (all zero).
+ *   rg_health_failure  statFailure(now, unreachable, reject) for RPCs that ended in an error / timeout on the host
+ *                      (flags bit0 = unreachable, bit1 = reject; reject also bumps recentRejection of the table).
+ *   rg_ready           Leader.isReady per group: 1 when self + healthy followers exceed half the followers, else 0
+ *                      (0 for non-leaders and for leaders that have not prepared replication). */
+int rg_health_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_ev_head_t *head,
+                     const rg_reply_t *reply, const int64_t *now, int memspace);
+int rg_health_failure(rg_table_t *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now);
+int rg_ready(rg_table_t *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready, int memspace);
+/* request_success / request_failure / recent_failure: [count * (cluster-1)], index g*(P-1)+j like rg_group_state_t peers */
+int rg_health_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure,
+                   int32_t *recent_failure);
+
 /* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
 /* Page-locked host memory for RG_MEM_HOST batches (JNI: wrap it with NewDirectByteBuffer): staging then runs at PCIe
  * speed instead of through the driver's pageable bounce buffers. */

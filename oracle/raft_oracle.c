@@ -30,6 +30,8 @@ typedef struct {                 /* Leadership.State, member/Leadership.java:26-
     int64_t last_epoch, next_index, match_index;
     int32_t rejection;
     uint8_t pending;
+    int64_t request_success, request_failure;   /* N4b: health statistics, member/Leadership.java:30-34 */
+    int32_t recent_failure;
 } peer_t;
 
 typedef struct {
@@ -56,6 +58,7 @@ struct orc_table {
     uint32_t groups, cluster, self, followers;
     int      pre_vote;
     int      majority;           /* RaftContext.majority()  context/RaftContext.java:170 */
+    const int64_t *clock;        /* N4b: System.currentTimeMillis() per round of the next orc_submit (orc_health_clock) */
     group_t *g;
 };
 
@@ -64,6 +67,8 @@ typedef struct {                 /* what one event task produced */
     uint32_t status;
     int64_t  resp_term;
     int64_t  log_from;
+    int64_t  now;                /* N4b: wall clock of this round; valid when timed */
+    int      timed;
 } fx_t;
 
 static inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -220,10 +225,14 @@ static int switch_to(const orc_table_t *t, group_t *g, fx_t *fx, int role, int64
     g->current_leader = RG_NO_NODE;
     g->votes = 1;
     g->repl_prepared = 0;
+    if (role == RG_LEADER)                 /* State objects only exist from prepareReplication on (member/Leader.java:30-50); */
+        for (uint32_t j = 0; j < t->followers; j++) {   /* a new Leader therefore starts from zeroed statistics */
+            g->peers[j].request_success = g->peers[j].request_failure = 0;
+            g->peers[j].recent_failure = 0;
+        }
     fx->flags |= RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER;
     fx->flags &= ~RG_F_EMIT_MASK;
     if (role == RG_CANDIDATE) fx->flags |= RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT;   /* startElection */
-    (void)t;
     return 1;
 }
 
@@ -239,6 +248,8 @@ static void prepare_replication(const orc_table_t *t, group_t *g)
         s->match_index = 0;
         s->rejection = 0;
         s->pending = 0;
+        s->request_success = s->request_failure = 0;
+        s->recent_failure = 0;
     }
     g->repl_prepared = 1;
 }
@@ -474,7 +485,11 @@ static void on_replicate_ack(const orc_table_t *t, group_t *g, fx_t *fx, int sna
         return;
     }
     peer_t *s = &g->peers[j];
-    if (!success) s->rejection = (int32_t)((uint32_t)s->rejection + 1u);   /* statSuccess member/Leadership.java:53-63 */
+    if (fx->timed) {                                              /* statSuccess member/Leadership.java:53-57 */
+        if (fx->now > s->request_success) s->request_success = fx->now;
+        if (s->recent_failure != 0) s->recent_failure = 0;
+    }
+    if (!success) s->rejection = (int32_t)((uint32_t)s->rejection + 1u);   /* statSuccess member/Leadership.java:58-63 */
     else if (s->rejection != 0) s->rejection = 0;
     int st = update_index(s, epoch_at_send, snapshot ? epoch_at_send : last_sent, success, snapshot);
     if (st) { fx->status = (uint32_t)st; return; }
@@ -565,7 +580,8 @@ static void step(const orc_table_t *t, group_t *g, const rg_batch_t *in, size_t 
     const uint32_t hdr = in->head[row].hdr, aux = in->head[row].aux;
     const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), flag = RG_HDR_FLAG(hdr), n = RG_HDR_N(hdr);
     const int64_t a = in->ab[row].x, b = in->ab[row].y, c = in->cd[row].x, d = in->cd[row].y;
-    fx_t fx = {0, RG_OK, 0, 0};
+    fx_t fx = {0, RG_OK, 0, 0, 0, 0};
+    if (t->clock) { fx.now = t->clock[row / in->count]; fx.timed = 1; }
 
     switch (kind) {
     case RG_EV_NONE:
@@ -694,6 +710,7 @@ int orc_load_state(orc_table_t *t, uint32_t first, uint32_t count, const rg_grou
             p->match_index = s->peer_match_index[(size_t)i * F + j];
             p->rejection = s->peer_rejection[(size_t)i * F + j];
             p->pending = s->peer_pending[(size_t)i * F + j] != 0;
+            p->request_success = p->request_failure = 0; p->recent_failure = 0;   /* statistics are not part of the snapshot */
         }
     }
     return 0;
@@ -897,6 +914,71 @@ int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *dea
 {
     if (!t || !deadline || (uint64_t)first + count > t->groups) return -1;
     memcpy(deadline, t->deadline + first, (size_t)count * sizeof(int64_t));
+    return 0;
+}
+
+/* ---- N4b: follower health and Leader.isReady ---------------------------------------------------- */
+
+/* the wall clock the following orc_submit calls see, one value per round (NULL: statistics are not kept) */
+int orc_health_clock(orc_table_t *t, const int64_t *now_per_round)
+{
+    if (!t) return -1;
+    t->clock = now_per_round;
+    return 0;
+}
+
+/* State.statFailure(now, unreachable, reject): member/Leadership.java:65-73; callers member/Leader.java:187,235,240.
+ * Rows for groups that are not prepared leaders have no State object to land on and are ignored. */
+int orc_health_failure(orc_table_t *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now)
+{
+    if (!t || (n && (!gid || !slot || !flags))) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (gid[i] >= t->groups || slot[i] >= t->cluster || slot[i] == t->self) continue;
+        group_t *g = &t->g[gid[i]];
+        if (g->role != RG_LEADER || !g->repl_prepared) continue;
+        peer_t *s = &g->peers[slot[i] < t->self ? slot[i] : slot[i] - 1];
+        if (now > s->request_failure) s->request_failure = now;
+        if (flags[i] & 1u) s->recent_failure = (int32_t)((uint32_t)s->recent_failure + 1u);
+        if (flags[i] & 2u) s->rejection = (int32_t)((uint32_t)s->rejection + 1u);
+    }
+    return 0;
+}
+
+/* State.isUnhealthy / State.isReady: member/Leadership.java:43-51 */
+static int state_ready(const peer_t *s, int32_t critical_point, int64_t cool_down, int64_t now)
+{
+    int unhealthy = (critical_point > 0 && (uint32_t)s->recent_failure > (uint32_t)critical_point) ||
+                    (cool_down > 0 && wsub(now, s->request_failure) < cool_down);
+    return s->request_success != 0 && !(s->pending || unhealthy);
+}
+
+/* Leader.isReady: member/Leader.java:52-64 (false for every other role: command/RaftStub.java:80-87) */
+int orc_ready(orc_table_t *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready)
+{
+    if (!t || !ready) return -1;
+    for (uint32_t i = 0; i < t->groups; i++) {
+        const group_t *g = &t->g[i];
+        ready[i] = 0;
+        if (g->role != RG_LEADER || !g->repl_prepared) continue;
+        int n = 1, half = (int)t->followers / 2;
+        for (uint32_t j = 0; j < t->followers; j++)
+            if (state_ready(&g->peers[j], critical_point, cool_down_ms, now) && ++n > half) { ready[i] = 1; break; }
+    }
+    return 0;
+}
+
+int orc_health_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure,
+                    int32_t *recent_failure)
+{
+    if (!t || !request_success || !request_failure || !recent_failure || (uint64_t)first + count > t->groups) return -1;
+    const uint32_t F = t->followers;
+    for (uint32_t i = 0; i < count; i++)
+        for (uint32_t j = 0; j < F; j++) {
+            const peer_t *s = &t->g[first + i].peers[j];
+            request_success[(size_t)i * F + j] = s->request_success;
+            request_failure[(size_t)i * F + j] = s->request_failure;
+            recent_failure[(size_t)i * F + j] = s->recent_failure;
+        }
     return 0;
 }
 

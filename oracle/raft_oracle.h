@@ -52,6 +52,14 @@ int orc_timers_arm(orc_table_t *t, int64_t now);
 int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count);
 int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
 
+/* N4b health: statSuccess happens inside orc_submit at the place the reference calls it (Leader.java:229), with the clock
+ * given by orc_health_clock; the rest mirrors rg_health_failure / rg_ready / rg_health_read */
+int orc_health_clock(orc_table_t *t, const int64_t *now_per_round);
+int orc_health_failure(orc_table_t *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now);
+int orc_ready(orc_table_t *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready);
+int orc_health_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure,
+                    int32_t *recent_failure);
+
 /* CPU baseline: apply a dense batch with `threads` worker threads, groups dealt round-robin to the threads
  * like EventLoopGroup.next (support/EventLoopGroup.java:77-80; the reference uses 3), in chunks of 64 groups.
  * Returns wall seconds of the apply phase (thread start/join excluded via a start barrier). */

@@ -20,6 +20,9 @@ namespace rg {
 hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s);
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s);
+hipError_t launch_health_update(const HealthParams &p, hipStream_t s);
+hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, hipStream_t s);
+hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s);
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
@@ -55,7 +58,9 @@ struct rg_table {
     uint32_t *timer_counts = nullptr;           // [waves + 1]: per-wave counts / offsets, last = total
     int64_t election_ms = 900, heartbeat_ms = 300;   // raft1.xml:10-13
     uint64_t timer_seed = 0;
-    Staging st_tgid;
+    Staging st_tgid, st_hgid, st_hslot, st_hflag, st_ready;
+    int64_t *health_ok = nullptr, *health_fail = nullptr;   // [F][G] N4b
+    int32_t *health_recent = nullptr;
     std::string err;
 };
 
@@ -126,7 +131,8 @@ int rg_table_destroy(rg_table_t *t)
                     t->dt.peer_en, t->dt.peer_m, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
                     t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline,
-                    t->timer_counts, t->st_tgid.ptr};
+                    t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
+                    t->health_fail, t->health_recent};
     for (void *c : cols) if (c) (void)hipFree(c);
     for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (t->region0) { (void)hipEventDestroy(t->region0); (void)hipEventDestroy(t->region1); }
@@ -184,6 +190,12 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->timer_deadline, G * sizeof(int64_t)));
     CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 63) / 64 + 1) * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
+    CREATE_TRY(hipMalloc((void **)&t->health_ok, G * F * sizeof(int64_t)));
+    CREATE_TRY(hipMalloc((void **)&t->health_fail, G * F * sizeof(int64_t)));
+    CREATE_TRY(hipMalloc((void **)&t->health_recent, G * F * sizeof(int32_t)));
+    CREATE_TRY(hipMemsetAsync(t->health_ok, 0, G * F * sizeof(int64_t), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->health_fail, 0, G * F * sizeof(int64_t), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->health_recent, 0, G * F * sizeof(int32_t), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.term_commit, 0, G * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.epoch, 0, G * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.window, 0, G * sizeof(I64x2), t->stream));
@@ -277,6 +289,11 @@ int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_
         HIP_TRY(t, hipMemcpyAsync(t->dt.peer_m + j * G + first, pm.data() + j * n, n * sizeof(rg::Match), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(t, hipMemsetAsync(t->timer_deadline + first, 0, n * sizeof(int64_t), st));   // loaded groups hold no timer ticket yet
+    for (size_t j = 0; j < F; j++) {                                                       // ... and fresh health statistics
+        HIP_TRY(t, hipMemsetAsync(t->health_ok + j * G + first, 0, n * sizeof(int64_t), st));
+        HIP_TRY(t, hipMemsetAsync(t->health_fail + j * G + first, 0, n * sizeof(int64_t), st));
+        HIP_TRY(t, hipMemsetAsync(t->health_recent + j * G + first, 0, n * sizeof(int32_t), st));
+    }
     HIP_TRY(t, hipStreamSynchronize(st));
     return 0;
 }
@@ -588,6 +605,115 @@ int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadl
     if (bind(t)) return -2;
     HIP_TRY(t, hipMemcpyAsync(deadline, t->timer_deadline + first, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+/* ---- N4b: health ------------------------------------------------------------------------------------- */
+
+static rg::HealthParams health_params(rg_table *t)
+{
+    rg::HealthParams p{};
+    p.ok = t->health_ok; p.fail = t->health_fail; p.recent = t->health_recent; p.t = t->dt;
+    p.followers = t->F; p.self = t->self;
+    return p;
+}
+
+int rg_health_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_ev_head_t *head,
+                     const rg_reply_t *reply, const int64_t *now, int memspace)
+{
+    if (!t) return -1;
+    if (!head || !reply || !now || rounds == 0) return fail(t, -1, "rg_health_update: head, reply, now and rounds are required");
+    if (gid ? (rounds != 1 || count > t->G) : count != t->G) return fail(t, -1, "rg_health_update: %u rows for %u groups", count, t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    const size_t rows = (size_t)rounds * count;
+    const rg_ev_head_t *d_head = head; const rg_reply_t *d_reply = reply; const uint32_t *d_gid = gid;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_reply, rows * sizeof(rg_reply_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_head.ptr, head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(t, hipMemcpyAsync(t->st_reply.ptr, reply, rows * sizeof(rg_reply_t), hipMemcpyHostToDevice, s));
+        d_head = (const rg_ev_head_t *)t->st_head.ptr; d_reply = (const rg_reply_t *)t->st_reply.ptr;
+        if (gid) {
+            for (uint32_t i = 0; i < count; i++)
+                if (gid[i] >= t->G || (i && gid[i] <= gid[i - 1])) return fail(t, -1, "rg_health_update: bad gid list at row %u", i);
+            if (reserve(t, t->st_gid, count * sizeof(uint32_t))) return -2;
+            HIP_TRY(t, hipMemcpyAsync(t->st_gid.ptr, gid, count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+            d_gid = (const uint32_t *)t->st_gid.ptr;
+        }
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_health_update: unknown memspace %d", memspace);
+    }
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 64) {
+        rg::HealthParams p = health_params(t);
+        p.rounds = rounds - r0 < 64 ? rounds - r0 : 64; p.count = count; p.gid = d_gid;
+        p.head = d_head + (size_t)r0 * count; p.reply = d_reply + (size_t)r0 * count;
+        for (uint32_t k = 0; k < p.rounds; k++) p.now[k] = now[r0 + k];
+        HIP_TRY(t, rg::launch_health_update(p, s));
+    }
+    if (memspace == RG_MEM_HOST) HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_health_failure(rg_table_t *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now)
+{
+    if (!t) return -1;
+    if (n && (!gid || !slot || !flags)) return fail(t, -1, "rg_health_failure: gid, slot and flags are required");
+    if (n == 0) return 0;
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    if (reserve(t, t->st_hgid, n * sizeof(uint32_t)) || reserve(t, t->st_hslot, n) || reserve(t, t->st_hflag, n)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(t->st_hgid.ptr, gid, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_hslot.ptr, slot, n, hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_hflag.ptr, flags, n, hipMemcpyHostToDevice, s));
+    rg::HealthParams p = health_params(t);
+    p.now[0] = now;
+    HIP_TRY(t, rg::launch_health_failure(p, n, (const uint32_t *)t->st_hgid.ptr, (const uint8_t *)t->st_hslot.ptr,
+                                         (const uint8_t *)t->st_hflag.ptr, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_ready(rg_table_t *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready, int memspace)
+{
+    if (!t || !ready) return -1;
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    uint8_t *d_ready = ready;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_ready, t->G)) return -2;
+        d_ready = (uint8_t *)t->st_ready.ptr;
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_ready: unknown memspace %d", memspace);
+    }
+    HIP_TRY(t, rg::launch_ready(health_params(t), now, critical_point, cool_down_ms, d_ready, s));
+    if (memspace == RG_MEM_HOST) {
+        HIP_TRY(t, hipMemcpyAsync(ready, d_ready, t->G, hipMemcpyDeviceToHost, s));
+        HIP_TRY(t, hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int rg_health_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure,
+                   int32_t *recent_failure)
+{
+    if (!t || !request_success || !request_failure || !recent_failure) return -1;
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_health_read: range exceeds %u groups", t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    const size_t n = count, F = t->F, G = t->G;
+    std::vector<int64_t> ok(n * F), fl(n * F);
+    std::vector<int32_t> rc(n * F);
+    for (size_t j = 0; j < F; j++) {
+        HIP_TRY(t, hipMemcpyAsync(ok.data() + j * n, t->health_ok + j * G + first, n * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(t, hipMemcpyAsync(fl.data() + j * n, t->health_fail + j * G + first, n * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(t, hipMemcpyAsync(rc.data() + j * n, t->health_recent + j * G + first, n * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    }
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < F; j++) {
+            request_success[i * F + j] = ok[j * n + i]; request_failure[i * F + j] = fl[j * n + i]; recent_failure[i * F + j] = rc[j * n + i];
+        }
     return 0;
 }
 

@@ -95,6 +95,17 @@ struct TimerParams {                 // N4: RaftRoutine.resetTimer / electionTim
     uint64_t seed;
 };
 
+struct HealthParams {                // N4b: Leadership.State health fields + Leader.isReady (rg_kernels.hip)
+    int64_t *ok, *fail;              // [F][G] requestSuccess / requestFailure
+    int32_t *recent;                 // [F][G] recentFailure
+    DevTable t;
+    uint32_t rounds, count, followers, self;
+    const uint32_t *gid;
+    const rg_ev_head_t *head;
+    const rg_reply_t *reply;
+    int64_t now[64];
+};
+
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }

@@ -450,6 +450,89 @@ hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now
     return hipGetLastError();
 }
 
+// ---- N4b: follower health + Leader.isReady -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void health_update_kernel(const HealthParams p)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.count) return;
+    const uint32_t g = p.gid ? p.gid[i] : i;
+    const size_t G = p.t.groups;
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const size_t row = (size_t)r * p.count + i;
+        const rg_reply_t rep = p.reply[row];
+        if ((rep.flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(rep.flags) == RG_LEADER) {      // new Leader: new State objects
+            for (uint32_t j = 0; j < p.followers; j++) { p.ok[j * G + g] = 0; p.fail[j * G + g] = 0; p.recent[j * G + g] = 0; }
+            continue;
+        }
+        const uint32_t hdr = p.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(rep.flags);
+        const bool ack = kind == RG_EV_AE_ACK || kind == RG_EV_IS_ACK;
+        // statSuccess ran iff the callback got past the fence and the term check and the row was applied
+        const bool reached = st == RG_OK || st == RG_A_MATCH_ROLLBACK || st == RG_NPE_MAJOR_NULL || st == RG_A_COMMIT_ROLLBACK;
+        if (!ack || !reached || (rep.flags & RG_F_ROLE_CHANGED) || slot >= p.followers + 1 || slot == p.self) continue;
+        const uint32_t j = slot < p.self ? slot : slot - 1;
+        const int64_t cur = p.ok[j * G + g];
+        if (p.now[r] > cur) p.ok[j * G + g] = p.now[r];                          // increaseMono
+        p.recent[j * G + g] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void health_failure_kernel(const HealthParams p, uint32_t n, const uint32_t *gid, const uint8_t *slot,
+                                                             const uint8_t *flags)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = gid[i], s = slot[i];
+    if (g >= p.t.groups || s > p.followers || s == p.self) return;
+    const uint32_t meta = p.t.ident[g].meta;
+    if ((meta & META_ROLE) != RG_LEADER || !(meta & META_PREP)) return;        // no State object to land on
+    const uint32_t j = s < p.self ? s : s - 1;
+    const size_t G = p.t.groups, at = j * G + g;
+    if (p.now[0] > p.fail[at]) p.fail[at] = p.now[0];                            // statFailure: increaseMono(requestFailure)
+    if (flags[i] & 1u) atomicAdd(&p.recent[at], 1);                              // unreachable (rows may repeat a (group, follower))
+    if (flags[i] & 2u) atomicAdd(&p.t.peer_m[at].rejection, 1);                  // reject
+}
+
+// Leader.isReady: ready = 1; for every State that isReady(...): ++ready > followers/2 -> true
+__global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_t now, int32_t critical_point, int64_t cool_down, uint8_t *ready)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.t.groups) return;
+    const Ident id = p.t.ident[g];
+    uint8_t out = 0;
+    if ((id.meta & META_ROLE) == RG_LEADER && (id.meta & META_PREP)) {
+        const uint32_t pend = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+        const size_t G = p.t.groups;
+        uint32_t n = 1;
+        for (uint32_t j = 0; j < p.followers; j++) {
+            const int64_t ok = p.ok[j * G + g], fail = p.fail[j * G + g];
+            const uint32_t recent = (uint32_t)p.recent[j * G + g];
+            const bool unhealthy = (critical_point > 0 && recent > (uint32_t)critical_point) ||        // Integer.compareUnsigned
+                                   (cool_down > 0 && wsub(now, fail) < cool_down);
+            const bool is_ready = ok != 0 && !(((pend >> j) & 1u) || unhealthy);
+            if (is_ready && ++n > p.followers / 2) { out = 1; break; }
+        }
+    }
+    ready[g] = out;
+}
+
+hipError_t launch_health_update(const HealthParams &p, hipStream_t s)
+{
+    if (p.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(health_update_kernel, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(health_failure_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, n, gid, slot, flags);
+    return hipGetLastError();
+}
+hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s)
+{
+    hipLaunchKernelGGL(ready_kernel, dim3((p.t.groups + 255) / 256), dim3(256), 0, s, p, now, cp, cd, ready);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;

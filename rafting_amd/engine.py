@@ -26,7 +26,8 @@ def exported_symbols():
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
         "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
-        "rg_timers_expired", "rg_timers_arm", "rg_timers_read", "rg_timing_enable",
+        "rg_timers_expired", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
+        "rg_timing_enable",
         "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
 
@@ -84,6 +85,10 @@ def lib():
         L.rg_timers_expired.argtypes = [vp, C.c_int64, vp, u32, C.POINTER(u32), i32]
         L.rg_timers_arm.argtypes = [vp, C.c_int64]
         L.rg_timers_read.argtypes = [vp, u32, u32, vp]
+        L.rg_health_update.argtypes = [vp, u32, u32, vp, vp, vp, vp, i32]
+        L.rg_health_failure.argtypes = [vp, u32, vp, vp, vp, C.c_int64]
+        L.rg_ready.argtypes = [vp, C.c_int64, i32, C.c_int64, vp, i32]
+        L.rg_health_read.argtypes = [vp, u32, u32, vp, vp, vp]
         L.rg_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.rg_host_free.argtypes = [vp, vp]
         L.rg_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -288,6 +293,42 @@ class Table:
         out = np.zeros(count, dtype=np.int64)
         self._check(lib().rg_timers_read(self._h, first, count, out.ctypes.data))
         return out
+
+    # N4b health / readiness -------------------------------------------------------------------------
+    def health_update(self, batch, reply, now):
+        """Fold a finished batch (its event heads + reply rows) into Leadership.State's statistics."""
+        now = np.ascontiguousarray(now, dtype=np.int64)
+        reply = np.ascontiguousarray(reply)
+        assert len(now) == batch.rounds and len(reply) == batch.rounds * batch.count
+        self._check(lib().rg_health_update(self._h, batch.rounds, batch.count, None if batch.gid is None else batch.gid.ctypes.data,
+                                           batch.head.ctypes.data, reply.ctypes.data, now.ctypes.data, abi.MEM_HOST))
+
+    def submit_timed(self, batch, now, fill=0):
+        """submit + health_update: what a flush at wall-clock `now` (one value per round) does."""
+        out = self.submit(batch, fill=fill)
+        self.health_update(batch, out.reply, now)
+        return out
+
+    def health_failure(self, gid, slot, flags, now):
+        """State.statFailure(now, unreachable=flags&1, reject=flags&2) per (group, peer slot) row."""
+        gid = np.ascontiguousarray(gid, dtype=np.uint32)
+        slot = np.ascontiguousarray(slot, dtype=np.uint8)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert len(gid) == len(slot) == len(flags)
+        self._check(lib().rg_health_failure(self._h, len(gid), gid.ctypes.data, slot.ctypes.data, flags.ctypes.data, now))
+
+    def ready(self, now, critical_point, cool_down_ms):
+        """Leader.isReady for every group (uint8[groups])."""
+        out = np.zeros(self.groups, dtype=np.uint8)
+        self._check(lib().rg_ready(self._h, now, critical_point, cool_down_ms, out.ctypes.data, abi.MEM_HOST))
+        return out
+
+    def health_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        F = self.cluster - 1
+        ok, fl, rc = np.zeros((count, F), np.int64), np.zeros((count, F), np.int64), np.zeros((count, F), np.int32)
+        self._check(lib().rg_health_read(self._h, first, count, ok.ctypes.data, fl.ctypes.data, rc.ctypes.data))
+        return ok, fl, rc
 
     def replicate(self, gid=None, heartbeat=None, in_flight=None):
         """Leader.replicateLog for `gid` (None = every group): returns (head[count], send[count, F])."""

@@ -41,6 +41,7 @@ struct Msg {
     bool success = false;
     uint32_t epoch = 0;                           // role epoch of the requester when it sent the request
     int64_t epochAtSend = 0, lastSent = 0;        // Leader.replicateLog closure state echoed by the response
+    int64_t sentTick = 0;                         // when the request left (echoed): pairs a response with its Async
 };
 
 static const int P = 3;
@@ -53,6 +54,7 @@ struct Group {
     std::vector<std::string> file;                // FileMachine: "<index>:<line>"
     int64_t applied = 0;
     int inflight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // State.requestInFlight per peer
+    std::deque<int64_t> outstanding[8];           // send ticks of the AppendEntries still waiting for a response or a timeout
 };
 
 struct Node {
@@ -70,6 +72,9 @@ static std::map<std::pair<uint32_t, int64_t>, int> leader_of_term;
 static int violations = 0;
 
 static const int64_t TICK_MS = 50;                // simulation step = network delay; timers keep millisecond deadlines
+static const int64_t BROADCAST_TICKS = 3;         // broadcast timeout = 0.5 x 300 ms (raft1.xml:13) = 3 steps; a round trip takes 2
+static const int32_t CRITICAL_POINT = 1;          // raft1.xml:30 avail-critical-point
+static const int64_t COOL_DOWN_MS = 100;          // raft1.xml:31 recovery-cool-down
 static void fail(const char *what, uint32_t gid) { fprintf(stderr, "INVARIANT VIOLATED (tick %lld, group %u): %s\n", (long long)now_tick, gid, what); violations++; }
 static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term) + "-cmd" + std::to_string(e.index); }
 
@@ -77,12 +82,11 @@ static void send(Node &n, Msg m) { m.from = n.id; if (n.connected) wire_next.pus
 
 // Leader.replicateLog (member/Leader.java:142-245): WHAT to send is decided on the GPU (rg_replicate, one launch for
 // all leader contexts of the node that emitted a heartbeat this drain); the host only reads the payload range
-static void replicate(Node &n, std::vector<Group *> &leaders)
+static void replicate(Node &n, std::vector<Group *> &leaders, const std::vector<uint8_t> &hb)
 {
     if (leaders.empty()) return;
     const size_t F = P - 1;
     std::vector<RaftContext *> ctxs;
-    std::vector<uint8_t> hb(leaders.size(), 1);
     std::vector<uint16_t> fl;
     for (Group *g : leaders) {
         ctxs.push_back(g->ctx);
@@ -104,7 +108,9 @@ static void replicate(Node &n, std::vector<Group *> &leaders)
             } else {
                 m.type = AE; m.x = s.prev_index; m.y = s.prev_term; m.z = pl.head.leader_commit; m.lastSent = s.last_index;
                 for (uint32_t k = 1; k <= s.count; k++) m.entries.push_back(*c.replicatedLog().get(s.prev_index + k));
+                m.sentTick = now_tick;
                 g.inflight[peer]++;
+                g.outstanding[peer].push_back(now_tick);
             }
             send(n, std::move(m));
         }
@@ -156,10 +162,20 @@ int main(int argc, char **argv)
     }
     const int64_t cut_at = ticks / 3, heal_at = 2 * ticks / 3, quiet_at = ticks - 200;
     int cut_node = -1;
-    uint64_t commands = 0, elections = 0, rollbacks = 0;
+    uint64_t commands = 0, elections = 0, rollbacks = 0, not_ready = 0, rpc_timeouts = 0;
 
     for (now_tick = 0; now_tick < ticks; now_tick++) {
-        for (Msg &m : wire) if (nodes[m.to].connected && nodes[m.from].connected) nodes[m.to].g[m.gid].inbox.push_back(std::move(m));
+        for (Msg &m : wire) {
+            if (!(nodes[m.to].connected && nodes[m.from].connected)) continue;
+            Group &g = nodes[m.to].g[m.gid];
+            if (m.type == AE_RESP) {                    // completes its Async unless that already ended in a timeout / abort
+                auto &o = g.outstanding[m.from];
+                auto it = std::find(o.begin(), o.end(), m.sentTick);
+                if (it == o.end()) continue;
+                o.erase(it);
+            }
+            g.inbox.push_back(std::move(m));
+        }
         wire.clear();
         if (now_tick == cut_at) {                       // "a human kills the leader's process"
             for (Node &n : nodes) if (n.g[0].ctx->role() == RG_LEADER) cut_node = n.id;
@@ -171,8 +187,21 @@ int main(int argc, char **argv)
           std::vector<char> commanded(groups, 0);
           // broadcast timeout = 0.5 tick (raft1.xml:13): every request still unanswered a tick later has
           // completed with a timeout error, which releases its in-flight slot (Leader.java:221,235)
-          for (Group &g : n.g) for (int &x : g.inflight) x = 0;
           const int64_t now_ms = now_tick * TICK_MS;
+          std::vector<ContextManager::RpcFailure> timed_out;
+          for (Group &g : n.g)                           // requests unanswered for the broadcast timeout complete with an error:
+              for (int peer = 0; peer < P; peer++) {     // the callback frees the in-flight slot and calls statFailure (Leader.java:221,235)
+                  auto &o = g.outstanding[peer];
+                  while (!o.empty() && o.front() + BROADCAST_TICKS <= now_tick) {
+                      o.pop_front();
+                      if (g.inflight[peer] > 0) g.inflight[peer]--;
+                      timed_out.push_back({g.ctx, peer, true, false});
+                      rpc_timeouts++;
+                  }
+              }
+          n.mgr->statFailure(timed_out, now_ms);
+          // RaftStub.process: a Leader takes commands only while isReady (command/RaftStub.java:80-87), raft1.xml:30-31
+          const std::vector<uint8_t> ready = n.mgr->isReady(now_ms, CRITICAL_POINT, COOL_DOWN_MS);
           for (RaftContext *c : n.mgr->expiredTimers(now_ms)) n.g[c->gid()].timer_due = true;   // electionTimeout / keepAlive fired
           for (int sub = 0; sub < 8; sub++) {             // several EventLoop drains per tick: one row per context each
             struct Src { Group *g; Msg msg; int what; };   // what: 0 message, 1 timer, 2 client command
@@ -208,6 +237,8 @@ int main(int argc, char **argv)
                     }
                     src.push_back({&g, std::move(m), 0});
                 } else if (c.role() == RG_LEADER && now_tick < quiet_at && !commanded[c.gid()] && (now_tick + c.gid()) % 4 == 0) {
+                    commanded[c.gid()] = 1;
+                    if (!ready[c.gid()]) { not_ready++; continue; }  // NotReadyException
                     c.acceptCommand(1);                             // TestNode: submit(AppendCommand(...))
                     commanded[c.gid()] = 1;
                     src.push_back({&g, Msg{}, 2});
@@ -216,6 +247,7 @@ int main(int argc, char **argv)
             if (src.empty()) break;
             std::vector<Outcome> out = n.mgr->flush(now_ms);    // also folds RESET_TIMER / ROLE_CHANGED into the device timers
             std::vector<Group *> to_replicate;
+            std::vector<uint8_t> heartbeat;                     // replicateLog(true) from onTimeout, (false) from acceptCommand
             for (size_t i = 0; i < out.size(); i++) {
                 Group &g = *src[i].g;
                 RaftContext &c = *g.ctx;
@@ -231,7 +263,7 @@ int main(int argc, char **argv)
                 if (src[i].what == 0 && o.response) {
                     const Msg &q = src[i].msg;
                     Msg r; r.to = q.from; r.gid = q.gid; r.term = o.response->term; r.success = o.response->success;
-                    r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent;
+                    r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent; r.sentTick = q.sentTick;
                     r.type = q.type == AE ? AE_RESP : q.type == PV ? PV_RESP : RV_RESP;
                     send(n, std::move(r));
                 }
@@ -242,7 +274,10 @@ int main(int argc, char **argv)
                             (long long)c.currentTerm(), o.roleEpoch, o.status, o.flags, o.response ? (int)o.response->success : -1,
                             (long long)(o.response ? o.response->term : -1), (long long)(c.replicatedLog().last() ? c.replicatedLog().last()->index : -1),
                             (long long)c.replicatedLog().lastCommitted());
-                if (o.roleChanged()) for (int &x : g.inflight) x = 0;          // AsyncHead.abortRequests
+                if (o.roleChanged()) {                                          // AsyncHead.abortRequests
+                    for (int &x : g.inflight) x = 0;
+                    for (auto &q : g.outstanding) q.clear();
+                }
                 if (o.roleChanged() && o.role == RG_LEADER) {
                     elections++;
                     auto key = std::make_pair(c.gid(), c.currentTerm());
@@ -251,9 +286,9 @@ int main(int argc, char **argv)
                 }
                 if (o.emit() == RG_EMIT_PREVOTE) broadcast_vote(n, g, true, o.roleEpoch);
                 else if (o.emit() == RG_EMIT_REQVOTE) broadcast_vote(n, g, false, o.roleEpoch);
-                else if (o.emit() == RG_EMIT_HEARTBEAT) to_replicate.push_back(&g);
+                else if (o.emit() == RG_EMIT_HEARTBEAT) { to_replicate.push_back(&g); heartbeat.push_back(src[i].what != 2); }
             }
-            replicate(n, to_replicate);
+            replicate(n, to_replicate, heartbeat);
           }
         }
         // state-machine safety, every tick
@@ -298,6 +333,8 @@ int main(int argc, char **argv)
                 fail("journal does not hold the participant's (term, votedFor)", g.ctx->gid());
         }
     }
+    fprintf(stderr, "readiness gate: %llu commands refused (NotReadyException), %llu RPC timeouts\n", (unsigned long long)not_ready,
+            (unsigned long long)rpc_timeouts);
     fprintf(stderr, "durability: %llu (term, votedFor) records in %llu fdatasyncs\n", (unsigned long long)persisted, (unsigned long long)syncs);
     for (uint32_t i = 0; i < groups && !identical && i < 4096; i++) {
         bool same = true;

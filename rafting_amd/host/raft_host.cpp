@@ -284,8 +284,30 @@ void ContextManager::submit(std::vector<size_t> &which, bool hinted, std::vector
     if (rg_submit(table_, &in, &out, RG_MEM_HOST) != 0) throw std::runtime_error(rg_last_error(table_));
     if (now >= 0 && rg_timers_update(table_, 1, (uint32_t)n, gid.data(), o_rep.data(), &now, RG_MEM_HOST) != 0)
         throw std::runtime_error(rg_last_error(table_));
+    if (now >= 0 && rg_health_update(table_, 1, (uint32_t)n, gid.data(), head.data(), o_rep.data(), &now, RG_MEM_HOST) != 0)
+        throw std::runtime_error(rg_last_error(table_));
     for (size_t k = 0; k < n; k++) { rep[which[k]] = o_rep[k]; lfx[which[k]] = o_lfx[k]; per[which[k]] = o_per[k]; }
     rows_decided_ += n;
+}
+
+void ContextManager::statFailure(const std::vector<RpcFailure> &failures, int64_t now)
+{
+    if (failures.empty()) return;
+    std::vector<uint32_t> gid; std::vector<uint8_t> slot, flags;
+    for (const RpcFailure &f : failures) {
+        gid.push_back(f.ctx->gid()); slot.push_back((uint8_t)f.peer);
+        flags.push_back((uint8_t)((f.unreachable ? 1 : 0) | (f.reject ? 2 : 0)));
+    }
+    if (rg_health_failure(table_, (uint32_t)gid.size(), gid.data(), slot.data(), flags.data(), now) != 0)
+        throw std::runtime_error(rg_last_error(table_));
+}
+
+std::vector<uint8_t> ContextManager::isReady(int64_t now, int32_t criticalPoint, int64_t coolDownMs)
+{
+    std::vector<uint8_t> ready(capacity_);
+    if (rg_ready(table_, now, criticalPoint, coolDownMs, ready.data(), RG_MEM_HOST) != 0) throw std::runtime_error(rg_last_error(table_));
+    ready.resize(contexts_.size());
+    return ready;
 }
 
 std::vector<Outcome> ContextManager::flush(int64_t now)

@@ -190,6 +190,14 @@ class ContextManager {
     void armTimers(int64_t now);
     std::vector<RaftContext *> expiredTimers(int64_t now);
 
+    // N4b: Leadership.State health statistics live next to the timers. flush(now) folds statSuccess for every ack row
+    // (member/Leader.java:182,229); statFailure is for RPCs the host saw fail — timeout, transport error, peer service not
+    // available (member/Leader.java:187,235,240); isReady is the gate RaftStub.process applies before acceptCommand
+    // (command/RaftStub.java:80-87, member/Leader.java:52-64) with RaftConfig's availableCriticalPoint / recoveryCoolDownMills.
+    struct RpcFailure { const RaftContext *ctx; ID peer; bool unreachable, reject; };
+    void statFailure(const std::vector<RpcFailure> &failures, int64_t now);
+    std::vector<uint8_t> isReady(int64_t now, int32_t criticalPoint, int64_t coolDownMs);   // indexed by RaftContext::gid()
+
     bool pending(const RaftContext &c) const;  // a row for this context is already queued (one per context per flush)
     // The EventLoop drain: decide every queued row on the GPU, apply effects, complete tickets.
     // Outcome i answers ticket i of this flush; tickets restart at 0 afterwards.

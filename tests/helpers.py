@@ -52,6 +52,7 @@ def simple_log(last, term=1, first=1):
 class Sim:
     def __init__(self, table, group=0):
         self.t, self.g = table, group
+        self.now = None                      # set: events carry this wall clock (Leadership.State statistics are kept)
 
     def load(self, **kw):
         st = make_state(self.t.cluster, self.t.groups, **kw)
@@ -81,7 +82,7 @@ class Sim:
         row = b.put(0, self.g, kind, **kw)
         if hint is not None:
             b.set_hint(row, *hint)
-        out = self.t.submit(b, fill=0xAB)
+        out = self.t.submit(b, fill=0xAB) if self.now is None else self.t.submit_timed(b, [self.now], fill=0xAB)
         f = int(out.reply["flags"][row])
         return SimpleNamespace(
             flags=f, status=(f >> abi.F_STATUS_SHIFT) & 0xFF,

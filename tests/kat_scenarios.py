@@ -622,5 +622,88 @@ def none_rows_do_nothing(mk):
     assert (r.status, r.replied, r.role, r.role_epoch, r.flags & 0xFF) == (abi.OK, False, C, 9, 0)
 
 
+# --------------------------------------------------------------------------------------------------
+# N4b: follower health + Leader.isReady  member/Leadership.java:43-73, member/Leader.java:52-64
+
+def health_ready_gate(mk):
+    CP, CD = 2, 500                                            # availableCriticalPoint, recoveryCoolDownMills
+    s = _sim(mk, cluster=5, role=C, term=5, voted_for=0, role_epoch=2, log=simple_log(100, 5))
+    t = s.t
+    s.now = 1000
+    assert s.rv_reply(1, 5, True, 2).status == abi.OK
+    assert s.rv_reply(2, 5, True, 2).role == L                 # majority of 5
+    assert t.ready(1000, CP, CD)[0] == 0                       # followerStatus == null (Leader.java:53)
+    s.on_timeout()                                             # keepAlive -> prepareReplication
+    assert t.ready(1001, CP, CD)[0] == 0                       # requestSuccess == 0 everywhere (Leadership.java:49)
+    s.now = 2000
+    assert s.ae_ack(1, 5, True, 0, 100, 3).status == abi.OK
+    ok, fl, rc = t.health_read()
+    assert ok[0].tolist() == [2000, 0, 0, 0] and not fl.any() and not rc.any()
+    assert t.ready(2001, CP, CD)[0] == 0                       # ready = 1+1 = 2, half = 4/2 = 2: 2 > 2 is false
+    s.now = 2100
+    s.ae_ack(3, 5, False, 0, 100, 3)                           # a rejection is still a statSuccess (Leader.java:229)
+    assert t.ready(2101, CP, CD)[0] == 1                       # 3 > 2
+    s.now = 1500
+    s.ae_ack(3, 5, False, 0, 99, 3)                            # increaseMono: the clock never moves back (Leadership.java:39-41)
+    assert t.health_read()[0][0].tolist() == [2000, 0, 2100, 0]
+    # statFailure: unreachable x3 > criticalPoint 2 -> unhealthy
+    for k in range(3):
+        t.health_failure([0], [3], [1], 3000 + k)
+        assert t.ready(10_000, CP, CD)[0] == (1 if k < 2 else 0), k          # Integer.compareUnsigned(recent, 2) > 0 at 3
+    ok, fl, rc = t.health_read()
+    assert fl[0].tolist() == [0, 0, 3002, 0] and rc[0].tolist() == [0, 0, 3, 0]
+    assert t.ready(10_000, 0, CD)[0] == 1                      # criticalPoint 0 switches the check off
+    s.now = 10_000
+    s.ae_ack(3, 5, True, 0, 100, 3)                            # one success clears recentFailure (Leadership.java:55-57)
+    assert t.health_read()[2][0].tolist() == [0, 0, 0, 0]
+    assert t.ready(10_001, CP, CD)[0] == 1
+    # cool-down: a failure less than CD ms ago keeps the peer out
+    t.health_failure([0], [1], [0], 10_100)                    # error == null, result == null: neither counter moves
+    assert t.health_read()[2][0].tolist() == [0, 0, 0, 0]
+    assert t.ready(10_599, CP, CD)[0] == 0                     # now - requestFailure = 499 < 500
+    assert t.ready(10_600, CP, CD)[0] == 1
+    assert t.ready(10_599, CP, 0)[0] == 1                      # coolDown 0 switches the check off
+    rej0 = s.state().peers[0][3]
+    t.health_failure([0], [1], [2], 10_050)                    # reject: recentRejection++ ; requestFailure keeps its max
+    assert s.state().peers[0][3] == rej0 + 1 and t.health_read()[1][0, 0] == 10_100
+    # fenced / stale callbacks do not count
+    s.now = 20_000
+    assert s.ae_ack(2, 5, True, 0, 100, 2).status == abi.DROPPED_STALE_ROLE
+    assert t.health_read()[0][0].tolist() == [2000, 0, 10_000, 0]
+    # a higher term in the response: no statistics, the Leader steps down, isReady is false from then on
+    r = s.ae_ack(2, 6, False, 0, 100, 3)
+    assert r.role_changed and r.role == F
+    assert t.health_read()[0][0, 1] == 0 and t.ready(20_001, CP, CD)[0] == 0
+    t.health_failure([0], [1], [1], 20_002)                    # no State object any more: ignored
+    assert t.health_read()[2][0].tolist() == [0, 0, 0, 0]
+
+
+def health_small_clusters_and_pending(mk):
+    s = _leader(mk, cluster=3)                                 # half = 2/2 = 1: one live follower is enough
+    s.now = 500
+    s.ae_ack(2, 5, True, 0, 100, 3)
+    assert s.t.ready(501, 3, 100)[0] == 1
+    s = _leader(mk, cluster=2)                                 # half = 1/2 = 0, but ++ready only runs for a ready State
+    assert s.t.ready(501, 3, 100)[0] == 0
+    s.now = 500
+    s.ae_ack(1, 5, True, 0, 100, 3)
+    assert s.t.ready(501, 3, 100)[0] == 1
+    s = _leader(mk, cluster=3, peers=[(0, 101, 0, 0, 1), (0, 101, 0, 0, 0)])
+    s.now = 700
+    assert s.is_ack(1, 5, False, 0, 3).status == abi.OK        # IS-Echo: statSuccess too (Leader.java:182), still pending
+    assert s.t.health_read()[0][0].tolist() == [700, 0]
+    assert s.t.ready(701, 3, 100)[0] == 0                      # pendingInstallation (Leadership.java:49)
+    s.is_ack(1, 5, True, 0, 3)
+    assert s.t.ready(701, 3, 100)[0] == 1
+    # match index rollback throws AFTER statSuccess (Leader.java:229-230)
+    s = _leader(mk, cluster=3, peers=[(0, 101, 90, 0, 0), (0, 101, 0, 0, 0)])
+    s.now = 900
+    assert s.ae_ack(1, 5, True, 0, 80, 3).status == abi.A_MATCH_ROLLBACK
+    assert s.t.health_read()[0][0].tolist() == [900, 0]
+    # a reloaded table starts from zeroed statistics
+    s.load(role=L, term=5, voted_for=0, role_epoch=3, repl_prepared=1, log=simple_log(10, 5), peers=[(0, 11, 0, 0, 0)] * 2)
+    assert not s.t.health_read()[0].any()
+
+
 SCENARIOS = [v for k, v in sorted(globals().items())
              if callable(v) and getattr(v, "__module__", None) == __name__ and not k.startswith("_")]

@@ -45,6 +45,10 @@ def lib():
         L.orc_timers_arm.argtypes = [C.c_void_p, C.c_int64]
         L.orc_timers_expired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_timers_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_health_clock.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_health_failure.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_ready.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
+        L.orc_health_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_log_term.restype = C.c_int
         L.orc_log_term.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_log_conflict.restype = C.c_int64
@@ -87,13 +91,44 @@ class OracleTable:
             raise ValueError("orc_read_state failed: %d" % rc)
         return st
 
-    def submit(self, batch, out=None, fill=0):
+    def submit(self, batch, out=None, fill=0, now=None):
+        """now: one wall-clock value per round -> Leadership.State statistics are kept for this submit."""
         out = abi.Outcome(batch.rounds * batch.count, fill) if out is None else out
         b, o = batch.as_struct(), out.as_struct()
-        rc = lib().orc_submit(self._h, C.byref(b), C.byref(o))
+        clock = None
+        if now is not None:
+            clock = np.ascontiguousarray(now, dtype=np.int64)
+            assert len(clock) == batch.rounds
+            assert lib().orc_health_clock(self._h, clock.ctypes.data) == 0
+        try:
+            rc = lib().orc_submit(self._h, C.byref(b), C.byref(o))
+        finally:
+            if clock is not None:
+                lib().orc_health_clock(self._h, None)
         if rc:
             raise ValueError("orc_submit failed: %d" % rc)
         return out
+
+    def submit_timed(self, batch, now, fill=0):
+        return self.submit(batch, fill=fill, now=now)
+
+    def health_failure(self, gid, slot, flags, now):
+        gid = np.ascontiguousarray(gid, dtype=np.uint32)
+        slot = np.ascontiguousarray(slot, dtype=np.uint8)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert lib().orc_health_failure(self._h, len(gid), gid.ctypes.data, slot.ctypes.data, flags.ctypes.data, now) == 0
+
+    def ready(self, now, critical_point, cool_down_ms):
+        out = np.zeros(self.groups, dtype=np.uint8)
+        assert lib().orc_ready(self._h, now, critical_point, cool_down_ms, out.ctypes.data) == 0
+        return out
+
+    def health_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        F = self.cluster - 1
+        ok, fl, rc = np.zeros((count, F), np.int64), np.zeros((count, F), np.int64), np.zeros((count, F), np.int32)
+        assert lib().orc_health_read(self._h, first, count, ok.ctypes.data, fl.ctypes.data, rc.ctypes.data) == 0
+        return ok, fl, rc
 
     def timers_configure(self, election_ms, heartbeat_ms, seed=0):
         assert lib().orc_timers_configure(self._h, election_ms, heartbeat_ms, seed) == 0

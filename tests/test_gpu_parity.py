@@ -8,7 +8,7 @@ import pytest
 
 from rafting_amd import abi, engine
 from tests import fuzz, kat_scenarios, oracle_lib
-from tests.helpers import compare_outcomes, compare_states
+from tests.helpers import compare_outcomes, compare_states, make_state, simple_log
 
 pytestmark = pytest.mark.gpu
 
@@ -302,3 +302,80 @@ def test_timer_driven_replay_matches_oracle():
     gpu.timers_update(3, G, og.reply, nows)
     orc.timers_update(3, G, oo.reply, nows)
     assert np.array_equal(gpu.timers_read(), orc.timers_read())
+
+
+def test_health_replay_matches_oracle():
+    """N4b in a closed loop: acks fold into requestSuccess / recentFailure through rg_health_update (derived from the reply
+    rows), RPC failures through rg_health_failure; statistics and Leader.isReady must equal the oracle, which keeps them
+    inside its ack handler where the reference does."""
+    G, P = 4096, 5
+    rng = np.random.default_rng(5)
+    st0 = fuzz.random_initial_state(G, P, 1, 91)
+    gpu, orc = engine.Table(G, P, 1, True), oracle_lib.OracleTable(G, P, 1, True)
+    fz = fuzz.Fuzzer(G, P, 1, 91, allow_miss=False)
+    for t in (gpu, orc):
+        t.load_state(st0)
+    ready_seen = np.zeros(2, dtype=np.int64)
+    for r in range(50):
+        now = 50_000 + 40 * r
+        b = abi.Batch(1, G)
+        cur = gpu.read_state()
+        fz.round(cur, b, 0)
+        og = gpu.submit(b, fill=0xAB)
+        _resolve_need_host(gpu, orc, b, og, cur)
+        gpu.health_update(b, og.reply, [now])
+        oo = orc.submit(b, fill=0xAB, now=[now])
+        compare_outcomes(oo, og, "round %d" % r)
+        n = int(rng.integers(0, G // 2))                                   # RPC errors / timeouts, repeats of a (group, peer) included
+        fg = rng.integers(0, G, n).astype(np.uint32)
+        fs = rng.integers(0, P, n).astype(np.uint8)                        # the self slot shows up too: ignored
+        ff = rng.integers(0, 4, n).astype(np.uint8)
+        gpu.health_failure(fg, fs, ff, now + 7)
+        orc.health_failure(fg, fs, ff, now + 7)
+        for a, c in zip(gpu.health_read(), orc.health_read()):
+            assert np.array_equal(a, c), r
+        compare_states(orc.read_state(), gpu.read_state(), "after failures %d" % r)
+        for cp, cd in ((0, 0), (1, 0), (0, 60), (2, 100), (1, 10 ** 9)):
+            rg_, ro_ = gpu.ready(now + 20, cp, cd), orc.ready(now + 20, cp, cd)
+            assert np.array_equal(rg_, ro_), (r, cp, cd)
+            ready_seen += np.bincount(ro_, minlength=2)[:2]
+    assert ready_seen[0] and ready_seen[1]
+
+
+def test_health_multi_round_and_sparse_fold():
+    """rg_health_update over a multi-round batch (clock per round) and over a sparse batch == the oracle."""
+    G, P = 256, 4
+    st = make_state(P, G, role=abi.LEADER, term=5, voted_for=0, role_epoch=3, repl_prepared=1, log=simple_log(50, 5),
+                    peers=[(0, 51, 0, 0, 0)] * 3)
+    gpu, orc = engine.Table(G, P, 0, True), oracle_lib.OracleTable(G, P, 0, True)
+    for t in (gpu, orc):
+        t.load_state(st)
+    big = abi.Batch(3, G)
+    for g in range(G):
+        big.put(0, g, abi.EV_AE_ACK, slot=1 + g % 3, flag=1, a=5, b=0, c=40, aux=3)
+        if g % 4 == 1:
+            big.put(1, g, abi.EV_AE_ACK, slot=1 + (g + 1) % 3, flag=g % 8 == 1, a=5 + (g % 16 == 5), b=0, c=45, aux=3)
+        if g % 2 == 0:
+            big.put(2, g, abi.EV_IS_ACK, slot=3, flag=0, a=5, b=0, aux=3 - (g % 6 == 0))
+    nows = [90_000, 90_010, 90_005]                                        # the third clock runs behind: increaseMono
+    og = gpu.submit(big, fill=0xAB)
+    gpu.health_update(big, og.reply, nows)
+    oo = orc.submit(big, fill=0xAB, now=nows)
+    compare_outcomes(oo, og, "multi-round")
+    for a, c in zip(gpu.health_read(), orc.health_read()):
+        assert np.array_equal(a, c)
+    assert gpu.health_read()[0].max() == 90_010
+    gids = np.arange(3, G, 5, dtype=np.uint32)
+    sp = abi.Batch(1, len(gids), gid=gids)
+    for k in range(len(gids)):
+        sp.put(0, k, abi.EV_AE_ACK, slot=2, flag=1, a=5, b=0, c=50, aux=3)
+    og = gpu.submit(sp, fill=0xAB)
+    gpu.health_update(sp, og.reply, [95_000])
+    oo = orc.submit(sp, fill=0xAB, now=[95_000])
+    compare_outcomes(oo, og, "sparse")
+    for a, c in zip(gpu.health_read(), orc.health_read()):
+        assert np.array_equal(a, c)
+    assert np.array_equal(gpu.ready(95_001, 1, 10), orc.ready(95_001, 1, 10)) and gpu.ready(95_001, 1, 10).any()
+    first, count = 17, 100                                                 # ranged read
+    for a, c in zip(gpu.health_read(first, count), orc.health_read(first, count)):
+        assert np.array_equal(a, c)
