@@ -147,13 +147,25 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 #ifdef RG_PROFILE
         const uint64_t tp2 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RG_PROFILE_TIERS
+        uint64_t tpa = tp2, tpb = tp2;                  // -DRG_PROFILE -DRG_PROFILE_TIERS: split "decide" into tier 1 / tier 2 / epilogue
+#endif
 
         if (active) {
             const uint32_t kind = RG_HDR_KIND(cur.hdr);
             if (blocked && kind != RG_EV_NONE) {
                 st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-            } else if (!st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.e0, cur.e1, cur.e2, cur.e3)) {
-                st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.hx, cur.hy, cur.e0, cur.e1, cur.e2, cur.e3);
+            } else {
+                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.e0, cur.e1, cur.e2, cur.e3);
+#ifdef RG_PROFILE_TIERS
+                tpa = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
+                if (!done) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.hx, cur.hy, cur.e0, cur.e1, cur.e2, cur.e3);
+#endif
+#ifdef RG_PROFILE_TIERS
+                tpb = __builtin_amdgcn_s_memtime();
+#endif
             }
             const uint32_t status = st.fx.status, flags = st.fx.flags;
             if (status == RG_NEED_HOST) blocked = true;
@@ -177,7 +189,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 #ifdef RG_PROFILE
         {   // experiment build only: cycles spent draining / issuing / deciding, reported through the tallies
             const uint64_t tp3 = __builtin_amdgcn_s_memtime();
+#ifdef RG_PROFILE_TIERS
+            if (lane == 0) { c_need += (uint32_t)(tpa - tp2); c_stale += (uint32_t)(tpb - tpa); c_append += (uint32_t)(tp3 - tpb); }
+#else
             if (lane == 0) { c_need += (uint32_t)(tp1 - tp0); c_stale += (uint32_t)(tp2 - tp1); c_append += (uint32_t)(tp3 - tp2); }
+#endif
         }
 #endif
         cur = near;
