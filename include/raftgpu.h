@@ -186,7 +186,7 @@ typedef struct {
     const rg_ev_pair_t *ab;           /* [rounds*count] fields a,b */
     const rg_ev_pair_t *cd;           /* [rounds*count] fields c,d */
     const int64_t      *entry_terms;  /* AE_REQ entry terms, addressed by head.aux; may be NULL if no row has n>0 */
-    uint64_t            entry_count;  /* length of entry_terms */
+    uint64_t            entry_count;  /* length of entry_terms; at most 2^29 per batch */
     const rg_ev_pair_t *hint;         /* optional [rounds*count]; consulted only for rows with RG_HDR_HINT_BIT:
                                          AE_REQ: x = term of the host log at prevLogIndex (-1 = no such entry),
                                                  y = RaftLog.conflict(entries).index() (0 = none)

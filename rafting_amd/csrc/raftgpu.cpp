@@ -394,6 +394,7 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
         return fail(t, -1, "rg_submit: dense batch has %u rows per round, table has %u groups", in->count, t->G);
     }
     if (in->entry_count && !in->entry_terms) return fail(t, -1, "rg_submit: entry_count without entry_terms");
+    if (in->entry_count > (1ull << 29)) return fail(t, -1, "rg_submit: at most 2^29 entry terms per batch (%llu given)", (unsigned long long)in->entry_count);
     if (in->count == 0) return 0;
     if (bind(t)) return -2;
 

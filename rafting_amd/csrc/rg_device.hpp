@@ -111,6 +111,32 @@ __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
 
+// State.majorIndices (member/Leadership.java:116-130): sorted[0] ("full") and sorted[F/2] ("major") of the F follower
+// matchIndex values. One 64-bit compare per compare-exchange; for F = 4 (five nodes) only the two order statistics
+// that are used get completed: pairs, then min of the minima / max of the maxima, then the larger of the middle two.
+__device__ __forceinline__ void cmp_exchange(int64_t &a, int64_t &b)
+{
+    const bool sw = a > b;
+    const int64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+template <int F>
+__device__ __forceinline__ void major_indices(int64_t (&m)[F], int64_t &full, int64_t &major)
+{
+    if constexpr (F == 4) {
+        cmp_exchange(m[0], m[1]); cmp_exchange(m[2], m[3]);
+        cmp_exchange(m[0], m[2]); cmp_exchange(m[1], m[3]);
+        full = m[0]; major = m[1] > m[2] ? m[1] : m[2];
+    } else {
+#pragma unroll
+        for (int a = 1; a < F; a++) {                                   // insertion network, F <= 6
+#pragma unroll
+            for (int b = a; b > 0; b--) cmp_exchange(m[b - 1], m[b]);
+        }
+        full = m[0]; major = m[F / 2];
+    }
+}
+
 // Math.round(Math.log(Math.E + r)) as integer thresholds (member/Leadership.java:105).
 __device__ __forceinline__ int64_t rejection_step(int32_t r)
 {
@@ -550,15 +576,8 @@ struct Stepper {
             int64_t m[F];
 #pragma unroll
             for (int i = 0; i < F; i++) m[i] = (i == j) ? s_match : pe.match_index[i * BLOCK];
-#pragma unroll
-            for (int a = 1; a < F; a++) {                               // insertion network, F <= 6
-#pragma unroll
-                for (int b = a; b > 0; b--) {
-                    const int64_t lo = min64(m[b - 1], m[b]), hi = max64(m[b - 1], m[b]);
-                    m[b - 1] = lo; m[b] = hi;
-                }
-            }
-            const int64_t full = m[0], major = m[F / 2];
+            int64_t full, major;
+            major_indices<F>(m, full, major);
             if (major != 0) {
                 if (!g.present(major)) {
                     commit_status = RG_NPE_MAJOR_NULL;
@@ -724,15 +743,8 @@ struct Stepper {
             const int64_t mi = pe.match_index[i * BLOCK];
             m[i] = ((uint32_t)i == j) ? n_match : mi;
         }
-#pragma unroll
-        for (int x = 1; x < F; x++) {
-#pragma unroll
-            for (int y = x; y > 0; y--) {
-                const int64_t lo = min64(m[y - 1], m[y]), hi = max64(m[y - 1], m[y]);
-                m[y - 1] = lo; m[y] = hi;
-            }
-        }
-        const int64_t full = m[0], major = m[F / 2];
+        int64_t full, major;
+        major_indices<F>(m, full, major);
         const bool lookup = flag & (major != 0);
         const bool major_ok = has_log & (major >= g_first) & (major <= g_last) & (major >= g_s0);   // present and cached
         const int64_t mt = g.term_at(major);
@@ -808,7 +820,7 @@ struct Stepper {
     {
         fx = Fx{0u, RG_OK, 0, 0};
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
-        const bool flag = RG_HDR_FLAG(hdr) != 0, hinted = RG_HDR_HINT(hdr) != 0;
+        const bool flag = RG_HDR_FLAG(hdr) != 0, hinted = (RG_HDR_HINT(hdr) != 0) & (p.hint != nullptr);   // no hint column: the bit means nothing
         const uint32_t P = (uint32_t)p.cluster;
         switch (kind) {
         case RG_EV_NONE:

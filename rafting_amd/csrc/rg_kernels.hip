@@ -17,38 +17,42 @@
 
 namespace rg {
 
-struct Event {
+struct EventRow {                   // what the row index addresses: 8 + 16 + 16 bytes
     uint32_t hdr, aux;
-    int64_t a, b, c, d, hx, hy;
+    int64_t a, b, c, d;
+};
+struct EventTail {                  // what the header addresses
+    int64_t hx, hy;                 // hint (only meaningful when the header carries RG_HDR_HINT_BIT)
     int64_t e0, e1, e2, e3;         // first entry terms of an AppendEntries request
 };
 
 // Stage 1 of the event pipeline: the three row-addressed loads (8 + 16 + 16 B per lane). Nothing here
 // depends on loaded data, so the loads are issued two rounds ahead of their use.
-__device__ __forceinline__ void load_event(const StepParams &p, size_t row, Event &e)
+__device__ __forceinline__ void load_event(const StepParams &p, size_t row, EventRow &e)
 {
     const rg_ev_head_t h = p.head[row];
     const I64x2 ab = p.ab[row], cd = p.cd[row];
     e.hdr = h.hdr; e.aux = h.aux;
     e.a = ab.x; e.b = ab.y; e.c = cd.x; e.d = cd.y;
-    e.hx = 0; e.hy = 0; e.e0 = 0; e.e1 = 0; e.e2 = 0; e.e3 = 0;
 }
 
 // Stage 2, one round later (the header has landed by now): loads whose ADDRESS comes from the header —
 // the first entry terms of an AppendEntries request and the optional hint. Issued one round ahead of use.
-__device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, Event &e)
+__device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, const EventRow &e, EventTail &t)
 {
-    if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; e.hx = hh.x; e.hy = hh.y; }
-    // four unconditional 8-byte loads: lanes without a k-th entry read a harmless dummy word (the row's own
-    // header) instead of branching around the load
+    if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; t.hx = hh.x; t.hy = hh.y; }
+    // four unconditional 8-byte loads at 32-bit offsets from one uniform base: lanes without a k-th entry read the
+    // word at offset 0 (always readable) instead of branching around the load. The host keeps entry_count <= 2^29,
+    // so (aux + k) * 8 cannot wrap.
     const uint32_t n = RG_HDR_N(e.hdr);
-    const bool ae = (RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ) & (n > 0) & (p.entry_terms != nullptr) &
-                    ((uint64_t)e.aux + n <= p.entry_count);
-    const int64_t *dummy = reinterpret_cast<const int64_t *>(p.head + row);
-    const int64_t *t = p.entry_terms + e.aux;
-    const int64_t *q0 = ae ? t : dummy, *q1 = (ae & (n > 1u)) ? t + 1 : dummy, *q2 = (ae & (n > 2u)) ? t + 2 : dummy,
-                  *q3 = (ae & (n > 3u)) ? t + 3 : dummy;
-    e.e0 = *q0; e.e1 = *q1; e.e2 = *q2; e.e3 = *q3;
+    const bool have_terms = (p.entry_terms != nullptr) & (p.entry_count != 0);
+    const char *base = have_terms ? reinterpret_cast<const char *>(p.entry_terms) : reinterpret_cast<const char *>(p.head);
+    const bool ae = (RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ) & (n > 0) & have_terms & ((uint64_t)e.aux + n <= p.entry_count);
+    const uint32_t o = e.aux * 8u;
+    const uint32_t o0 = ae ? o : 0u, o1 = (ae & (n > 1u)) ? o + 8u : 0u, o2 = (ae & (n > 2u)) ? o + 16u : 0u,
+                   o3 = (ae & (n > 3u)) ? o + 24u : 0u;
+    t.e0 = *reinterpret_cast<const int64_t *>(base + o0); t.e1 = *reinterpret_cast<const int64_t *>(base + o1);
+    t.e2 = *reinterpret_cast<const int64_t *>(base + o2); t.e3 = *reinterpret_cast<const int64_t *>(base + o3);
 }
 
 // LANES = raft groups per wavefront (the upper lanes are simply masked off). Measured at 64 / 32 / 16 / 8 on
@@ -64,7 +68,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     const uint32_t lane = threadIdx.x;
     const uint32_t i = blockIdx.x * LANES + lane;
     const bool active = lane < (uint32_t)LANES && i < p.count;
-    const uint32_t gi = active ? (SPARSE ? p.gid[i] : i) : 0u;
+    // Lanes past the end of the batch (tail wavefront, or the masked half of a narrow one) shadow the batch's last row:
+    // they load and decide like everybody else — so the round loop has no divergent control flow around it — and only
+    // their stores are switched off.
+    const uint32_t ir = active ? i : p.count - 1u;
+    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     const uint32_t G = p.t.groups;
 
     Group g;
@@ -87,14 +95,13 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         g.log_dirty = false; g.peers_dirty = false;
     }
     // start the event pipeline before anything that has to wait for the state loads above
-    Event cur, near, far;
-    cur = Event{}; near = Event{}; far = Event{};
-    if (active) {
-        load_event(p, i, cur);
-        if (p.rounds > 1) load_event(p, (size_t)p.count + i, near);
-    }
+    EventRow cur{}, near{}, far{};
+    EventTail cur_t{}, near_t{};
+    const uint32_t last_round = p.rounds - 1u;            // the host never launches with rounds == 0
+    load_event(p, ir, cur);
+    load_event(p, (size_t)(last_round < 1u ? last_round : 1u) * p.count + ir, near);
     Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
-    if (active && g.prepared) {
+    if (g.prepared) {
 #pragma unroll
         for (int j = 0; j < F; j++) {
             const I64x2 en = p.t.peer_en[(size_t)j * G + gi];
@@ -120,9 +127,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // three-deep event pipeline: `far` = round r+2 (row loads in flight), `near` = round r+1 (header landed,
     // header-addressed loads in flight), `cur` = round r (complete). Every wait falls at the top of a
     // round, for memory operations issued a full round earlier, so their latency overlaps decision work.
-    if (active) load_event_tail(p, i, cur);
+    load_event_tail(p, ir, cur, cur_t);
     for (uint32_t r = 0; r < p.rounds; r++) {
-        const size_t row = (size_t)r * p.count + i;
+        const size_t row = (size_t)r * p.count + ir;
         // Drain HERE, before issuing anything new: the vm counter retires in order and (on gfx9-class ISAs)
         // counts stores too, so (a) a wait placed lazily inside the divergent decision code would degrade to
         // vmcnt(0) and also wait for the loads issued below, and (b) draining right after the outcome stores
@@ -135,15 +142,15 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 #ifdef RG_PROFILE
         const uint64_t tp1 = __builtin_amdgcn_s_memtime();
 #endif
-        if (active) {
-            if (r > 0) {
-                p.reply[row - p.count] = pend_rep;
-                if (pend_w_lfx) p.logfx[row - p.count] = pend_lfx;
-                if (pend_w_per) p.persist[row - p.count] = pend_per;
-            }
-            if (r + 2 < p.rounds) load_event(p, row + 2 * (size_t)p.count, far);
-            if (r + 1 < p.rounds) load_event_tail(p, row + p.count, near);
+        if (r > 0) {
+            if (active) p.reply[row - p.count] = pend_rep;
+            if (pend_w_lfx) p.logfx[row - p.count] = pend_lfx;
+            if (pend_w_per) p.persist[row - p.count] = pend_per;
         }
+        // prefetch without conditions: past the last round the pipeline simply re-reads the last round's rows
+        const uint32_t r1 = r + 1u < p.rounds ? r + 1u : last_round, r2 = r + 2u < p.rounds ? r + 2u : last_round;
+        load_event(p, (size_t)r2 * p.count + ir, far);
+        load_event_tail(p, (size_t)r1 * p.count + ir, near, near_t);
 #ifdef RG_PROFILE
         const uint64_t tp2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -151,17 +158,17 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         uint64_t tpa = tp2, tpb = tp2;                  // -DRG_PROFILE -DRG_PROFILE_TIERS: split "decide" into tier 1 / tier 2 / epilogue
 #endif
 
-        if (active) {
+        {
             const uint32_t kind = RG_HDR_KIND(cur.hdr);
             if (blocked && kind != RG_EV_NONE) {
                 st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
             } else {
-                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.e0, cur.e1, cur.e2, cur.e3);
+                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
 #ifdef RG_PROFILE_TIERS
                 tpa = __builtin_amdgcn_s_memtime();
 #endif
 #ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
-                if (!done) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur.hx, cur.hy, cur.e0, cur.e1, cur.e2, cur.e3);
+                if (!done) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
 #endif
 #ifdef RG_PROFILE_TIERS
                 tpb = __builtin_amdgcn_s_memtime();
@@ -172,9 +179,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
             pend_rep.flags = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
             pend_rep.role_epoch = g.role_epoch;
-            pend_w_lfx = (flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) || status == RG_NEED_HOST;
+            pend_w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
             pend_lfx = I64x2{g.commit, st.fx.log_from};
-            pend_w_per = (flags & RG_F_PERSIST) != 0;
+            pend_w_per = active & ((flags & RG_F_PERSIST) != 0);
             pend_per.term = g.term; pend_per.voted_for = g.voted_for; pend_per.role = g.role;
 
             c_rows += kind != RG_EV_NONE ? 1u : 0u;
@@ -196,11 +203,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 #endif
         }
 #endif
-        cur = near;
+        cur = near; cur_t = near_t;
         near = far;
     }
     if (active && p.rounds > 0) {
-        const size_t row = (size_t)(p.rounds - 1) * p.count + i;
+        const size_t row = (size_t)(p.rounds - 1) * p.count + ir;
         p.reply[row] = pend_rep;
         if (pend_w_lfx) p.logfx[row] = pend_lfx;
         if (pend_w_per) p.persist[row] = pend_per;
