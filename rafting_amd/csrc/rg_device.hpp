@@ -764,14 +764,17 @@ struct Stepper {
         // ---- vote replies that only count, change nothing, or reach a fenced participant --------------
         const bool is_pv = kind == RG_EV_PV_REPLY;
         const bool vr_shape = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
-        const bool cur_epoch = aux == g_repoch;
-        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
-        const int64_t T = is_pv ? wadd(g_term, 1) : g_term;
-        const bool count_only = vr_shape & cur_epoch & sender_ok & (a <= T) & (!flag | (g_votes + 1 < p.majority));
-        const bool late = !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
-        const bool late_noop = vr_shape & late & (a <= el_term) &
-                               (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
-        const bool vote_drop = vr_shape & !cur_epoch & !late;
+        bool count_only = false, late_noop = false, vote_drop = false;
+        if (__builtin_amdgcn_ballot_w64(vr_shape) != 0) {                // wave-uniform: steady replication carries no vote replies
+            const bool cur_epoch = aux == g_repoch;
+            const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
+            const int64_t T = is_pv ? wadd(g_term, 1) : g_term;
+            count_only = vr_shape & cur_epoch & sender_ok & (a <= T) & (!flag | (g_votes + 1 < p.majority));
+            const bool late = !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
+            late_noop = vr_shape & late & (a <= el_term) &
+                        (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
+            vote_drop = vr_shape & !cur_epoch & !late;
+        }
         const bool fv = count_only | late_noop | vote_drop;
 
         const bool fast = fa | fk | fc | fv | ack_drop;
