@@ -697,6 +697,9 @@ struct Stepper {
     // is left untouched and goes to run().
     // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
     // into exec-mask branches, which is exactly what this tier exists to avoid.
+#ifdef RG_COUNT_SLOW
+    uint32_t dbg_reason = 0u;
+#endif
     __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
                                              int64_t d, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
     {
@@ -778,6 +781,13 @@ struct Stepper {
         const bool fv = count_only | late_noop | vote_drop;
 
         const bool fast = fa | fk | fc | fv | ack_drop;
+#ifdef RG_COUNT_SLOW   // experiment build: why an ack row leaves tier 1 (first failing precondition)
+        dbg_reason = 0u;
+        if (ack_shape & !fk & !ack_drop) {
+            dbg_reason = !((role == RG_LEADER) & g_prep) ? 1u : (a > g_term) ? 2u : (b != s_epoch) ? 3u : s_pend ? 4u :
+                         (c < s_match) ? 5u : !(flag | (s_match != 0)) ? 6u : (lookup & !major_ok) ? 7u : 8u;
+        }
+#endif
         if (fk) {
             pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
             pe.next_index[j * BLOCK] = n_next;

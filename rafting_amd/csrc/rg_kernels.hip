@@ -117,6 +117,9 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // wavefront once at the end
     uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
     bool blocked = false;
+#ifdef RG_COUNT_SLOW
+    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // [0] slow AppendEntries; [1..7] first failing precondition of a slow ack
+#endif
 
     // outcome of the previous round, stored one round late (see the drain below)
     rg_reply_t pend_rep{0, 0u, 0u};
@@ -166,6 +169,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
                 const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
 #ifdef RG_PROFILE_TIERS
                 tpa = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef RG_COUNT_SLOW                                   // experiment build: which rows leave tier 1 (reported through three tallies)
+                dbg[0] += !done & (kind == RG_EV_AE_REQ); dbg[1] += st.dbg_reason == 1u; dbg[2] += st.dbg_reason == 2u;
+                dbg[3] += st.dbg_reason == 3u; dbg[4] += (st.dbg_reason == 4u) | (st.dbg_reason == 5u); dbg[5] += st.dbg_reason == 6u;
+                dbg[6] += st.dbg_reason == 7u; dbg[7] += st.dbg_reason == 8u;
 #endif
 #ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
                 if (!done) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
@@ -244,7 +252,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // Wavefront reduction of the tallies: butterfly over the 64 lanes, then each wave adds into its own
     // 64-byte slot of the counter table with a plain read-modify-write (8 atomics per wave onto 8 shared
     // words cost ~60 us per launch at 1024 waves). rg_counters_read sums the slots.
+#ifdef RG_COUNT_SLOW
+    uint32_t tally[RG_NUM_COUNTERS] = {dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]};
+#else
     uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
+#endif
 #pragma unroll
     for (int c = 0; c < RG_NUM_COUNTERS; c++) {
         uint32_t v = active ? tally[c] : 0u;
