@@ -23,7 +23,8 @@ def main():
         cluster, self_slot = shapes[runs % len(shapes)]
         pre_vote = (runs // len(shapes)) % 2 == 0
         os.environ["RG_FAST"] = "0" if runs % 5 == 4 else "1"
-        groups, rounds = (1024, 150) if runs % 3 else (256, 400)
+        # group counts that are not multiples of the wavefront size exercise the shadow lanes of the tail wavefront
+        groups, rounds = ((1024, 150), (1000, 150), (257, 400), (65, 600))[runs % 4]
         _, _, _, h, m, _ = T._lockstep(groups, cluster, self_slot, pre_vote, rounds, seed, allow_miss=True)
         hist += h
         misses += m
