@@ -225,7 +225,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/r01_traffic.json)",
-                "kernel": "rg::step_kernel<%d,false>" % F,
+                "kernel": "%s<%d,false>" % (table.step_kernel(), F),
                 "avg_kernel_ms": avg_kernel_s * 1e3, "launches": launches,
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "algorithmic_bytes_per_decision": alg_bytes / max(decisions, 1),

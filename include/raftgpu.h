@@ -41,7 +41,8 @@
  * reference would have hit them (the handler dies, no reply is sent, earlier side effects stay).
  *
  * Environment knobs read by rg_table_create (experiments / tests only): RG_FAST=0 routes every row through the
- * general handlers (no fast-path tier); RG_LANES=8|16|32|64 sets the raft groups per wavefront (default 64).
+ * general handlers (no fast-path tier); RG_SPLIT=1|0 forces the two-wavefront (decide + I/O) or the single-wavefront
+ * step kernel instead of choosing per launch; RG_LANES=8|16|32|64 sets the raft groups per wavefront of the latter.
  *
  * Threading: a table is not re-entrant; one host thread + one HIP stream per table.  Different
  * tables (different GPUs) are fully independent.  No RCCL, no cross-table traffic.
@@ -255,6 +256,9 @@ int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_
  * rows keep their previous content; a sparse gid list is trusted (it cannot be inspected from the host). */
 int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace);
 int rg_sync(rg_table_t *t);
+/* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
+ * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel" */
+const char *rg_step_kernel(rg_table_t *t, uint32_t count);
 
 /* ---- N1: the leader's send side ---------------------------------------------------------------- */
 /* Leader.replicateLog (member/Leader.java:142-245) for many leader groups at once: WHAT to send to each follower —

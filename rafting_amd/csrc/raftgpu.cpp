@@ -46,7 +46,8 @@ struct rg_table {
     unsigned long long *counters = nullptr;     // [counter_slots][RG_NUM_COUNTERS], one slot per wave of a dense launch
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
-    int lanes = 64;                             // raft groups per wavefront (RG_LANES env: 8/16/32/64)
+    int lanes = -1;                             // -1: pick per launch; 0: split kernel; 8/16/32/64: single-wave kernel (RG_LANES / RG_SPLIT env)
+    uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -178,11 +179,17 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->dt.runs, G * rg::K * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_en, G * F * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_m, G * F * sizeof(rg::Match)));
-    t->lanes = 64;
+    {
+        hipDeviceProp_t prop;
+        CREATE_TRY(hipGetDeviceProperties(&prop, device));
+        t->simds = (uint32_t)prop.multiProcessorCount * 4u;
+    }
+    t->lanes = -1;
     if (const char *e = getenv("RG_LANES")) {
         const int v = atoi(e);
         if (v == 8 || v == 16 || v == 32 || v == 64) t->lanes = v;
     }
+    if (const char *e = getenv("RG_SPLIT")) t->lanes = atoi(e) != 0 ? 0 : (t->lanes > 0 ? t->lanes : 64);   // force either kernel
     if (const char *e = getenv("RG_FAST")) t->fast_paths = atoi(e) != 0;
     t->counter_slots = (G + 7) / 8;             // enough for the narrowest wavefronts
     CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
@@ -216,6 +223,14 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
 }
 
 /* ---- state ------------------------------------------------------------------------------------ */
+
+// 0 = step_split_kernel, otherwise the raft groups per wavefront of step_kernel
+static int step_lanes(const rg_table *t, uint32_t count)
+{
+    if (t->lanes >= 0) return t->lanes;
+    const uint32_t wavefronts = (count + 63u) / 64u;
+    return wavefronts <= t->simds ? 0 : 64;
+}
 
 static bool state_complete(const rg_group_state_t *s)
 {
@@ -371,7 +386,10 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
         e0 = t->ev_pool[t->ev_used].first; e1 = t->ev_pool[t->ev_used].second;
         HIP_TRY(t, hipEventRecord(e0, t->stream));
     }
-    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, t->lanes, t->stream));
+    // Up to one wavefront of groups per SIMD, a lone deciding wavefront leaves half of its SIMD's issue slots empty:
+    // give it an I/O partner (step_split_kernel). With more groups the SIMDs are shared by several deciding
+    // wavefronts anyway and the single-wavefront kernel is the faster one.
+    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, step_lanes(t, p.count), t->stream));
     if (t->timing) {
         HIP_TRY(t, hipEventRecord(e1, t->stream));
         t->ev_used += 1;
@@ -716,6 +734,12 @@ int rg_health_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *reque
             request_success[i * F + j] = ok[j * n + i]; request_failure[i * F + j] = fl[j * n + i]; recent_failure[i * F + j] = rc[j * n + i];
         }
     return 0;
+}
+
+const char *rg_step_kernel(rg_table_t *t, uint32_t count)
+{
+    if (!t) return "";
+    return step_lanes(t, count) == 0 ? "rg::step_split_kernel" : "rg::step_kernel";
 }
 
 int rg_sync(rg_table_t *t)

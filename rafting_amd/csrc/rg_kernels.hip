@@ -55,6 +55,70 @@ __device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row,
     t.e2 = *reinterpret_cast<const int64_t *>(base + o2); t.e3 = *reinterpret_cast<const int64_t *>(base + o3);
 }
 
+// Group state: table -> registers (nine 16-byte coalesced loads), follower columns of a prepared leader -> LDS, and back.
+__device__ __forceinline__ void load_group(const DevTable &t, uint32_t gi, Group &g)
+{
+    const uint32_t G = t.groups;
+    const I64x2 tc = t.term_commit[gi], ep = t.epoch[gi], w = t.window[gi];
+    const Ident id = t.ident[gi];
+    const Elect el = t.elect[gi];
+    g.term = tc.x; g.commit = tc.y; g.epoch_index = ep.x; g.epoch_term = ep.y; g.first = w.x; g.last = w.y;
+    g.voted_for = id.voted_for; g.leader = id.leader; g.role_epoch = id.role_epoch;
+    g.role = (int32_t)(id.meta & META_ROLE);
+    g.td = (id.meta & META_TD) != 0; g.prepared = (id.meta & META_PREP) != 0;
+    g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
+    g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+    g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
+    const I64x2 r0 = t.runs[gi], r1 = t.runs[(size_t)G + gi], r2 = t.runs[(size_t)2 * G + gi], r3 = t.runs[(size_t)3 * G + gi];
+    g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
+    g.log_dirty = false; g.peers_dirty = false;
+}
+
+template <int F>
+__device__ __forceinline__ void stage_peers(const DevTable &t, uint32_t gi, const Group &g, Peers<F> &pe)
+{
+    if (!g.prepared) return;
+    const uint32_t G = t.groups;
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const I64x2 en = t.peer_en[(size_t)j * G + gi];
+        const Match m = t.peer_m[(size_t)j * G + gi];
+        pe.last_epoch[j * BLOCK] = en.x; pe.next_index[j * BLOCK] = en.y;
+        pe.match_index[j * BLOCK] = m.match_index; pe.rejection[j * BLOCK] = m.rejection;
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void store_group(const DevTable &t, uint32_t gi, uint32_t G, const Group &g, const Peers<F> &pe)
+{
+    t.term_commit[gi] = I64x2{g.term, g.commit};
+    t.epoch[gi] = I64x2{g.epoch_index, g.epoch_term};
+    t.window[gi] = I64x2{g.first, g.last};
+    Ident id;
+    id.voted_for = g.voted_for; id.leader = g.leader; id.role_epoch = g.role_epoch;
+    id.meta = (uint32_t)g.role | (g.td ? META_TD : 0u) | (g.prepared ? META_PREP : 0u) |
+              ((uint32_t)g.rc << META_RC_SHIFT) | (g.pending << META_PEND_SHIFT);
+    t.ident[gi] = id;
+    Elect el;
+    el.elected_term = g.elected_term; el.elected_epoch = g.elected_epoch; el.votes = g.votes;
+    t.elect[gi] = el;
+    if (g.log_dirty) {
+        t.runs[gi] = I64x2{g.s0, g.t0};
+        t.runs[(size_t)G + gi] = I64x2{g.s1, g.t1};
+        t.runs[(size_t)2 * G + gi] = I64x2{g.s2, g.t2};
+        t.runs[(size_t)3 * G + gi] = I64x2{g.s3, g.t3};
+    }
+    if (g.peers_dirty) {
+#pragma unroll
+        for (int j = 0; j < F; j++) {
+            t.peer_en[(size_t)j * G + gi] = I64x2{pe.last_epoch[j * BLOCK], pe.next_index[j * BLOCK]};
+            Match m;
+            m.match_index = pe.match_index[j * BLOCK]; m.rejection = pe.rejection[j * BLOCK]; m.pad = 0;
+            t.peer_m[(size_t)j * G + gi] = m;
+        }
+    }
+}
+
 // LANES = raft groups per wavefront (the upper lanes are simply masked off). Measured at 64 / 32 / 16 / 8 on
 // 65 536 groups: 0.193 / 0.204 / 0.358 / 0.527 ms — a half-masked wavefront still costs both passes of a wave64
 // instruction, so narrower wavefronts buy more instruction streams per SIMD but no throughput. 64 is the default;
@@ -76,24 +140,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     const uint32_t G = p.t.groups;
 
     Group g;
-    {
-        const I64x2 tc = p.t.term_commit[gi], ep = p.t.epoch[gi], w = p.t.window[gi];
-        const Ident id = p.t.ident[gi];
-        const Elect el = p.t.elect[gi];
-        g.term = tc.x; g.commit = tc.y; g.epoch_index = ep.x; g.epoch_term = ep.y; g.first = w.x; g.last = w.y;
-        g.voted_for = id.voted_for; g.leader = id.leader; g.role_epoch = id.role_epoch;
-        g.role = (int32_t)(id.meta & META_ROLE);
-        g.td = (id.meta & META_TD) != 0; g.prepared = (id.meta & META_PREP) != 0;
-        g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
-        g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
-        g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
-        {
-            const I64x2 r0 = p.t.runs[gi], r1 = p.t.runs[(size_t)G + gi], r2 = p.t.runs[(size_t)2 * G + gi],
-                        r3 = p.t.runs[(size_t)3 * G + gi];
-            g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
-        }
-        g.log_dirty = false; g.peers_dirty = false;
-    }
+    load_group(p.t, gi, g);
     // start the event pipeline before anything that has to wait for the state loads above
     EventRow cur{}, near{}, far{};
     EventTail cur_t{}, near_t{};
@@ -101,15 +148,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     load_event(p, ir, cur);
     load_event(p, (size_t)(last_round < 1u ? last_round : 1u) * p.count + ir, near);
     Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
-    if (g.prepared) {
-#pragma unroll
-        for (int j = 0; j < F; j++) {
-            const I64x2 en = p.t.peer_en[(size_t)j * G + gi];
-            const Match m = p.t.peer_m[(size_t)j * G + gi];
-            pe.last_epoch[j * BLOCK] = en.x; pe.next_index[j * BLOCK] = en.y;
-            pe.match_index[j * BLOCK] = m.match_index; pe.rejection[j * BLOCK] = m.rejection;
-        }
-    }
+    stage_peers<F>(p.t, gi, g, pe);
 
     Stepper<F> st(p, g, pe);
     const bool FAST = p.fast_paths != 0;                 // RG_FAST=0 forces every row through the general handlers (tests)
@@ -221,34 +260,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         if (pend_w_per) p.persist[row] = pend_per;
     }
 
-    if (active) {
-        p.t.term_commit[gi] = I64x2{g.term, g.commit};
-        p.t.epoch[gi] = I64x2{g.epoch_index, g.epoch_term};
-        p.t.window[gi] = I64x2{g.first, g.last};
-        Ident id;
-        id.voted_for = g.voted_for; id.leader = g.leader; id.role_epoch = g.role_epoch;
-        id.meta = (uint32_t)g.role | (g.td ? META_TD : 0u) | (g.prepared ? META_PREP : 0u) |
-                  ((uint32_t)g.rc << META_RC_SHIFT) | (g.pending << META_PEND_SHIFT);
-        p.t.ident[gi] = id;
-        Elect el;
-        el.elected_term = g.elected_term; el.elected_epoch = g.elected_epoch; el.votes = g.votes;
-        p.t.elect[gi] = el;
-        if (g.log_dirty) {
-            p.t.runs[gi] = I64x2{g.s0, g.t0};
-            p.t.runs[(size_t)G + gi] = I64x2{g.s1, g.t1};
-            p.t.runs[(size_t)2 * G + gi] = I64x2{g.s2, g.t2};
-            p.t.runs[(size_t)3 * G + gi] = I64x2{g.s3, g.t3};
-        }
-        if (g.peers_dirty) {
-#pragma unroll
-            for (int j = 0; j < F; j++) {
-                p.t.peer_en[(size_t)j * G + gi] = I64x2{pe.last_epoch[j * BLOCK], pe.next_index[j * BLOCK]};
-                Match m;
-                m.match_index = pe.match_index[j * BLOCK]; m.rejection = pe.rejection[j * BLOCK]; m.pad = 0;
-                p.t.peer_m[(size_t)j * G + gi] = m;
-            }
-        }
-    }
+    if (active) store_group<F>(p.t, gi, G, g, pe);
     // Wavefront reduction of the tallies: butterfly over the 64 lanes, then each wave adds into its own
     // 64-byte slot of the counter table with a plain read-modify-write (8 atomics per wave onto 8 shared
     // words cost ~60 us per launch at 1024 waves). rg_counters_read sums the slots.
@@ -271,6 +283,159 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
         *slot += v;
     }
+}
+
+// ---- step_split_kernel: the same decisions, two instruction streams per 64 groups -----------------------------
+// One wavefront per SIMD gets one issue slot every ~4 cycles and leaves half of the SIMD's VALU slots empty (DESIGN.md
+// §6). This variant gives every 64 groups a workgroup of TWO wavefronts with different jobs:
+//   wave 1 (I/O)     row addressing, the event loads (same three-stage prefetch as above), the outcome stores and the
+//                    decision counters — everything that does not need the group's state;
+//   wave 0 (decide)  group state in registers, follower state in LDS, tier 1 / tier 2 — and nothing else.
+// They meet once per round at an LDS-only barrier. Events travel through a two-slot LDS ring written one round ahead,
+// outcomes through a two-slot ring read one round behind, so neither wave ever waits for the other's memory traffic:
+//   round r:  I/O    writes event r+1 -> ev[(r+1)&1], reads outcome r-1 <- out[(r-1)&1] and stores it, issues next loads
+//             decide reads event r <- ev[r&1], decides, writes outcome r -> out[r&1]
+//   barrier   (s_waitcnt lgkmcnt(0) + s_barrier: LDS traffic only — global loads/stores stay in flight across it)
+enum { EV_HEAD = 0, EV_A, EV_B, EV_C, EV_D, EV_HX, EV_HY, EV_E0, EV_E1, EV_E2, EV_E3, EV_FIELDS };
+enum { OUT_RESP = 0, OUT_FLAGS, OUT_COMMIT, OUT_FROM, OUT_TERM, OUT_VOTE, OUT_FIELDS };
+
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt/expcnt untouched: my LDS writes have landed
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int F, bool SPARSE>
+__global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
+{
+    __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
+    __shared__ int32_t sh_rej[F * BLOCK];
+    __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
+    __shared__ uint64_t sh_out[2][OUT_FIELDS][BLOCK];
+
+    const uint32_t lane = threadIdx.x & (BLOCK - 1);
+    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
+    const uint32_t i = blockIdx.x * BLOCK + lane;
+    const bool active = i < p.count;
+    const uint32_t ir = active ? i : p.count - 1u;       // lanes past the end shadow the last row; only their stores are off
+    const uint32_t last_round = p.rounds - 1u;
+
+    if (io_wave) {
+        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
+            sh_ev[slot][EV_HEAD][lane] = (uint64_t)e.hdr | ((uint64_t)e.aux << 32);
+            sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
+            sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
+            sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
+            sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0; sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
+            sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
+        };
+        uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
+        auto retire = [&](uint32_t r, uint32_t hdr) {      // outcome of round r: LDS -> global, plus the tallies
+            const uint32_t slot = r & 1u;
+            const size_t row = (size_t)r * p.count + ir;
+            const uint64_t fe = sh_out[slot][OUT_FLAGS][lane];
+            const uint32_t flags_all = (uint32_t)fe, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
+            rg_reply_t rep;
+            rep.resp_term = (int64_t)sh_out[slot][OUT_RESP][lane]; rep.flags = flags_all; rep.role_epoch = (uint32_t)(fe >> 32);
+            if (active) p.reply[row] = rep;
+            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
+            if (w_lfx) p.logfx[row] = I64x2{(int64_t)sh_out[slot][OUT_COMMIT][lane], (int64_t)sh_out[slot][OUT_FROM][lane]};
+            if (active & ((flags & RG_F_PERSIST) != 0)) {
+                const uint64_t v = sh_out[slot][OUT_VOTE][lane];
+                rg_persist_t per;
+                per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
+                p.persist[row] = per;
+            }
+            c_rows += RG_HDR_KIND(hdr) != RG_EV_NONE ? 1u : 0u;
+            c_replied += (flags >> 1) & 1u; c_conv += (flags >> 3) & 1u; c_commit += (flags >> 5) & 1u; c_append += (flags >> 7) & 1u;
+            c_assert += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
+            c_need += status == RG_NEED_HOST ? 1u : 0u;
+            c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
+        };
+
+        EventRow nxt{}, far{};           // rows r+1 (complete with its tail) and r+2 (landed by the top of round r)
+        EventTail nxt_t{};
+        uint32_t hdr_cur, hdr_prev = 0u; // headers of rounds r and r-1 (the tallies need the kind of a retired row)
+        {
+            EventRow first{};
+            EventTail first_t{};
+            load_event(p, row_of(0), first);
+            load_event(p, row_of(1), nxt);
+            load_event(p, row_of(2), far);
+            load_event_tail(p, row_of(0), first, first_t);
+            publish(0u, first, first_t);
+            load_event_tail(p, row_of(1), nxt, nxt_t);
+            hdr_cur = first.hdr;
+        }
+        lds_barrier();                                   // event 0 is visible
+        for (uint32_t r = 0; r < p.rounds; r++) {
+            publish((r + 1u) & 1u, nxt, nxt_t);          // loads issued a full round ago
+            if (r > 0) retire(r - 1u, hdr_prev);
+            hdr_prev = hdr_cur; hdr_cur = nxt.hdr;
+            nxt = far;
+            load_event(p, row_of(r + 3u), far);
+            load_event_tail(p, row_of(r + 2u), nxt, nxt_t);
+            lds_barrier();
+        }
+        retire(last_round, hdr_prev);
+
+        uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
+#pragma unroll
+        for (int c = 0; c < RG_NUM_COUNTERS; c++) {
+            uint32_t v = active ? tally[c] : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            tally[c] = v;
+        }
+        if (lane < RG_NUM_COUNTERS) {
+            uint32_t v = tally[0];
+#pragma unroll
+            for (int c = 1; c < RG_NUM_COUNTERS; c++) v = (lane == (uint32_t)c) ? tally[c] : v;
+            unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
+            *slot += v;
+        }
+        return;
+    }
+
+    // ---- the deciding wavefront ----------------------------------------------------------------------------------
+    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
+    const uint32_t G = p.t.groups;
+    Group g;
+    load_group(p.t, gi, g);
+    Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
+    stage_peers<F>(p.t, gi, g, pe);
+    Stepper<F> st(p, g, pe);
+    const bool FAST = p.fast_paths != 0;
+    bool blocked = false;
+    lds_barrier();                                       // event 0 is visible
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const uint32_t slot = r & 1u;
+        const uint64_t head = sh_ev[slot][EV_HEAD][lane];
+        const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
+        const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
+                      c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
+        const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
+        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane], e1 = (int64_t)sh_ev[slot][EV_E1][lane],
+                      e2 = (int64_t)sh_ev[slot][EV_E2][lane], e3 = (int64_t)sh_ev[slot][EV_E3][lane];
+        const uint32_t kind = RG_HDR_KIND(hdr);
+        if (blocked && kind != RG_EV_NONE) {
+            st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, e1, e2, e3)) {
+            st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+        }
+        const uint32_t status = st.fx.status, flags = st.fx.flags;
+        if (status == RG_NEED_HOST) blocked = true;
+        const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+        sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
+        sh_out[slot][OUT_FLAGS][lane] = (uint64_t)flags_all | ((uint64_t)g.role_epoch << 32);
+        sh_out[slot][OUT_COMMIT][lane] = (uint64_t)g.commit;
+        sh_out[slot][OUT_FROM][lane] = (uint64_t)st.fx.log_from;
+        sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
+        sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
+        lds_barrier();
+    }
+    if (active) store_group<F>(p.t, gi, G, g, pe);
 }
 
 // N1 — Leader.replicateLog (member/Leader.java:142-245) for many groups: one lane per row, F sends per lane.
@@ -585,9 +750,20 @@ static hipError_t launch_fl(const StepParams &p, bool sparse, hipStream_t s)
 }
 
 template <int F>
+static hipError_t launch_split(const StepParams &p, bool sparse, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    if (blocks == 0) return hipSuccess;
+    if (sparse) hipLaunchKernelGGL((step_split_kernel<F, true>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step_split_kernel<F, false>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int F>
 static hipError_t launch_f(const StepParams &p, bool sparse, int lanes, hipStream_t s)
 {
     switch (lanes) {
+    case 0:  return launch_split<F>(p, sparse, s);      // two wavefronts (decide + I/O) per 64 groups
     case 64: return launch_fl<F, 64>(p, sparse, s);
     case 32: return launch_fl<F, 32>(p, sparse, s);
     case 16: return launch_fl<F, 16>(p, sparse, s);

@@ -24,7 +24,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -80,6 +80,8 @@ def lib():
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_sync.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
+        L.rg_step_kernel.restype = C.c_char_p
+        L.rg_step_kernel.argtypes = [vp, u32]
         L.rg_timers_configure.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64]
         L.rg_timers_update.argtypes = [vp, u32, u32, vp, vp, vp, i32]
         L.rg_timers_expired.argtypes = [vp, C.c_int64, vp, u32, C.POINTER(u32), i32]
@@ -265,6 +267,10 @@ class Table:
 
     def sync(self):
         self._check(lib().rg_sync(self._h))
+
+    def step_kernel(self, count=None):
+        """Name of the step kernel that decides a batch with `count` rows per round (default: every group)."""
+        return lib().rg_step_kernel(self._h, self.groups if count is None else count).decode()
 
     # N4 timers ------------------------------------------------------------------------------------
     def timers_configure(self, election_ms, heartbeat_ms, seed=0):

@@ -13,6 +13,13 @@ from tests.helpers import compare_outcomes, compare_states, make_state, simple_l
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["split", "single"])
+def step_kernel_variant(request, monkeypatch):
+    """Every test of this module runs against both step kernels: `split` = decide + I/O wavefront per 64 groups (what the
+    library picks up to one wavefront of groups per SIMD), `single` = one wavefront does both (picked beyond that)."""
+    monkeypatch.setenv("RG_SPLIT", "1" if request.param == "split" else "0")
+
+
 def mk_gpu(groups, cluster, self_slot, pre_vote):
     return engine.Table(groups, cluster, self_slot, pre_vote)
 

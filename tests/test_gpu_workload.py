@@ -37,6 +37,15 @@ def _replay(cfg, rounds, batches=2, first=0, count=None):
     return gen, fin_g, hist, rows
 
 
+@pytest.mark.parametrize("split", ["0", "1"])
+def test_both_step_kernels_at_full_size(monkeypatch, split):
+    """config 3 (65 536 groups) and config 5's churn mix at 131 072 groups, with the kernel choice forced either way."""
+    monkeypatch.setenv("RG_SPLIT", split)
+    for cfg, rounds in ((workload.config(3), 24), (workload.config(5, 131072), 12)):
+        _, _, hist, rows = _replay(cfg, rounds)
+        assert hist[abi.OK] == rows
+
+
 @pytest.mark.parametrize("number,rounds", [(2, 64), (3, 48), (4, 6), (5, 6)])
 def test_baseline_config_full_size(number, rounds):
     """configs[1..4] of BASELINE.json at their full group counts (4 096 / 65 536 / 1 M / 1 M churn)."""
