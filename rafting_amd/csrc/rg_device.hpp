@@ -157,6 +157,21 @@ struct Fx {
     int64_t log_from;
 };
 
+// Two facts about an AppendEntries request that do not depend on the group's state — "the carried entry terms are
+// readable" and "the first min(n, 4) entry terms are all equal" — are worked out where the event is loaded. The
+// two-wavefront kernel hands them to the deciding wavefront in the two unused bits of its LDS copy of the header.
+constexpr uint32_t HDR_SAME = 1u << 10, HDR_ENTRIES_OK = 1u << 11;
+__device__ __forceinline__ bool entries_readable(const StepParams &p, uint32_t hdr, uint32_t aux)
+{
+    const uint32_t n = RG_HDR_N(hdr);
+    return (n == 0) | ((n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)aux + n <= p.entry_count));
+}
+__device__ __forceinline__ bool entries_same_term(uint32_t hdr, int64_t e0, int64_t e1, int64_t e2, int64_t e3)
+{
+    const uint32_t n = RG_HDR_N(hdr);
+    return ((n < 2u) | (e1 == e0)) & ((n < 3u) | (e2 == e0)) & ((n < 4u) | (e3 == e0));
+}
+
 template <int F>
 struct Peers {                       // LDS columns of this lane
     int64_t *last_epoch, *next_index, *match_index;
@@ -700,8 +715,9 @@ struct Stepper {
 #ifdef RG_COUNT_SLOW
     uint32_t dbg_reason = 0u;
 #endif
+    // pe0 = the first carried entry term; entries_ok / same = entries_readable() / entries_same_term() of the row
     __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
-                                             int64_t d, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
+                                             int64_t d, int64_t pe0, bool entries_ok, bool same)
     {
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
         const bool flag = RG_HDR_FLAG(hdr) != 0;
@@ -714,8 +730,6 @@ struct Stepper {
         const bool peer_ok = (slot < P) & (slot != self);
 
         // ---- AppendEntries request at a follower --------------------------------------------------
-        const bool entries_ok = (n == 0) | ((n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)aux + n <= p.entry_count));
-        const bool same = ((n < 2u) | (pe1 == pe0)) & ((n < 3u) | (pe2 == pe0)) & ((n < 4u) | (pe3 == pe0));
         const bool contains = c == lt;                                   // prevLogTerm == term of the tail
         const bool refresh = (a > g_term) | g_td;                        // switchTo(Follower, term, lastCandidate)
         const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;

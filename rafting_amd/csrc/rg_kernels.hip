@@ -205,7 +205,8 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             if (blocked && kind != RG_EV_NONE) {
                 st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
             } else {
-                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
+                                              entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3));
 #ifdef RG_PROFILE_TIERS
                 tpa = __builtin_amdgcn_s_memtime();
 #endif
@@ -323,7 +324,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     if (io_wave) {
         auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
         auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
-            sh_ev[slot][EV_HEAD][lane] = (uint64_t)e.hdr | ((uint64_t)e.aux << 32);
+            const uint32_t hdr = (e.hdr & ~(HDR_SAME | HDR_ENTRIES_OK)) | (entries_readable(p, e.hdr, e.aux) ? HDR_ENTRIES_OK : 0u) |
+                                 (entries_same_term(e.hdr, t.e0, t.e1, t.e2, t.e3) ? HDR_SAME : 0u);
+            sh_ev[slot][EV_HEAD][lane] = (uint64_t)hdr | ((uint64_t)e.aux << 32);
             sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
             sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
             sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
@@ -415,13 +418,15 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
                       c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
-        const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
-        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane], e1 = (int64_t)sh_ev[slot][EV_E1][lane],
-                      e2 = (int64_t)sh_ev[slot][EV_E2][lane], e3 = (int64_t)sh_ev[slot][EV_E3][lane];
+        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
         const uint32_t kind = RG_HDR_KIND(hdr);
         if (blocked && kind != RG_EV_NONE) {
             st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, e1, e2, e3)) {
+        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0)) {
+            // the general handlers also want the hint and the other prefetched entry terms: read only here
+            const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
+            const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
+                          e3 = (int64_t)sh_ev[slot][EV_E3][lane];
             st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
         }
         const uint32_t status = st.fx.status, flags = st.fx.flags;
