@@ -1,18 +1,20 @@
 // rg_kernels.hip — gfx950 kernels of the batched multi-Raft decision engine.
 //
-// step_kernel<F, SPARSE>: the replacement of the reference EventLoop drain
+// step_kernel<F, SPARSE, LANES> / step_split_kernel<F, SPARSE>: the replacement of the reference EventLoop drain
 // (support/EventLoopGroup.java:32-46).  One lane = one raft group for the whole launch:
 //   * group state is read ONCE (16-byte coalesced loads from the structure-of-structs table),
 //     kept in VGPRs across all `rounds` of the batch, and written back once;
 //   * the per-follower Leadership.State columns are staged in LDS ([follower][lane]) only for groups
 //     that lead, so the runtime responder slot indexes LDS, not registers;
-//   * per round every lane loads its 40-byte event as 8+16+16 B, with the next round's event
-//     already in flight (software prefetch) — the event/outcome streams are what HBM sees;
+//   * per round every lane loads its 40-byte event as 8+16+16 B, two rounds ahead of its use (software
+//     prefetch) — the event/outcome streams are what HBM sees;
 //   * outcomes: the 16-byte reply is always stored; log/commit effects and the durable
 //     (term, votedFor) pair are stored only for rows that have them;
-//   * decision counters are wave-level: ballot + popcount per round into scalar registers, added to
-//     the wave's own slot of a counter table at the end (no atomics).
-// Workgroup = one wavefront (64 lanes): lanes never share LDS columns, so no barrier exists anywhere.
+//   * decision counters are per-lane tallies, reduced over the wavefront once and added to the wave's own
+//     slot of a counter table at the end (no atomics).
+// step_kernel: workgroup = one wavefront that does all of it (lanes never share LDS columns, no barrier anywhere).
+// step_split_kernel: workgroup = a deciding and an I/O wavefront for the same 64 groups, one LDS-only barrier per
+// round (see its header comment). The host picks per launch (raftgpu.cpp: step_lanes).
 #include "rg_device.hpp"
 
 namespace rg {
