@@ -37,6 +37,20 @@ def _replay(cfg, rounds, batches=2, first=0, count=None):
     return gen, fin_g, hist, rows
 
 
+def test_kernel_choice_follows_batch_size(monkeypatch):
+    """up to one wavefront of groups per SIMD (65 536 rows on MI355X) a batch is decided by the two-wavefront kernel,
+    beyond by the single-wavefront one; RG_SPLIT overrides"""
+    monkeypatch.delenv("RG_SPLIT", raising=False)
+    monkeypatch.delenv("RG_LANES", raising=False)
+    t = engine.Table(131072, 5, 0, True)
+    assert t.step_kernel(64) == "rg::step_split_kernel" and t.step_kernel(65536) == "rg::step_split_kernel"
+    assert t.step_kernel(65537) == "rg::step_kernel" and t.step_kernel() == "rg::step_kernel"
+    monkeypatch.setenv("RG_SPLIT", "1")
+    assert engine.Table(131072, 5, 0, True).step_kernel() == "rg::step_split_kernel"
+    monkeypatch.setenv("RG_SPLIT", "0")
+    assert engine.Table(64, 5, 0, True).step_kernel() == "rg::step_kernel"
+
+
 @pytest.mark.parametrize("split", ["0", "1"])
 def test_both_step_kernels_at_full_size(monkeypatch, split):
     """config 3 (65 536 groups) and config 5's churn mix at 131 072 groups, with the kernel choice forced either way."""
