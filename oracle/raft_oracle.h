@@ -9,8 +9,9 @@
  * PARITY UNPINNED BY THE REFERENCE: the reference (Java 8 + Maven deps) cannot run in this
  * environment (no JDK) and its own tests hold no golden vector for this path.
  * The oracle is pinned instead by hand-derived known-answer tests (tests/test_oracle_kat.py), each
- * citing the reference lines it was derived from, and by the one in-source golden table
- * (member/Leadership.java:121-126).
+ * citing the reference lines it was derived from, by the one in-source golden table
+ * (member/Leadership.java:121-126) and by the literal constants of the path, both extracted from the
+ * reference's source text into tests/golden/reference_pins.json (tests/test_reference_pins.py).
  *
  * The log model is LOSSLESS: an unbounded run-length encoding of (index -> term) over the contiguous
  * key window RocksLog keeps (storage/RocksLog.java), so it answers RaftLog.get(i) for every index —
