@@ -315,6 +315,10 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     __shared__ int32_t sh_rej[F * BLOCK];
     __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
     __shared__ uint64_t sh_out[2][OUT_FIELDS][BLOCK];
+#ifdef RG_PROFILE
+    __shared__ uint32_t sh_prof[4];
+    uint32_t prof_read = 0, prof_decide = 0, prof_publish = 0;
+#endif
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
@@ -384,6 +388,11 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             lds_barrier();
         }
         retire(last_round, hdr_prev);
+#ifdef RG_PROFILE   // experiment build: the deciding wavefront's cycle sums (LDS-read wait / decide / publish+barrier) replace three tallies
+        lds_barrier();
+        c_need = sh_prof[0]; c_stale = sh_prof[1]; c_append = sh_prof[2];
+        if (lane != 0) { c_need = 0; c_stale = 0; c_append = 0; }
+#endif
 
         uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
 #pragma unroll
@@ -421,6 +430,11 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
                       c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
         const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
+#ifdef RG_PROFILE
+        const uint64_t tq0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const uint64_t tq1 = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t kind = RG_HDR_KIND(hdr);
         if (blocked && kind != RG_EV_NONE) {
             st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
@@ -432,6 +446,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
         }
         const uint32_t status = st.fx.status, flags = st.fx.flags;
+#ifdef RG_PROFILE
+        const uint64_t tq2 = __builtin_amdgcn_s_memtime();
+#endif
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
         sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
@@ -441,7 +458,15 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
         sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
         lds_barrier();
+#ifdef RG_PROFILE
+        const uint64_t tq3 = __builtin_amdgcn_s_memtime();
+        prof_read += (uint32_t)(tq1 - tq0); prof_decide += (uint32_t)(tq2 - tq1); prof_publish += (uint32_t)(tq3 - tq2);
+#endif
     }
+#ifdef RG_PROFILE
+    if (lane == 0) { sh_prof[0] = prof_read; sh_prof[1] = prof_decide; sh_prof[2] = prof_publish; }
+    lds_barrier();
+#endif
     if (active) store_group<F>(p.t, gi, G, g, pe);
 }
 
