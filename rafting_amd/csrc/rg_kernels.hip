@@ -443,7 +443,11 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
             const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
                           e3 = (int64_t)sh_ev[slot][EV_E3][lane];
+#ifndef RG_TIER1_ONLY
             st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+#else
+            (void)hx; (void)hy; (void)e1; (void)e2; (void)e3;
+#endif
         }
         const uint32_t status = st.fx.status, flags = st.fx.flags;
 #ifdef RG_PROFILE

@@ -4,7 +4,8 @@
 set -e
 OUT=${1:-/tmp/isa}; mkdir -p $OUT
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -I$(dirname $0)/../include ${EXTRA} -S --cuda-device-only -o $OUT/rg.s $(dirname $0)/../rafting_amd/csrc/rg_kernels.hip 2>/dev/null
-awk '/^_ZN2rg11step_kernelILi4ELb0ELi64EEEvNS_10StepParamsE:/{p=1} p{print} /\.end_amdhsa_kernel/{if(p){exit}}' $OUT/rg.s > $OUT/k4.s
+KERNEL=${KERNEL:-_ZN2rg11step_kernelILi4ELb0ELi64EEEvNS_10StepParamsE}     # KERNEL=_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE for the split kernel
+awk -v k="^$KERNEL:" '$0 ~ k {p=1} p{print} /\.end_amdhsa_kernel/{if(p){exit}}' $OUT/rg.s > $OUT/k4.s
 python3 - $OUT/k4.s <<'PY'
 import sys,re
 from collections import Counter
