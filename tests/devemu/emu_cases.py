@@ -1,0 +1,73 @@
+"""Cases run by tests/test_devemu_cpu.py in a subprocess whose RG_LIB points at tests/devemu/libraftgpu_emu.so: the
+product's device decision code and C-ABI host code, compiled for the host (lane-serial grid, see hip/hip_runtime.h),
+against the oracle. TEST INFRASTRUCTURE — a way to exercise rg_device.hpp without a GPU, not a CPU path of the product.
+Not collected by a plain `pytest tests` (the file name matches no test pattern); never run against the real library."""
+import os
+
+import numpy as np
+import pytest
+
+assert os.environ.get("RG_LIB", "").endswith("libraftgpu_emu.so"), "these cases are for the host emulation library only"
+assert os.environ.get("RG_SPLIT") == "0", "the two-wavefront kernel needs a real barrier"
+
+from rafting_amd import abi, engine, workload  # noqa: E402
+from tests import fuzz, kat_scenarios, oracle_lib  # noqa: E402
+from tests import test_gpu_parity as T  # noqa: E402
+from tests.helpers import compare_outcomes, compare_states  # noqa: E402
+
+NEEDS_WAVEFRONT = {"timers_follow_reset_timer"}          # rg_timers_expired compacts with wavefront ballots
+
+
+@pytest.mark.parametrize("scenario", [s for s in kat_scenarios.SCENARIOS if s.__name__ not in NEEDS_WAVEFRONT],
+                         ids=lambda f: f.__name__)
+def test_kat(scenario):
+    scenario(T.mk_gpu)
+
+
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (5, 4, False, 13), (2, 1, True, 14),
+                                                             (4, 0, False, 15), (7, 3, True, 16), (6, 5, True, 17)])
+def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
+    _, _, _, hist, misses, _ = T._lockstep(192, cluster, self_slot, pre_vote, 100, seed, allow_miss=True)
+    assert {abi.OK, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER} <= set(np.flatnonzero(hist).tolist())
+
+
+def test_fuzz_general_handlers_only(monkeypatch):
+    monkeypatch.setenv("RG_FAST", "0")
+    _, _, _, hist, _, _ = T._lockstep(192, 5, 0, True, 80, 41, allow_miss=True)
+    assert hist[abi.OK] > 0
+
+
+def test_multi_round_launch_on_resident_buffers():
+    G, P = 256, 5
+    st0, batches, outs, _, misses, _ = T._lockstep(G, P, 1, True, 48, 21, allow_miss=False)
+    assert misses == 0
+    big, ref = fuzz.concat_batches(batches), fuzz.concat_outcomes(outs)
+    gpu = engine.Table(G, P, 1, True)
+    gpu.load_state(st0)
+    db = engine.DeviceBatch(gpu, big)
+    gpu.submit_device(db)
+    gpu.sync()
+    compare_outcomes(ref, db.outcome(), "multi-round")
+    db.free()
+
+
+def test_workload_replay_configs():
+    for number in (3, 5):
+        cfg = workload.config(number, 1000)              # not a multiple of the wavefront size: shadow lanes
+        gen = workload.ReplayGenerator(cfg)
+        gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        st0 = gen.initial_state()
+        gpu.load_state(st0)
+        orc.load_state(st0)
+        for _ in range(3):
+            b = gen.next_batch(16)
+            compare_outcomes(orc.submit(b), gpu.submit(b), cfg.name)
+        compare_states(orc.read_state(), gpu.read_state(), cfg.name)
+
+
+def test_split_kernel_is_refused_not_hung(monkeypatch):
+    monkeypatch.setenv("RG_SPLIT", "1")
+    t = engine.Table(64, 3, 0, True)
+    with pytest.raises(engine.EngineError):
+        t.submit(abi.Batch(1, 64))

@@ -1,0 +1,105 @@
+// tests/devemu/hip/hip_runtime.h — TEST INFRASTRUCTURE, not a product path.
+//
+// A stand-in for <hip/hip_runtime.h> that lets g++ compile rafting_amd/csrc/{rg_kernels.hip, raftgpu.cpp} UNCHANGED
+// into tests/devemu/libraftgpu_emu.so, so that `pytest -m "not gpu"` can run the real device decision code
+// (rg_device.hpp: Stepper::try_fast / run and everything under them) and the real host side of the C-ABI against the
+// oracle on a machine without a GPU. "Device memory" is the heap, a kernel launch runs every (block, thread) of the
+// grid one after the other on the calling thread.
+//
+// What a lane-serial grid can and cannot reproduce:
+//   + every kernel whose lanes are independent: step_kernel (one lane = one raft group), replicate_kernel, the
+//     timers update/arm kernels, the health kernels, copy_kernel;
+//   - anything that needs lanes to meet: wavefront shuffles/ballots (the decision counters come out per lane, not
+//     summed; rg_timers_expired's ballot compaction is wrong), barriers (step_split_kernel would dead-lock and is
+//     refused below). Tests that use this library force RG_SPLIT=0 and do not look at counters or expired-timer lists.
+// Nothing in rafting_amd/ knows about this file; libraftgpu.so itself has no CPU path and fails without a HIP device.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define __device__
+#define __host__
+#define __global__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { unsigned x, y, z, w; };
+
+namespace hipemu {
+extern thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+struct Deadlock {};
+}
+#define threadIdx (::hipemu::threadIdx_)
+#define blockIdx (::hipemu::blockIdx_)
+#define blockDim (::hipemu::blockDim_)
+#define gridDim (::hipemu::gridDim_)
+
+// ---- device intrinsics the kernels use ---------------------------------------------------------------------------
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_memtime() (0ull)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_ballot_w64(x) ((x) ? 1ull : 0ull)      /* a wavefront of one lane */
+#define __builtin_amdgcn_s_barrier() (throw ::hipemu::Deadlock())  /* a lane-serial grid cannot pass a barrier */
+#define __syncthreads() ((void)0)
+#define __ballot(x) ((x) ? 1ull : 0ull)
+#define __popcll(x) __builtin_popcountll(x)
+template <class T> static inline T __shfl_xor(T, int, int) { return T(0); }     /* no partner lane: adds nothing */
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+
+// ---- the slice of the runtime API raftgpu.cpp uses -----------------------------------------------------------------
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
+typedef enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 } hipMemcpyKind;
+typedef struct hipemu_stream *hipStream_t;
+typedef struct hipemu_event { double t_ms; } *hipEvent_t;
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0 };
+
+namespace hipemu { extern thread_local hipError_t last_error; }
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "emulated HIP error"; }
+static inline hipError_t hipGetLastError() { hipError_t e = ::hipemu::last_error; ::hipemu::last_error = hipSuccess; return e; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 256; strcpy(p->name, "lane-serial host emulation"); return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0.0}; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t_ms = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
+
+namespace hipemu {
+template <class Body>
+static inline void launch(dim3 grid, dim3 block, Body body)
+{
+    gridDim_ = grid; blockDim_ = block;
+    try {
+        for (unsigned b = 0; b < grid.x; b++)
+            for (unsigned t = 0; t < block.x; t++) {
+                blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
+                body();
+            }
+    } catch (const Deadlock &) {
+        last_error = hipErrorNotSupported;          // a kernel that needs its lanes to meet at a barrier
+    }
+}
+}  // namespace hipemu
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })

@@ -1,0 +1,36 @@
+"""The product's device decision code (rafting_amd/csrc/rg_device.hpp, rg_kernels.hip) and C-ABI host code
+(raftgpu.cpp), compiled UNCHANGED for the host against a stand-in for the HIP headers (tests/devemu/hip/hip_runtime.h:
+heap for device memory, a lane-serial grid for a launch), run against the oracle — so that `-m "not gpu"` already
+catches a logic error in the decision code. This is test infrastructure: nothing in rafting_amd/ can load that library,
+and libraftgpu.so has no CPU path."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "devemu")
+LIB = os.path.join(EMU, "libraftgpu_emu.so")
+SOURCES = [os.path.join(ROOT, "rafting_amd", "csrc", f) for f in ("rg_kernels.hip", "raftgpu.cpp", "rg_device.hpp")] + [
+    os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "raftgpu.h")]
+
+
+@pytest.fixture(scope="module")
+def emulation_library():
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SOURCES):
+        subprocess.run(["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + EMU, "-I" + os.path.join(ROOT, "include"),
+                        "-x", "c++", SOURCES[0], SOURCES[1], SOURCES[3], "-o", LIB], check=True, cwd=EMU)
+    return LIB
+
+
+def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", PYTHONPATH=ROOT)
+    env.pop("RG_FAST", None)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-6000:] + p.stderr[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
