@@ -66,6 +66,20 @@ def test_workload_replay_configs():
         compare_states(orc.read_state(), gpu.read_state(), cfg.name)
 
 
+def test_replicate_kernel_on_fuzzed_state():
+    T.test_replicate_matches_oracle_on_fuzzed_state()          # N1: one lane per row, no cross-lane work
+
+
+def test_health_kernels_in_a_closed_loop():
+    T.test_health_replay_matches_oracle()                      # N4b: health_update / health_failure / ready kernels
+    T.test_health_multi_round_and_sparse_fold()
+
+
+def test_sparse_rows_and_need_host_protocol():
+    T.test_sparse_rows_only_touch_their_groups()
+    T.test_need_host_blocks_later_rounds()
+
+
 def test_split_kernel_is_refused_not_hung(monkeypatch):
     monkeypatch.setenv("RG_SPLIT", "1")
     t = engine.Table(64, 3, 0, True)
