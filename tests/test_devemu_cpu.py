@@ -34,3 +34,17 @@ def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-6000:] + p.stderr[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_cpp_host_mirror_runs_a_whole_exchange_on_the_emulation(emulation_library):
+    """rafting_amd/host (RaftContext, ContextManager, StableStore) above the C-ABI: three nodes from start-up timeouts
+    through PreVote, election, client commands, back-off replication, commit, fencing, the readiness gate, step-down and
+    the durability journal (tests/devemu/host_flow.cpp); every decision by the device code on the host emulation."""
+    exe = os.path.join(ROOT, "build", "devemu_host_flow")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(EMU, "host_flow.cpp"), os.path.join(host, "raft_host.cpp"), os.path.join(host, "stable_store.cpp"),
+                    "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-o", exe], check=True)
+    p = subprocess.run([exe], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "host flow ok" in p.stdout, p.stdout + p.stderr
