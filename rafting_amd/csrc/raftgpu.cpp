@@ -195,7 +195,9 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
     t->dt.groups = groups;
     CREATE_TRY(hipMalloc((void **)&t->timer_deadline, G * sizeof(int64_t)));
-    CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 63) / 64 + 1) * sizeof(uint32_t)));
+    // timers_count_kernel runs whole 256-lane workgroups: every one of their wavefronts stores a count, also those past the
+    // last group, so the array covers the grid (found by the host emulation: ceil(G/64) + 1 entries were 2 short at G = 300)
+    CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 255) / 256 * 4 + 1) * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->health_ok, G * F * sizeof(int64_t)));
     CREATE_TRY(hipMalloc((void **)&t->health_fail, G * F * sizeof(int64_t)));

@@ -1,0 +1,68 @@
+"""Cases for the WAVEFRONT mode of the host emulation (RG_EMU_WAVES=1: every lane of a workgroup is an OS thread, so
+shuffles, ballots and barriers really meet): the two-wavefront step kernel with its LDS hand-over protocol, the decision
+counters, the ballot-compacted expiry list. Run by tests/test_devemu_cpu.py in a subprocess; TEST INFRASTRUCTURE.
+One thing this mode cannot do: a collective executed by only SOME lanes of a wavefront (the GPU's exec mask) — rows that
+are skipped after a NEED_HOST never reach the ballot inside tier 1, so multi-round launches with blocked lanes stay with
+the lane-serial mode and the GPU tests."""
+import os
+
+import numpy as np
+import pytest
+
+assert os.environ.get("RG_LIB", "").endswith("libraftgpu_emu.so"), "these cases are for the host emulation library only"
+assert os.environ.get("RG_EMU_WAVES") == "1" and os.environ.get("RG_SPLIT") == "1"
+
+from rafting_amd import abi, engine  # noqa: E402
+from tests import fuzz, kat_scenarios, oracle_lib  # noqa: E402
+from tests import test_gpu_parity as T  # noqa: E402
+from tests.helpers import compare_outcomes, compare_states  # noqa: E402
+
+
+@pytest.mark.parametrize("scenario", kat_scenarios.SCENARIOS, ids=lambda f: f.__name__)
+def test_kat_on_the_two_wavefront_kernel(scenario):
+    scenario(T.mk_gpu)                                     # includes timers_follow_reset_timer: ballot + popcount compaction
+
+
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (7, 3, True, 16)])
+def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
+    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 40, seed, allow_miss=True)
+    c = gpu.counters()
+    assert c[0] > 0 and c[1] > 0 and c[2] > 0
+
+
+def test_multi_round_launch_with_exact_counters():
+    """ONE 32-round launch of the two-wavefront kernel: outcomes, final state and the I/O wavefront's tallies"""
+    G, P = 128, 5
+    st0, batches, outs, _, misses, _ = T._lockstep(G, P, 1, True, 32, 21, allow_miss=False)
+    assert misses == 0
+    big, ref = fuzz.concat_batches(batches), fuzz.concat_outcomes(outs)
+    gpu = engine.Table(G, P, 1, True)
+    assert gpu.step_kernel() == "rg::step_split_kernel"
+    gpu.load_state(st0)
+    db = engine.DeviceBatch(gpu, big)
+    gpu.submit_device(db)
+    gpu.sync()
+    compare_outcomes(ref, db.outcome(), "multi-round")
+    orc = oracle_lib.OracleTable(G, P, 1, True)
+    orc.load_state(st0)
+    orc.submit(big)
+    compare_states(orc.read_state(), gpu.read_state(), "multi-round final")
+    c = gpu.counters()
+    assert c[0] == int(np.count_nonzero(big.head["hdr"] & 0xF))
+    assert c[1] == int(np.count_nonzero(ref.reply["flags"] & abi.F_REPLIED))
+    assert c[2] == int(np.count_nonzero(ref.reply["flags"] & abi.F_ROLE_CHANGED))
+    assert c[3] == int(np.count_nonzero(ref.reply["flags"] & abi.F_COMMIT))
+    db.free()
+
+
+def test_expired_timers_are_compacted_in_order():
+    G = 300                                                # two workgroups of the timer kernels, a ragged last wavefront
+    gpu, orc = engine.Table(G, 3, 0, True), oracle_lib.OracleTable(G, 3, 0, True)
+    for t in (gpu, orc):
+        t.timers_configure(900, 300, 7)
+        t.timers_arm(1000)
+    for now in (1900, 2300, 2800, 4000):
+        eg, ng = gpu.timers_expired(now, capacity=G if now != 2300 else 17)
+        eo, no = orc.timers_expired(now, capacity=G if now != 2300 else 17)
+        assert ng == no and np.array_equal(eg, eo)
+        assert np.array_equal(gpu.timers_read(), orc.timers_read())

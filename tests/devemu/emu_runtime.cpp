@@ -1,6 +1,154 @@
-// tests/devemu/emu_runtime.cpp — state of the lane-serial grid emulation (see hip/hip_runtime.h). TEST INFRASTRUCTURE.
+// tests/devemu/emu_runtime.cpp — the two grid executors of the host emulation (see hip/hip_runtime.h). TEST INFRASTRUCTURE.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 namespace hipemu {
+
 thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 thread_local hipError_t last_error = hipSuccess;
+
+namespace {
+
+// A set of lanes that meet: a generation completes when every lane that is still alive has arrived.
+struct Meeting {
+    std::mutex m;
+    std::condition_variable cv;
+    int alive = 0, arrived = 0;
+    unsigned long long gen = 0;
+    std::vector<unsigned long long> slot, out;
+    std::vector<char> here, out_here;
+
+    void init(int n)
+    {
+        alive = n; arrived = 0; gen = 0;
+        slot.assign(n, 0); out.assign(n, 0); here.assign(n, 0); out_here.assign(n, 0);
+    }
+    void complete()
+    {
+        out = slot; out_here = here;
+        std::fill(here.begin(), here.end(), 0);
+        arrived = 0; gen++;
+        cv.notify_all();
+    }
+    // contribute v as member idx, wait for the others, then read the completed generation under the lock
+    template <class Reader>
+    unsigned long long meet(int idx, unsigned long long v, Reader read)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        slot[idx] = v; here[idx] = 1; arrived++;
+        if (arrived == alive) {
+            complete();
+        } else {
+            const unsigned long long g = gen;
+            if (!cv.wait_for(lk, std::chrono::seconds(30), [&] { return gen != g; })) throw Deadlock();   // a lane never came
+        }
+        return read(out, out_here);
+    }
+    void leave()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        alive--;
+        if (alive > 0 && arrived == alive) complete();
+    }
+};
+
+thread_local Meeting *my_wave = nullptr, *my_block = nullptr;
+thread_local int my_lane = 0;
+
+bool waves_mode()
+{
+    static const bool on = [] { const char *e = getenv("RG_EMU_WAVES"); return e && atoi(e) != 0; }();
+    return on;
 }
+
+}  // namespace
+
+unsigned long long wave_ballot(bool p)
+{
+    if (!my_wave) return p ? 1ull : 0ull;
+    return my_wave->meet(my_lane, p ? 1ull : 0ull, [](const std::vector<unsigned long long> &out, const std::vector<char> &here) {
+        unsigned long long mask = 0;
+        for (size_t i = 0; i < out.size(); i++) if (here[i] && out[i]) mask |= 1ull << i;
+        return mask;
+    });
+}
+
+unsigned long long wave_exchange_xor(unsigned long long bits, int lane_xor)
+{
+    if (!my_wave) return 0ull;
+    const int partner = my_lane ^ lane_xor;
+    return my_wave->meet(my_lane, bits, [partner](const std::vector<unsigned long long> &out, const std::vector<char> &here) {
+        return partner >= 0 && (size_t)partner < out.size() && here[partner] ? out[partner] : 0ull;
+    });
+}
+
+unsigned long long wave_first(unsigned long long v)
+{
+    if (!my_wave) return v;
+    return my_wave->meet(my_lane, v, [](const std::vector<unsigned long long> &out, const std::vector<char> &here) {
+        for (size_t i = 0; i < out.size(); i++) if (here[i]) return out[i];
+        return 0ull;
+    });
+}
+
+void workgroup_barrier(bool required)
+{
+    if (!my_block) {
+        if (required) throw Deadlock();            // a lane-serial grid cannot pass an s_barrier
+        return;                                    // __syncthreads on a lane-serial grid: a no-op (documented as inexact)
+    }
+    my_block->meet((int)threadIdx_.x, 0ull, [](const std::vector<unsigned long long> &, const std::vector<char> &) { return 0ull; });
+}
+
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
+{
+    if (!waves_mode()) {
+        gridDim_ = grid; blockDim_ = block;
+        try {
+            for (unsigned b = 0; b < grid.x; b++)
+                for (unsigned t = 0; t < block.x; t++) {
+                    blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
+                    body();
+                }
+        } catch (const Deadlock &) {
+            last_error = hipErrorNotSupported;      // a kernel that needs its lanes to meet at a barrier
+        }
+        return;
+    }
+    const unsigned waves = (block.x + 63u) / 64u;
+    std::mutex err_m;
+    bool failed = false;
+    for (unsigned b = 0; b < grid.x; b++) {
+        Meeting wg;
+        std::vector<Meeting> wv(waves);
+        wg.init((int)block.x);
+        for (unsigned w = 0; w < waves; w++) wv[w].init((int)std::min(64u, block.x - w * 64u));
+        std::vector<std::thread> lanes;
+        lanes.reserve(block.x);
+        for (unsigned t = 0; t < block.x; t++) {
+            lanes.emplace_back([&, t, b] {
+                gridDim_ = grid; blockDim_ = block; blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
+                my_block = &wg; my_wave = &wv[t / 64u]; my_lane = (int)(t % 64u);
+                try {
+                    body();
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(err_m);
+                    failed = true;
+                }
+                my_wave->leave(); my_block->leave();          // a lane that has returned is not waited for any more
+                my_wave = nullptr; my_block = nullptr;
+            });
+        }
+        for (std::thread &th : lanes) th.join();
+        if (failed) break;
+    }
+    if (failed) last_error = hipErrorNotSupported;
+}
+
+}  // namespace hipemu

@@ -6,12 +6,17 @@
 // oracle on a machine without a GPU. "Device memory" is the heap, a kernel launch runs every (block, thread) of the
 // grid one after the other on the calling thread.
 //
-// What a lane-serial grid can and cannot reproduce:
-//   + every kernel whose lanes are independent: step_kernel (one lane = one raft group), replicate_kernel, the
-//     timers update/arm kernels, the health kernels, copy_kernel;
-//   - anything that needs lanes to meet: wavefront shuffles/ballots (the decision counters come out per lane, not
-//     summed; rg_timers_expired's ballot compaction is wrong), barriers (step_split_kernel would dead-lock and is
-//     refused below). Tests that use this library force RG_SPLIT=0 and do not look at counters or expired-timer lists.
+// Two ways to run a grid (emu_runtime.cpp):
+//   lane-serial (default): every (block, thread) one after the other on the calling thread. Fast, and exact for every
+//     kernel whose lanes are independent — step_kernel (one lane = one raft group), replicate_kernel, the timers
+//     update/arm kernels, the health kernels, copy_kernel. It cannot reproduce what needs lanes to MEET: wavefront
+//     shuffles/ballots (the decision counters come out per lane, not summed; rg_timers_expired's ballot compaction is
+//     wrong) and barriers (step_split_kernel is refused, not dead-locked). Tests on it force RG_SPLIT=0 and do not look
+//     at counters or expired-timer lists.
+//   wavefronts (RG_EMU_WAVES=1): every lane of a workgroup is an OS thread; shuffles, ballots, readfirstlane meet per
+//     64-lane wavefront, __syncthreads / s_barrier per workgroup, a lane that returns stops being waited for. Slow, but
+//     it runs ALL kernels, including the two-wavefront step kernel with its LDS hand-over and the ballot compaction.
+//     (It checks the protocol, not the hardware: LDS visibility and waitcnt placement are the GPU tests' business.)
 // Nothing in rafting_amd/ knows about this file; libraftgpu.so itself has no CPU path and fails without a HIP device.
 #pragma once
 
@@ -35,9 +40,15 @@ struct dim3 {
 };
 struct uint4 { unsigned x, y, z, w; };
 
+#include <functional>
 namespace hipemu {
 extern thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 struct Deadlock {};
+unsigned long long wave_ballot(bool p);                    // lane-serial: a wavefront of one lane
+unsigned long long wave_exchange_xor(unsigned long long bits, int lane_xor);   // lane-serial: no partner, 0
+unsigned long long wave_first(unsigned long long v);
+void workgroup_barrier(bool required);                      // required (s_barrier) throws Deadlock on a lane-serial grid
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 }
 #define threadIdx (::hipemu::threadIdx_)
 #define blockIdx (::hipemu::blockIdx_)
@@ -47,14 +58,14 @@ struct Deadlock {};
 // ---- device intrinsics the kernels use ---------------------------------------------------------------------------
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 #define __builtin_amdgcn_s_memtime() (0ull)
-#define __builtin_amdgcn_readfirstlane(x) (x)
-#define __builtin_amdgcn_ballot_w64(x) ((x) ? 1ull : 0ull)      /* a wavefront of one lane */
-#define __builtin_amdgcn_s_barrier() (throw ::hipemu::Deadlock())  /* a lane-serial grid cannot pass a barrier */
-#define __syncthreads() ((void)0)
-#define __ballot(x) ((x) ? 1ull : 0ull)
+#define __builtin_amdgcn_readfirstlane(x) ((decltype(x))::hipemu::wave_first((unsigned long long)(x)))
+#define __builtin_amdgcn_ballot_w64(x) (::hipemu::wave_ballot(x))
+#define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
+#define __syncthreads() (::hipemu::workgroup_barrier(false))
+#define __ballot(x) (::hipemu::wave_ballot(x))
 #define __popcll(x) __builtin_popcountll(x)
-template <class T> static inline T __shfl_xor(T, int, int) { return T(0); }     /* no partner lane: adds nothing */
-template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T __shfl_xor(T v, int lane_xor, int) { return (T)::hipemu::wave_exchange_xor((unsigned long long)v, lane_xor); }
+template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 // ---- the slice of the runtime API raftgpu.cpp uses -----------------------------------------------------------------
 typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
@@ -86,20 +97,4 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 
-namespace hipemu {
-template <class Body>
-static inline void launch(dim3 grid, dim3 block, Body body)
-{
-    gridDim_ = grid; blockDim_ = block;
-    try {
-        for (unsigned b = 0; b < grid.x; b++)
-            for (unsigned t = 0; t < block.x; t++) {
-                blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
-                body();
-            }
-    } catch (const Deadlock &) {
-        last_error = hipErrorNotSupported;          // a kernel that needs its lanes to meet at a barrier
-    }
-}
-}  // namespace hipemu
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::launch((grid), (block), [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::run_grid((grid), (block), [&]() { kernel(__VA_ARGS__); })

@@ -22,7 +22,7 @@ def emulation_library():
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SOURCES):
-        subprocess.run(["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-w", "-I" + EMU, "-I" + os.path.join(ROOT, "include"),
+        subprocess.run(["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-w", "-pthread", "-I" + EMU, "-I" + os.path.join(ROOT, "include"),
                         "-x", "c++", SOURCES[0], SOURCES[1], SOURCES[3], "-o", LIB], check=True, cwd=EMU)
     return LIB
 
@@ -31,6 +31,17 @@ def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
     env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", PYTHONPATH=ROOT)
     env.pop("RG_FAST", None)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-6000:] + p.stderr[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_kernels_that_need_lanes_to_meet_on_emulated_wavefronts(emulation_library):
+    """RG_EMU_WAVES=1: every lane of a workgroup is an OS thread, shuffles / ballots meet per 64-lane wavefront, barriers per
+    workgroup — the two-wavefront step kernel with its LDS rings, the decision counters, the ballot-compacted timer list."""
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", PYTHONPATH=ROOT)
+    env.pop("RG_FAST", None)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases_waves.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-6000:] + p.stderr[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
@@ -45,6 +56,6 @@ def test_cpp_host_mirror_runs_a_whole_exchange_on_the_emulation(emulation_librar
     host = os.path.join(ROOT, "rafting_amd", "host")
     subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"),
                     os.path.join(EMU, "host_flow.cpp"), os.path.join(host, "raft_host.cpp"), os.path.join(host, "stable_store.cpp"),
-                    "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-o", exe], check=True)
+                    "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
     p = subprocess.run([exe], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "host flow ok" in p.stdout, p.stdout + p.stderr
