@@ -80,6 +80,46 @@ def test_sparse_rows_and_need_host_protocol():
     T.test_need_host_blocks_later_rounds()
 
 
+def test_device_memspace_variants_equal_the_host_ones():
+    """RG_MEM_DEVICE entry points of N1 / N4 (the caller's buffers already live on the device): on the emulation device
+    memory is the heap, so numpy arrays can stand in for resident buffers; results must equal the RG_MEM_HOST path."""
+    import ctypes as C
+    L = engine.lib()
+    G, P = 320, 4
+    F = P - 1
+    st0 = fuzz.random_initial_state(G, P, 1, 5)
+    a, b = engine.Table(G, P, 1, True), engine.Table(G, P, 1, True)
+    fz = fuzz.Fuzzer(G, P, 1, 5, allow_miss=False)
+    for t in (a, b):
+        t.load_state(st0)
+        t.timers_configure(900, 300, 3)
+        t.timers_arm(1000)
+    for r in range(12):
+        now = 1000 + 170 * r
+        batch = abi.Batch(1, G)
+        fz.round(a.read_state(), batch, 0)
+        oa, ob = a.submit(batch), b.submit(batch)
+        compare_outcomes(oa, ob, "same input")
+        nows = np.array([now], dtype=np.int64)
+        a.timers_update(1, G, oa.reply, nows)
+        a.health_update(batch, oa.reply, nows)
+        assert L.rg_timers_update(b._h, 1, G, None, ob.reply.ctypes.data, nows.ctypes.data, abi.MEM_DEVICE) == 0
+        assert L.rg_health_update(b._h, 1, G, None, batch.head.ctypes.data, ob.reply.ctypes.data, nows.ctypes.data, abi.MEM_DEVICE) == 0
+        assert np.array_equal(a.timers_read(), b.timers_read())
+        for x, y in zip(a.health_read(), b.health_read()):
+            assert np.array_equal(x, y)
+        ready_dev = np.zeros(G, dtype=np.uint8)
+        assert L.rg_ready(b._h, now + 5, 1, 100, ready_dev.ctypes.data, abi.MEM_DEVICE) == 0
+        b.sync()
+        assert np.array_equal(a.ready(now + 5, 1, 100), ready_dev)
+        head_h, send_h = a.replicate(heartbeat=r % 2)
+        hb = np.full(G, r % 2, dtype=np.uint8)
+        head_d, send_d = np.zeros(G, dtype=abi.SEND_HEAD_DT), np.zeros(G * F, dtype=abi.SEND_DT)
+        assert L.rg_replicate(b._h, G, None, hb.ctypes.data, None, head_d.ctypes.data, send_d.ctypes.data, abi.MEM_DEVICE) == 0
+        b.sync()
+        assert np.array_equal(head_h, head_d) and np.array_equal(send_h, np.ascontiguousarray(send_d.reshape(F, G).T))
+
+
 def test_split_kernel_is_refused_not_hung(monkeypatch):
     monkeypatch.setenv("RG_SPLIT", "1")
     t = engine.Table(64, 3, 0, True)
