@@ -120,6 +120,11 @@ def test_device_memspace_variants_equal_the_host_ones():
         assert np.array_equal(head_h, head_d) and np.array_equal(send_h, np.ascontiguousarray(send_d.reshape(F, G).T))
 
 
+def test_api_misuse_and_small_entry_points():
+    T.test_api_misuse_is_reported()
+    assert engine.Table(8, 3).copy_bandwidth(1 << 22, 2) > 0       # the copy kernel runs (its speed means nothing here)
+
+
 def test_split_kernel_is_refused_not_hung(monkeypatch):
     monkeypatch.setenv("RG_SPLIT", "1")
     t = engine.Table(64, 3, 0, True)
