@@ -65,6 +65,9 @@ def lib():
                 "there is no CPU fallback for the decision path" % LIB_PATH)
         _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
+        if hasattr(L, "rg_is_host_emulation") and os.environ.get("RG_ALLOW_HOST_EMULATION") != "1":
+            raise EngineError("%s is the test-only host emulation of the kernels (tests/devemu), not libraftgpu.so; "
+                              "the decision path has no CPU fallback" % LIB_PATH)
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         L.rg_abi_version.restype = i32
         L.rg_table_create.argtypes = [i32, u32, u32, u32, i32, C.POINTER(vp)]

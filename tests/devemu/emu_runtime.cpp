@@ -8,6 +8,10 @@
 #include <thread>
 #include <vector>
 
+// The marker rafting_amd/engine.py looks for: a library that exports it is refused unless the caller says, through
+// RG_ALLOW_HOST_EMULATION=1 (only tests/test_devemu_cpu.py does), that it knows it is not talking to a GPU.
+extern "C" int rg_is_host_emulation() { return 1; }
+
 namespace hipemu {
 
 thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;

@@ -28,7 +28,7 @@ def emulation_library():
 
 
 def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
-    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", PYTHONPATH=ROOT)
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)
     env.pop("RG_FAST", None)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
@@ -39,7 +39,7 @@ def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
 def test_kernels_that_need_lanes_to_meet_on_emulated_wavefronts(emulation_library):
     """RG_EMU_WAVES=1: every lane of a workgroup is an OS thread, shuffles / ballots meet per 64-lane wavefront, barriers per
     workgroup — the two-wavefront step kernel with its LDS rings, the decision counters, the ballot-compacted timer list."""
-    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", PYTHONPATH=ROOT)
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)
     env.pop("RG_FAST", None)
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases_waves.py"), "-x", "-q", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
@@ -59,3 +59,12 @@ def test_cpp_host_mirror_runs_a_whole_exchange_on_the_emulation(emulation_librar
                     "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
     p = subprocess.run([exe], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "host flow ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_the_product_binding_refuses_the_emulation_library(emulation_library):
+    """rafting_amd.engine must not be talked into a CPU path by pointing RG_LIB at the test artefact"""
+    env = dict(os.environ, RG_LIB=emulation_library, PYTHONPATH=ROOT)
+    env.pop("RG_ALLOW_HOST_EMULATION", None)
+    p = subprocess.run([sys.executable, "-c", "from rafting_amd import engine; engine.Table(4, 3)"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "test-only host emulation" in p.stderr
