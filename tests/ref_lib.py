@@ -1,0 +1,125 @@
+"""ctypes binding of oracle/_ref/libref.so — the reference's own decision classes, mechanically translated from the Java
+sources by tools/make_ref.py and compiled (TEST INFRASTRUCTURE ONLY; nothing under rafting_amd/ may import this).
+
+`RefTable` has the surface of tests.oracle_lib.OracleTable, so every known-answer scenario and the lockstep fuzzer can be
+played against the reference's code itself.  The library exists only where it was built from /root/reference
+(`make -C oracle ref`); `available()` says whether it is there."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rafting_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "libref.so")
+REFERENCE = "/root/reference/src/main/java/io/lubricant/consensus/raft"
+_LIB = None
+
+
+def available():
+    if os.path.isdir(REFERENCE):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "ref"], check=True)
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libref.so is not built (needs /root/reference)")
+        L = C.CDLL(LIB_PATH)
+        L.ref_table_create.restype = C.c_void_p
+        L.ref_table_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.ref_table_destroy.argtypes = [C.c_void_p]
+        L.ref_load_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
+        L.ref_read_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
+        L.ref_submit.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
+        L.ref_clock.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_is_better.restype = C.c_int
+        L.ref_is_better.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int32]
+        L.ref_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_update_index.restype = C.c_int
+        L.ref_update_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int64, C.c_int64, C.c_int, C.c_int]
+        L.ref_rejection_step.restype = C.c_int64
+        L.ref_rejection_step.argtypes = [C.c_int32]
+        _LIB = L
+    return _LIB
+
+
+class RefTable:
+    """Same surface as tests.oracle_lib.OracleTable, backed by the translated reference classes."""
+
+    def __init__(self, groups, cluster, self_slot=0, pre_vote=True):
+        self.groups, self.cluster, self.self_slot, self.pre_vote = groups, cluster, self_slot, pre_vote
+        self._h = lib().ref_table_create(groups, cluster, self_slot, int(pre_vote))
+        if not self._h:
+            raise ValueError("ref_table_create rejected the arguments")
+
+    def close(self):
+        if self._h:
+            lib().ref_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def load_state(self, state, first=0):
+        s = state.as_struct()
+        rc = lib().ref_load_state(self._h, first, state.count, C.byref(s))
+        if rc:
+            raise ValueError("ref_load_state failed: %d" % rc)
+
+    def read_state(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        st = abi.GroupState(count, self.cluster)
+        s = st.as_struct()
+        rc = lib().ref_read_state(self._h, first, count, C.byref(s))
+        if rc:
+            raise ValueError("ref_read_state failed: %d" % rc)
+        return st
+
+    def submit(self, batch, out=None, fill=0, now=None):
+        out = abi.Outcome(batch.rounds * batch.count, fill) if out is None else out
+        b, o = batch.as_struct(), out.as_struct()
+        clock = None
+        if now is not None:
+            clock = np.ascontiguousarray(now, dtype=np.int64)
+            assert len(clock) == batch.rounds
+            assert lib().ref_clock(self._h, clock.ctypes.data) == 0
+        try:
+            rc = lib().ref_submit(self._h, C.byref(b), C.byref(o))
+        finally:
+            if clock is not None:
+                lib().ref_clock(self._h, None)
+        if rc:
+            raise ValueError("ref_submit failed: %d" % rc)
+        return out
+
+    def submit_timed(self, batch, now, fill=0):
+        return self.submit(batch, fill=fill, now=now)
+
+
+def rejection_step(r):
+    return int(lib().ref_rejection_step(int(r)))
+
+
+def major_indices(match):
+    m = np.ascontiguousarray(match, dtype=np.int64)
+    out = np.zeros(2, dtype=np.int64)
+    lib().ref_major_indices(m.ctypes.data, len(m), out.ctypes.data)
+    return int(out[0]), int(out[1])
+
+
+def is_better(new, cur):
+    r = lib().ref_is_better(new[0], new[1], new[2], cur[0], cur[1], cur[2])
+    return r if r < 0 else bool(r)
+
+
+def update_index(last_epoch, next_index, match_index, rejection, pending, epoch, index, success, snapshot):
+    st = np.array([last_epoch, next_index, match_index], dtype=np.int64)
+    rej, pen = C.c_int32(rejection), C.c_uint8(pending)
+    rc = lib().ref_update_index(st.ctypes.data, C.byref(rej), C.byref(pen), epoch, index, int(success), int(snapshot))
+    return rc, (int(st[0]), int(st[1]), int(st[2]), int(rej.value), int(pen.value))
