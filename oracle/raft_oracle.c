@@ -1,5 +1,6 @@
 /*
- * raft_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See raft_oracle.h.
+ * raft_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See raft_oracle.h (incl. how it is pinned to the
+ * reference's own compiled sources, oracle/_ref).
  *
  * Every function cites the reference lines it restates.  Paths are relative to
  *   /root/reference/src/main/java/io/lubricant/consensus/raft/
@@ -208,6 +209,17 @@ int orc_is_better(int nr, int64_t nt, int32_t nb, int cr, int64_t ct, int32_t cb
     return 0;
 }
 
+void orc_is_better_batch(uint32_t n, const int32_t *nr, const int64_t *nt, const int32_t *nb, const int32_t *cr, const int64_t *ct,
+                         const int32_t *cb, int32_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = orc_is_better(nr[i], nt[i], nb[i], cr[i], ct[i], cb[i]);
+}
+
+void orc_major_indices_batch(uint32_t n, int f, const int64_t *match, int64_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) orc_major_indices(match + (size_t)i * f, f, out + 2 * (size_t)i);
+}
+
 /* RaftContext.switchTo/trySwitchTo -> RaftRoutine.trySwitch + switchTo + convertTo
  * (context/RaftContext.java:195-215, context/RaftRoutine.java:140-216) and the constructors of the
  * new participant (member/RaftMember.java:20-26, Follower.java:26-28, Candidate.java:22-25, Leader.java:25-28).
@@ -296,6 +308,25 @@ static int update_index(peer_t *s, int64_t epoch, int64_t index, int success, in
     }
     if (s->next_index <= epoch && !s->pending) s->pending = 1;
     return RG_OK;
+}
+
+/* exposed for differential tests: State.updateIndex on (lastEpoch, nextIndex, matchIndex), recentRejection, pendingInstallation */
+int orc_update_index(int64_t st[3], int32_t *rejection, uint8_t *pending, int64_t epoch, int64_t index, int success, int snapshot)
+{
+    peer_t s;
+    memset(&s, 0, sizeof s);
+    s.last_epoch = st[0]; s.next_index = st[1]; s.match_index = st[2]; s.rejection = *rejection; s.pending = *pending != 0;
+    int rc = update_index(&s, epoch, index, success, snapshot);
+    st[0] = s.last_epoch; st[1] = s.next_index; st[2] = s.match_index; *rejection = s.rejection; *pending = s.pending;
+    return rc;
+}
+
+/* batch forms for differential fuzzing against oracle/_ref (one call, n independent inputs) */
+void orc_update_index_batch(uint32_t n, int64_t *st, int32_t *rejection, uint8_t *pending, const int64_t *epoch, const int64_t *index,
+                            const uint8_t *success, const uint8_t *snapshot, int32_t *rc)
+{
+    for (uint32_t i = 0; i < n; i++)
+        rc[i] = orc_update_index(st + 3 * (size_t)i, &rejection[i], &pending[i], epoch[i], index[i], success[i], snapshot[i]);
 }
 
 /* Leadership.State.majorIndices: member/Leadership.java:116-130 */

@@ -6,12 +6,16 @@
  * reference EventLoop would run it.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may link or call this; the product path (rafting_amd/, libraftgpu.so) never does.
  *
- * PARITY UNPINNED BY THE REFERENCE: the reference (Java 8 + Maven deps) cannot run in this
- * environment (no JDK) and its own tests hold no golden vector for this path.
- * The oracle is pinned instead by hand-derived known-answer tests (tests/test_oracle_kat.py), each
- * citing the reference lines it was derived from, by the one in-source golden table
- * (member/Leadership.java:121-126) and by the literal constants of the path, both extracted from the
- * reference's source text into tests/golden/reference_pins.json (tests/test_reference_pins.py).
+ * HOW IT IS PINNED: the reference (Java 8 + Maven deps) cannot run here (no JDK) and its own tests hold no
+ * golden vector for this path.  Its decision classes are however compiled FROM THEIR OWN
+ * SOURCES: tools/make_ref.py translates Follower / Candidate / Leader / Leadership.State / Membership / RaftMember /
+ * TimerTicket / RocksLog / RaftRoutine / RaftContext token by token into C++ (oracle/_ref/libref.so, built by
+ * `make -C oracle ref` from /root/reference, sha-pinned source ranges, no hand-edited output), and
+ * tests/test_ref_parity.py requires this oracle to answer exactly like that library: all 43 known-answer
+ * scenarios, >= 10^6 random inputs per pure function, the lockstep fuzzer over seven cluster shapes (outcome rows
+ * and full state after every round), the BASELINE replay streams; tests/golden/replay_digests.json is generated
+ * by that library, not by this oracle.  Hand-derived KATs (tests/test_oracle_kat.py) and the constants extracted
+ * from the reference text (tests/test_reference_pins.py) remain as the second, independent pin.
  *
  * The log model is LOSSLESS: an unbounded run-length encoding of (index -> term) over the contiguous
  * key window RocksLog keeps (storage/RocksLog.java), so it answers RaftLog.get(i) for every index —
@@ -75,9 +79,18 @@ int64_t orc_log_conflict(const orc_table_t *t, uint32_t gid, int64_t e0, uint32_
 /* exposed pieces for known-answer tests */
 int64_t orc_rejection_step(int32_t recent_rejection);                 /* Leadership.java:105 */
 void    orc_major_indices(const int64_t *match, int n, int64_t out[2]); /* Leadership.java:116-130 */
+/* State.updateIndex (member/Leadership.java:75-114) on st = {lastEpoch, nextIndex, matchIndex}; returns 0 or the RG_A_* status */
+int     orc_update_index(int64_t st[3], int32_t *rejection, uint8_t *pending, int64_t epoch, int64_t index, int success, int snapshot);
 /* Membership.isBetter (member/Membership.java:74-108): 1 better, 0 not, <0 = -(RG_A_* status) */
 int     orc_is_better(int new_role, int64_t new_term, int32_t new_ballot,
                       int cur_role, int64_t cur_term, int32_t cur_ballot);
+
+/* batch forms of the three above (n independent inputs) for differential fuzzing against oracle/_ref */
+void    orc_update_index_batch(uint32_t n, int64_t *st, int32_t *rejection, uint8_t *pending, const int64_t *epoch, const int64_t *index,
+                               const uint8_t *success, const uint8_t *snapshot, int32_t *rc);
+void    orc_is_better_batch(uint32_t n, const int32_t *nr, const int64_t *nt, const int32_t *nb, const int32_t *cr, const int64_t *ct,
+                            const int32_t *cb, int32_t *out);
+void    orc_major_indices_batch(uint32_t n, int f, const int64_t *match, int64_t *out);
 
 #ifdef __cplusplus
 }

@@ -187,37 +187,80 @@ inline JArr<jbyte> jbytes(const char *s) { size_t n = strlen(s); JArr<jbyte> a =
 inline std::string jkey(const JArr<jbyte> &a) { std::string k; for (jint i = 0; i < a->length; i++) k.push_back((char)a[i]); return k; }
 inline JArr<jbyte> jval(const std::string &s) { JArr<jbyte> a = JArr<jbyte>::make((jlong)s.size()); for (size_t i = 0; i < s.size(); i++) a[(jlong)i] = (jbyte)s[i]; return a; }
 struct ColumnFamilyHandle : virtual Object { Class *klass_() override { return nullptr; } };
+// The default column family holds only 8-byte keys (storage/RocksLog.java:86,190); equal neighbouring values are stored as
+// one run [start, end] so that a log of 2^60 entries costs one node.  Order = RocksDB's bytewise comparator = unsigned
+// order of the big-endian key.  This is a representation of the fake, invisible through get / put / deleteRange / iterators.
 struct RocksDB : virtual Object {
     Class *klass_() override { return nullptr; }
     static constexpr jint NOT_FOUND = -1;
-    std::map<std::string, std::string> kv, cf;       // default column family, "epoch" column family
+    struct Run { uint64_t end; std::string val; };
+    std::map<uint64_t, Run> kv;                      // start -> run
+    std::map<std::string, std::string> cf;           // "epoch" column family
     // observations for the driver (what the host-owned RaftLog plugin was told to do during one event)
     jlong puts_new = 0; jlong first_new_key = 0; bool truncated = false; jlong trunc_from = 0;
+    static uint64_t ukey(const JArr<jbyte> &a)
+    {
+        if (a->length != 8) throw IllegalArgumentException("fake RocksDB: default column family keys are 8 bytes");
+        uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | (uint8_t)a[i]; return v;
+    }
+    static JArr<jbyte> kbytes(uint64_t v) { JArr<jbyte> a = JArr<jbyte>::make(8); for (int i = 7; i >= 0; i--) { a[i] = (jbyte)(v & 0xFF); v >>= 8; } return a; }
     static jlong key_to_long(const std::string &k) { uint64_t v = 0; for (int i = 0; i < 8; i++) v = (v << 8) | (uint8_t)k[(size_t)i]; return (jlong)v; }
     void observe_reset() { puts_new = 0; first_new_key = 0; truncated = false; trunc_from = 0; }
-    JArr<jbyte> get(const JArr<jbyte> &key) { auto it = kv.find(jkey(key)); return it == kv.end() ? JArr<jbyte>(nullptr) : jval(it->second); }
+    std::map<uint64_t, Run>::iterator find_run(uint64_t k)
+    {
+        auto it = kv.upper_bound(k);
+        if (it == kv.begin()) return kv.end();
+        --it;
+        return it->second.end >= k ? it : kv.end();
+    }
+    void erase_range(uint64_t a, uint64_t b_incl)                 // remove keys a..b_incl
+    {
+        auto it = kv.upper_bound(a);
+        if (it != kv.begin()) --it;
+        while (it != kv.end() && it->first <= b_incl) {
+            uint64_t s0 = it->first, e0 = it->second.end; std::string v = it->second.val;
+            if (e0 < a) { ++it; continue; }
+            it = kv.erase(it);
+            if (s0 < a) kv[s0] = Run{a - 1, v};
+            if (e0 > b_incl) { kv[b_incl + 1] = Run{e0, v}; break; }
+        }
+    }
+    JArr<jbyte> get(const JArr<jbyte> &key) { auto it = find_run(ukey(key)); return it == kv.end() ? JArr<jbyte>(nullptr) : jval(it->second.val); }
     jint get(const JArr<jbyte> &key, const JArr<jbyte> &buf)
     {
-        auto it = kv.find(jkey(key));
+        auto it = find_run(ukey(key));
         if (it == kv.end()) return NOT_FOUND;
-        for (jint i = 0; i < buf->length && (size_t)i < it->second.size(); i++) buf[i] = (jbyte)it->second[(size_t)i];
-        return (jint)it->second.size();
+        const std::string &v = it->second.val;
+        for (jint i = 0; i < buf->length && (size_t)i < v.size(); i++) buf[i] = (jbyte)v[(size_t)i];
+        return (jint)v.size();
     }
     void put(const JArr<jbyte> &key, const JArr<jbyte> &val)
     {
-        std::string k = jkey(key);
-        if (!kv.count(k)) { if (puts_new == 0) first_new_key = key_to_long(k); puts_new++; }
-        kv[k] = jkey(val);
+        uint64_t k = ukey(key); std::string v = jkey(val);
+        auto it = find_run(k);
+        if (it == kv.end()) { if (puts_new == 0) first_new_key = (jlong)k; puts_new++; }
+        else if (it->second.val == v) return;
+        else erase_range(k, k);
+        uint64_t s0 = k, e0 = k;
+        auto nx = kv.find(k + 1);
+        if (k != UINT64_MAX && nx != kv.end() && nx->second.val == v) { e0 = nx->second.end; kv.erase(nx); }
+        if (k != 0) {
+            auto pv = find_run(k - 1);
+            if (pv != kv.end() && pv->second.val == v) { s0 = pv->first; kv.erase(pv); }
+        }
+        kv[s0] = Run{e0, v};
     }
     void put(Ref<ColumnFamilyHandle>, const JArr<jbyte> &key, const JArr<jbyte> &val) { cf[jkey(key)] = jkey(val); }
     void flushWal(jboolean) {}
     void deleteRange(const JArr<jbyte> &a, const JArr<jbyte> &b)
     {
-        std::string ka = jkey(a), kb = jkey(b);
-        if (ka >= kb) return;                                     // RocksDB: empty or inverted range deletes nothing
-        auto lo = kv.lower_bound(ka), hi = kv.lower_bound(kb);
-        if (lo != hi) { truncated = true; trunc_from = key_to_long(ka); }
-        kv.erase(lo, hi);
+        uint64_t ka = ukey(a), kb = ukey(b);
+        if (ka >= kb) return;                                     // RocksDB: an empty or inverted range deletes nothing
+        auto it = kv.upper_bound(kb - 1);                         // is any key inside [ka, kb)?
+        bool any = false;
+        if (it != kv.begin()) { --it; any = it->second.end >= ka; }
+        if (any) { truncated = true; trunc_from = (jlong)ka; }
+        erase_range(ka, kb - 1);
     }
     Ref<List<JArr<jbyte>>> multiGetAsList(Ref<List<JArr<jbyte>>> keys)
     {
@@ -229,18 +272,19 @@ struct RocksDB : virtual Object {
 };
 struct RocksIterator : virtual Object {
     Class *klass_() override { return nullptr; }
-    RocksDB *db; std::map<std::string, std::string>::iterator it; bool valid = false;
+    RocksDB *db; uint64_t k = 0; std::string v; bool valid = false;
     RocksIterator(RocksDB *d) : db(d) {}
-    void seekToLast() { valid = !db->kv.empty(); if (valid) it = std::prev(db->kv.end()); }
+    void seekToLast() { valid = !db->kv.empty(); if (valid) { auto it = std::prev(db->kv.end()); k = it->second.end; v = it->second.val; } }
     void seekForPrev(const JArr<jbyte> &key)                      // last entry whose key <= target
     {
-        auto ub = db->kv.upper_bound(jkey(key));
-        valid = ub != db->kv.begin();
-        if (valid) it = std::prev(ub);
+        uint64_t t = RocksDB::ukey(key);
+        auto it = db->kv.upper_bound(t);
+        valid = it != db->kv.begin();
+        if (valid) { --it; k = it->second.end < t ? it->second.end : t; v = it->second.val; }
     }
     jboolean isValid() { return valid; }
-    JArr<jbyte> key() { return jval(it->first); }
-    JArr<jbyte> value() { return jval(it->second); }
+    JArr<jbyte> key() { return RocksDB::kbytes(k); }
+    JArr<jbyte> value() { return jval(v); }
 };
 inline Ref<RocksIterator> RocksDB::newIterator() { return jnew<RocksIterator>(this); }
 struct RocksSerializer : virtual Object {                          // value = 8-byte term prefix + payload (none here)

@@ -42,6 +42,8 @@ struct RefEnv {
     std::vector<Ref<PendingCall>> outbox;
     bool install_result = true;
     uint32_t status = RG_OK;
+    bool timer_armed = false;                         // rg_timers_* contract: no ticket until rg_timers_arm / the first reset
+    std::deque<std::function<void()>> held;           // loop tasks queued by a fired timer, waiting for their RG_EV_TIMEOUT row
 };
 
 struct ref_table {
@@ -58,6 +60,7 @@ static const char *&last_error_fmt() { static const char *f = nullptr; return f;
 jboolean RaftRoutineObserved::resetTimer(Ref<RaftContext> context, Ref<RaftParticipant> participant, jboolean muted)
 {
     env->reset_timer = true;
+    env->timer_armed = true;
     return RaftRoutine::resetTimer(context, participant, muted);
 }
 void RaftRoutine::commitState(Ref<RaftContext>, const std::function<Ref<Promise>(Ref<Entry>)> &, jint) {}
@@ -186,16 +189,52 @@ static void remember_participant(RefEnv &e)
         e.parts.swap(keep);
     }
 }
+// AsyncFuture arms a timer of broadcastTimeout per request (transport/rpc/Async.java:41-47,225-229) and RaftConfig insists on
+// broadcast < heartbeat < election (support/RaftConfig.java:116-118): by the time a LATER election has been won, every
+// RequestVote of an earlier winner has long completed with a TimeoutException.  The replay format carries no time, so the
+// driver applies that fact when the later win happens (the C-ABI keeps one un-aborted winner head per group for the same reason).
+static void expire_older_winners(RefEnv &e)
+{
+    int newest = -1;
+    for (size_t i = 0; i < e.parts.size(); i++) {
+        Candidate *c = dynamic_cast<Candidate *>(e.parts[i].p.get());
+        if (c && c->elected) newest = (int)i;
+    }
+    for (int i = 0; i < newest; i++) {
+        Candidate *c = dynamic_cast<Candidate *>(e.parts[(size_t)i].p.get());
+        if (!c || !c->elected || e.parts[(size_t)i].head->aborted) continue;
+        std::vector<Ref<PendingCall>> live;
+        live.swap(e.parts[(size_t)i].head->calls);
+        for (auto &pc : live) if (!pc->done) { pc->done = true; pc->cb(nullptr, jnew<Exception>("TimeoutException"), false); }
+    }
+}
 static Ref<ID> id_of(RefEnv &e, uint32_t slot)
 {
     if ((jint)slot == e.cluster->self->slot) return e.cluster->self;
     for (auto &r : e.cluster->remotes->v) if (r->slot == (jint)slot) return r;
     return jnew<ID>((jint)slot);
 }
+static uint64_t timer_mix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
 static void new_context(ref_table *t, RefEnv &e)
 {
     e.t = t;
     e.cfg = jnew<RaftConfig>(); e.cfg->pre_vote = t->pre_vote != 0;
+    e.cfg->election_ms = t->election_ms; e.cfg->heartbeat_ms = t->heartbeat_ms;
+    RefEnv *ep = &e;
+    // RaftConfig.electionTimeout() is ThreadLocalRandom in [E, 2E] (support/RaftConfig.java:187-190); the draw used here is
+    // the counter-based one of the C-ABI (include/raftgpu.h, rg_timers_update) so that deadlines can be compared
+    e.cfg->election_draw = [ep]() -> jlong {
+        ref_table *tt = ep->t;
+        uint64_t h = timer_mix(tt->timer_seed ^ timer_mix((uint64_t)ep->gid * 0xD1342543DE82EF95ull ^ ((uint64_t)ep->epoch_counter << 32) ^ (uint64_t)jrt::now_ms()));
+        return tt->election_ms + (jlong)(h % (uint64_t)(tt->election_ms + 1));
+    };
+    e.timer_armed = false; e.held.clear();
     e.cluster = jnew<RaftCluster>(&e, (jint)t->cluster, (jint)t->self);
     e.db = jnew<RocksDB>();
     e.log = jnew<RocksLog>(e.db, jnew<RocksSerializer>());
@@ -298,7 +337,12 @@ static void play(ref_table *t, RefEnv &e, const rg_batch_t *in, size_t row, rg_r
         case RG_EV_TIMEOUT: {
             if (aux != 0) {                                   // the ticket that fired belonged to the participant of that epoch
                 PartRec *rec = find_rec(e, aux);
-                if (!rec || rec->p != before) { e.status = RG_DROPPED_STALE_ROLE; break; }   // context/RaftRoutine.java:70
+                if (!rec || rec->p != before) { e.status = RG_DROPPED_STALE_ROLE; e.held.clear(); break; }   // context/RaftRoutine.java:70
+            }
+            if (!e.held.empty()) {                            // rg_timers_expired already fired the ticket: run what it queued
+                e.loop->q.swap(e.held);
+                e.held.clear();
+                break;
             }
             Ref<TimerTicket> ticket = e.ctx->ticketHolder->get();
             e.loop->in_loop = false;                          // timer pool thread
@@ -335,6 +379,7 @@ static void play(ref_table *t, RefEnv &e, const rg_batch_t *in, size_t row, rg_r
         else { if (getenv("REF_TRACE")) fprintf(stderr, "ref: swallowed: %s\n", last_error_fmt()); e.status = REF_SWALLOWED_EXCEPTION; }
     }
     remember_participant(e);
+    expire_older_winners(e);
 
     Ref<RaftParticipant> after = e.ctx->participant();
     uint32_t flags = 0;
@@ -385,6 +430,7 @@ ref_table *ref_table_create(uint32_t groups, uint32_t cluster, uint32_t self_slo
         new_context(t, e);
         g_env = &e;
         force_participant(e, Follower_class, 0, nullptr, 1);      // RaftContext.initialize: switchTo(Follower, restore.term, restore.ballot)
+        e.timer_armed = false;
         g_env = nullptr;
     }
     return t;
@@ -415,11 +461,9 @@ int ref_load_state(ref_table *t, uint32_t first, uint32_t count, const rg_group_
             if (rc) {
                 if (s->run_start[ro] != s->first_index[i] || s->last_index[i] < s->run_start[ro + rc - 1]) return -2;
                 if (s->first_index[i] != s->epoch_index[i] && s->first_index[i] != s->epoch_index[i] + 1) return -3;
-                if (s->last_index[i] - s->first_index[i] > (1 << 22)) return -4;      // the fake stores every key
-                for (uint32_t k = 0; k < rc; k++) {
+                for (uint32_t k = 0; k < rc; k++) {                 // straight into the fake's run representation
                     jlong end = k + 1 < rc ? s->run_start[ro + k + 1] - 1 : s->last_index[i];
-                    for (jlong idx = s->run_start[ro + k]; idx <= end; idx++)
-                        e.db->put(RocksLog::longToBytes(idx), RocksLog::longToBytes(s->run_term[ro + k]));
+                    e.db->kv[(uint64_t)s->run_start[ro + k]] = RocksDB::Run{(uint64_t)end, jkey(RocksLog::longToBytes(s->run_term[ro + k]))};
                 }
             }
             e.log->epochEntry = jnew<EntryKey>((jlong)s->epoch_index[i], (jlong)s->epoch_term[i]);
@@ -461,6 +505,7 @@ int ref_load_state(ref_table *t, uint32_t first, uint32_t count, const rg_group_
                 }
             }
             e.loop->q.clear();
+            e.timer_armed = false;
         } catch (const Throwable &th) {
             if (getenv("REF_TRACE")) fprintf(stderr, "ref_load_state: %s at %s: %s\n", th.kind(), th.where, th.msg.c_str());
             g_env = nullptr;
@@ -493,7 +538,7 @@ int ref_read_state(ref_table *t, uint32_t first, uint32_t count, rg_group_state_
         d->elected_epoch[i] = 0; d->elected_term[i] = 0;
         for (auto &r : e.parts) {                                  // newest winner whose head is still live
             Candidate *c = dynamic_cast<Candidate *>(r.p.get());
-            if (c && c->elected && !r.head->aborted && r.p != p) { d->elected_epoch[i] = r.epoch; d->elected_term[i] = c->currentTerm(); }
+            if (c && c->elected && !r.head->aborted && !r.head->calls.empty() && r.p != p) { d->elected_epoch[i] = r.epoch; d->elected_term[i] = c->currentTerm(); }
         }
         d->commit_index[i] = e.log->commitIndex;
         d->epoch_index[i] = e.log->epoch()->index();
@@ -502,9 +547,9 @@ int ref_read_state(ref_table *t, uint32_t first, uint32_t count, rg_group_state_
         std::vector<std::pair<jlong, jlong>> runs;
         jlong firstk = 0, lastk = 0; bool any = false;
         for (auto &kv : e.db->kv) {
-            jlong idx = RocksDB::key_to_long(kv.first), term = RocksDB::key_to_long(kv.second);
+            jlong idx = (jlong)kv.first, term = RocksDB::key_to_long(kv.second.val);
             if (!any) { firstk = idx; any = true; }
-            lastk = idx;
+            lastk = (jlong)kv.second.end;
             if (runs.empty() || runs.back().second != term) runs.emplace_back(idx, term);
         }
         uint32_t rc = (uint32_t)std::min<size_t>(runs.size(), RG_TERM_RUNS);
@@ -547,6 +592,167 @@ int ref_submit(ref_table *t, const rg_batch_t *in, const rg_outcome_t *out)
 
 int ref_clock(ref_table *t, const int64_t *now_per_round) { if (!t) return -1; t->clock = now_per_round; return 0; }
 
+
+// ---- N1: Leader.replicateLog (member/Leader.java:142-245) — what the reference itself sends ----------------------------
+int ref_replicate(ref_table *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,
+                  rg_send_head_t *head, rg_send_t *send)
+{
+    if (!t || !head || !send) return -1;
+    if (gid ? count > t->groups : count != t->groups) return -1;
+    const uint32_t F = t->cluster - 1;
+    for (uint32_t i = 0; i < count; i++) {
+        if (gid && (gid[i] >= t->groups || (i && gid[i] <= gid[i - 1]))) return -1;
+        RefEnv &e = *t->g[gid ? gid[i] : i];
+        begin_event(e);
+        Ref<RaftParticipant> p = e.ctx->participant();
+        Leader *l = dynamic_cast<Leader *>(p.get());
+        rg_send_head_t *h = &head[i];
+        h->term = p->currentTerm(); h->leader_commit = e.log->commitIndex;
+        h->epoch_index = e.log->epoch()->index(); h->epoch_term = e.log->epoch()->term();
+        h->role_epoch = e.epoch_counter; h->is_leader = l != nullptr;
+        for (uint32_t j = 0; j < F; j++) send[(size_t)j * count + i] = rg_send_t{0, 0, 0, 0, RG_SEND_NONE};
+        if (!l) { g_env = nullptr; continue; }
+        const bool hb = heartbeat && heartbeat[i];
+        int rc = 0;
+        try {
+            l->prepareReplication();                                       // so that the host-owned in-flight counts have a home
+            for (uint32_t j = 0; j < F; j++)
+                l->followerStatus->get(id_of(e, j < t->self ? j : j + 1))->requestInFlight = in_flight ? in_flight[(size_t)j * count + i] : 0;
+            l->replicateLog(hb);
+        } catch (const Throwable &th) { rc = (int)status_of(th); }
+        if (rc) { g_env = nullptr; return -100 - rc; }
+        for (uint32_t j = 0; j < F; j++) {                                 // no send recorded = the in-flight gate (:162-166)
+            rg_send_t o = {h->epoch_index, h->epoch_term, h->epoch_index, 0, RG_SEND_GATED};
+            const int slot = (int)(j < t->self ? j : j + 1);
+            for (auto &pc : e.outbox) {
+                if (pc->peer != slot) continue;
+                if (pc->kind == REF_RPC_IS) { o.kind = RG_SEND_SNAPSHOT; }
+                else { o.prev_index = pc->a; o.prev_term = pc->b; o.last_index = pc->last_index; o.count = (uint32_t)pc->count; o.kind = RG_SEND_APPEND; }
+            }
+            send[(size_t)j * count + i] = o;
+        }
+        l->replication->calls.clear();                                     // nobody answers these through the closures
+        g_env = nullptr;
+    }
+    return 0;
+}
+
+// ---- N4b: Leadership.State statistics, State.isReady, Leader.isReady (member/Leadership.java:40-73, member/Leader.java:52-64) ---
+int ref_health_failure(ref_table *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now)
+{
+    if (!t || (n && (!gid || !slot || !flags))) return -1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (gid[i] >= t->groups || slot[i] >= t->cluster || slot[i] == t->self) continue;
+        RefEnv &e = *t->g[gid[i]];
+        Leader *l = dynamic_cast<Leader *>(e.ctx->participant().get());
+        if (!l || l->followerStatus == nullptr) continue;
+        l->followerStatus->get(id_of(e, slot[i]))->statFailure(now, (flags[i] & 1u) != 0, (flags[i] & 2u) != 0);
+    }
+    return 0;
+}
+
+int ref_ready(ref_table *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready)
+{
+    if (!t || !ready) return -1;
+    jrt::now_ms() = now;
+    for (uint32_t i = 0; i < t->groups; i++) {
+        RefEnv &e = *t->g[i];
+        e.cfg->critical_point = critical_point; e.cfg->cool_down = cool_down_ms;
+        Leader *l = dynamic_cast<Leader *>(e.ctx->participant().get());
+        ready[i] = l ? (l->isReady() ? 1 : 0) : 0;                         // command/RaftStub.java:80-87: only a Leader is asked
+    }
+    return 0;
+}
+
+int ref_health_read(ref_table *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure, int32_t *recent_failure)
+{
+    if (!t || (uint64_t)first + count > t->groups) return -1;
+    const uint32_t F = t->cluster - 1;
+    for (uint32_t i = 0; i < count; i++) {
+        RefEnv &e = *t->g[first + i];
+        Leader *l = dynamic_cast<Leader *>(e.ctx->participant().get());
+        for (uint32_t j = 0; j < F; j++) {
+            size_t o = (size_t)i * F + j;
+            request_success[o] = request_failure[o] = 0; recent_failure[o] = 0;
+            if (l && l->followerStatus != nullptr) {
+                Ref<State> st = l->followerStatus->get(id_of(e, j < t->self ? j : j + 1));
+                request_success[o] = st->requestSuccess; request_failure[o] = st->requestFailure; recent_failure[o] = st->recentFailure;
+            }
+        }
+    }
+    return 0;
+}
+
+// ---- N4 timers: the reference's own RaftRoutine.resetTimer / electionTimeout / keepAlive on a virtual clock -------------
+int ref_timers_configure(ref_table *t, int64_t election_ms, int64_t heartbeat_ms, uint64_t seed)
+{
+    if (!t || election_ms <= 0 || heartbeat_ms <= 0) return -1;
+    t->election_ms = election_ms; t->heartbeat_ms = heartbeat_ms; t->timer_seed = seed;
+    for (auto &e : t->g) { e->cfg->election_ms = election_ms; e->cfg->heartbeat_ms = heartbeat_ms; }
+    return 0;
+}
+static Ref<TimerTicket> ticket_of(RefEnv &e) { return e.ctx->ticketHolder->get(); }
+int ref_timers_arm(ref_table *t, int64_t now)
+{
+    if (!t) return -1;
+    jrt::now_ms() = now;
+    for (auto &ep : t->g) {
+        RefEnv &e = *ep;
+        if (e.timer_armed) continue;
+        g_env = &e;
+        Ref<TimerTicket> old = ticket_of(e);
+        Ref<RaftParticipant> p = e.ctx->participant();
+        if (old != nullptr && old->schedule() != nullptr) old->schedule()->cancel(true);
+        e.ctx->ticketHolder->set(nullptr);                        // as convertTo leaves it before the first resetTimer (:198)
+        e.loop->in_loop = true;
+        e.routine->resetTimer(e.ctx, p, false);
+        g_env = nullptr;
+    }
+    return 0;
+}
+int ref_timers_read(ref_table *t, uint32_t first, uint32_t count, int64_t *deadline)
+{
+    if (!t || !deadline || (uint64_t)first + count > t->groups) return -1;
+    for (uint32_t i = 0; i < count; i++) {
+        RefEnv &e = *t->g[first + i];
+        Ref<TimerTicket> tk = ticket_of(e);
+        if (!e.timer_armed || tk == nullptr) { deadline[i] = 0; continue; }
+        jlong d = tk->get();
+        if (d < 0 || tk->schedule()->ran) deadline[i] = -1;       // TimerTicket.TIMEOUT / a heartbeat that fired
+        else deadline[i] = d == Long::MAX_VALUE ? tk->schedule()->due : d;
+    }
+    return 0;
+}
+/* the timer pools: every scheduled task that is due runs (electionTimeout / keepAlive, off-loop); the loop task it queues
+ * is HELD until the host delivers the group's RG_EV_TIMEOUT row */
+int ref_timers_expired(ref_table *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count)
+{
+    if (!t || !out_count) return -1;
+    jrt::now_ms() = now;
+    uint32_t n = 0;
+    for (auto &ep : t->g) {
+        RefEnv &e = *ep;
+        Ref<TimerTicket> tk = ticket_of(e);
+        if (!e.timer_armed || tk == nullptr || tk->schedule() == nullptr) continue;
+        Ref<ScheduledFuture> f = tk->schedule();
+        if (f->cancelled || f->ran || f->due > now) continue;
+        if (n < capacity) {
+            g_env = &e;
+            out_gid[n] = e.gid;
+            f->ran = true;
+            e.loop->in_loop = false;
+            f->task();
+            e.loop->in_loop = true;
+            e.held.swap(e.loop->q);
+            e.loop->q.clear();
+            g_env = nullptr;
+        }
+        n++;
+    }
+    *out_count = n;
+    return 0;
+}
+
 // ---- function-level entry points for differential fuzzing --------------------------------------------------------------
 /* Membership.isBetter: 1 better, 0 not, <0 = -(RG_A_* status) */
 int ref_is_better(int nr, int64_t nt, int32_t nb, int cr, int64_t ct, int32_t cb)
@@ -588,6 +794,22 @@ int64_t ref_rejection_step(int32_t r)
     jlong nx = s->nextIndex;                                        // min(next-1, max(next-step, 1)) = next - step for step >= 1
     jlong step = ((jlong)1 << 40) - nx;
     return step;
+}
+
+void ref_update_index_batch(uint32_t n, int64_t *st, int32_t *rejection, uint8_t *pending, const int64_t *epoch, const int64_t *index,
+                            const uint8_t *success, const uint8_t *snapshot, int32_t *rc)
+{
+    for (uint32_t i = 0; i < n; i++)
+        rc[i] = ref_update_index(st + 3 * (size_t)i, &rejection[i], &pending[i], epoch[i], index[i], success[i], snapshot[i]);
+}
+void ref_is_better_batch(uint32_t n, const int32_t *nr, const int64_t *nt, const int32_t *nb, const int32_t *cr, const int64_t *ct,
+                         const int32_t *cb, int32_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) out[i] = ref_is_better(nr[i], nt[i], nb[i], cr[i], ct[i], cb[i]);
+}
+void ref_major_indices_batch(uint32_t n, int f, const int64_t *match, int64_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) ref_major_indices(match + (size_t)i * f, f, out + 2 * (size_t)i);
 }
 
 }  // extern "C"

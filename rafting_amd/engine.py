@@ -318,6 +318,12 @@ class Table:
         self.health_update(batch, out.reply, now)
         return out
 
+    def submit_and_update_timers(self, batch, now, fill=0):
+        """one drain + the timer pass over its reply rows: rg_submit, then rg_timers_update with the round clocks `now`."""
+        out = self.submit(batch, fill=fill)
+        self.timers_update(batch.rounds, batch.count, out.reply, now, gid=batch.gid)
+        return out
+
     def health_failure(self, gid, slot, flags, now):
         """State.statFailure(now, unreachable=flags&1, reject=flags&2) per (group, peer slot) row."""
         gid = np.ascontiguousarray(gid, dtype=np.uint32)

@@ -157,6 +157,20 @@ def _same(a, b, what, where):
             where, what, len(bad), len(a), i, a[i] if i >= 0 else None, b[i] if i >= 0 else None))
 
 
+def canonical_state(st):
+    """Zero the fields of a GroupState image that name an object which does not exist in the reference at that moment:
+    the vote counter outside a running (pre-)election (`AtomicInteger votes` is a local of startElection / prepareElection),
+    the winner's term without a live winner head, and the Leadership.State columns of a group that has not run
+    prepareReplication.  The C-ABI keeps stale values there; the reference has nothing to compare them with."""
+    live = (st.role == C) | ((st.role == F) & (st.timeout_detected != 0))
+    st.votes[~live] = 1
+    st.elected_term[st.elected_epoch == 0] = 0
+    dead = np.repeat(st.repl_prepared == 0, st.followers)
+    for nm in ("peer_last_epoch", "peer_next_index", "peer_match_index", "peer_rejection", "peer_pending"):
+        getattr(st, nm)[dead] = 0
+    return st
+
+
 def compare_states(ref, got, where=""):
     """Bit-exact comparison of two GroupState images. Peer columns only matter once
     repl_prepared; the device run cache must be a suffix of the oracle's run list."""

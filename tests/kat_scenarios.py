@@ -558,9 +558,7 @@ def timers_follow_reset_timer(mk):
     def step(now, **ev):
         b = abi.Batch(1, 1)
         b.put(0, 0, **ev)
-        out = t.submit(b)
-        t.timers_update(1, 1, out.reply, [now])
-        return out
+        return t.submit_and_update_timers(b, [now])
 
     step(1500, kind=abi.EV_AE_REQ, slot=1, a=5, b=10, c=5, d=0)   # heartbeat: Follower.java:43,84 re-arm the timer
     d1 = int(t.timers_read()[0])
@@ -581,14 +579,12 @@ def timers_follow_reset_timer(mk):
     t.timers_configure(E, H, 11)
     b = abi.Batch(1, 1)
     b.put(0, 0, abi.EV_RV_REPLY, slot=1, flag=1, a=6, aux=3)    # majority of 3 -> Leader
-    out = t.submit(b)
-    t.timers_update(1, 1, out.reply, [7000])
+    t.submit_and_update_timers(b, [7000])
     assert int(t.timers_read()[0]) == 7000                      # first keepAlive at once (:117-118 exist == null ? 0)
     assert t.timers_expired(7000)[0].tolist() == [0]
     b = abi.Batch(1, 1)
     b.put(0, 0, abi.EV_TIMEOUT)                                 # the heartbeat tick itself
-    out = t.submit(b)
-    t.timers_update(1, 1, out.reply, [7001])
+    t.submit_and_update_timers(b, [7001])
     assert int(t.timers_read()[0]) == 7001 + H
 
 

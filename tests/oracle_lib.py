@@ -53,6 +53,11 @@ def lib():
         L.orc_log_term.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_log_conflict.restype = C.c_int64
         L.orc_log_conflict.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32, C.c_void_p]
+        L.orc_update_index.restype = C.c_int
+        L.orc_update_index.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_int64, C.c_int64, C.c_int, C.c_int]
+        L.orc_update_index_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 8
+        L.orc_is_better_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 7
+        L.orc_major_indices_batch.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_is_better.restype = C.c_int
         L.orc_is_better.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int32]
         _LIB = L
@@ -111,6 +116,12 @@ class OracleTable:
 
     def submit_timed(self, batch, now, fill=0):
         return self.submit(batch, fill=fill, now=now)
+
+    def submit_and_update_timers(self, batch, now, fill=0):
+        """one drain + the timer pass over its reply rows (rg_submit, then rg_timers_update)"""
+        out = self.submit(batch, fill=fill)
+        self.timers_update(batch.rounds, batch.count, out.reply, now, gid=getattr(batch, "gid", None))
+        return out
 
     def health_failure(self, gid, slot, flags, now):
         gid = np.ascontiguousarray(gid, dtype=np.uint32)
@@ -197,3 +208,10 @@ def is_better(new, cur):
     """new/cur = (role, term, ballot). Returns True/False or the negative RG_A_* code."""
     r = lib().orc_is_better(new[0], new[1], new[2], cur[0], cur[1], cur[2])
     return r if r < 0 else bool(r)
+
+
+def update_index(last_epoch, next_index, match_index, rejection, pending, epoch, index, success, snapshot):
+    st = np.array([last_epoch, next_index, match_index], dtype=np.int64)
+    rej, pen = C.c_int32(rejection), C.c_uint8(pending)
+    rc = lib().orc_update_index(st.ctypes.data, C.byref(rej), C.byref(pen), epoch, index, int(success), int(snapshot))
+    return rc, (int(st[0]), int(st[1]), int(st[2]), int(rej.value), int(pen.value))

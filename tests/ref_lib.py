@@ -38,6 +38,17 @@ def lib():
         L.ref_read_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
         L.ref_submit.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
         L.ref_clock.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_replicate.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
+        L.ref_health_failure.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.ref_ready.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
+        L.ref_health_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_timers_configure.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]
+        L.ref_timers_arm.argtypes = [C.c_void_p, C.c_int64]
+        L.ref_timers_expired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.ref_timers_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.ref_update_index_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 8
+        L.ref_is_better_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 7
+        L.ref_major_indices_batch.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_is_better.restype = C.c_int
         L.ref_is_better.argtypes = [C.c_int, C.c_int64, C.c_int32, C.c_int, C.c_int64, C.c_int32]
         L.ref_major_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -100,6 +111,56 @@ class RefTable:
 
     def submit_timed(self, batch, now, fill=0):
         return self.submit(batch, fill=fill, now=now)
+
+    def submit_and_update_timers(self, batch, now, fill=0):
+        """the reference re-arms its timers INSIDE the handlers, at the wall clock of the round"""
+        return self.submit(batch, fill=fill, now=now)
+
+    def timers_configure(self, election_ms, heartbeat_ms, seed=0):
+        assert lib().ref_timers_configure(self._h, election_ms, heartbeat_ms, seed) == 0
+
+    def timers_arm(self, now):
+        assert lib().ref_timers_arm(self._h, now) == 0
+
+    def timers_expired(self, now, capacity=None):
+        capacity = self.groups if capacity is None else capacity
+        out = np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        assert lib().ref_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n)) == 0
+        return out[: min(n.value, capacity)], n.value
+
+    def timers_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        out = np.zeros(count, dtype=np.int64)
+        assert lib().ref_timers_read(self._h, first, count, out.ctypes.data) == 0
+        return out
+
+    def replicate(self, gid=None, heartbeat=None, in_flight=None):
+        from rafting_amd.engine import _replicate
+
+        def call(*a):
+            rc = lib().ref_replicate(self._h, *a)
+            if rc:
+                raise ValueError("ref_replicate failed: %d" % rc)
+        return _replicate(call, self.groups, self.cluster, gid, heartbeat, in_flight)
+
+    def health_failure(self, gid, slot, flags, now):
+        gid = np.ascontiguousarray(gid, dtype=np.uint32)
+        slot = np.ascontiguousarray(slot, dtype=np.uint8)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert lib().ref_health_failure(self._h, len(gid), gid.ctypes.data, slot.ctypes.data, flags.ctypes.data, now) == 0
+
+    def ready(self, now, critical_point, cool_down_ms):
+        out = np.zeros(self.groups, dtype=np.uint8)
+        assert lib().ref_ready(self._h, now, critical_point, cool_down_ms, out.ctypes.data) == 0
+        return out
+
+    def health_read(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        F = self.cluster - 1
+        ok, fl, rc = np.zeros((count, F), np.int64), np.zeros((count, F), np.int64), np.zeros((count, F), np.int32)
+        assert lib().ref_health_read(self._h, first, count, ok.ctypes.data, fl.ctypes.data, rc.ctypes.data) == 0
+        return ok, fl, rc
 
 
 def rejection_step(r):

@@ -1,5 +1,6 @@
-"""Committed fixtures (tests/golden/replay_digests.json, made by tools/make_golden.py): the oracle must still produce
-them (CPU), and the HIP path must produce them WITHOUT the oracle in the loop (GPU)."""
+"""Committed fixtures (tests/golden/replay_digests.json, made by tools/make_golden.py FROM THE REFERENCE'S OWN CODE,
+oracle/_ref): the oracle must produce them (CPU), the translated reference must still produce them wherever it can be
+built (CPU), and the HIP path must produce them with neither in the loop (GPU)."""
 import json
 import os
 
@@ -16,6 +17,16 @@ def test_oracle_reproduces_committed_digests(name):
     from tests import oracle_lib
     c = GOLDEN[name]
     got = make_golden.replay(lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
+
+
+@pytest.mark.parametrize("name", sorted(n for n in GOLDEN if GOLDEN[n]["groups"] * GOLDEN[n]["rounds"] <= 1 << 18))
+def test_reference_code_reproduces_committed_digests(name):
+    from tests import ref_lib
+    if not ref_lib.available():
+        pytest.skip("oracle/_ref/libref.so needs the reference checkout to be built")
+    c = GOLDEN[name]
+    got = make_golden.replay(lambda g, p, s, v: ref_lib.RefTable(g, p, s, v), c["number"], c["groups"], c["rounds"])
     assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
 
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Regenerate tests/golden/replay_digests.json: SHA-256 digests of the canonical outcomes and final state of small
-replays, computed with the CPU oracle. The reference (Java) cannot run here and ships no vectors for this path, so
-these fixtures do not pin the oracle to the REFERENCE — they pin it to ITSELF across rounds (any change of restated
-semantics must be deliberate and show up as a fixture diff), and they let the GPU path be checked against committed
-vectors without the oracle in the loop.  usage: python tools/make_golden.py"""
+"""Regenerate tests/golden/replay_digests.json: SHA-256 digests of the canonical outcomes and final state of BASELINE
+replays, computed BY THE REFERENCE'S OWN CODE — oracle/_ref/libref.so, the Java decision classes translated mechanically
+by tools/make_ref.py (needs /root/reference).  The reference ships no vectors for this path and cannot travel to the GPU
+box; these digests are how its answers travel: the oracle must reproduce them (CPU suite) and the HIP path must reproduce
+them with neither oracle nor reference in the loop (GPU suite), including the metric's own configuration at full size
+(config 3, 65 536 groups).  usage: python tools/make_golden.py"""
 import hashlib
 import json
 import os
@@ -15,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from rafting_amd import abi, workload  # noqa: E402
 
-CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048, 32)]
+CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048, 32),
+         ("config3_full_size", 3, 65536, 16), ("config5_full_shard", 5, 131072, 8)]
 
 
 def canonical_outcome_digest(out):
@@ -35,6 +37,8 @@ def canonical_outcome_digest(out):
 
 
 def state_digest(st):
+    from tests.helpers import canonical_state
+    st = canonical_state(st)           # fields naming objects the reference does not have at that moment are zeroed
     h = hashlib.sha256()
     for n in ("current_term", "voted_for", "role", "current_leader", "timeout_detected", "repl_prepared", "role_epoch", "votes",
               "elected_epoch", "elected_term", "commit_index", "epoch_index", "epoch_term", "first_index", "last_index",
@@ -55,9 +59,10 @@ def replay(make_table, number, groups, rounds):
 
 
 def main():
-    from tests import oracle_lib
-    mk = lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v)   # noqa: E731
-    doc = {"generator": "tools/make_golden.py (CPU oracle)", "cases": {}}
+    from tests import ref_lib
+    mk = lambda g, p, s, v: ref_lib.RefTable(g, p, s, v)   # noqa: E731
+    doc = {"generator": "tools/make_golden.py over oracle/_ref/libref.so (the reference's Java decision classes, "
+                        "mechanically translated by tools/make_ref.py)", "cases": {}}
     for name, number, groups, rounds in CASES:
         doc["cases"][name] = dict(number=number, groups=groups, rounds=rounds, **replay(mk, number, groups, rounds))
     path = os.path.join(ROOT, "tests", "golden", "replay_digests.json")
