@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      1
+#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_pipelined */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -79,10 +79,19 @@ enum {
     RG_EV_PV_REQ        = 5,  /* RaftParticipant.preVote            same fields */
     RG_EV_RV_REPLY      = 6,  /* Candidate.startElection callback    a=result.term slot=responder flag=result.success aux=roleEpoch */
     RG_EV_PV_REPLY      = 7,  /* Follower.prepareElection callback   same fields */
-    RG_EV_TIMEOUT       = 8,  /* RaftParticipant.onTimeout (election timer for F/C, heartbeat tick for L) */
+    RG_EV_TIMEOUT       = 8,  /* RaftParticipant.onTimeout (election timer for F/C, heartbeat tick for L).
+                                 aux = role epoch of the participant whose ticket fired (rg_timers_expired_epochs reports it), or 0 =
+                                 "whoever is current". The reference runs onTimeout only if ticket.participant() == context.participant()
+                                 (context/RaftRoutine.java:70): a row whose aux names a replaced participant is RG_DROPPED_STALE_ROLE */
     RG_EV_CLIENT_APPEND = 9,  /* Leader.acceptCommand x n            n=#commands appended at currentTerm */
-    RG_EV_LOG_FLUSH     = 10  /* RaftLog.flush(index, term)          a=index b=term (log compaction / snapshot install moved the epoch) */
+    RG_EV_LOG_FLUSH     = 10, /* RaftLog.flush(index, term)          a=index b=term (log compaction / snapshot install moved the epoch) */
+    RG_EV_IS_REQ        = 11  /* RaftParticipant.installSnapshot    a=term b=lastIncludedIndex c=lastIncludedTerm slot=leaderId
+                                 flag = what RaftContext.installSnapshot returns (context/RaftContext.java:270-278: the host downloads and
+                                 applies the snapshot; the decision row only carries its verdict). The term checks, the assertion, the
+                                 Follower refresh after a timeout and the timer handling are member/Follower.java:129-152 and
+                                 member/RaftMember.java:61-66. After a successful install the host submits the RG_EV_LOG_FLUSH row. */
 };
+#define RG_EV_IS_REQ_DEFINED 1
 
 #define RG_HDR_KIND(h)        ((uint32_t)(h) & 0xFu)
 #define RG_HDR_SLOT(h)        (((uint32_t)(h) >> 4) & 0xFu)
@@ -92,7 +101,10 @@ enum {
 #define RG_HDR_MAKE(kind, slot, flag, n) \
     (((uint32_t)(kind) & 0xFu) | (((uint32_t)(slot) & 0xFu) << 4) | (((uint32_t)(flag) & 1u) << 8) | ((uint32_t)(n) << 12))
 #define RG_HDR_HINT_BIT       (1u << 9)
-#define RG_MAX_ENTRIES        ((1u << 20) - 1)
+#define RG_MAX_ENTRIES        ((1u << 20) - 1)   /* what the header field can carry */
+#define RG_MAX_AE_ENTRIES     200u               /* what a row may carry: 4 x REPLICATE_LIMIT (member/Leadership.java:10; the reference never
+                                                    ships more than REPLICATE_LIMIT per request, member/Leader.java:194). Larger -> RG_BAD_EVENT:
+                                                    one lane walks the entries of its row, an oversized row would stall its whole wavefront */
 
 /* ---- wire structs: structure-of-small-structs so every lane issues 16-byte accesses -------- */
 typedef struct { uint32_t hdr; uint32_t aux; } rg_ev_head_t;       /*  8 B */
@@ -138,6 +150,10 @@ typedef struct {
 #define RG_EMIT_HEARTBEAT 3u          /* Leader.onTimeout -> replicateLog(true)      member/Leader.java:120-126  */
 #define RG_F_ROLE_SHIFT   10          /* role after the row                                                 */
 #define RG_F_ROLE_MASK    (3u << 10)
+#define RG_F_TIMER_MUTED  (1u << 12)  /* the handler left the election timer MUTED: it called resetTimer(this, true) (deadline = Long.MAX_VALUE,
+                                         context/RaftRoutine.java:101-107) and returned or threw before the un-muting call — Follower.java:43 then
+                                         the throw at :48-50, Follower.java:118 then the throw in logUpToDate, Follower.java:134 then :136-139.
+                                         The timer does not fire until a later handler re-arms it. Only set together with RG_F_RESET_TIMER */
 #define RG_F_STATUS_SHIFT 16
 #define RG_F_STATUS(f)    (((f) >> RG_F_STATUS_SHIFT) & 0xFFu)
 #define RG_F_EMIT(f)      (((f) & RG_F_EMIT_MASK) >> RG_F_EMIT_SHIFT)
@@ -166,6 +182,10 @@ enum {
     RG_DROPPED_STALE_ROLE       = 17,  /* response to a fenced participant (transport/rpc/Async.java:157-171) */
     RG_NOT_LEADER               = 18,  /* command/RaftStub.java:79-91: command submitted to a non-leader */
     RG_FLUSH_OUT_OF_BOUNDS      = 19,  /* storage/RocksLog.java:230-233 (IndexOutOfBoundsException) */
+    RG_A_INSTALL_BEFORE_AE      = 20,  /* member/RaftMember.java:61-66, member/Follower.java:138-139: installSnapshot with term >= currentTerm at a
+                                          Leader/Candidate, or term > currentTerm at a Follower */
+    RG_A_NO_DOWNGRADE           = 21,  /* context/RaftRoutine.java:170-172 (unreachable when every switch goes through trySwitch first, as it does
+                                          under one-row-per-group serialisation; kept so every assertion site of the path has a code) */
     RG_NEED_HOST                = 32,  /* term-run cache miss: row NOT applied; host looks up the term of
                                           logfx.log_from in its RaftLog and resubmits the row with a hint */
     RG_SKIPPED_AFTER_NEED_HOST  = 33,  /* later round of a group that hit NEED_HOST in this launch: NOT applied */
@@ -320,6 +340,11 @@ int rg_timers_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint3
 /* out_gid: caller buffer for up to `capacity` group ids (host or device per memspace); *out_count receives the number of
  * expired groups (may exceed capacity: then only the first `capacity` were written AND marked fired). Synchronous. */
 int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count, int memspace);
+/* the same, also reporting for every expired group the role epoch of the participant whose ticket fired: the host puts it into
+ * the aux field of the RG_EV_TIMEOUT row, so a timeout that is overtaken by a row which replaces the participant is dropped like
+ * the reference drops it (context/RaftRoutine.java:70). out_epoch: [capacity], same memspace as out_gid. */
+int rg_timers_expired_epochs(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count,
+                             int memspace);
 /* arm every group that has no ticket yet (after rg_load_state): role from the table, as rg_timers_update would */
 int rg_timers_arm(rg_table_t *t, int64_t now);
 int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);

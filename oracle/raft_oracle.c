@@ -428,7 +428,8 @@ static void on_append_entries(const orc_table_t *t, group_t *g, fx_t *fx, int64_
     if (term > g->current_term || g->timeout_detected) {          /* :45-47, re-dispatched on the fresh Follower */
         if (switch_to(t, g, fx, RG_FOLLOWER, term, g->voted_for) < 0) return;
     } else if (g->current_leader != RG_NO_NODE && leader != g->current_leader) {
-        fx->status = RG_A_TWO_LEADERS; return;                    /* :48-50 */
+        fx->status = RG_A_TWO_LEADERS;                            /* :48-50: thrown after the mute at :43, outside the try whose */
+        fx->flags |= RG_F_TIMER_MUTED; return;                    /* finally un-mutes (:55-85): the timer stays at Long.MAX_VALUE */
     }
     g->current_leader = leader;                                   /* :54 */
     int c = log_contains(g, fx, prev_index, prev_term);           /* :57 */
@@ -496,9 +497,9 @@ static void on_vote_request(const orc_table_t *t, group_t *g, fx_t *fx, int pre,
     /* Follower.requestVote member/Follower.java:108-127 */
     if (term < g->current_term) { reply(fx, g->current_term, 0); return; }
     if (term == g->current_term) { reply(fx, g->current_term, cand == g->voted_for); return; }
-    fx->flags |= RG_F_RESET_TIMER;
-    int ok = log_up_to_date(g, fx, last_index, last_term);
-    if (ok < 0) return;
+    fx->flags |= RG_F_RESET_TIMER;                                /* :118 resetTimer(this, true) — nothing un-mutes on this path: */
+    int ok = log_up_to_date(g, fx, last_index, last_term);        /* the fresh Follower of :125 gets a new ticket, but a throw */
+    if (ok < 0) { fx->flags |= RG_F_TIMER_MUTED; return; }        /* in logUpToDate leaves this one muted */
     if (switch_to(t, g, fx, RG_FOLLOWER, term, ok ? cand : RG_NO_NODE) < 0) return;
     reply(fx, g->current_term, cand == g->voted_for);             /* re-dispatched: term == currentTerm now */
 }
@@ -566,9 +567,29 @@ static void on_vote_reply(const orc_table_t *t, group_t *g, fx_t *fx, int pre, u
     fx->status = RG_DROPPED_STALE_ROLE;
 }
 
-/* RaftParticipant.onTimeout: member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126 */
-static void on_timeout(const orc_table_t *t, group_t *g, fx_t *fx)
+/* RaftParticipant.installSnapshot: member/Follower.java:129-152; Candidate and Leader inherit member/RaftMember.java:61-66.
+ * `host_ok` is what RaftContext.installSnapshot returned (download + apply are host work, context/RaftContext.java:270-278). */
+static void on_install_snapshot(const orc_table_t *t, group_t *g, fx_t *fx, int64_t term, int host_ok)
 {
+    if (g->role != RG_FOLLOWER) {                                 /* RaftMember.installSnapshot */
+        if (term >= g->current_term) { fx->status = RG_A_INSTALL_BEFORE_AE; return; }
+        reply(fx, g->current_term, 0);
+        return;
+    }
+    fx->flags |= RG_F_RESET_TIMER;                                /* :134 resetTimer(this, true) BEFORE the term checks */
+    if (term < g->current_term) { fx->flags |= RG_F_TIMER_MUTED; reply(fx, g->current_term, 0); return; }   /* :136-137, never un-muted */
+    if (term > g->current_term) { fx->flags |= RG_F_TIMER_MUTED; fx->status = RG_A_INSTALL_BEFORE_AE; return; }   /* :138-139 */
+    if (g->timeout_detected) {                                    /* :140-142 refresh, then the fresh Follower runs the same method */
+        if (switch_to(t, g, fx, RG_FOLLOWER, g->current_term, g->voted_for) < 0) return;
+    }
+    reply(fx, g->current_term, host_ok);                          /* :147-152 (the finally un-mutes) */
+}
+
+/* RaftParticipant.onTimeout: member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126.
+ * Only run for the participant whose ticket fired (context/RaftRoutine.java:57,70): `ticket_epoch` 0 = whoever is current. */
+static void on_timeout(const orc_table_t *t, group_t *g, fx_t *fx, uint32_t ticket_epoch)
+{
+    if (ticket_epoch != 0 && ticket_epoch != g->role_epoch) { fx->status = RG_DROPPED_STALE_ROLE; return; }
     if (g->role == RG_FOLLOWER) {
         if (t->pre_vote) {
             if (switch_to(t, g, fx, RG_FOLLOWER, g->current_term, g->voted_for) < 0) return;
@@ -618,7 +639,7 @@ static void step(const orc_table_t *t, group_t *g, const rg_batch_t *in, size_t 
     case RG_EV_NONE:
         break;
     case RG_EV_AE_REQ:
-        if (slot >= t->cluster || (n > 0 && (in->entry_terms == NULL || (uint64_t)aux + n > in->entry_count))) {
+        if (slot >= t->cluster || n > RG_MAX_AE_ENTRIES || (n > 0 && (in->entry_terms == NULL || (uint64_t)aux + n > in->entry_count))) {
             fx.status = RG_BAD_EVENT; break;
         }
         on_append_entries(t, g, &fx, a, (int32_t)slot, b, c, n, n ? in->entry_terms + aux : NULL, d);
@@ -639,7 +660,11 @@ static void step(const orc_table_t *t, group_t *g, const rg_batch_t *in, size_t 
         on_vote_reply(t, g, &fx, kind == RG_EV_PV_REPLY, slot, a, (int)flag, aux);
         break;
     case RG_EV_TIMEOUT:
-        on_timeout(t, g, &fx);
+        on_timeout(t, g, &fx, aux);
+        break;
+    case RG_EV_IS_REQ:
+        if (slot >= t->cluster) { fx.status = RG_BAD_EVENT; break; }
+        on_install_snapshot(t, g, &fx, a, (int)flag);
         break;
     case RG_EV_CLIENT_APPEND:
         on_client_append(t, g, &fx, n);
@@ -885,11 +910,12 @@ static int64_t election_timeout(uint64_t seed, uint32_t gid, uint32_t role_epoch
 /* the deadline resetTimer leaves behind: a handler mutes (deadline MAX) and un-mutes, so the un-muted reset sees
  * moment == MAX and lands on now + timeout (:105-107); a Leader is re-scheduled heartbeatInterval ahead, at once
  * when the ticket is new (:117-118); a ticket that already fired (moment < 0) is not replaced (:96-98) */
-static int64_t rearm(const orc_table_t *t, int64_t d, uint32_t gid, int role, int fresh, uint32_t role_epoch, int64_t now)
+static int64_t rearm(const orc_table_t *t, int64_t d, uint32_t gid, int role, int fresh, int muted, uint32_t role_epoch, int64_t now)
 {
     if (fresh) d = 0;                                            /* convertTo: ticketHolder.set(null) :198 */
     if (role == RG_LEADER) return d == 0 ? now : wadd(now, t->heartbeat_ms);
     if (d < 0) return d;
+    if (muted) return INT64_MAX;                                 /* resetTimer(.., true) with no un-muting call after it :101-107 */
     return wadd(now, election_timeout(t->timer_seed, gid, role_epoch, now, t->election_ms));
 }
 
@@ -911,7 +937,8 @@ int orc_timers_update(orc_table_t *t, uint32_t rounds, uint32_t count, const uin
         for (uint32_t r = 0; r < rounds; r++) {
             const rg_reply_t *rep = &reply[(size_t)r * count + i];
             if (rep->flags & RG_F_RESET_TIMER)
-                d = rearm(t, d, g, (int)RG_F_ROLE(rep->flags), (rep->flags & RG_F_ROLE_CHANGED) != 0, rep->role_epoch, now[r]);
+                d = rearm(t, d, g, (int)RG_F_ROLE(rep->flags), (rep->flags & RG_F_ROLE_CHANGED) != 0,
+                          (rep->flags & RG_F_TIMER_MUTED) != 0, rep->role_epoch, now[r]);
         }
         t->deadline[g] = d;
     }
@@ -922,23 +949,28 @@ int orc_timers_arm(orc_table_t *t, int64_t now)
 {
     if (!t) return -1;
     for (uint32_t g = 0; g < t->groups; g++)
-        if (t->deadline[g] == 0) t->deadline[g] = rearm(t, 0, g, t->g[g].role, 1, t->g[g].role_epoch, now);
+        if (t->deadline[g] == 0) t->deadline[g] = rearm(t, 0, g, t->g[g].role, 1, 0, t->g[g].role_epoch, now);
     return 0;
 }
 
 /* electionTimeout / keepAlive firing: deadline reached -> CAS to TimerTicket.TIMEOUT, onTimeout gets queued (:53-77) */
-int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count)
+int orc_timers_expired_epochs(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count)
 {
     if (!t || !out_count) return -1;
     uint32_t n = 0;
     for (uint32_t g = 0; g < t->groups; g++) {
         if (t->deadline[g] > 0 && t->deadline[g] <= now) {
-            if (n < capacity) { out_gid[n] = g; t->deadline[g] = -1; }
+            if (n < capacity) { out_gid[n] = g; if (out_epoch) out_epoch[n] = t->g[g].role_epoch; t->deadline[g] = -1; }
             n++;
         }
     }
     *out_count = n;
     return 0;
+}
+
+int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count)
+{
+    return orc_timers_expired_epochs(t, now, out_gid, NULL, capacity, out_count);
 }
 
 int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline)

@@ -55,6 +55,7 @@ int orc_timers_configure(orc_table_t *t, int64_t election_ms, int64_t heartbeat_
 int orc_timers_update(orc_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_reply_t *reply, const int64_t *now);
 int orc_timers_arm(orc_table_t *t, int64_t now);
 int orc_timers_expired(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count);
+int orc_timers_expired_epochs(orc_table_t *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count);
 int orc_timers_read(orc_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
 
 /* N4b health: statSuccess happens inside orc_submit at the place the reference calls it (Leader.java:229), with the clock

@@ -135,10 +135,8 @@ static uint32_t status_of(const Throwable &e)
         {"Membership.java:89", RG_A_LEADER_UNCHANGED}, {"Membership.java:104", RG_A_CAND_BALLOT},
         {"Leadership.java:77", RG_A_MATCH_ROLLBACK}, {"Leader.java:252", RG_A_IMPOSSIBLE_REPLICATION},
         {"RocksLog.java:231", RG_FLUSH_OUT_OF_BOUNDS},
-#ifdef RG_A_INSTALL_BEFORE_AE
         {"RaftMember.java:63", RG_A_INSTALL_BEFORE_AE}, {"Follower.java:139", RG_A_INSTALL_BEFORE_AE},
         {"RaftRoutine.java:171", RG_A_NO_DOWNGRADE},
-#endif
     };
     for (auto &m : map) if (!strcmp(m.where, e.where)) return m.st;
     if (getenv("REF_TRACE")) fprintf(stderr, "ref: unmapped %s at %s: %s\n", e.kind(), e.where, e.msg.c_str());
@@ -283,7 +281,7 @@ static void play(ref_table *t, RefEnv &e, const rg_batch_t *in, size_t row, rg_r
         switch (kind) {
         case RG_EV_NONE: break;
         case RG_EV_AE_REQ: {
-            if (slot >= t->cluster || (n > 0 && (in->entry_terms == NULL || (uint64_t)aux + n > in->entry_count))) { e.status = RG_BAD_EVENT; break; }
+            if (slot >= t->cluster || n > RG_MAX_AE_ENTRIES || (n > 0 && (in->entry_terms == NULL || (uint64_t)aux + n > in->entry_count))) { e.status = RG_BAD_EVENT; break; }
             JArr<Ref<Entry>> entries = JArr<Ref<Entry>>::make(n);
             for (uint32_t k = 0; k < n; k++) {
                 jlong term = in->entry_terms[aux + k];
@@ -386,7 +384,11 @@ static void play(ref_table *t, RefEnv &e, const rg_batch_t *in, size_t row, rg_r
     if (resp != nullptr) flags |= RG_F_REPLIED | (resp->success() ? RG_F_SUCCESS : 0);
     if (e.persists) flags |= RG_F_PERSIST;
     if (after != before) flags |= RG_F_ROLE_CHANGED;
-    if (e.reset_timer) flags |= RG_F_RESET_TIMER;
+    if (e.reset_timer) {
+        flags |= RG_F_RESET_TIMER;
+        Ref<TimerTicket> tk = e.ctx->ticketHolder->get();            // still muted after the handler: deadline Long.MAX_VALUE (:101-107)
+        if (role_of(after) != RG_LEADER && tk != nullptr && tk->get() == Long::MAX_VALUE) flags |= RG_F_TIMER_MUTED;
+    }
     if (e.log->commitIndex != commit_before) flags |= RG_F_COMMIT;
     jlong log_from = 0;
     if (kind == RG_EV_AE_REQ) {
@@ -719,13 +721,18 @@ int ref_timers_read(ref_table *t, uint32_t first, uint32_t count, int64_t *deadl
         if (!e.timer_armed || tk == nullptr) { deadline[i] = 0; continue; }
         jlong d = tk->get();
         if (d < 0 || tk->schedule()->ran) deadline[i] = -1;       // TimerTicket.TIMEOUT / a heartbeat that fired
-        else deadline[i] = d == Long::MAX_VALUE ? tk->schedule()->due : d;
+        else deadline[i] = (d == Long::MAX_VALUE && role_of(e.ctx->participant()) == RG_LEADER) ? tk->schedule()->due : d;
     }
     return 0;
 }
 /* the timer pools: every scheduled task that is due runs (electionTimeout / keepAlive, off-loop); the loop task it queues
  * is HELD until the host delivers the group's RG_EV_TIMEOUT row */
+int ref_timers_expired_epochs(ref_table *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count);
 int ref_timers_expired(ref_table *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count)
+{
+    return ref_timers_expired_epochs(t, now, out_gid, nullptr, capacity, out_count);
+}
+int ref_timers_expired_epochs(ref_table *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count)
 {
     if (!t || !out_count) return -1;
     jrt::now_ms() = now;
@@ -739,6 +746,7 @@ int ref_timers_expired(ref_table *t, int64_t now, uint32_t *out_gid, uint32_t ca
         if (n < capacity) {
             g_env = &e;
             out_gid[n] = e.gid;
+            if (out_epoch) out_epoch[n] = e.epoch_counter;
             f->ran = true;
             e.loop->in_loop = false;
             f->task();

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MIN_CLUSTER, MAX_CLUSTER = 2, 7
 TERM_RUNS = 4
 NO_NODE = -1
@@ -16,7 +16,8 @@ NO_NODE = -1
 FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
 
 EV_NONE, EV_AE_REQ, EV_AE_ACK, EV_IS_ACK, EV_RV_REQ, EV_PV_REQ = 0, 1, 2, 3, 4, 5
-EV_RV_REPLY, EV_PV_REPLY, EV_TIMEOUT, EV_CLIENT_APPEND, EV_LOG_FLUSH = 6, 7, 8, 9, 10
+EV_RV_REPLY, EV_PV_REPLY, EV_TIMEOUT, EV_CLIENT_APPEND, EV_LOG_FLUSH, EV_IS_REQ = 6, 7, 8, 9, 10, 11
+MAX_AE_ENTRIES = 200
 HDR_HINT_BIT = 1 << 9
 
 F_SUCCESS, F_REPLIED, F_PERSIST, F_ROLE_CHANGED = 1 << 0, 1 << 1, 1 << 2, 1 << 3
@@ -24,6 +25,7 @@ F_RESET_TIMER, F_COMMIT, F_LOG_TRUNC, F_LOG_APPEND = 1 << 4, 1 << 5, 1 << 6, 1 <
 F_EMIT_SHIFT, F_EMIT_MASK = 8, 3 << 8
 EMIT_NONE, EMIT_PREVOTE, EMIT_REQVOTE, EMIT_HEARTBEAT = 0, 1, 2, 3
 F_ROLE_SHIFT, F_ROLE_MASK = 10, 3 << 10
+F_TIMER_MUTED = 1 << 12
 F_STATUS_SHIFT = 16
 
 OK = 0
@@ -32,6 +34,7 @@ A_COMMIT_ROLLBACK, A_LOG_NOT_CONTINUOUS, A_LEADER_SELF_AE, A_SAME_TERM_LEADER = 
 A_LEADER_NOT_SELF_VOTE, A_CAND_SELF_RV, A_CAND_NOT_SELF_VOTE, A_LEADER_UNCHANGED = 9, 10, 11, 12
 A_CAND_BALLOT, A_MATCH_ROLLBACK, A_IMPOSSIBLE_REPLICATION, NPE_MAJOR_NULL = 13, 14, 15, 16
 DROPPED_STALE_ROLE, NOT_LEADER, FLUSH_OUT_OF_BOUNDS = 17, 18, 19
+A_INSTALL_BEFORE_AE, A_NO_DOWNGRADE = 20, 21
 NEED_HOST, SKIPPED_AFTER_NEED_HOST, BAD_EVENT, UNSUPPORTED_LOG_STATE = 32, 33, 34, 35
 
 MEM_HOST, MEM_DEVICE = 0, 1

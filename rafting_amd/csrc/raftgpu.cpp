@@ -25,8 +25,8 @@ hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32
 hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s);
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
-hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
-                                 uint32_t *out_gid, uint32_t capacity, hipStream_t s);
+hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+                                 uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
 }  // namespace rg
 
 using rg::DevTable;
@@ -592,21 +592,23 @@ int rg_timers_arm(rg_table_t *t, int64_t now)
     return 0;
 }
 
-int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count, int memspace)
+int rg_timers_expired_epochs(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count, int memspace)
 {
     if (!t) return -1;
     if (!out_count || (capacity && !out_gid)) return fail(t, -1, "rg_timers_expired: out_gid/out_count are required");
     if (bind(t)) return -2;
     hipStream_t s = t->stream;
-    uint32_t *d_out = out_gid;
+    uint32_t *d_out = out_gid, *d_ep = out_epoch;
+    const size_t cap = capacity ? capacity : 1;
     if (memspace == RG_MEM_HOST) {
-        if (reserve(t, t->st_tgid, (size_t)(capacity ? capacity : 1) * sizeof(uint32_t))) return -2;
+        if (reserve(t, t->st_tgid, 2 * cap * sizeof(uint32_t))) return -2;      // gids, then epochs
         d_out = (uint32_t *)t->st_tgid.ptr;
+        d_ep = out_epoch ? d_out + cap : nullptr;
     } else if (memspace != RG_MEM_DEVICE) {
         return fail(t, -1, "rg_timers_expired: unknown memspace %d", memspace);
     }
     const uint32_t waves = (t->G + 63) / 64;
-    HIP_TRY(t, rg::launch_timers_expired(t->timer_deadline, t->G, now, t->timer_counts, t->timer_counts + waves, d_out, capacity, s));
+    HIP_TRY(t, rg::launch_timers_expired(t->timer_deadline, t->dt.ident, t->G, now, t->timer_counts, t->timer_counts + waves, d_out, d_ep, capacity, s));
     uint32_t total = 0;
     HIP_TRY(t, hipMemcpyAsync(&total, t->timer_counts + waves, sizeof total, hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
@@ -614,9 +616,15 @@ int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t ca
     const uint32_t n = total < capacity ? total : capacity;
     if (memspace == RG_MEM_HOST && n) {
         HIP_TRY(t, hipMemcpyAsync(out_gid, d_out, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (out_epoch) HIP_TRY(t, hipMemcpyAsync(out_epoch, d_ep, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(t, hipStreamSynchronize(s));
     }
     return 0;
+}
+
+int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t capacity, uint32_t *out_count, int memspace)
+{
+    return rg_timers_expired_epochs(t, now, out_gid, nullptr, capacity, out_count, memspace);
 }
 
 int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline)

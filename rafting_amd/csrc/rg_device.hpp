@@ -421,7 +421,8 @@ struct Stepper {
         if (term > g.term || g.td) {
             if (switch_to(RG_FOLLOWER, term, g.voted_for) < 0) return;
         } else if (g.leader != RG_NO_NODE && leader != g.leader) {
-            fx.status = RG_A_TWO_LEADERS; return;
+            fx.status = RG_A_TWO_LEADERS;                 // thrown after the mute (:43), outside the try whose finally un-mutes
+            fx.flags |= RG_F_TIMER_MUTED; return;
         }
         g.leader = leader;
 
@@ -542,9 +543,9 @@ struct Stepper {
         }
         if (term < g.term) { reply(g.term, false); return; }
         if (term == g.term) { reply(g.term, cand == g.voted_for); return; }
-        fx.flags |= RG_F_RESET_TIMER;
+        fx.flags |= RG_F_RESET_TIMER;                     // :118 resetTimer(this, true); only the fresh Follower of :125 gets a live ticket
         const int ok = log_up_to_date(last_index, last_term);
-        if (ok < 0) return;
+        if (ok < 0) { fx.flags |= RG_F_TIMER_MUTED; return; }
         if (switch_to(RG_FOLLOWER, term, ok ? cand : RG_NO_NODE) < 0) return;
         reply(g.term, cand == g.voted_for);
     }
@@ -661,8 +662,25 @@ struct Stepper {
         fx.status = RG_DROPPED_STALE_ROLE;
     }
 
-    __device__ __forceinline__ void on_timeout()
+    // RaftParticipant.installSnapshot: member/Follower.java:129-152, member/RaftMember.java:61-66 (Candidate, Leader)
+    __device__ __forceinline__ void on_install_snapshot(int64_t term, bool host_ok)
     {
+        if (g.role != RG_FOLLOWER) {
+            if (term >= g.term) { fx.status = RG_A_INSTALL_BEFORE_AE; return; }
+            reply(g.term, false);
+            return;
+        }
+        fx.flags |= RG_F_RESET_TIMER;                     // :134 mutes BEFORE the term checks; :136-139 never un-mute
+        if (term < g.term) { fx.flags |= RG_F_TIMER_MUTED; reply(g.term, false); return; }
+        if (term > g.term) { fx.flags |= RG_F_TIMER_MUTED; fx.status = RG_A_INSTALL_BEFORE_AE; return; }
+        if (g.td) { if (switch_to(RG_FOLLOWER, g.term, g.voted_for) < 0) return; }
+        reply(g.term, host_ok);
+    }
+
+    __device__ __forceinline__ void on_timeout(uint32_t ticket_epoch)
+    {
+        // context/RaftRoutine.java:57,70: only the participant whose ticket fired runs onTimeout (0 = whoever is current)
+        if (ticket_epoch != 0u && ticket_epoch != g.role_epoch) { fx.status = RG_DROPPED_STALE_ROLE; return; }
         if (g.role == RG_FOLLOWER) {
             if (p.pre_vote) {
                 if (switch_to(RG_FOLLOWER, g.term, g.voted_for) < 0) return;
@@ -735,10 +753,14 @@ struct Stepper {
         const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;
         const bool want_commit = contains & (d > g_epoch);
         const int64_t ae_x = min64(d, ae_last);
+#ifdef RG_EXP_NO_AE      // experiment build (tools/exp_class_split.sh): the instruction stream of a wavefront that never decides AppendEntries
+        const bool fa = false;
+#else
         const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a >= g_term) &
                         (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
                         (b > g_epoch) & (c != 0) & entries_ok & (!contains | (n == 0) | same) &
                         !(want_commit & (ae_x < g_commit));
+#endif
         const bool ae_refresh = fa & refresh;
         const bool ae_commit = fa & want_commit & (ae_x > g_commit);
         const bool ae_append = fa & contains & (n > 0);
@@ -746,7 +768,11 @@ struct Stepper {
 
         // ---- AppendEntries ack at a leader ----------------------------------------------------------
         const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
+#ifdef RG_EXP_NO_ACK     // experiment build: the instruction stream of a wavefront that never decides acks / client appends
+        const bool ack_shape = false;
+#else
         const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
+#endif
         const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
         const int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
         const int32_t s_rej = pe.rejection[j * BLOCK];
@@ -774,7 +800,11 @@ struct Stepper {
         const bool ack_drop = allow & ack_kind & peer_ok & (aux != g_repoch);       // AsyncHead aborted: response dropped
 
         // ---- client append at a leader ----------------------------------------------------------------
+#ifdef RG_EXP_NO_ACK
+        const bool fc = false;
+#else
         const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
+#endif
         const bool fc_newrun = fc & (lt != g_term);
         const bool fc_prepare = fc & !g_prep;
 
@@ -853,7 +883,7 @@ struct Stepper {
         case RG_EV_NONE:
             break;
         case RG_EV_AE_REQ:
-            if (slot >= P || (n > 0 && (p.entry_terms == nullptr || (uint64_t)aux + n > p.entry_count))) {
+            if (slot >= P || n > RG_MAX_AE_ENTRIES || (n > 0 && (p.entry_terms == nullptr || (uint64_t)aux + n > p.entry_count))) {
                 fx.status = RG_BAD_EVENT; break;
             }
             on_append_entries(a, (int32_t)slot, b, c, n, p.entry_terms + aux, Pre{pe0, pe1, pe2, pe3}, d, hinted, hx, hy);
@@ -874,7 +904,11 @@ struct Stepper {
             on_vote_reply(kind == RG_EV_PV_REPLY, slot, a, flag, aux);
             break;
         case RG_EV_TIMEOUT:
-            on_timeout();
+            on_timeout(aux);
+            break;
+        case RG_EV_IS_REQ:
+            if (slot >= P) { fx.status = RG_BAD_EVENT; break; }
+            on_install_snapshot(a, flag);
             break;
         case RG_EV_CLIENT_APPEND:
             on_client_append(n);

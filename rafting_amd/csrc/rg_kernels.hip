@@ -588,11 +588,12 @@ __host__ __device__ __forceinline__ int64_t election_timeout(uint64_t seed, uint
     return E + (int64_t)(h % (uint64_t)(E + 1));
 }
 // what RaftRoutine.resetTimer leaves behind for a participant of `role` (context/RaftRoutine.java:86-130)
-__device__ __forceinline__ int64_t rearm(const TimerParams &p, int64_t d, uint32_t g, int role, bool fresh, uint32_t role_epoch, int64_t now)
+__device__ __forceinline__ int64_t rearm(const TimerParams &p, int64_t d, uint32_t g, int role, bool fresh, bool muted, uint32_t role_epoch, int64_t now)
 {
     if (fresh) d = 0;                                            // convertTo: ticketHolder.set(null)
     if (role == RG_LEADER) return d == 0 ? now : wadd(now, p.heartbeat_ms);   // keepAlive: schedule(exist == null ? 0 : timeout)
     if (d < 0) return d;                                         // moment < 0: the fired ticket stays
+    if (muted) return INT64_MAX;                                 // resetTimer(.., true) and no un-muting call after it (:101-107)
     return wadd(now, election_timeout(p.seed, g, role_epoch, now, p.election_ms));
 }
 
@@ -605,7 +606,8 @@ __global__ __launch_bounds__(256) void timers_update_kernel(const TimerParams p)
     for (uint32_t r = 0; r < p.rounds; r++) {
         const rg_reply_t rep = p.reply[(size_t)r * p.count + i];
         if (rep.flags & RG_F_RESET_TIMER)
-            d = rearm(p, d, g, (int)RG_F_ROLE(rep.flags), (rep.flags & RG_F_ROLE_CHANGED) != 0, rep.role_epoch, p.now[r]);
+            d = rearm(p, d, g, (int)RG_F_ROLE(rep.flags), (rep.flags & RG_F_ROLE_CHANGED) != 0, (rep.flags & RG_F_TIMER_MUTED) != 0,
+                      rep.role_epoch, p.now[r]);
     }
     p.deadline[g] = d;
 }
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(256) void timers_arm_kernel(const TimerParams p)
     if (g >= p.groups) return;
     if (p.deadline[g] != 0) return;
     const Ident id = p.ident[g];
-    p.deadline[g] = rearm(p, 0, g, (int)(id.meta & META_ROLE), true, id.role_epoch, p.now[0]);
+    p.deadline[g] = rearm(p, 0, g, (int)(id.meta & META_ROLE), true, false, id.role_epoch, p.now[0]);
 }
 
 // Expired groups in ascending order, three passes so the list is deterministic:
@@ -652,8 +654,8 @@ __global__ __launch_bounds__(1024) void timers_scan_kernel(uint32_t *counts, uin
     if (tid == 1023) *total = part[1023];
 }
 
-__global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, uint32_t groups, int64_t now, const uint32_t *offsets,
-                                                          uint32_t *out_gid, uint32_t capacity)
+__global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const uint32_t *offsets,
+                                                          uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t d = g < groups ? deadline[g] : 0;
@@ -662,7 +664,11 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, uin
     if (!exp) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t pos = offsets[g >> 6] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (pos < capacity) { out_gid[pos] = g; deadline[g] = -1; }
+    if (pos < capacity) {
+        out_gid[pos] = g;
+        if (out_epoch) out_epoch[pos] = ident[g].role_epoch;      // the participant whose ticket fired (RG_EV_TIMEOUT.aux)
+        deadline[g] = -1;
+    }
 }
 
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s)
@@ -676,13 +682,13 @@ hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s)
     hipLaunchKernelGGL(timers_arm_kernel, dim3((p.groups + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
-hipError_t launch_timers_expired(int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
-                                 uint32_t *out_gid, uint32_t capacity, hipStream_t s)
+hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+                                 uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s)
 {
     const uint32_t blocks = (groups + 255) / 256, waves = (groups + 63) / 64;
     hipLaunchKernelGGL(timers_count_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, counts);
     hipLaunchKernelGGL(timers_scan_kernel, dim3(1), dim3(1024), 0, s, counts, waves, total);
-    hipLaunchKernelGGL(timers_emit_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, counts, out_gid, capacity);
+    hipLaunchKernelGGL(timers_emit_kernel, dim3(blocks), dim3(256), 0, s, deadline, ident, groups, now, counts, out_gid, out_epoch, capacity);
     return hipGetLastError();
 }
 

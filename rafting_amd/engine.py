@@ -20,13 +20,20 @@ class EngineError(RuntimeError):
     pass
 
 
+def library_sha16():
+    """first 16 hex digits of the SHA-256 of the loaded libraftgpu.so: ties a profile to the build it describes"""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
         "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
-        "rg_timers_expired", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
+        "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
         "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
     ]
@@ -88,6 +95,7 @@ def lib():
         L.rg_timers_configure.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64]
         L.rg_timers_update.argtypes = [vp, u32, u32, vp, vp, vp, i32]
         L.rg_timers_expired.argtypes = [vp, C.c_int64, vp, u32, C.POINTER(u32), i32]
+        L.rg_timers_expired_epochs.argtypes = [vp, C.c_int64, vp, vp, u32, C.POINTER(u32), i32]
         L.rg_timers_arm.argtypes = [vp, C.c_int64]
         L.rg_timers_read.argtypes = [vp, u32, u32, vp]
         L.rg_health_update.argtypes = [vp, u32, u32, vp, vp, vp, vp, i32]
@@ -296,6 +304,15 @@ class Table:
         n = C.c_uint32()
         self._check(lib().rg_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n), abi.MEM_HOST))
         return out[: min(n.value, capacity)], n.value
+
+    def timers_expired_epochs(self, now, capacity=None):
+        """-> (gids, role epochs of the participants whose tickets fired, total): the epochs go into RG_EV_TIMEOUT.aux"""
+        capacity = self.groups if capacity is None else capacity
+        out, ep = np.zeros(max(capacity, 1), dtype=np.uint32), np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        self._check(lib().rg_timers_expired_epochs(self._h, now, out.ctypes.data, ep.ctypes.data, capacity, C.byref(n), abi.MEM_HOST))
+        k = min(n.value, capacity)
+        return out[:k], ep[:k], n.value
 
     def timers_read(self, first=0, count=None):
         count = self.groups - first if count is None else count

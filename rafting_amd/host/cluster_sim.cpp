@@ -51,6 +51,7 @@ struct Group {
     RaftContext *ctx = nullptr;
     std::deque<Msg> inbox;
     bool timer_due = false;                       // the device reported this context's ticket as fired
+    uint32_t timer_epoch = 0;                     // ... for the participant of this role epoch (RG_EV_TIMEOUT.aux)
     std::vector<std::string> file;                // FileMachine: "<index>:<line>"
     int64_t applied = 0;
     int inflight[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // State.requestInFlight per peer
@@ -202,27 +203,25 @@ int main(int argc, char **argv)
           n.mgr->statFailure(timed_out, now_ms);
           // RaftStub.process: a Leader takes commands only while isReady (command/RaftStub.java:80-87), raft1.xml:30-31
           const std::vector<uint8_t> ready = n.mgr->isReady(now_ms, CRITICAL_POINT, COOL_DOWN_MS);
-          for (RaftContext *c : n.mgr->expiredTimers(now_ms)) n.g[c->gid()].timer_due = true;   // electionTimeout / keepAlive fired
+          for (auto &tk : n.mgr->expiredTickets(now_ms)) {                                       // electionTimeout / keepAlive fired
+              n.g[tk.first->gid()].timer_due = true;
+              n.g[tk.first->gid()].timer_epoch = tk.second;
+          }
           for (int sub = 0; sub < 8; sub++) {             // several EventLoop drains per tick: one row per context each
             struct Src { Group *g; Msg msg; int what; };   // what: 0 message, 1 timer, 2 client command
             std::vector<Src> src;
             for (Group &g : n.g) {
                 RaftContext &c = *g.ctx;
                 if (g.timer_due) {                                  // timers are urgent (EventLoop.execute(evt, true))
-                    c.onTimeout();
+                    c.onTimeout(g.timer_epoch);                     // dropped if a row replaced that participant meanwhile
                     g.timer_due = false;
                     src.push_back({&g, Msg{}, 1});
                 } else if (!g.inbox.empty()) {
                     Msg m = std::move(g.inbox.front()); g.inbox.pop_front();
-                    if (m.type == IS) {
-                        // Follower.installSnapshot (member/Follower.java:130-153) is host-side work (download + RaftLog.flush);
-                        // no compaction happens in this demo, so the snapshot at epoch (0,0) is empty: answer from the mirror
-                        Msg r; r.to = m.from; r.gid = m.gid; r.type = IS_RESP; r.term = c.currentTerm();
-                        r.success = m.term >= c.currentTerm(); r.epoch = m.epoch; r.epochAtSend = m.epochAtSend;
-                        send(n, std::move(r));
-                        continue;
-                    }
                     switch (m.type) {
+                    // Follower.installSnapshot (member/Follower.java:129-152): download + RaftLog.flush are host work; no compaction
+                    // happens in this demo, so the snapshot at epoch (0,0) is empty and "installs" at once — the decision is the row's
+                    case IS: c.installSnapshot(m.term, m.from, m.x, m.y, true); break;
                     case AE: c.appendEntries(m.term, m.from, m.x, m.y, m.entries, m.z); break;
                     case PV: c.preVote(m.term, m.from, m.x, m.y); break;
                     case RV: c.requestVote(m.term, m.from, m.x, m.y); break;
@@ -233,7 +232,6 @@ int main(int argc, char **argv)
                     case PV_RESP: c.onVoteResponse(true, m.from, {m.term, m.success}, m.epoch); break;
                     case RV_RESP: c.onVoteResponse(false, m.from, {m.term, m.success}, m.epoch); break;
                     case IS_RESP: c.onInstallSnapshotResponse(m.from, {m.term, m.success}, m.epochAtSend, m.epoch); break;
-                    case IS: break;
                     }
                     src.push_back({&g, std::move(m), 0});
                 } else if (c.role() == RG_LEADER && now_tick < quiet_at && !commanded[c.gid()] && (now_tick + c.gid()) % 4 == 0) {
@@ -257,6 +255,7 @@ int main(int argc, char **argv)
                     // late rejection are acknowledged after a longer one (Leadership.java:76-81 throws, the callback dies)
                     rollbacks++;
                 } else if (o.status != RG_OK && o.status != RG_DROPPED_STALE_ROLE && o.status != RG_NOT_LEADER) {
+                    if (o.status == RG_A_INSTALL_BEFORE_AE) { fail("a leader sent InstallSnapshot before AppendEntries", c.gid()); }
                     fprintf(stderr, "tick %lld node %d group %u: status %u\n", (long long)now_tick, n.id, c.gid(), o.status);
                     if (o.status < RG_NPE_MAJOR_NULL) fail("an AssertionError site of the reference was reached", c.gid());
                 }
@@ -264,7 +263,7 @@ int main(int argc, char **argv)
                     const Msg &q = src[i].msg;
                     Msg r; r.to = q.from; r.gid = q.gid; r.term = o.response->term; r.success = o.response->success;
                     r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent; r.sentTick = q.sentTick;
-                    r.type = q.type == AE ? AE_RESP : q.type == PV ? PV_RESP : RV_RESP;
+                    r.type = q.type == AE ? AE_RESP : q.type == PV ? PV_RESP : q.type == IS ? IS_RESP : RV_RESP;
                     send(n, std::move(r));
                 }
                 if (src[i].what == 2 && o.status == RG_OK) commands++;

@@ -134,7 +134,7 @@ Ticket RaftContext::appendEntries(int64_t term, ID leaderId, int64_t prevLogInde
     // (member/Leader.java:192-212); anything else is what RocksLog would reject as "not continuous"
     for (size_t k = 0; k < entries.size(); k++)
         if (entries[k].index != prevLogIndex + 1 + (int64_t)k) throw std::logic_error("log index is not continuous");
-    if (entries.size() > RG_MAX_ENTRIES) throw std::length_error("too many entries in one AppendEntries");
+    if (entries.size() > RG_MAX_AE_ENTRIES) throw std::length_error("too many entries in one AppendEntries");
     ContextManager::Row r{this, RG_HDR_MAKE(RG_EV_AE_REQ, leaderId, 0, entries.size()), 0, term, prevLogIndex, prevLogTerm,
                           leaderCommit, entries};
     return mgr_->enqueue(*this, std::move(r));
@@ -147,7 +147,14 @@ Ticket RaftContext::requestVote(int64_t term, ID cand, int64_t lastLogIndex, int
 {
     return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_RV_REQ, cand, 0, 0), 0, term, lastLogIndex, lastLogTerm, 0, {}});
 }
-Ticket RaftContext::onTimeout() { return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_TIMEOUT, 0, 0, 0), 0, 0, 0, 0, 0, {}}); }
+Ticket RaftContext::installSnapshot(int64_t term, ID leaderId, int64_t lastIncludedIndex, int64_t lastIncludedTerm, bool installed)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_IS_REQ, leaderId, installed, 0), 0, term, lastIncludedIndex, lastIncludedTerm, 0, {}});
+}
+Ticket RaftContext::onTimeout(uint32_t ticketEpoch)
+{
+    return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_TIMEOUT, 0, 0, 0), ticketEpoch, 0, 0, 0, 0, {}});
+}
 Ticket RaftContext::onAppendEntriesResponse(ID peer, RaftResponse res, int64_t epochAtSend, int64_t lastIndexSent, uint32_t sentEpoch)
 {
     return mgr_->enqueue(*this, {this, RG_HDR_MAKE(RG_EV_AE_ACK, peer, res.success, 0), sentEpoch, res.term, epochAtSend, lastIndexSent, 0, {}});
@@ -224,15 +231,22 @@ void ContextManager::armTimers(int64_t now)
     if (rg_timers_arm(table_, now) != 0) throw std::runtime_error(rg_last_error(table_));
 }
 
+std::vector<std::pair<RaftContext *, uint32_t>> ContextManager::expiredTickets(int64_t now)
+{
+    std::vector<uint32_t> gids(contexts_.size() ? contexts_.size() : 1), epochs(gids.size());
+    uint32_t n = 0;
+    if (rg_timers_expired_epochs(table_, now, gids.data(), epochs.data(), (uint32_t)contexts_.size(), &n, RG_MEM_HOST) != 0)
+        throw std::runtime_error(rg_last_error(table_));
+    std::vector<std::pair<RaftContext *, uint32_t>> out;
+    for (uint32_t i = 0; i < n && i < contexts_.size(); i++)
+        if (gids[i] < contexts_.size()) out.emplace_back(contexts_[gids[i]].get(), epochs[i]);
+    return out;
+}
+
 std::vector<RaftContext *> ContextManager::expiredTimers(int64_t now)
 {
-    std::vector<uint32_t> gids(contexts_.size() ? contexts_.size() : 1);
-    uint32_t n = 0;
-    if (rg_timers_expired(table_, now, gids.data(), (uint32_t)contexts_.size(), &n, RG_MEM_HOST) != 0)
-        throw std::runtime_error(rg_last_error(table_));
     std::vector<RaftContext *> out;
-    for (uint32_t i = 0; i < n && i < contexts_.size(); i++)
-        if (gids[i] < contexts_.size()) out.push_back(contexts_[gids[i]].get());
+    for (auto &pr : expiredTickets(now)) out.push_back(pr.first);
     return out;
 }
 

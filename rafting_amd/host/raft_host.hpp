@@ -127,7 +127,12 @@ class RaftContext {
                          const std::vector<Entry> &entries, int64_t leaderCommit);
     Ticket preVote(int64_t term, ID candidateId, int64_t lastLogIndex, int64_t lastLogTerm);
     Ticket requestVote(int64_t term, ID candidateId, int64_t lastLogIndex, int64_t lastLogTerm);
-    Ticket onTimeout();
+    // lastIncludedIndex/Term as in RaftParticipant.java:49; installed = the verdict of RaftContext.installSnapshot
+    // (context/RaftContext.java:270-278: download + apply are the host's job, the decision row carries only the result)
+    Ticket installSnapshot(int64_t term, ID leaderId, int64_t lastIncludedIndex, int64_t lastIncludedTerm, bool installed);
+    // ticketEpoch: role epoch of the participant whose timer fired (ContextManager::expiredTickets), 0 = whoever is current;
+    // a timeout overtaken by a row that replaced the participant is dropped (context/RaftRoutine.java:70)
+    Ticket onTimeout(uint32_t ticketEpoch = 0);
     // ---- response callbacks ------------------------------------------------------------------------
     Ticket onAppendEntriesResponse(ID peer, RaftResponse result, int64_t epochIndexAtSend, int64_t lastIndexSent,
                                    uint32_t roleEpochAtSend);
@@ -189,6 +194,8 @@ class ContextManager {
     void configureTimers(int64_t electionMs, int64_t heartbeatMs, uint64_t seed);
     void armTimers(int64_t now);
     std::vector<RaftContext *> expiredTimers(int64_t now);
+    // the same with the role epoch of the participant whose ticket fired: pass it to ctx.onTimeout(epoch)
+    std::vector<std::pair<RaftContext *, uint32_t>> expiredTickets(int64_t now);
 
     // N4b: Leadership.State health statistics live next to the timers. flush(now) folds statSuccess for every ack row
     // (member/Leader.java:182,229); statFailure is for RPCs the host saw fail — timeout, transport error, peer service not

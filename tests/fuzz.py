@@ -163,6 +163,17 @@ class Fuzzer:
         b.put(r, g, abi.EV_PV_REPLY if pre else abi.EV_RV_REPLY, slot=peer, flag=int(rng.random() < 0.7),
               a=max(resp, 0), aux=epoch)
 
+    def _is_req(self, b, r, g, v):
+        rng = self.rng
+        term = rng.choices([v.term - 1, v.term, v.term + 1], [15, 75, 10])[0]
+        b.put(r, g, abi.EV_IS_REQ, slot=rng.choice(self.others), flag=int(rng.random() < 0.8), a=max(term, 0),
+              b=v.eidx + rng.randint(0, 40), c=max(v.eterm, 1))
+
+    def _timeout(self, b, r, g, v):
+        """the ticket that fired: usually the live participant's (or 0 = host-owned timers), sometimes a replaced one's"""
+        x = self.rng.random()
+        b.put(r, g, abi.EV_TIMEOUT, aux=0 if x < 0.4 else (v.epoch if x < 0.9 else max(v.epoch - 1, 1)))
+
     def _flush(self, b, r, g, v):
         rng = self.rng
         if v.has_log and v.commit >= v.floor and v.commit <= v.last and rng.random() < 0.8:
@@ -190,6 +201,9 @@ class Fuzzer:
             if x < 0.07:
                 self._flush(b, r, g, v)
                 continue
+            if x < 0.085:
+                self._is_req(b, r, g, v)
+                continue
             if v.role == F:
                 if x < 0.62:
                     self._ae(b, r, g, v)
@@ -198,7 +212,7 @@ class Fuzzer:
                 elif x < 0.82:
                     self._vote_req(b, r, g, v, pre=True)
                 elif x < 0.90:
-                    b.put(r, g, abi.EV_TIMEOUT)
+                    self._timeout(b, r, g, v)
                 elif x < 0.97 and v.td:
                     self._vote_reply(b, r, g, v, pre=True)
                 elif x < 0.985:
@@ -215,13 +229,13 @@ class Fuzzer:
                 elif x < 0.85:
                     self._vote_req(b, r, g, v, pre=rng.random() < 0.4)
                 elif x < 0.95:
-                    b.put(r, g, abi.EV_TIMEOUT)
+                    self._timeout(b, r, g, v)
                 else:
                     self._vote_reply(b, r, g, v, pre=True)    # fenced pre-vote reply
             else:
                 if not v.prepared:
                     if x < 0.5:
-                        b.put(r, g, abi.EV_TIMEOUT)
+                        self._timeout(b, r, g, v)
                     elif x < 0.8:
                         b.put(r, g, abi.EV_CLIENT_APPEND, n=rng.randint(1, 3))
                     elif v.elected_epoch and x < 0.9:
@@ -233,7 +247,7 @@ class Fuzzer:
                 elif x < 0.75:
                     b.put(r, g, abi.EV_CLIENT_APPEND, n=rng.randint(1, 3))
                 elif x < 0.80:
-                    b.put(r, g, abi.EV_TIMEOUT)
+                    self._timeout(b, r, g, v)
                 elif x < 0.88:
                     self._ae(b, r, g, v)
                 elif x < 0.95:

@@ -90,7 +90,7 @@ class Sim:
             resp_term=int(out.reply["resp_term"][row]), role_epoch=int(out.reply["role_epoch"][row]),
             role=(f & abi.F_ROLE_MASK) >> abi.F_ROLE_SHIFT, emit=(f & abi.F_EMIT_MASK) >> abi.F_EMIT_SHIFT,
             persist=bool(f & abi.F_PERSIST), role_changed=bool(f & abi.F_ROLE_CHANGED),
-            reset_timer=bool(f & abi.F_RESET_TIMER), commit_adv=bool(f & abi.F_COMMIT),
+            reset_timer=bool(f & abi.F_RESET_TIMER), muted=bool(f & abi.F_TIMER_MUTED), commit_adv=bool(f & abi.F_COMMIT),
             truncated=bool(f & abi.F_LOG_TRUNC), appended=bool(f & abi.F_LOG_APPEND),
             commit=int(out.logfx["commit_index"][row]), log_from=int(out.logfx["log_from"][row]),
             p_term=int(out.persist["term"][row]), p_vote=int(out.persist["voted_for"][row]),
@@ -107,8 +107,11 @@ class Sim:
     def pre_vote(self, term, cand, last_index, last_term):
         return self.event(abi.EV_PV_REQ, slot=cand, a=term, b=last_index, c=last_term)
 
-    def on_timeout(self):
-        return self.event(abi.EV_TIMEOUT)
+    def on_timeout(self, ticket_epoch=0):
+        return self.event(abi.EV_TIMEOUT, aux=ticket_epoch)
+
+    def install_snapshot(self, term, leader, last_index, last_term, host_ok=True):
+        return self.event(abi.EV_IS_REQ, slot=leader, flag=int(host_ok), a=term, b=last_index, c=last_term)
 
     # response callbacks -------------------------------------------------------------------------
     def ae_ack(self, peer, resp_term, success, epoch_at_send, last_sent, sent_epoch, hint=None):

@@ -618,6 +618,99 @@ def none_rows_do_nothing(mk):
     assert (r.status, r.replied, r.role, r.role_epoch, r.flags & 0xFF) == (abi.OK, False, C, 9, 0)
 
 
+def install_snapshot_request(mk):
+    """RaftParticipant.installSnapshot: member/Follower.java:129-152; Candidate / Leader inherit member/RaftMember.java:61-66"""
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=1, role_epoch=3, log=simple_log(10, 5))
+    r = s.install_snapshot(4, 1, 50, 4)                        # :136-137 stale term -> failure(currentTerm); :134 muted the timer first
+    assert (r.status, r.replied, r.success, r.resp_term, r.reset_timer, r.muted, r.role_changed) == (abi.OK, True, False, 5, True, True, False)
+    r = s.install_snapshot(6, 1, 50, 4)                        # :138-139 a leader must appendEntries first
+    assert (r.status, r.replied, r.reset_timer, r.muted) == (abi.A_INSTALL_BEFORE_AE, False, True, True)
+    r = s.install_snapshot(5, 1, 50, 4, host_ok=True)          # :147-152 the verdict of ctx.installSnapshot, timer un-muted by the finally
+    assert (r.status, r.replied, r.success, r.resp_term, r.muted, r.persist) == (abi.OK, True, True, 5, False, False)
+    r = s.install_snapshot(5, 1, 50, 4, host_ok=False)
+    assert (r.replied, r.success, r.resp_term) == (True, False, 5)
+    assert s.state().epoch == (0, 0) and s.state().last == 10  # the epoch moves with the host's RG_EV_LOG_FLUSH, not here
+    s.on_timeout()                                             # pre-vote pending: timeoutDetected
+    assert s.state().timeout_detected == 1 and s.state().role_epoch == 4
+    r = s.install_snapshot(5, 1, 50, 4)                        # :140-142 refresh to a fresh Follower of the same term, then as above
+    assert (r.status, r.success, r.persist, r.role_changed, r.role_epoch, r.p_term, r.p_vote, r.muted) == (abi.OK, True, True, True, 5, 5, 1, False)
+    assert s.state().timeout_detected == 0 and s.state().leader == abi.NO_NODE
+    for role in (C, L):                                        # RaftMember.installSnapshot: term >= currentTerm asserts, lower fails
+        s = _sim(mk, role=role, term=5, voted_for=0, role_epoch=2)
+        r = s.install_snapshot(4, 1, 9, 3)
+        assert (r.status, r.replied, r.success, r.resp_term, r.reset_timer) == (abi.OK, True, False, 5, False)
+        for term in (5, 6):
+            r = s.install_snapshot(term, 1, 9, 3)
+            assert (r.status, r.replied, r.reset_timer) == (abi.A_INSTALL_BEFORE_AE, False, False)
+        assert s.state().role == role and s.state().role_epoch == 2
+
+
+def timeout_of_a_replaced_participant_is_dropped(mk):
+    """context/RaftRoutine.java:70: the queued timeout task runs onTimeout only if ticket.participant() == context.participant()"""
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=1, role_epoch=7, log=simple_log(10, 5))
+    r = s.append_entries(6, 2, 10, 5, [], 0)                   # a higher-term leader replaces the participant (epoch 8) ...
+    assert r.role_epoch == 8
+    r = s.on_timeout(ticket_epoch=7)                           # ... before the timeout of the old one is drained: ignored
+    assert (r.status, r.role_changed, r.persist, r.emit, r.role_epoch) == (abi.DROPPED_STALE_ROLE, False, False, 0, 8)
+    assert s.state().timeout_detected == 0 and s.state().term == 6
+    r = s.on_timeout(ticket_epoch=8)                           # the live participant's own ticket
+    assert (r.status, r.role_changed, r.emit, r.role_epoch) == (abi.OK, True, 1, 9)
+    r = s.on_timeout()                                         # aux 0: whoever is current (host-owned timers)
+    assert (r.status, r.role_changed, r.role_epoch) == (abi.OK, True, 10)
+    s = _sim(mk, role=L, term=5, voted_for=0, role_epoch=4, log=simple_log(3, 5))
+    assert s.on_timeout(ticket_epoch=3).status == abi.DROPPED_STALE_ROLE and s.state().repl_prepared == 0
+    r = s.on_timeout(ticket_epoch=4)                           # keepAlive of the live Leader (:57)
+    assert (r.status, r.emit, r.reset_timer) == (abi.OK, 3, True) and s.state().repl_prepared == 1
+
+
+def handlers_that_leave_the_timer_muted(mk):
+    """resetTimer(this, true) parks the deadline at Long.MAX_VALUE (context/RaftRoutine.java:101-107); three paths return or
+    throw before the un-muting call, and the election timer then never fires until a later handler re-arms it"""
+    E, H = 900, 300
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=1, log=simple_log(10, 5))
+    t = s.t
+    t.timers_configure(E, H, 3)
+    t.timers_arm(1000)
+
+    def step(now, **ev):
+        b = abi.Batch(1, 1)
+        b.put(0, 0, **ev)
+        return t.submit_and_update_timers(b, [now])
+
+    out = step(1100, kind=abi.EV_AE_REQ, slot=2, a=5, b=10, c=5, d=0)        # member/Follower.java:43 mutes, :48-50 throws
+    f = int(out.reply["flags"][0])
+    assert (f >> abi.F_STATUS_SHIFT) & 0xFF == abi.A_TWO_LEADERS and f & abi.F_TIMER_MUTED and f & abi.F_RESET_TIMER
+    assert int(t.timers_read()[0]) == 2 ** 63 - 1 and t.timers_expired(10 ** 12)[1] == 0
+    out = step(5000, kind=abi.EV_AE_REQ, slot=1, a=5, b=10, c=5, d=0)        # the next good heartbeat re-arms it (:84)
+    assert not int(out.reply["flags"][0]) & abi.F_TIMER_MUTED
+    assert 5000 + E <= int(t.timers_read()[0]) <= 5000 + 2 * E
+    out = step(5100, kind=abi.EV_AE_REQ, slot=1, a=5, b=0, c=3, d=0)         # logContains throws INSIDE the try: the finally un-mutes
+    f = int(out.reply["flags"][0])
+    assert (f >> abi.F_STATUS_SHIFT) & 0xFF == abi.A_PREV_ZERO_MISMATCH and not f & abi.F_TIMER_MUTED
+    assert 5100 + E <= int(t.timers_read()[0]) <= 5100 + 2 * E
+    out = step(5200, kind=abi.EV_IS_REQ, slot=1, flag=1, a=4, b=50, c=4)     # member/Follower.java:134 mutes, :136-137 returns
+    assert int(out.reply["flags"][0]) & abi.F_TIMER_MUTED and int(t.timers_read()[0]) == 2 ** 63 - 1
+    s = _sim(mk, role=F, term=5, voted_for=1, epoch=(20, 4))                 # empty log: logUpToDate can throw (:199-204)
+    t = s.t
+    t.timers_configure(E, H, 3)
+    t.timers_arm(1000)
+    out = step(1200, kind=abi.EV_RV_REQ, slot=2, a=6, b=20, c=3)             # :118 mutes, logUpToDate throws before :125
+    f = int(out.reply["flags"][0])
+    assert (f >> abi.F_STATUS_SHIFT) & 0xFF == abi.A_IMPOSSIBLE_LOG and f & abi.F_TIMER_MUTED
+    assert int(t.timers_read()[0]) == 2 ** 63 - 1
+    out = step(1300, kind=abi.EV_PV_REQ, slot=2, a=6, b=20, c=3)             # preVote needs timeoutDetected: not even muted (:94-96)
+    assert not int(out.reply["flags"][0]) & (abi.F_TIMER_MUTED | abi.F_RESET_TIMER)
+
+
+def oversized_append_entries_is_rejected(mk):
+    """a row may carry at most RG_MAX_AE_ENTRIES = 4 x REPLICATE_LIMIT entries (member/Leadership.java:10, member/Leader.java:194)"""
+    s = _sim(mk, role=F, term=5, voted_for=1, leader=1, log=simple_log(10, 5))
+    r = s.append_entries(5, 1, 10, 5, [5] * abi.MAX_AE_ENTRIES, 0)
+    assert (r.status, r.success) == (abi.OK, True) and s.state().last == 10 + abi.MAX_AE_ENTRIES
+    r = s.append_entries(5, 1, 210, 5, [5] * (abi.MAX_AE_ENTRIES + 1), 0)
+    assert (r.status, r.replied) == (abi.BAD_EVENT, False) and s.state().last == 210
+
+
 # --------------------------------------------------------------------------------------------------
 # N4b: follower health + Leader.isReady  member/Leadership.java:43-73, member/Leader.java:52-64
 

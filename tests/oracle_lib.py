@@ -44,6 +44,7 @@ def lib():
         L.orc_timers_update.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_timers_arm.argtypes = [C.c_void_p, C.c_int64]
         L.orc_timers_expired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_timers_expired_epochs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.orc_timers_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_health_clock.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_health_failure.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
@@ -160,6 +161,14 @@ class OracleTable:
         n = C.c_uint32()
         assert lib().orc_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n)) == 0
         return out[: min(n.value, capacity)], n.value
+
+    def timers_expired_epochs(self, now, capacity=None):
+        capacity = self.groups if capacity is None else capacity
+        out, ep = np.zeros(max(capacity, 1), dtype=np.uint32), np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        assert lib().orc_timers_expired_epochs(self._h, now, out.ctypes.data, ep.ctypes.data, capacity, C.byref(n)) == 0
+        k = min(n.value, capacity)
+        return out[:k], ep[:k], n.value
 
     def timers_read(self, first=0, count=None):
         count = self.groups - first if count is None else count

@@ -45,6 +45,7 @@ def lib():
         L.ref_timers_configure.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]
         L.ref_timers_arm.argtypes = [C.c_void_p, C.c_int64]
         L.ref_timers_expired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.ref_timers_expired_epochs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.ref_timers_read.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.ref_update_index_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 8
         L.ref_is_better_batch.argtypes = [C.c_uint32] + [C.c_void_p] * 7
@@ -128,6 +129,14 @@ class RefTable:
         n = C.c_uint32()
         assert lib().ref_timers_expired(self._h, now, out.ctypes.data, capacity, C.byref(n)) == 0
         return out[: min(n.value, capacity)], n.value
+
+    def timers_expired_epochs(self, now, capacity=None):
+        capacity = self.groups if capacity is None else capacity
+        out, ep = np.zeros(max(capacity, 1), dtype=np.uint32), np.zeros(max(capacity, 1), dtype=np.uint32)
+        n = C.c_uint32()
+        assert lib().ref_timers_expired_epochs(self._h, now, out.ctypes.data, ep.ctypes.data, capacity, C.byref(n)) == 0
+        k = min(n.value, capacity)
+        return out[:k], ep[:k], n.value
 
     def timers_read(self, first=0, count=None):
         count = self.groups - first if count is None else count

@@ -137,6 +137,26 @@ def test_bench_two_ranks_on_one_gpu():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["groups_total"] == 16384
+    assert d["config"]["config_number"] == 4 and d["config"]["seed"] == "0xc0ffee03"      # N > 1 measures BASELINE config 4
     assert d["value"] > 0 and d["cpu_baseline"] is None
     # both ranks' decisions are in the aggregate: about twice one rank's share
     assert 1.8 < d["value"] * d["ms_per_step"] * 1e-3 / d["config"]["decisions_per_step_per_gpu"] < 2.2
+
+
+def test_bench_n_gt_1_defaults_to_config4_shards():
+    """the command the driver runs for N > 1 (no workload flags): BASELINE config 4, 131 072-group shards of the 1 048 576-group
+    table, seed 0xC0FFEE03, scalars added up through gloo — here with two ranks sharing the one GPU of the test box"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--rounds", "4", "--device", "0"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert (c["config_number"], c["seed"], c["groups_per_gpu"], c["groups_total"]) == (4, "0xc0ffee03", 131072, 262144)
+    assert c["workload"].startswith("config4: 1048576 groups") and "no RCCL" in c["parallelism"]

@@ -1,6 +1,10 @@
-"""Summarise the rocprofv3 CSVs written by tools/prof.sh: per-kernel stats and per-dispatch counter means."""
+"""Summarise the rocprofv3 CSVs written by tools/prof.sh: per-kernel stats and per-dispatch counter means, and write
+traffic_entry.json — HBM bytes per launch of the step kernel (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, guide: MI355X_MICROARCH.md
+"HBM") tied to the workload of the profiled command and to the SHA of the library that ran; tools/collect_profile.py merges it
+into profiles/traffic.json, which bench.py quotes as roofline.traffic."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -8,6 +12,7 @@ from collections import defaultdict
 
 def main(out):
     lines = []
+    counters = {}
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True):
         lines.append("== kernel stats (%s)" % os.path.relpath(f, out))
         for row in csv.DictReader(open(f)):
@@ -28,6 +33,26 @@ def main(out):
                 lines.append("  %s" % name[:90])
                 for c, vals in sorted(ctrs.items()):
                     lines.append("    %-24s mean/dispatch=%.4g  dispatches=%d" % (c, sum(vals) / len(vals), len(vals)))
+                    counters[c] = sum(vals) / len(vals)
+    # the bench line of the traced pass names the workload; FETCH_SIZE / WRITE_SIZE are in KB
+    bench = None
+    try:
+        for ln in open(os.path.join(out, "trace.log")):
+            if ln.startswith("{"):
+                bench = json.loads(ln)
+    except OSError:
+        pass
+    if bench and "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from rafting_amd import engine
+        entry = {"config": bench["config"].get("config_number"), "groups_per_gpu": bench["config"]["groups_per_gpu"],
+                 "rounds": bench["config"]["rounds_per_step"], "kernel": bench["roofline"]["kernel"],
+                 "fetch_size_kb_per_launch": counters["FETCH_SIZE"], "write_size_kb_per_launch": counters["WRITE_SIZE"],
+                 "gfx950_fetch_correction": 2.0,
+                 "traffic_bytes_per_launch": (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0,
+                 "lib_sha16": engine.library_sha16(), "source": "profiles/%s" % os.path.basename(out.rstrip("/"))}
+        json.dump(entry, open(os.path.join(out, "traffic_entry.json"), "w"), indent=1)
+        lines.append("== traffic entry: %.1f MB per launch (fetch x2 + write), lib %s" % (entry["traffic_bytes_per_launch"] / 1e6, entry["lib_sha16"]))
     text = "\n".join(lines)
     open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
     print(text)
