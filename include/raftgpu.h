@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_pipelined */
+#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async, 48-byte rg_send_head_t */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -276,6 +276,22 @@ int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_
  * rows keep their previous content; a sparse gid list is trusted (it cannot be inspected from the host). */
 int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace);
 int rg_sync(rg_table_t *t);
+
+/* The host-memory path, PIPELINED. rg_submit(RG_MEM_HOST) is one synchronous H2D -> kernel -> D2H chain: the link idles while the
+ * kernel runs and each direction idles while the other moves. rg_submit_async stages a batch on a copy-in stream, runs the step kernel
+ * on the table's stream and returns the outcome on a copy-out stream, chained by events, and RETURNS AT ONCE; up to
+ * RG_PIPELINE_DEPTH batches are in flight (one more call first waits for the oldest), so the upload of batch k+1 overlaps the kernel
+ * and the download of batch k — PCIe is full duplex. Batches apply in submission order (their kernels share one stream).
+ *   - caller buffers (in->*, out->*) must stay valid and untouched until the batch has been waited for, and should be page-locked
+ *     (rg_host_alloc): pageable memory makes every copy synchronous;
+ *   - out->reply is written for every row; out->logfx / out->persist only for rows whose flags say so (other rows keep their previous
+ *     content — unlike rg_submit, nothing is zeroed: that is 32 B per row that need not cross the link... the rows are still copied
+ *     densely);
+ *   - rg_submit_wait blocks until the OLDEST batch in flight has landed in its buffers; returns 1 when nothing is in flight;
+ *   - every other entry point that touches the table first drains the pipeline. */
+#define RG_PIPELINE_DEPTH 2
+int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
+int rg_submit_wait(rg_table_t *t);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
  * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel" */
 const char *rg_step_kernel(rg_table_t *t, uint32_t count);
@@ -303,7 +319,8 @@ typedef struct {                 /* one per row */
     int64_t  epoch_term;
     uint32_t role_epoch;         /* tag for the response rows                      */
     uint32_t is_leader;          /* 0: every send of this row is RG_SEND_NONE      */
-} rg_send_head_t;                /* 40 B */
+    uint64_t reserved;           /* 0; pads the row to three 16-byte words so a wavefront stores whole 1 KiB lines */
+} rg_send_head_t;                /* 48 B */
 
 typedef struct {                 /* one per (row, follower j); j = slot<self ? slot : slot-1 */
     int64_t  prev_index;

@@ -854,7 +854,7 @@ int orc_replicate(orc_table_t *t, uint32_t count, const uint32_t *gid, const uin
         const size_t os = count;
         h->term = g->current_term; h->leader_commit = g->commit_index;
         h->epoch_index = g->epoch_index; h->epoch_term = g->epoch_term;
-        h->role_epoch = g->role_epoch; h->is_leader = g->role == RG_LEADER;
+        h->role_epoch = g->role_epoch; h->is_leader = g->role == RG_LEADER; h->reserved = 0;
         if (g->role != RG_LEADER) {
             for (uint32_t j = 0; j < F; j++) out[j * os] = (rg_send_t){0, 0, 0, 0, RG_SEND_NONE};
             continue;

@@ -611,7 +611,7 @@ int ref_replicate(ref_table *t, uint32_t count, const uint32_t *gid, const uint8
         rg_send_head_t *h = &head[i];
         h->term = p->currentTerm(); h->leader_commit = e.log->commitIndex;
         h->epoch_index = e.log->epoch()->index(); h->epoch_term = e.log->epoch()->term();
-        h->role_epoch = e.epoch_counter; h->is_leader = l != nullptr;
+        h->role_epoch = e.epoch_counter; h->is_leader = l != nullptr; h->reserved = 0;
         for (uint32_t j = 0; j < F; j++) send[(size_t)j * count + i] = rg_send_t{0, 0, 0, 0, RG_SEND_NONE};
         if (!l) { g_env = nullptr; continue; }
         const bool hb = heartbeat && heartbeat[i];

@@ -18,6 +18,7 @@ FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
 EV_NONE, EV_AE_REQ, EV_AE_ACK, EV_IS_ACK, EV_RV_REQ, EV_PV_REQ = 0, 1, 2, 3, 4, 5
 EV_RV_REPLY, EV_PV_REPLY, EV_TIMEOUT, EV_CLIENT_APPEND, EV_LOG_FLUSH, EV_IS_REQ = 6, 7, 8, 9, 10, 11
 MAX_AE_ENTRIES = 200
+PIPELINE_DEPTH = 2
 HDR_HINT_BIT = 1 << 9
 
 F_SUCCESS, F_REPLIED, F_PERSIST, F_ROLE_CHANGED = 1 << 0, 1 << 1, 1 << 2, 1 << 3
@@ -46,11 +47,11 @@ REPLY_DT = np.dtype([("resp_term", "<i8"), ("flags", "<u4"), ("role_epoch", "<u4
 LOGFX_DT = np.dtype([("commit_index", "<i8"), ("log_from", "<i8")])
 PERSIST_DT = np.dtype([("term", "<i8"), ("voted_for", "<i4"), ("role", "<i4")])
 SEND_HEAD_DT = np.dtype([("term", "<i8"), ("leader_commit", "<i8"), ("epoch_index", "<i8"), ("epoch_term", "<i8"),
-                         ("role_epoch", "<u4"), ("is_leader", "<u4")])
+                         ("role_epoch", "<u4"), ("is_leader", "<u4"), ("reserved", "<u8")])
 SEND_DT = np.dtype([("prev_index", "<i8"), ("prev_term", "<i8"), ("last_index", "<i8"), ("count", "<u4"), ("kind", "<u4")])
 SEND_NONE, SEND_APPEND, SEND_SNAPSHOT, SEND_GATED, SEND_NEED_HOST = 0, 1, 2, 3, 4
 REPLICATE_LIMIT, IN_FLIGHT_LIMIT = 50, 20
-assert SEND_HEAD_DT.itemsize == 40 and SEND_DT.itemsize == 32
+assert SEND_HEAD_DT.itemsize == 48 and SEND_DT.itemsize == 32
 assert HEAD_DT.itemsize == 8 and PAIR_DT.itemsize == 16 and REPLY_DT.itemsize == 16
 assert LOGFX_DT.itemsize == 16 and PERSIST_DT.itemsize == 16
 

@@ -37,6 +37,11 @@ struct Staging {
     size_t cap = 0;
 };
 
+struct PipeSlot {                               // one batch in flight on the pipelined host-memory path (rg_submit_async)
+    Staging gid, head, ab, cd, hint, terms, reply, logfx, persist;
+    hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+};
+
 struct rg_table {
     int device = 0;
     uint32_t G = 0, P = 0, self = 0, F = 0;
@@ -62,6 +67,9 @@ struct rg_table {
     Staging st_tgid, st_hgid, st_hslot, st_hflag, st_ready;
     int64_t *health_ok = nullptr, *health_fail = nullptr;   // [F][G] N4b
     int32_t *health_recent = nullptr;
+    hipStream_t s_in = nullptr, s_out = nullptr; // copy-in / copy-out streams of the pipelined path
+    PipeSlot pipe[RG_PIPELINE_DEPTH];
+    uint64_t pipe_head = 0, pipe_tail = 0;       // batches submitted / waited for
     std::string err;
 };
 
@@ -84,9 +92,20 @@ static int fail(rg_table *t, int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail((t), -2, "%s failed: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
-static int bind(rg_table *t)
+static int wait_oldest(rg_table *t)
+{
+    if (t->pipe_tail == t->pipe_head) return 1;
+    HIP_TRY(t, hipEventSynchronize(t->pipe[t->pipe_tail % RG_PIPELINE_DEPTH].down));
+    t->pipe_tail += 1;
+    return 0;
+}
+
+// every entry point starts here: select the device and (unless the caller IS the pipeline) let batches in flight land first
+static int bind(rg_table *t, bool drain = true)
 {
     HIP_TRY(t, hipSetDevice(t->device));
+    while (drain && t->pipe_tail != t->pipe_head)
+        if (int rc = wait_oldest(t); rc < 0) return rc;
     return 0;
 }
 
@@ -135,6 +154,13 @@ int rg_table_destroy(rg_table_t *t)
                     t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
                     t->health_fail, t->health_recent};
     for (void *c : cols) if (c) (void)hipFree(c);
+    for (PipeSlot &sl : t->pipe) {
+        if (sl.down) (void)hipEventSynchronize(sl.down);
+        for (Staging *st : {&sl.gid, &sl.head, &sl.ab, &sl.cd, &sl.hint, &sl.terms, &sl.reply, &sl.logfx, &sl.persist}) if (st->ptr) (void)hipFree(st->ptr);
+        for (hipEvent_t ev : {sl.up, sl.done, sl.down}) if (ev) (void)hipEventDestroy(ev);
+    }
+    if (t->s_in) (void)hipStreamDestroy(t->s_in);
+    if (t->s_out) (void)hipStreamDestroy(t->s_out);
     for (auto &e : t->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (t->region0) { (void)hipEventDestroy(t->region0); (void)hipEventDestroy(t->region1); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
@@ -399,9 +425,8 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
     return 0;
 }
 
-int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace)
+static int check_batch(rg_table *t, const rg_batch_t *in, const rg_outcome_t *out, bool host_memory)
 {
-    if (!t) return -1;
     if (!in || !out) return fail(t, -1, "rg_submit: NULL batch or outcome");
     if (!in->head || !in->ab || !in->cd || !out->reply || !out->logfx || !out->persist)
         return fail(t, -1, "rg_submit: head/ab/cd/reply/logfx/persist are required");
@@ -415,10 +440,17 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     }
     if (in->entry_count && !in->entry_terms) return fail(t, -1, "rg_submit: entry_count without entry_terms");
     if (in->entry_count > (1ull << 29)) return fail(t, -1, "rg_submit: at most 2^29 entry terms per batch (%llu given)", (unsigned long long)in->entry_count);
-    if (in->count == 0) return 0;
-    if (bind(t)) return -2;
+    if (sparse && host_memory) {
+        for (uint32_t i = 0; i < in->count; i++) {
+            if (in->gid[i] >= t->G) return fail(t, -1, "rg_submit: gid[%u]=%u out of range", i, in->gid[i]);
+            if (i && in->gid[i] <= in->gid[i - 1]) return fail(t, -1, "rg_submit: gid must be strictly ascending (row %u)", i);
+        }
+    }
+    return 0;
+}
 
-    const size_t rows = (size_t)in->rounds * in->count;
+static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
+{
     rg::StepParams p{};
     p.t = t->dt;
     p.rounds = in->rounds; p.count = in->count;
@@ -426,6 +458,83 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     p.counters = t->counters;
     p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
     p.fast_paths = t->fast_paths;
+    return p;
+}
+
+/* the pipelined host-memory path: see include/raftgpu.h */
+int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
+{
+    if (!t) return -1;
+    if (int rc = check_batch(t, in, out, true)) return rc;
+    if (in->count == 0) return 0;
+    if (bind(t, false)) return -2;
+    if (!t->s_in) {
+        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_in, hipStreamNonBlocking));
+        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_out, hipStreamNonBlocking));
+        for (PipeSlot &sl : t->pipe) {
+            HIP_TRY(t, hipEventCreate(&sl.up)); HIP_TRY(t, hipEventCreate(&sl.done)); HIP_TRY(t, hipEventCreate(&sl.down));
+        }
+    }
+    if (t->pipe_head - t->pipe_tail == RG_PIPELINE_DEPTH)
+        if (int rc = wait_oldest(t); rc < 0) return rc;
+    PipeSlot &sl = t->pipe[t->pipe_head % RG_PIPELINE_DEPTH];
+    const bool sparse = in->gid != nullptr;
+    const size_t rows = (size_t)in->rounds * in->count;
+    rg::StepParams p = step_params(t, in);
+    if (reserve(t, sl.head, rows * sizeof(rg_ev_head_t)) || reserve(t, sl.ab, rows * sizeof(I64x2)) || reserve(t, sl.cd, rows * sizeof(I64x2)) ||
+        reserve(t, sl.reply, rows * sizeof(rg_reply_t)) || reserve(t, sl.logfx, rows * sizeof(I64x2)) || reserve(t, sl.persist, rows * sizeof(rg_persist_t)))
+        return -2;
+    hipStream_t si = t->s_in, so = t->s_out;
+    HIP_TRY(t, hipMemcpyAsync(sl.head.ptr, in->head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, si));
+    HIP_TRY(t, hipMemcpyAsync(sl.ab.ptr, in->ab, rows * sizeof(I64x2), hipMemcpyHostToDevice, si));
+    HIP_TRY(t, hipMemcpyAsync(sl.cd.ptr, in->cd, rows * sizeof(I64x2), hipMemcpyHostToDevice, si));
+    p.head = (const rg_ev_head_t *)sl.head.ptr; p.ab = (const I64x2 *)sl.ab.ptr; p.cd = (const I64x2 *)sl.cd.ptr;
+    if (sparse) {
+        if (reserve(t, sl.gid, in->count * sizeof(uint32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(sl.gid.ptr, in->gid, in->count * sizeof(uint32_t), hipMemcpyHostToDevice, si));
+        p.gid = (const uint32_t *)sl.gid.ptr;
+    }
+    if (in->hint) {
+        if (reserve(t, sl.hint, rows * sizeof(I64x2))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(sl.hint.ptr, in->hint, rows * sizeof(I64x2), hipMemcpyHostToDevice, si));
+        p.hint = (const I64x2 *)sl.hint.ptr;
+    }
+    if (in->entry_count) {
+        if (reserve(t, sl.terms, in->entry_count * sizeof(int64_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(sl.terms.ptr, in->entry_terms, in->entry_count * sizeof(int64_t), hipMemcpyHostToDevice, si));
+        p.entry_terms = (const int64_t *)sl.terms.ptr;
+    }
+    HIP_TRY(t, hipEventRecord(sl.up, si));
+    HIP_TRY(t, hipStreamWaitEvent(t->stream, sl.up, 0));                  // the kernel of this batch needs its upload ...
+    p.reply = (rg_reply_t *)sl.reply.ptr; p.logfx = (I64x2 *)sl.logfx.ptr; p.persist = (rg_persist_t *)sl.persist.ptr;
+    if (int rc = launch(t, p, sparse)) return rc;                          // ... and, being on the table's stream, runs after the batch before it
+    HIP_TRY(t, hipEventRecord(sl.done, t->stream));
+    HIP_TRY(t, hipStreamWaitEvent(so, sl.done, 0));
+    HIP_TRY(t, hipMemcpyAsync(out->reply, sl.reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, so));
+    HIP_TRY(t, hipMemcpyAsync(out->logfx, sl.logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, so));
+    HIP_TRY(t, hipMemcpyAsync(out->persist, sl.persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, so));
+    HIP_TRY(t, hipEventRecord(sl.down, so));
+    t->pipe_head += 1;
+    return 0;
+}
+
+int rg_submit_wait(rg_table_t *t)
+{
+    if (!t) return -1;
+    if (bind(t, false)) return -2;
+    return wait_oldest(t);
+}
+
+int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int memspace)
+{
+    if (!t) return -1;
+    if (int rc = check_batch(t, in, out, memspace == RG_MEM_HOST)) return rc;
+    if (in->count == 0) return 0;
+    if (bind(t)) return -2;
+    const bool sparse = in->gid != nullptr;
+
+    const size_t rows = (size_t)in->rounds * in->count;
+    rg::StepParams p = step_params(t, in);
 
     if (memspace == RG_MEM_DEVICE) {
         p.gid = in->gid; p.head = in->head;
@@ -436,12 +545,6 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     }
     if (memspace != RG_MEM_HOST) return fail(t, -1, "rg_submit: unknown memspace %d", memspace);
 
-    if (sparse) {
-        for (uint32_t i = 0; i < in->count; i++) {
-            if (in->gid[i] >= t->G) return fail(t, -1, "rg_submit: gid[%u]=%u out of range", i, in->gid[i]);
-            if (i && in->gid[i] <= in->gid[i - 1]) return fail(t, -1, "rg_submit: gid must be strictly ascending (row %u)", i);
-        }
-    }
     hipStream_t s = t->stream;
     if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_ab, rows * sizeof(I64x2)) ||
         reserve(t, t->st_cd, rows * sizeof(I64x2)) || reserve(t, t->st_reply, rows * sizeof(rg_reply_t)) ||

@@ -474,60 +474,92 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     if (active) store_group<F>(p.t, gi, G, g, pe);
 }
 
+// this wavefront's earlier LDS writes are visible to its later LDS reads (other wavefronts are not involved)
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+}
+// outputs nobody on the device reads again: write-through, do not keep them in the caches
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+__device__ __forceinline__ void stream_store(uint4 *dst, const uint4 v)
+{
+    const u32x4 q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<u32x4 *>(dst));
+}
+
 // N1 — Leader.replicateLog (member/Leader.java:142-245) for many groups: one lane per row, F sends per lane.
-// HBM-bound integer scan: reads the group's scalar columns + the F {lastEpoch,nextIndex} pairs, writes 40 + 32 F bytes.
+// HBM-bound integer scan. Reads: the four 16-byte scalar columns of the row; for a Leader also the F {lastEpoch, nextIndex}
+// pairs, its in-flight counts and the term runs it needs (run 0 always, runs 1-3 only when the log has more than one run).
+// Writes: 48 B head + 32 F B sends per row. The outputs are arrays of structs (what the host reads), so a lane's own struct
+// is not a coalesced unit; every wavefront therefore transposes through LDS and stores WHOLE 1 KiB lines, 16 B per lane:
+// three store instructions for the 64 heads, two per follower for the 64 sends of that follower.
 template <int F>
 __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.count) return;
-    const uint32_t gi = p.gid ? p.gid[i] : i;
+    __shared__ uint4 stage[4][3 * 64];                // per wavefront: 64 heads (3 x 16 B) or 64 sends (2 x 16 B)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * blockDim.x + wave * 64u;      // first row of this wavefront
+    const uint32_t i = i0 + lane;
+    const bool active = i < p.count;
+    const uint32_t ir = active ? i : p.count - 1u;              // lanes past the end shadow the last row; their stores are clipped
+    const uint32_t gi = p.gid ? p.gid[ir] : ir;
     const uint32_t G = p.t.groups;
     const I64x2 tc = p.t.term_commit[gi], ep = p.t.epoch[gi], w = p.t.window[gi];
     Ident id = p.t.ident[gi];
     const bool leader = (id.meta & META_ROLE) == RG_LEADER;
-    rg_send_head_t h;
-    h.term = tc.x; h.leader_commit = tc.y; h.epoch_index = ep.x; h.epoch_term = ep.y;
-    h.role_epoch = id.role_epoch; h.is_leader = leader ? 1u : 0u;
-    p.head[i] = h;
-    rg_send_t *out = p.send + i;                          // follower-major: element (j, row) at j * count + row
-    const size_t ostride = p.count;
-    if (!leader) {
-#pragma unroll
-        for (int j = 0; j < F; j++) out[j * ostride] = rg_send_t{0, 0, 0, 0u, RG_SEND_NONE};
-        return;
-    }
     const int rc = (int)((id.meta >> META_RC_SHIFT) & 7u);
     const bool has_log = rc > 0;
     const int64_t first = w.x, last = w.y;
-    const bool hb = p.heartbeat != nullptr && p.heartbeat[i] != 0;
+    const bool prepared = (id.meta & META_PREP) != 0;
+    // issue every load a Leader needs before anything is decided (one round trip instead of three dependent ones)
+    I64x2 en[F];
+    uint32_t fl[F];
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        en[j] = I64x2{0, 0}; fl[j] = 0u;
+        if (leader & prepared) en[j] = p.t.peer_en[(size_t)j * G + gi];
+        if (leader && p.in_flight) fl[j] = p.in_flight[(size_t)j * p.count + ir];
+    }
+    I64x2 r0{0, 0}, r1{0, 0}, r2{0, 0}, r3{0, 0};
+    if (leader & has_log) {
+        r0 = p.t.runs[gi];
+        if (rc > 1) { r1 = p.t.runs[(size_t)G + gi]; }
+        if (rc > 2) { r2 = p.t.runs[(size_t)2 * G + gi]; }
+        if (rc > 3) { r3 = p.t.runs[(size_t)3 * G + gi]; }
+    }
+    const bool hb = p.heartbeat != nullptr && p.heartbeat[ir] != 0;
+
+    rg_send_head_t h;
+    h.term = tc.x; h.leader_commit = tc.y; h.epoch_index = ep.x; h.epoch_term = ep.y;
+    h.role_epoch = id.role_epoch; h.is_leader = leader ? 1u : 0u; h.reserved = 0;
+
     const uint32_t limit = hb ? RG_IN_FLIGHT_LIMIT / 10 : RG_IN_FLIGHT_LIMIT;
     const int64_t fetch = hb ? RG_REPLICATE_LIMIT / 2 : RG_REPLICATE_LIMIT;
     uint32_t pend = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
-    const bool prepared = (id.meta & META_PREP) != 0;
-    if (!prepared) {                                  // Leader.prepareReplication :30-50
+    if (leader & !prepared & active) {                // Leader.prepareReplication :30-50
         const int64_t next0 = wadd(has_log ? last : ep.x, 1);
 #pragma unroll
         for (int j = 0; j < F; j++) {
             p.t.peer_en[(size_t)j * G + gi] = I64x2{ep.x, next0};
             p.t.peer_m[(size_t)j * G + gi] = Match{0, 0, 0};
         }
-        pend = 0;
         id.meta = (id.meta & ~(0x7Fu << META_PEND_SHIFT)) | META_PREP;
         p.t.ident[gi] = id;
     }
-    // cached runs (only needed for the term of prev_index)
-    const I64x2 r0 = p.t.runs[gi], r1 = p.t.runs[(size_t)G + gi], r2 = p.t.runs[(size_t)2 * G + gi], r3 = p.t.runs[(size_t)3 * G + gi];
+    if (!prepared) pend = 0;
+    rg_send_t sends[F];
 #pragma unroll
     for (int j = 0; j < F; j++) {
-        const uint32_t fl = p.in_flight ? p.in_flight[(size_t)j * ostride + i] : 0u;
         rg_send_t s{ep.x, ep.y, ep.x, 0u, RG_SEND_APPEND};
-        if (fl > limit) {
+        if (!leader) {
+            s = rg_send_t{0, 0, 0, 0u, RG_SEND_NONE};
+        } else if (fl[j] > limit) {
             s.kind = RG_SEND_GATED;
         } else if ((pend >> j) & 1u) {
             s.kind = RG_SEND_SNAPSHOT;
         } else {
-            const int64_t next_index = prepared ? p.t.peer_en[(size_t)j * G + gi].y : wadd(has_log ? last : ep.x, 1);
+            const int64_t next_index = prepared ? en[j].y : wadd(has_log ? last : ep.x, 1);
             const int64_t next = max64(wsub(next_index, 1), ep.x);
             int64_t idx = next, len = fetch + 1;                  // RaftLog.batch(next, fetch + 1)  storage/RocksLog.java:131-166
             if (idx == ep.x) { idx = wadd(idx, 1); len -= 1; }
@@ -553,7 +585,38 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
                 s.last_index = s.count == 0 ? s.prev_index : wadd(s.prev_index, (int64_t)s.count);
             }
         }
-        out[j * ostride] = s;
+        sends[j] = s;
+    }
+
+    // ---- transposed, line-sized stores -------------------------------------------------------------------------------
+    // each wavefront owns its slice of `stage`: LDS operations of one wavefront execute in order, so a wave-level
+    // scheduling barrier + lgkmcnt(0) is all the synchronisation the transpose needs (no workgroup barrier)
+    uint4 *st = stage[wave];
+    const uint32_t rows_here = p.count > i0 ? (p.count - i0 < 64u ? p.count - i0 : 64u) : 0u;
+    {
+        const uint4 *hv = reinterpret_cast<const uint4 *>(&h);
+        st[lane * 3 + 0] = hv[0]; st[lane * 3 + 1] = hv[1]; st[lane * 3 + 2] = hv[2];
+        wave_lds_sync();
+        uint4 *dst = reinterpret_cast<uint4 *>(p.head + i0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const uint32_t c = (uint32_t)k * 64u + lane;              // 16-byte chunk of the wavefront's 3 KiB
+            if (c < rows_here * 3u) stream_store(dst + c, st[c]);
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const uint4 *sv = reinterpret_cast<const uint4 *>(&sends[j]);
+        st[lane * 2 + 0] = sv[0]; st[lane * 2 + 1] = sv[1];
+        wave_lds_sync();
+        uint4 *dst = reinterpret_cast<uint4 *>(p.send + (size_t)j * p.count + i0);   // follower-major: element (j, row) at j * count + row
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t c = (uint32_t)k * 64u + lane;
+            if (c < rows_here * 2u) stream_store(dst + c, st[c]);
+        }
+        wave_lds_sync();
     }
 }
 

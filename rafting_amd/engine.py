@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit_async", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -88,6 +88,8 @@ def lib():
         L.rg_load_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_read_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
+        L.rg_submit_async.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
+        L.rg_submit_wait.argtypes = [vp]
         L.rg_sync.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_step_kernel.restype = C.c_char_p
@@ -271,6 +273,26 @@ class Table:
         b, o = batch.as_struct(), out.as_struct()
         self._check(lib().rg_submit(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
         return out
+
+    def submit_async(self, batch, out):
+        """Pipelined host-buffer submission (rg_submit_async): returns at once; `batch` and `out` must stay alive and untouched
+        until submit_wait() has returned for them. Keeps the ctypes structs alive itself."""
+        b, o = batch.as_struct(), out.as_struct()
+        self._inflight = getattr(self, "_inflight", [])
+        if len(self._inflight) >= abi.PIPELINE_DEPTH:      # the library waits for the oldest batch itself before taking a new one
+            self._inflight.pop(0)
+        self._inflight.append((b, o, batch, out))
+        self._check(lib().rg_submit_async(self._h, C.byref(b), C.byref(o)))
+        return out
+
+    def submit_wait(self):
+        """Blocks until the oldest batch in flight has landed; returns its Outcome (None when nothing was in flight)."""
+        rc = lib().rg_submit_wait(self._h)
+        if rc == 1:                                         # nothing in flight (any other entry point drains the pipeline too)
+            self._inflight = []
+            return None
+        self._check(rc)
+        return self._inflight.pop(0)[3]
 
     def submit_device(self, dbatch):
         """HBM-resident submission (RG_MEM_DEVICE): asynchronous on the table's stream."""

@@ -110,9 +110,13 @@ void workgroup_barrier(bool required)
     my_block->meet((int)threadIdx_.x, 0ull, [](const std::vector<unsigned long long> &, const std::vector<char> &) { return 0ull; });
 }
 
-void run_grid(dim3 grid, dim3 block, const std::function<void()> &body)
+// kernels whose lanes exchange data through LDS behind a __syncthreads (not a required s_barrier): a lane-serial grid would
+// silently compute garbage for them, so they always run with one OS thread per lane
+static bool lanes_must_meet(const char *kernel) { return kernel && strstr(kernel, "replicate_kernel") != nullptr; }
+
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel)
 {
-    if (!waves_mode()) {
+    if (!waves_mode() && !lanes_must_meet(kernel)) {
         gridDim_ = grid; blockDim_ = block;
         try {
             for (unsigned b = 0; b < grid.x; b++)

@@ -8,11 +8,12 @@
 //
 // Two ways to run a grid (emu_runtime.cpp):
 //   lane-serial (default): every (block, thread) one after the other on the calling thread. Fast, and exact for every
-//     kernel whose lanes are independent — step_kernel (one lane = one raft group), replicate_kernel, the timers
+//     kernel whose lanes are independent — step_kernel (one lane = one raft group), the timers
 //     update/arm kernels, the health kernels, copy_kernel. It cannot reproduce what needs lanes to MEET: wavefront
 //     shuffles/ballots (the decision counters come out per lane, not summed; rg_timers_expired's ballot compaction is
 //     wrong) and barriers (step_split_kernel is refused, not dead-locked). Tests on it force RG_SPLIT=0 and do not look
-//     at counters or expired-timer lists.
+//     at counters or expired-timer lists. replicate_kernel transposes its outputs through LDS behind __syncthreads, so it
+//     always runs the second way.
 //   wavefronts (RG_EMU_WAVES=1): every lane of a workgroup is an OS thread; shuffles, ballots, readfirstlane meet per
 //     64-lane wavefront, __syncthreads / s_barrier per workgroup, a lane that returns stops being waited for. Slow, but
 //     it runs ALL kernels, including the two-wavefront step kernel with its LDS hand-over and the ballot compaction.
@@ -48,7 +49,7 @@ unsigned long long wave_ballot(bool p);                    // lane-serial: a wav
 unsigned long long wave_exchange_xor(unsigned long long bits, int lane_xor);   // lane-serial: no partner, 0
 unsigned long long wave_first(unsigned long long v);
 void workgroup_barrier(bool required);                      // required (s_barrier) throws Deadlock on a lane-serial grid
-void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel);
 }
 #define threadIdx (::hipemu::threadIdx_)
 #define blockIdx (::hipemu::blockIdx_)
@@ -61,6 +62,8 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 #define __builtin_amdgcn_readfirstlane(x) ((decltype(x))::hipemu::wave_first((unsigned long long)(x)))
 #define __builtin_amdgcn_ballot_w64(x) (::hipemu::wave_ballot(x))
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
+#define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))      /* g++ has no such builtin; vectors via ext_vector_type are clang-only: */
 #define __syncthreads() (::hipemu::workgroup_barrier(false))
 #define __ballot(x) (::hipemu::wave_ballot(x))
 #define __popcll(x) __builtin_popcountll(x)
@@ -95,6 +98,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t_ms = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::run_grid((grid), (block), [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::run_grid((grid), (block), [&]() { kernel(__VA_ARGS__); }, #kernel)

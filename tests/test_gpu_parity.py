@@ -386,3 +386,51 @@ def test_health_multi_round_and_sparse_fold():
     first, count = 17, 100                                                 # ranged read
     for a, c in zip(gpu.health_read(first, count), orc.health_read(first, count)):
         assert np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+def test_pipelined_host_submissions_match_the_oracle():
+    """rg_submit_async / rg_submit_wait: a stream of host-memory batches, two in flight (upload of batch k+1 overlapping the
+    kernel and the download of batch k), dense and sparse rows, page-locked and pageable caller buffers — every outcome and
+    the final state equal to the oracle's sequential replay; a synchronous call in between drains the pipeline first."""
+    from rafting_amd import workload
+    cfg = workload.config(3, 4096)
+    gen = workload.ReplayGenerator(cfg)
+    st0 = gen.initial_state()
+    gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    batches = [gen.next_batch(4) for _ in range(7)]
+    refs = [orc.submit(b, fill=0xAB) for b in batches]
+    owners, outs = [], []
+    for k, b in enumerate(batches):
+        out = abi.Outcome(b.rounds * b.count, 0xAB)
+        if k % 3 != 2:                                   # two of three batches live in page-locked memory, the third is pageable
+            b.entry_terms = np.ascontiguousarray(b.entry_terms[:max(b.entry_count, 1)])
+            for obj, names in ((b, ("head", "ab", "cd", "entry_terms")), (out, ("reply", "logfx", "persist"))):
+                for nm in names:
+                    view, own = engine.pinned_like(gpu, getattr(obj, nm))
+                    setattr(obj, nm, view)
+                    owners.append(own)
+        outs.append(out)
+    assert gpu.submit_wait() is None                     # nothing in flight yet
+    for k in range(5):
+        gpu.submit_async(batches[k], outs[k])            # the third call waits for the first batch by itself
+    got = []
+    while True:
+        o = gpu.submit_wait()
+        if o is None:
+            break
+        got.append(o)
+    assert len(got) == 2                                 # three batches had already been waited for inside submit_async
+    gpu.submit_async(batches[5], outs[5])
+    mid = gpu.read_state()                               # a synchronous entry point drains the pipeline first
+    assert gpu.submit_wait() is None and int(mid.role_epoch.sum()) > 0
+    gpu.submit_async(batches[6], outs[6])
+    gpu.sync()
+    for k in range(7):
+        compare_outcomes(refs[k], outs[k], "pipelined batch %d" % k)
+    compare_states(orc.read_state(), gpu.read_state(), "after the pipeline")
+    for own in owners:
+        own.free()

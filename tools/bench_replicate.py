@@ -37,9 +37,9 @@ def main():
     ms = t.timing_end() / iters
     st = t.read_state()
     leaders = int(np.count_nonzero(st.role == abi.LEADER))
-    # algorithmic bytes: every row reads its four scalar columns (64 B) and writes head + F sends (40 + 32F);
+    # algorithmic bytes: every row reads its four scalar columns (64 B) and writes head + F sends (48 + 32F);
     # a leader row additionally reads its runs (64 B), F x {lastEpoch,nextIndex} (16F) and the gate inputs (1 + 2F)
-    nbytes = groups * (64 + 40 + 32 * F) + leaders * (64 + 16 * F + 1 + 2 * F)
+    nbytes = groups * (64 + 48 + 32 * F) + leaders * (64 + 16 * F + 1 + 2 * F)
     gbps = nbytes / (ms * 1e-3) / 1e9
     print(json.dumps({"kernel": "rg::replicate_kernel<%d>" % F, "groups": groups, "leaders": leaders, "ms_per_launch": ms,
                       "rows_per_s": groups / (ms * 1e-3), "sends_per_s": leaders * F / (ms * 1e-3),

@@ -7,7 +7,7 @@
 TAG=${1:-x}
 OUT=gpurun_out
 run() { # name lib override
-  RG_LIB=$2 python bench.py --no-cpu-baseline --steps 10 --warmup 2 ${3:+--override "$3"} > $OUT/exp_${TAG}_$1.json 2> $OUT/exp_${TAG}_$1.err
+  RG_LIB=$2 python bench.py --no-cpu-baseline --no-pcie --steps 10 --warmup 2 ${3:+--override "$3"} > $OUT/exp_${TAG}_$1.json 2> $OUT/exp_${TAG}_$1.err
   python - "$OUT/exp_${TAG}_$1.json" "$1" <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]

@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 1 $*"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pcie --steps 4 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc1 -o p -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -o p -- $BENCH > $OUT/pmc2.log 2>&1

@@ -12,9 +12,9 @@ bash tools/prof.sh $TAG > $OUT/prof_$TAG.log 2>&1
 python bench.py --copy-bw > $OUT/bench_${TAG}_c3.json 2> $OUT/bench_${TAG}_c3.err
 for spec in "2 4096" "4 131072" "5 131072" "5 65536"; do
   set -- $spec
-  python bench.py --config $1 --groups-per-gpu $2 --no-cpu-baseline > $OUT/bench_${TAG}_c$1_$2.json 2> $OUT/bench_${TAG}_c$1_$2.err
+  python bench.py --config $1 --groups-per-gpu $2 --no-cpu-baseline --no-pcie > $OUT/bench_${TAG}_c$1_$2.json 2> $OUT/bench_${TAG}_c$1_$2.err
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_c$1_$2 -o t -- \
-      python $ROOT/bench.py --config $1 --groups-per-gpu $2 --no-cpu-baseline --steps 4 --warmup 1 > $OUT/prof_${TAG}_c$1_$2.log 2>&1)
+      python $ROOT/bench.py --config $1 --groups-per-gpu $2 --no-cpu-baseline --no-pcie --steps 4 --warmup 1 > $OUT/prof_${TAG}_c$1_$2.log 2>&1)
 done
 python tools/bench_replicate.py 1048576 50 > $OUT/bench_${TAG}_repl.json 2> $OUT/bench_${TAG}_repl.err
 cd /tmp && export TMPDIR=/tmp
