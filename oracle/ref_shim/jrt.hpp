@@ -232,6 +232,7 @@ struct Long {
 };
 struct Integer {
     static constexpr jint MAX_VALUE = INT32_MAX;
+    static constexpr jint BYTES = 4;
     static jint compareUnsigned(jint a, jint b) { uint32_t x = (uint32_t)a, y = (uint32_t)b; return x < y ? -1 : (x == y ? 0 : 1); }
 };
 inline jlong jushr(jlong v, int n) { return (jlong)((uint64_t)v >> (n & 63)); }

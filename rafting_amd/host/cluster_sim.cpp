@@ -28,8 +28,10 @@
 #include <string>
 
 #include "raft_host.hpp"
+#include "wire.hpp"
 
 using namespace raftgpu::host;
+namespace rw = rafting::wire;
 
 enum MsgType { AE, AE_RESP, PV, PV_RESP, RV, RV_RESP, IS, IS_RESP };
 struct Msg {
@@ -42,6 +44,7 @@ struct Msg {
     uint32_t epoch = 0;                           // role epoch of the requester when it sent the request
     int64_t epochAtSend = 0, lastSent = 0;        // Leader.replicateLog closure state echoed by the response
     int64_t sentTick = 0;                         // when the request left (echoed): pairs a response with its Async
+    int32_t seq = 0;                              // wire mode: the sequence number of the Ping / Pong frame pair
 };
 
 static const int P = 3;
@@ -79,7 +82,99 @@ static const int64_t COOL_DOWN_MS = 100;          // raft1.xml:31 recovery-cool-
 static void fail(const char *what, uint32_t gid) { fprintf(stderr, "INVARIANT VIOLATED (tick %lld, group %u): %s\n", (long long)now_tick, gid, what); violations++; }
 static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term) + "-cmd" + std::to_string(e.index); }
 
-static void send(Node &n, Msg m) { m.from = n.id; if (n.connected) wire_next.push_back(std::move(m)); }
+// ---- SIM_WIRE=1: every message crosses the "network" as an encoded frame of the reference's wire protocol ---------------
+// (transport/EventCodec.java): the sender encodes (FixedBodyCodec stand-in for the Kryo body), the bytes sit in a per-connection
+// stream, the receiver's FrameSplitter gets them in random pieces and the decoded frame is turned back into the message.
+// A response carries only (scope, sequence, term, success): what the requester needs beyond that — the role epoch it sent
+// under and Leader.replicateLog's closure state — comes from ITS OWN table of pending invocations, as in AsyncService.
+static bool use_wire = false;
+struct Conn { std::string bytes; rw::FrameSplitter splitter; };
+static Conn conn[8][8];                                       // [from][to]
+struct PendingCall { uint32_t gid; MsgType type; uint32_t epoch; int64_t epochAtSend, lastSent, sentTick; };
+static std::map<int32_t, PendingCall> pending[8][8];          // [requester][responder] by sequence
+static int32_t next_seq[8];
+static uint64_t wire_bytes = 0, wire_frames = 0;
+
+static std::string ctx_name(uint32_t groups, uint32_t gid) { return groups == 1 ? "root" : "ctx-" + std::to_string(gid); }
+static uint32_t g_groups = 1;
+
+static void encode_msg(Msg &m)
+{
+    const rw::FixedBodyCodec codec;
+    rw::Frame f;
+    const bool request = m.type == AE || m.type == PV || m.type == RV || m.type == IS;
+    const rw::Method method = (m.type == AE || m.type == AE_RESP) ? rw::M_APPEND_ENTRIES : (m.type == PV || m.type == PV_RESP) ? rw::M_PRE_VOTE
+                            : (m.type == RV || m.type == RV_RESP) ? rw::M_REQUEST_VOTE : rw::M_INSTALL_SNAPSHOT;
+    f.head = rw::make_scope(method, ctx_name(g_groups, m.gid));
+    if (request) {
+        m.seq = next_seq[m.from]++;
+        pending[m.from][m.to][m.seq] = PendingCall{m.gid, m.type, m.epoch, m.epochAtSend, m.lastSent, m.sentTick};
+        rw::Request q;
+        q.term = m.term; q.node = m.from; q.x = m.x; q.y = m.y; q.leader_commit = m.z;
+        for (const Entry &e : m.entries) q.entry_terms.push_back(e.term);
+        codec.encode_request(method, q, f.body);
+        f.type = rw::ENQ;
+    } else {
+        codec.encode_response(rw::Response{m.term, m.success}, f.body);
+        f.type = rw::ACK;
+    }
+    f.sequence = m.seq;
+    const size_t before = conn[m.from][m.to].bytes.size();
+    rw::encode_frame(f, false, conn[m.from][m.to].bytes);
+    wire_bytes += conn[m.from][m.to].bytes.size() - before;
+    wire_frames++;
+}
+
+// one tick of the network: every connection delivers what was written to it, in arbitrary pieces
+static void deliver_frames(std::vector<Msg> &out)
+{
+    const rw::FixedBodyCodec codec;
+    for (int from = 0; from < P; from++)
+        for (int to = 0; to < P; to++) {
+            Conn &c = conn[from][to];
+            std::vector<rw::Frame> frames;
+            size_t at = 0;
+            while (at < c.bytes.size()) {
+                const size_t piece = std::min<size_t>(c.bytes.size() - at, 1 + rng() % 97);
+                c.splitter.feed(reinterpret_cast<const uint8_t *>(c.bytes.data()) + at, piece, frames);
+                at += piece;
+            }
+            c.bytes.clear();
+            if (c.splitter.failed()) { fail("a frame stream was rejected by the splitter", 0); return; }
+            for (const rw::Frame &f : frames) {
+                rw::Method method; std::string ctx;
+                if (!rw::parse_scope(f.head, method, ctx)) { fail("unknown scope on the wire", 0); continue; }
+                Msg m; m.from = from; m.to = to; m.seq = f.sequence;
+                m.gid = g_groups == 1 ? 0u : (uint32_t)atoi(ctx.c_str() + 4);
+                if (f.type == rw::ENQ) {
+                    rw::Request q;
+                    if (!codec.decode_request(method, f.body, q)) { fail("undecodable request body", m.gid); continue; }
+                    m.type = method == rw::M_APPEND_ENTRIES ? AE : method == rw::M_PRE_VOTE ? PV : method == rw::M_REQUEST_VOTE ? RV : IS;
+                    m.term = q.term; m.x = q.x; m.y = q.y; m.z = q.leader_commit;
+                    for (size_t k = 0; k < q.entry_terms.size(); k++) m.entries.push_back(Entry{q.x + 1 + (int64_t)k, q.entry_terms[k]});
+                } else {
+                    rw::Response r;
+                    if (!codec.decode_response(f.body, r)) { fail("undecodable response body", m.gid); continue; }
+                    auto &tab = pending[to][from];                  // the requester is the node the response arrives at
+                    auto it = tab.find(f.sequence);
+                    if (it == tab.end()) continue;                  // AsyncService: no invocation waiting under that sequence any more
+                    const PendingCall pc = it->second;
+                    tab.erase(it);
+                    m.type = pc.type == AE ? AE_RESP : pc.type == PV ? PV_RESP : pc.type == RV ? RV_RESP : IS_RESP;
+                    m.term = r.term; m.success = r.success;
+                    m.epoch = pc.epoch; m.epochAtSend = pc.epochAtSend; m.lastSent = pc.lastSent; m.sentTick = pc.sentTick;
+                }
+                out.push_back(std::move(m));
+            }
+        }
+}
+
+static void send(Node &n, Msg m)
+{
+    m.from = n.id;
+    if (!n.connected) return;
+    if (use_wire) encode_msg(m); else wire_next.push_back(std::move(m));
+}
 
 // Leader.replicateLog (member/Leader.java:142-245): WHAT to send is decided on the GPU (rg_replicate, one launch for
 // all leader contexts of the node that emitted a heartbeat this drain); the host only reads the payload range
@@ -137,6 +232,8 @@ int main(int argc, char **argv)
     const int64_t ticks = argc > 2 ? atoll(argv[2]) : 2400;
     rng.seed(argc > 3 ? (uint64_t)atoll(argv[3]) : 1);
     const int trace_group = getenv("SIM_TRACE_GROUP") ? atoi(getenv("SIM_TRACE_GROUP")) : -1;
+    use_wire = getenv("SIM_WIRE") && atoi(getenv("SIM_WIRE")) != 0;
+    g_groups = groups;
     std::vector<Node> nodes(P);
     for (int k = 0; k < P; k++) {
         nodes[k].id = k;
@@ -166,6 +263,7 @@ int main(int argc, char **argv)
     uint64_t commands = 0, elections = 0, rollbacks = 0, not_ready = 0, rpc_timeouts = 0;
 
     for (now_tick = 0; now_tick < ticks; now_tick++) {
+        if (use_wire) deliver_frames(wire);              // what was sent during the previous tick arrives, frame by frame
         for (Msg &m : wire) {
             if (!(nodes[m.to].connected && nodes[m.from].connected)) continue;
             Group &g = nodes[m.to].g[m.gid];
@@ -262,7 +360,7 @@ int main(int argc, char **argv)
                 if (src[i].what == 0 && o.response) {
                     const Msg &q = src[i].msg;
                     Msg r; r.to = q.from; r.gid = q.gid; r.term = o.response->term; r.success = o.response->success;
-                    r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent; r.sentTick = q.sentTick;
+                    r.epoch = q.epoch; r.epochAtSend = q.epochAtSend; r.lastSent = q.lastSent; r.sentTick = q.sentTick; r.seq = q.seq;
                     r.type = q.type == AE ? AE_RESP : q.type == PV ? PV_RESP : q.type == IS ? IS_RESP : RV_RESP;
                     send(n, std::move(r));
                 }
@@ -332,6 +430,7 @@ int main(int argc, char **argv)
                 fail("journal does not hold the participant's (term, votedFor)", g.ctx->gid());
         }
     }
+    if (use_wire) fprintf(stderr, "wire: %llu frames, %llu bytes through FrameSplitter / FixedBodyCodec\n", (unsigned long long)wire_frames, (unsigned long long)wire_bytes);
     fprintf(stderr, "readiness gate: %llu commands refused (NotReadyException), %llu RPC timeouts\n", (unsigned long long)not_ready,
             (unsigned long long)rpc_timeouts);
     fprintf(stderr, "durability: %llu (term, votedFor) records in %llu fdatasyncs\n", (unsigned long long)persisted, (unsigned long long)syncs);

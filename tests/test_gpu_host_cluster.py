@@ -11,10 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIM = os.path.join(ROOT, "build", "cluster_sim")
 
 
-def _run(groups, ticks, seed):
+def _run(groups, ticks, seed, wire=False):
     if not os.path.exists(SIM):
         subprocess.run(["make", "-C", os.path.join(ROOT, "rafting_amd", "host")], check=True)
-    p = subprocess.run([SIM, str(groups), str(ticks), str(seed)], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([SIM, str(groups), str(ticks), str(seed)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SIM_WIRE="1" if wire else "0"))
+    if wire:
+        assert re.search(r"wire: \d{4,} frames", p.stderr), p.stderr[-500:]
     assert p.returncode == 0, p.stdout + p.stderr
     m = re.search(r"commands_accepted=(\d+) elections=(\d+) partitioned_node=(-?\d+) lines\(min,max\)=\((\d+),(\d+)\) "
                   r"files_identical=(\d) gpu_rows=(\d+) hints=(\d+) match_rollbacks=(\d+) violations=(\d+) converged=(\d+) "
@@ -39,3 +42,14 @@ def test_many_contexts_per_node():
     commands, elections, cut, lo, hi, identical, rows, hints, rollbacks, violations, converged, median = _run(256, 1200, 7)
     assert violations == 0                       # election safety + state-machine safety held for every group at every tick
     assert converged >= 254 and median >= 100 and elections >= 256
+
+
+def test_cluster_over_encoded_frames():
+    """N2: the same cluster with every message crossing the network as a frame of the reference's wire protocol
+    (transport/EventCodec.java) — encoded by the sender, split from a byte stream that arrives in random pieces
+    (rafting_amd/host/wire.cpp FrameSplitter), responses matched to their pending invocation by sequence number —
+    before it becomes a row of rg_submit. Same invariants, same outcome as the in-memory run of the same seed."""
+    plain = _run(16, 1200, 5)
+    framed = _run(16, 1200, 5, wire=True)
+    assert framed[9] == 0 and framed[10] >= 15 and framed[1] >= 16
+    assert framed == plain                          # the encoding is transparent: message for message the same simulation

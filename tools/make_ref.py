@@ -77,6 +77,10 @@ inline RocksLog::RocksLog(Ref<RocksDB> db_, Ref<RocksSerializer> ser_)
     epochEntry = jnew<EntryKey>((jlong)0, (jlong)0);              // :74-75
 }
 """),
+    # N2: the wire frame grammar SOH|TYPE|{SEQ}|STX|HEADLEN|HEAD|BODYLEN|{BODY}|ETX[|EOT] — constants, EventFrame, the streaming
+    # FrameDecoder state machine and FrameEncoder.encode, over a ByteBuf stand-in (oracle/ref_shim/wire_env.hpp)
+    dict(file="transport/EventCodec.java", mode="class", keep=[(25, 51), (169, 196), (219, 335)], exclude=["allocateBuffer"],
+         hoist_statics=True, unit="wire"),
     dict(file="context/RaftRoutine.java", mode="methods", cls="RaftRoutine",
          ranges=[(53, 62), (65, 77), (86, 130), (140, 152), (159, 181), (183, 216)]),
     dict(file="context/RaftContext.java", mode="methods", cls="RaftContext",
@@ -98,7 +102,7 @@ SUBSTITUTIONS = [
 PRIMS = {"long": "jlong", "int": "jint", "boolean": "jboolean", "byte": "jbyte", "short": "jshort", "double": "jdouble",
          "void": "void", "char": "jchar", "float": "jfloat"}
 DROP_MODIFIERS = {"public", "private", "protected", "final", "volatile", "synchronized", "abstract", "transient", "default"}
-DROP_BASES = {"Serializable", "Closeable", "AutoCloseable", "Comparable"}
+DROP_BASES = {"Serializable", "Closeable", "AutoCloseable", "Comparable", "MessageToByteEncoder", "ByteToMessageDecoder"}
 GENERIC_TYPES = {"Map", "HashMap", "ConcurrentHashMap", "Set", "List", "ArrayList", "Collection", "Async", "AtomicReference",
                  "AtomicLongFieldUpdater", "AtomicIntegerFieldUpdater", "Class", "ScheduledFuture", "Function", "Future",
                  "Promise", "PendingTask", "CompletableFuture"}
@@ -109,10 +113,10 @@ KNOWN_TYPES = set(GENERIC_TYPES) | {
     "RaftCluster", "RaftConfig", "RaftMachine", "StableLock", "SnapshotArchive", "ContextEventLoop", "RocksDB",
     "RocksIterator", "ColumnFamilyHandle", "RocksSerializer", "RocksStateLoader", "Path", "Boolean", "Logger",
     "ScheduledExecutorService", "ExecutorService", "RaftContext", "RaftRoutine", "EntryKey", "Entry", "State", "Snapshot",
-    "NotLeaderException", "ObsoleteContextException"}
+    "NotLeaderException", "ObsoleteContextException", "ByteBuf", "ChannelHandlerContext", "CharSequence", "SerializeException"}
 # identifiers followed by `.` that denote static access (`::`)
 STATIC_SCOPES = {"Math", "Long", "Integer", "Arrays", "Objects", "System", "Async", "TimeUnit", "Boolean", "CompletableFuture",
-                 "RocksDB", "Collections", "String"}
+                 "RocksDB", "Collections", "String", "StandardCharsets", "Serialization"}
 QUALIFIER_ONLY = {"RaftLog", "RaftCluster", "RaftStub", "Leadership_"}   # `RaftLog.Entry` -> `Entry` (nested types are flattened)
 EXC_TYPES = {"Exception", "Throwable", "IOException", "InterruptedException", "RuntimeException", "AssertionError"}
 
@@ -533,7 +537,31 @@ def rewrite_body(toks, ctx, locals_):
         # ---- throw new X(...) -> throw X(...) -----------------------------------------------------------------
         if t.t == "throw" and nx == "new":
             close = match_close(toks, i + 3, "(", ")")
-            inner = rewrite_body(toks[i + 4:close], ctx, locals_)
+            inner = []
+            for arg in split_params(toks[i + 4:close]):        # "text" + value + ...: Java string concatenation -> jconcat(...)
+                parts, cur, depth = [], [], 0
+                for tk in arg:
+                    if tk.t in "([{":
+                        depth += 1
+                    elif tk.t in ")]}":
+                        depth -= 1
+                    if tk.t == "+" and depth == 0:
+                        parts.append(cur)
+                        cur = []
+                    else:
+                        cur.append(tk)
+                parts.append(cur)
+                if inner:
+                    inner.append(T("op", ",", ""))
+                if len(parts) > 1 and any(tk.k == "str" for tk in arg):
+                    inner.append(T("id", "jconcat("))
+                    for n_, part in enumerate(parts):
+                        if n_:
+                            inner.append(T("op", ",", ""))
+                        inner.extend(rewrite_body(part, ctx, locals_))
+                    inner.append(T("op", ")", ""))
+                else:
+                    inner.extend(rewrite_body(arg, ctx, locals_))
             out.append(t)
             out.append(T("id", "jat(%s(" % toks[i + 2].t))
             out.extend(inner)
@@ -731,13 +759,22 @@ def declared_names_of_field(toks):
     return names
 
 
-def emit_class(node, unit, all_nodes, known, static_scopes, collide_any, entry, outer=None):
+def emit_class(node, unit, all_nodes, known, static_scopes, collide_any, entry, outer=None, statics_base=None):
     name = node.name
+    hoist = None
+    if outer is None and entry.get("hoist_statics"):
+        # a nested Java class sees the static fields of its outer class unqualified; nested classes are flattened to top
+        # level here, so the outer class's statics move into <Outer>_statics, which the outer class and its nested classes inherit
+        hoist = []
+        statics_base = name + "_statics"
+        unit.fwd.append("struct %s;" % statics_base)
+        unit.decls.append(None)                          # placeholder, filled once the statics are known
+        hoist_slot = len(unit.decls) - 1
     # flatten nested types first (they become top-level structs declared BEFORE the outer one)
     keep = entry.get("keep")
     for m in node.members:
         if isinstance(m, ClassNode) and (keep is None or any(a <= m.line <= b for a, b in keep)):
-            emit_class(m, unit, all_nodes, known, static_scopes, collide_any, entry, outer=node)
+            emit_class(m, unit, all_nodes, known, static_scopes, collide_any, entry, outer=node, statics_base=statics_base)
     exclude = set(entry.get("exclude", []))
 
     def kept(m):
@@ -758,6 +795,8 @@ def emit_class(node, unit, all_nodes, known, static_scopes, collide_any, entry, 
             bases.append("public virtual " + b)
     if not node.extends or all(b in DROP_BASES for b in node.extends):
         bases.insert(0, "public virtual Object")
+    if statics_base:
+        bases.append("public " + statics_base)
     collide_here = all_nodes[name]["collide"]
     ctx = Ctx(name, collide_here, collide_any, known, static_scopes, os.path.basename(entry["file"]))
     is_iface = node.kind == "interface"
@@ -786,7 +825,12 @@ def emit_class(node, unit, all_nodes, known, static_scopes, collide_any, entry, 
                         s = s + "{}"
                 txt.append(tk.ws + s)
             static = m.static or is_iface
-            d.append("    %s%s%s  // :%d" % ("static inline " if static else "", cpp, "".join(txt), m.line))
+            const = static and cpp in PRIMS.values() and any(tk.t == "=" for tk in body)
+            line_ = "    %s%s%s  // :%d" % ("static constexpr " if const else "static inline " if static else "", cpp, "".join(txt), m.line)
+            if static and hoist is not None:
+                hoist.append(line_)
+            else:
+                d.append(line_)
         else:
             ptxt, pnames = cpp_params(m.params, known)
             if m.is_ctor:
@@ -823,6 +867,8 @@ def emit_class(node, unit, all_nodes, known, static_scopes, collide_any, entry, 
     if outer is None and entry.get("extra_members"):
         d.append(entry["extra_members"].rstrip("\n"))
     d.append("};")
+    if hoist is not None:
+        unit.decls[hoist_slot] = "struct %s {\n%s\n};\n" % (statics_base, "\n".join(hoist))
     unit.decls.append("\n".join(d) + "\n")
     if outer is None and entry.get("extra_defs"):
         unit.defs.append(entry["extra_defs"])
@@ -950,8 +996,9 @@ def main():
         collide_any |= inf["collide"]
     static_scopes = set(STATIC_SCOPES) | set(nodes.keys()) | {"AtomicLongFieldUpdater", "AtomicIntegerFieldUpdater"}
 
-    unit = Unit()
+    units = {}
     for e, node, payload in parsed:
+        unit = units.setdefault(e.get("unit", "ref"), Unit())
         if e["mode"] == "class":
             # lifted lambda bodies
             e["lift_done"] = []
@@ -1000,16 +1047,17 @@ def main():
 
     os.makedirs(args.out, exist_ok=True)
     banner = "// GENERATED by tools/make_ref.py from the reference's Java sources — do not edit, do not commit.\n"
-    with open(os.path.join(args.out, "ref_fwd.hpp"), "w") as f:
-        f.write(banner + "\n".join(dict.fromkeys(unit.fwd)) + "\n")
-    with open(os.path.join(args.out, "ref_decls.hpp"), "w") as f:
-        f.write(banner + "\n".join(unit.decls))
-    with open(os.path.join(args.out, "ref_defs.hpp"), "w") as f:
-        f.write(banner + "\n".join(unit.defs))
-    for cls, text in unit.incs.items():
-        with open(os.path.join(args.out, "%s.decls.inc" % cls), "w") as f:
-            f.write(banner + text)
-    print("make_ref: %d classes, %d definitions -> %s" % (len(unit.decls), len(unit.defs), args.out))
+    for uname, unit in units.items():
+        with open(os.path.join(args.out, "%s_fwd.hpp" % uname), "w") as f:
+            f.write(banner + "\n".join(dict.fromkeys(unit.fwd)) + "\n")
+        with open(os.path.join(args.out, "%s_decls.hpp" % uname), "w") as f:
+            f.write(banner + "\n".join(unit.decls))
+        with open(os.path.join(args.out, "%s_defs.hpp" % uname), "w") as f:
+            f.write(banner + "\n".join(unit.defs))
+        for cls, text in unit.incs.items():
+            with open(os.path.join(args.out, "%s.decls.inc" % cls), "w") as f:
+                f.write(banner + text)
+        print("make_ref: unit %s: %d classes, %d definitions -> %s" % (uname, len(unit.decls), len(unit.defs), args.out))
 
 
 if __name__ == "__main__":
