@@ -94,6 +94,8 @@ struct PendingCall { uint32_t gid; MsgType type; uint32_t epoch; int64_t epochAt
 static std::map<int32_t, PendingCall> pending[8][8];          // [requester][responder] by sequence
 static int32_t next_seq[8];
 static uint64_t wire_bytes = 0, wire_frames = 0;
+static std::vector<std::pair<int, int>> send_order;           // the network keeps the order the frames were written in
+static std::mt19937_64 chunk_rng(20240921);                   // piece sizes: their own stream, the simulation's draws stay as they are
 
 static std::string ctx_name(uint32_t groups, uint32_t gid) { return groups == 1 ? "root" : "ctx-" + std::to_string(gid); }
 static uint32_t g_groups = 1;
@@ -123,19 +125,21 @@ static void encode_msg(Msg &m)
     rw::encode_frame(f, false, conn[m.from][m.to].bytes);
     wire_bytes += conn[m.from][m.to].bytes.size() - before;
     wire_frames++;
+    send_order.emplace_back(m.from, m.to);
 }
 
 // one tick of the network: every connection delivers what was written to it, in arbitrary pieces
 static void deliver_frames(std::vector<Msg> &out)
 {
     const rw::FixedBodyCodec codec;
+    std::deque<std::pair<bool, Msg>> arrived[8][8];             // per connection, in order; false = decoded but dropped
     for (int from = 0; from < P; from++)
         for (int to = 0; to < P; to++) {
             Conn &c = conn[from][to];
             std::vector<rw::Frame> frames;
             size_t at = 0;
             while (at < c.bytes.size()) {
-                const size_t piece = std::min<size_t>(c.bytes.size() - at, 1 + rng() % 97);
+                const size_t piece = std::min<size_t>(c.bytes.size() - at, 1 + chunk_rng() % 97);
                 c.splitter.feed(reinterpret_cast<const uint8_t *>(c.bytes.data()) + at, piece, frames);
                 at += piece;
             }
@@ -143,30 +147,37 @@ static void deliver_frames(std::vector<Msg> &out)
             if (c.splitter.failed()) { fail("a frame stream was rejected by the splitter", 0); return; }
             for (const rw::Frame &f : frames) {
                 rw::Method method; std::string ctx;
-                if (!rw::parse_scope(f.head, method, ctx)) { fail("unknown scope on the wire", 0); continue; }
+                if (!rw::parse_scope(f.head, method, ctx)) { fail("unknown scope on the wire", 0); arrived[from][to].emplace_back(false, Msg{}); continue; }
                 Msg m; m.from = from; m.to = to; m.seq = f.sequence;
                 m.gid = g_groups == 1 ? 0u : (uint32_t)atoi(ctx.c_str() + 4);
                 if (f.type == rw::ENQ) {
                     rw::Request q;
-                    if (!codec.decode_request(method, f.body, q)) { fail("undecodable request body", m.gid); continue; }
+                    if (!codec.decode_request(method, f.body, q)) { fail("undecodable request body", m.gid); arrived[from][to].emplace_back(false, Msg{}); continue; }
                     m.type = method == rw::M_APPEND_ENTRIES ? AE : method == rw::M_PRE_VOTE ? PV : method == rw::M_REQUEST_VOTE ? RV : IS;
                     m.term = q.term; m.x = q.x; m.y = q.y; m.z = q.leader_commit;
                     for (size_t k = 0; k < q.entry_terms.size(); k++) m.entries.push_back(Entry{q.x + 1 + (int64_t)k, q.entry_terms[k]});
                 } else {
                     rw::Response r;
-                    if (!codec.decode_response(f.body, r)) { fail("undecodable response body", m.gid); continue; }
+                    if (!codec.decode_response(f.body, r)) { fail("undecodable response body", m.gid); arrived[from][to].emplace_back(false, Msg{}); continue; }
                     auto &tab = pending[to][from];                  // the requester is the node the response arrives at
                     auto it = tab.find(f.sequence);
-                    if (it == tab.end()) continue;                  // AsyncService: no invocation waiting under that sequence any more
+                    if (it == tab.end()) { arrived[from][to].emplace_back(false, Msg{}); continue; }   // AsyncService: no invocation waiting under that sequence
                     const PendingCall pc = it->second;
                     tab.erase(it);
                     m.type = pc.type == AE ? AE_RESP : pc.type == PV ? PV_RESP : pc.type == RV ? RV_RESP : IS_RESP;
                     m.term = r.term; m.success = r.success;
                     m.epoch = pc.epoch; m.epochAtSend = pc.epochAtSend; m.lastSent = pc.lastSent; m.sentTick = pc.sentTick;
                 }
-                out.push_back(std::move(m));
+                arrived[from][to].emplace_back(true, std::move(m));
             }
         }
+    for (auto &ft : send_order) {
+        auto &q = arrived[ft.first][ft.second];
+        if (q.empty()) { fail("a frame was lost between encoder and splitter", 0); continue; }
+        if (q.front().first) out.push_back(std::move(q.front().second));
+        q.pop_front();
+    }
+    send_order.clear();
 }
 
 static void send(Node &n, Msg m)

@@ -68,3 +68,15 @@ def test_the_product_binding_refuses_the_emulation_library(emulation_library):
     p = subprocess.run([sys.executable, "-c", "from rafting_amd import engine; engine.Table(4, 3)"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "test-only host emulation" in p.stderr
+
+
+def test_multi_device_manager_matches_a_single_table_on_the_emulation(emulation_library):
+    """rafting_amd/host/multi_device.cpp: three tables behind one routing manager, each drained by its own feeder thread, against one
+    table holding the same contexts under the same random traffic (rafting_amd/host/multi_device_unit.cpp) — on the host emulation"""
+    exe = os.path.join(ROOT, "build", "devemu_multi_device_unit")
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(host, "multi_device_unit.cpp"), os.path.join(host, "multi_device.cpp"), os.path.join(host, "raft_host.cpp"),
+                    os.path.join(host, "stable_store.cpp"), "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
+    p = subprocess.run([exe, "48", "3", "120"], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "multi-device ok=1" in p.stdout, p.stdout + p.stderr

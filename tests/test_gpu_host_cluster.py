@@ -53,3 +53,14 @@ def test_cluster_over_encoded_frames():
     framed = _run(16, 1200, 5, wire=True)
     assert framed[9] == 0 and framed[10] >= 15 and framed[1] >= 16
     assert framed == plain                          # the encoding is transparent: message for message the same simulation
+
+
+def test_multi_device_manager_matches_a_single_table():
+    """§8(e): contexts block-partitioned over several tables, one feeder thread per table (rafting_amd/host/multi_device.cpp), against
+    one table holding all of them — same random traffic, every outcome and every mirror identical. The test box has one GPU, so the
+    tables share device 0; on an 8-GPU node only the device ordinals differ. Unmeasured on N > 1 hardware."""
+    exe = os.path.join(ROOT, "build", "multi_device_unit")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rafting_amd", "host")], check=True)
+    p = subprocess.run([exe, "192", "4", "150"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "multi-device ok=1" in p.stdout, p.stdout + p.stderr
