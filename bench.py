@@ -167,7 +167,8 @@ def main():
             table.submit(hbs[k], houts[k])            # first calls size the staging buffers
         t1 = time.perf_counter()
         table.submit(hbs[0], houts[0])
-        pcie = workload.batch_stats(hbs[0], F)[0] / (time.perf_counter() - t1)
+        dt = time.perf_counter() - t1
+        pcie = workload.batch_stats(hbs[0], F)[0] / dt
         table.submit_async(hbs[2], houts[2]); table.submit_async(hbs[3], houts[3])      # sizes the pipeline's staging sets
         table.submit_wait(); table.submit_wait()
         moved = sum(sum(getattr(o, nm).nbytes for nm in names) for hb, ho in zip(hbs, houts)

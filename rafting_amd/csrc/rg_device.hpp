@@ -27,6 +27,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/raftgpu.h"
 
@@ -137,6 +138,27 @@ __device__ __forceinline__ void major_indices(int64_t (&m)[F], int64_t &full, in
     }
 }
 
+template <int F, class V>
+__device__ __forceinline__ void major_indices_v(V (&m)[F], V &full, V &major)
+{
+    if constexpr (sizeof(V) == 8) {
+        major_indices<F>(reinterpret_cast<int64_t (&)[F]>(m), reinterpret_cast<int64_t &>(full), reinterpret_cast<int64_t &>(major));
+    } else {                                                            // 32-bit: the ISA has integer min / max
+        auto cx = [](V &x, V &y) { const V lo = x < y ? x : y, hi = x < y ? y : x; x = lo; y = hi; };
+        if constexpr (F == 4) {
+            cx(m[0], m[1]); cx(m[2], m[3]); cx(m[0], m[2]); cx(m[1], m[3]);
+            full = m[0]; major = m[1] > m[2] ? m[1] : m[2];
+        } else {
+#pragma unroll
+            for (int x = 1; x < F; x++) {
+#pragma unroll
+                for (int y = x; y > 0; y--) cx(m[y - 1], m[y]);
+            }
+            full = m[0]; major = m[F / 2];
+        }
+    }
+}
+
 // Math.round(Math.log(Math.E + r)) as integer thresholds (member/Leadership.java:105).
 __device__ __forceinline__ int64_t rejection_step(int32_t r)
 {
@@ -148,6 +170,16 @@ __device__ __forceinline__ int64_t rejection_step(int32_t r)
     s += r >= 294267564; s += r >= 799902175;
     return s;
 }
+
+// The 32-bit tier. Raft terms and log indices are Java longs, but a group whose values all fit in 30 bits — every real
+// deployment for years — can be decided with 32-bit compares, selects and adds: half the VALU instructions of the 64-bit
+// forms (a 64-bit select is two v_cndmask, a 64-bit min/max a compare plus two, an add two). try_fast therefore exists in
+// two instantiations; the narrow one runs when EVERY lane of the wavefront has a narrow event and a narrow group (one
+// ballot), writes only the low words back (the high words are zero and stay zero: inputs below 2^30 plus increments below
+// 2^21 cannot reach 2^31), and is bit-for-bit the wide one on that domain — the differential tests run both.
+constexpr uint64_t NARROW_LIMIT = 1ull << 30;
+__device__ __forceinline__ bool is_narrow(int64_t v) { return (uint64_t)v < NARROW_LIMIT; }
+__device__ __forceinline__ int64_t with_lo(int64_t old, uint32_t lo) { return (int64_t)(((uint64_t)old & 0xFFFFFFFF00000000ull) | lo); }
 
 // effects of one row
 struct Fx {
@@ -188,6 +220,7 @@ struct Group {
     int32_t voted_for, leader, votes, role, rc;
     uint32_t role_epoch, elected_epoch, pending;
     bool td, prepared, log_dirty, peers_dirty;
+    bool narrow;                     // every 64-bit value of the group (and of its LDS follower columns) is in [0, NARROW_LIMIT): see try_fast
     static_assert(K == 4, "run cache is hand-unrolled for 4 runs");
 
     // NOTE on style: every method first copies the fields it needs into locals, computes with value
@@ -307,6 +340,7 @@ struct Stepper {
     Group &g;
     Peers<F> pe;
     Fx fx;
+    bool narrow_tier = true;             // false: this kernel never takes the 32-bit tier (a compile-time constant after inlining)
 
     __device__ __forceinline__ Stepper(const StepParams &p_, Group &g_, const Peers<F> &pe_) : p(p_), g(g_), pe(pe_) {}
 
@@ -733,15 +767,53 @@ struct Stepper {
 #ifdef RG_COUNT_SLOW
     uint32_t dbg_reason = 0u;
 #endif
-    // pe0 = the first carried entry term; entries_ok / same = entries_readable() / entries_same_term() of the row
+    // pe0 = the first carried entry term; entries_ok / same = entries_readable() / entries_same_term() of the row;
+    // ev_narrow = a, b, c, d, pe0 are all in [0, NARROW_LIMIT) (worked out where the event is loaded)
     __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
-                                             int64_t d, int64_t pe0, bool entries_ok, bool same)
+                                             int64_t d, int64_t pe0, bool entries_ok, bool same, bool ev_narrow)
     {
+#if defined(RG_EXP_ONLY_NARROW)      // analysis builds (tools/isa_stats.sh): one instantiation only, to count its instructions
+        (void)ev_narrow; return try_fast_v<int32_t>(allow, hdr, aux, (int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d, (int32_t)pe0, entries_ok, same);
+#elif defined(RG_EXP_ONLY_WIDE)
+        (void)ev_narrow; return try_fast_v<int64_t>(allow, hdr, aux, a, b, c, d, pe0, entries_ok, same);
+#endif
+        if (narrow_tier && __builtin_amdgcn_ballot_w64(!(ev_narrow & g.narrow)) == 0)       // wave-uniform: all 64 rows fit the 32-bit tier
+            return try_fast_v<int32_t>(allow, hdr, aux, (int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d, (int32_t)pe0, entries_ok, same);
+        const bool done = try_fast_v<int64_t>(allow, hdr, aux, a, b, c, d, pe0, entries_ok, same);
+        refresh_narrow();                                                    // 64-bit values went in: the group may have left the domain
+        return done;
+    }
+
+    // is every 64-bit value of the group (registers and LDS follower columns) in [0, NARROW_LIMIT)?
+    __device__ __forceinline__ void refresh_narrow()
+    {
+        if (!narrow_tier) return;
+        uint64_t w = (uint64_t)g.term | (uint64_t)g.commit | (uint64_t)g.epoch_index | (uint64_t)g.epoch_term | (uint64_t)g.first | (uint64_t)g.last |
+                     (uint64_t)g.elected_term | (uint64_t)g.s0 | (uint64_t)g.s1 | (uint64_t)g.s2 | (uint64_t)g.s3 | (uint64_t)g.t0 | (uint64_t)g.t1 |
+                     (uint64_t)g.t2 | (uint64_t)g.t3;
+        if (g.prepared) {
+#pragma unroll
+            for (int i = 0; i < F; i++) w |= (uint64_t)pe.last_epoch[i * BLOCK] | (uint64_t)pe.next_index[i * BLOCK] | (uint64_t)pe.match_index[i * BLOCK];
+        }
+        g.narrow = w < NARROW_LIMIT;
+    }
+
+    // V = int64_t: any values. V = int32_t: the narrow tier (see NARROW_LIMIT) — same statements, 32-bit arithmetic.
+    template <class V>
+    __device__ __forceinline__ bool try_fast_v(bool allow, uint32_t hdr, uint32_t aux, V a, V b, V c, V d, V pe0, bool entries_ok, bool same)
+    {
+        constexpr bool NARROW = sizeof(V) == 4;
+        auto vadd = [](V x, V y) -> V { typedef typename std::make_unsigned<V>::type U; return (V)((U)x + (U)y); };
+        auto vmin = [](V x, V y) -> V { return x < y ? x : y; };
+        auto keep = [](int64_t old, V v) -> int64_t { if constexpr (sizeof(V) == 4) return with_lo(old, (uint32_t)v); else return (int64_t)v; };
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
         const bool flag = RG_HDR_FLAG(hdr) != 0;
         const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
-        const int64_t g_term = g.term, g_last = g.last, g_commit = g.commit, g_epoch = g.epoch_index, g_first = g.first;
-        const int64_t lt = g.last_term(), g_s0 = g.s0, el_term = g.elected_term;
+        const V g_term = (V)g.term, g_last = (V)g.last, g_commit = (V)g.commit, g_epoch = (V)g.epoch_index, g_first = (V)g.first;
+        const V g_s0 = (V)g.s0, el_term = (V)g.elected_term;
+        const V q0 = (V)g.t0, q1 = (V)g.t1, q2 = (V)g.t2, q3 = (V)g.t3, b1 = (V)g.s1, b2 = (V)g.s2, b3 = (V)g.s3;
+        V lt = q0;                                                       // Group::last_term()
+        lt = g.rc > 1 ? q1 : lt; lt = g.rc > 2 ? q2 : lt; lt = g.rc > 3 ? q3 : lt;
         const int32_t rc = g.rc, role = g.role, g_leader = g.leader, g_votes = g.votes;
         const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
         const bool has_log = rc > 0, g_td = g.td, g_prep = g.prepared;
@@ -750,9 +822,9 @@ struct Stepper {
         // ---- AppendEntries request at a follower --------------------------------------------------
         const bool contains = c == lt;                                   // prevLogTerm == term of the tail
         const bool refresh = (a > g_term) | g_td;                        // switchTo(Follower, term, lastCandidate)
-        const int64_t ae_last = contains ? wadd(b, (int64_t)n) : g_last;
+        const V ae_last = contains ? vadd(b, (V)n) : g_last;
         const bool want_commit = contains & (d > g_epoch);
-        const int64_t ae_x = min64(d, ae_last);
+        const V ae_x = vmin(d, ae_last);
 #ifdef RG_EXP_NO_AE      // experiment build (tools/exp_class_split.sh): the instruction stream of a wavefront that never decides AppendEntries
         const bool fa = false;
 #else
@@ -774,24 +846,25 @@ struct Stepper {
         const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
 #endif
         const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
-        const int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
+        const V s_epoch = (V)pe.last_epoch[j * BLOCK], s_next = (V)pe.next_index[j * BLOCK], s_match = (V)pe.match_index[j * BLOCK];
         const int32_t s_rej = pe.rejection[j * BLOCK];
         const bool s_pend = ((g.pending >> j) & 1u) != 0;
         const bool adv = flag & (c > s_match);
-        const int64_t n_match = adv ? c : s_match;
-        const int64_t n_next = adv ? wadd(c, 1) : s_next;
-        int64_t m[F];
+        const V n_match = adv ? c : s_match;
+        const V n_next = adv ? vadd(c, 1) : s_next;
+        V m[F];
 #pragma unroll
         for (int i = 0; i < F; i++) {
-            const int64_t mi = pe.match_index[i * BLOCK];
+            const V mi = (V)pe.match_index[i * BLOCK];
             m[i] = ((uint32_t)i == j) ? n_match : mi;
         }
-        int64_t full, major;
-        major_indices<F>(m, full, major);
+        V full, major;
+        major_indices_v<F, V>(m, full, major);
         const bool lookup = flag & (major != 0);
         const bool major_ok = has_log & (major >= g_first) & (major <= g_last) & (major >= g_s0);   // present and cached
-        const int64_t mt = g.term_at(major);
-        const int64_t commit_to = lookup ? (mt == g_term ? major : full) : 0;
+        V mt = q0;                                                       // Group::term_at(major)
+        mt = ((rc > 1) & (b1 <= major)) ? q1 : mt; mt = ((rc > 2) & (b2 <= major)) ? q2 : mt; mt = ((rc > 3) & (b3 <= major)) ? q3 : mt;
+        const V commit_to = lookup ? (mt == g_term ? major : full) : (V)0;
         const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
         const bool fk = ack_shape & (aux == g_repoch) & (role == RG_LEADER) & g_prep & (a <= g_term) &
                         (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
@@ -815,7 +888,7 @@ struct Stepper {
         if (__builtin_amdgcn_ballot_w64(vr_shape) != 0) {                // wave-uniform: steady replication carries no vote replies
             const bool cur_epoch = aux == g_repoch;
             const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
-            const int64_t T = is_pv ? wadd(g_term, 1) : g_term;
+            const V T = is_pv ? vadd(g_term, 1) : g_term;
             count_only = vr_shape & cur_epoch & sender_ok & (a <= T) & (!flag | (g_votes + 1 < p.majority));
             const bool late = !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
             late_noop = vr_shape & late & (a <= el_term) &
@@ -834,16 +907,21 @@ struct Stepper {
 #endif
         if (fk) {
             pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
-            pe.next_index[j * BLOCK] = n_next;
-            pe.match_index[j * BLOCK] = n_match;
+            if constexpr (NARROW) {                       // the high words in LDS are zero already
+                reinterpret_cast<int32_t *>(&pe.next_index[j * BLOCK])[0] = n_next;
+                reinterpret_cast<int32_t *>(&pe.match_index[j * BLOCK])[0] = n_match;
+            } else {
+                pe.next_index[j * BLOCK] = n_next;
+                pe.match_index[j * BLOCK] = n_match;
+            }
         }
         if (ae_newrun | fc_newrun | fc_prepare) {          // rare: one wave-level branch for both
-            if (ae_newrun | fc_newrun) g.push(wadd(g_last, 1), ae_newrun ? pe0 : g_term);
+            if (ae_newrun | fc_newrun) g.push((int64_t)vadd(g_last, 1), (int64_t)(ae_newrun ? pe0 : g_term));
             if (fc_prepare) {                             // Leader.prepareReplication after the FIRST new entry
-                const int64_t next = wadd(g_last, 2);
+                const int64_t next = (int64_t)vadd(g_last, 2);
 #pragma unroll
                 for (int i = 0; i < F; i++) {
-                    pe.last_epoch[i * BLOCK] = g_epoch; pe.next_index[i * BLOCK] = next;
+                    pe.last_epoch[i * BLOCK] = (int64_t)g_epoch; pe.next_index[i * BLOCK] = next;
                     pe.match_index[i * BLOCK] = 0; pe.rejection[i * BLOCK] = 0;
                 }
                 g.pending = 0;
@@ -851,24 +929,121 @@ struct Stepper {
         }
         g.prepared = g_prep | fc_prepare;
         g.peers_dirty = g.peers_dirty | fk | fc_prepare;
-        g.term = ae_refresh ? a : g_term;
+        g.term = keep(g.term, ae_refresh ? a : g_term);
         g.role_epoch = g_repoch + (ae_refresh ? 1u : 0u);
         g.td = g_td & !ae_refresh;
         g.votes = ae_refresh ? 1 : (g_votes + ((count_only & flag) ? 1 : 0));
         g.leader = fa ? (int32_t)slot : g_leader;
-        g.last = ae_append ? ae_last : (fc ? wadd(g_last, (int64_t)n) : g.last);
+        {
+            const V cur_last = (V)g.last;                 // (a new run pushed above has already moved it)
+            g.last = keep(g.last, ae_append ? ae_last : (fc ? vadd(g_last, (V)n) : cur_last));
+        }
         g.log_dirty = g.log_dirty | ae_append | fc;
-        g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
+        g.commit = keep(g.commit, ae_commit ? ae_x : (ack_commit ? commit_to : g_commit));
         if (fast) {
             fx.status = (ack_drop | vote_drop) ? RG_DROPPED_STALE_ROLE : RG_OK;
-            fx.resp_term = a;                            // only read for AppendEntries: the request term (== currentTerm by now)
-            fx.log_from = wadd(g_last, 1);
+            fx.resp_term = (int64_t)a;                   // only read for AppendEntries: the request term (== currentTerm by now)
+            fx.log_from = (int64_t)vadd(g_last, 1);
             fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
                        (ae_refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) |
                        ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
                        (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
         }
         return fast;
+    }
+
+    // ---- tier 1.5: the rows that CHANGE A ROLE, with selects -----------------------------------------------------------
+    // Measured (tools/exp_profile2.sh, profiles/r02_cycle_breakdown.txt): at config 3 only ~0.9 % of the rows miss tier 1, but one such
+    // lane in 64 sends its whole wavefront through the general handlers — ~45 % of the wave-rounds, ~3 500 ticks each, more than a
+    // complete tier-1 round. Those rows are almost all of five shapes whose outcome is "a new participant": an election / heartbeat
+    // timeout (member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126), the vote reply that completes a majority or
+    // carries a higher term (Candidate.java:121-134, Follower.java:258-270), a replication response with a higher term
+    // (Leader.java:224-226), and RequestVote / PreVote at a Follower with a non-empty log (Follower.java:91-127). Under preconditions
+    // that make Membership.isBetter true (or the row a plain refusal) they are decided here in one pass of selects; everything
+    // else — assertion sites, empty logs, Candidate / Leader as voters, conflicts, hints — still goes to run(), the single source of
+    // truth. Only entered for lanes that missed tier 1 (one wave-level branch), so the fast path does not pay for it.
+    // MEASURED AND SWITCHED OFF (build with -DRG_TIER15 to get it back): functionally it takes 98.6 % of config 3's slow rows, but a
+    // slow-path visit usually has ONE active lane, for which the branchy general handlers cost no divergence — a visit came to
+    // ~1 150 ticks in here against ~1 500 in run(), and the larger loop body made every round slower: 0.1229 ms per launch against
+    // 0.1157 ms without it (gpurun_out r02i, profiles/r02_cycle_breakdown.txt).
+    __device__ __forceinline__ bool try_mid(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c)
+    {
+#ifndef RG_TIER15
+        (void)allow; (void)hdr; (void)aux; (void)a; (void)b; (void)c;
+        return false;
+#else
+        const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr);
+        const bool flag = RG_HDR_FLAG(hdr) != 0;
+        const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
+        const int64_t g_term = g.term, g_last = g.last, lt = g.last_term(), el_term = g.elected_term;
+        const int32_t role = g.role, g_votes = g.votes, g_voted = g.voted_for;
+        const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
+        const bool has_log = g.rc > 0, g_td = g.td, g_prep = g.prepared;
+        const bool peer_ok = (slot < P) & (slot != self);
+        const bool cur_epoch = aux == g_repoch;
+        const int64_t term1 = wadd(g_term, 1);
+
+        // (a) RG_EV_TIMEOUT of the live participant (aux 0 = whoever is current)
+        const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
+        const bool to_stale = to_kind & (aux != 0u) & !cur_epoch;                   // context/RaftRoutine.java:70
+        const bool to_live = to_kind & !to_stale;
+        const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);     // refresh + prepareElection
+        const bool bump_ok = term1 > g_term;                                         // currentTerm + 1 did not wrap (else: the general handlers)
+        const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & bump_ok;
+        const bool to_lead = to_live & (role == RG_LEADER);
+
+        // (b) vote replies that end a (pre-)election
+        const bool is_pv = kind == RG_EV_PV_REPLY;
+        const bool vr = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
+        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
+        const int64_t T = is_pv ? term1 : g_term;
+        const bool vr_cur = vr & cur_epoch & sender_ok & (bump_ok | !is_pv);
+        const bool vr_higher = vr_cur & (a > T);                                     // -> Follower(result.term, responder)
+        const bool vr_win = vr_cur & (a <= T) & flag & (g_votes + 1 >= p.majority);
+        const bool win_pre = vr_win & is_pv, win_rv = vr_win & !is_pv;
+        const bool vr_late = vr & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch) & (a > el_term);   // Q13: late higher-term reply
+        const bool late_conv = vr_late & (a >= g_term);                              // Follower is "better" from any role at >= term
+
+        // (c) a replication response with a higher term
+        const bool ack = allow & ((kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK)) & peer_ok & cur_epoch & (role == RG_LEADER) & g_prep & (a > g_term);
+
+        // (d) RequestVote / PreVote at a Follower that has a log
+        const bool vq = allow & ((kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ)) & (slot < P) & (role == RG_FOLLOWER) & has_log;
+        const bool pvq = vq & (kind == RG_EV_PV_REQ), rvq = vq & (kind == RG_EV_RV_REQ);
+        const bool utd = (c > lt) | ((c == lt) & (b >= g_last));                     // Follower.logUpToDate with a last entry
+        const bool pv_judge = pvq & (a > g_term) & g_td;                             // else failure(currentTerm), no timer touched
+        const bool rv_new = rvq & (a > g_term);                                      // else answered from the current membership
+        const bool rv_same = rvq & (a == g_term);
+
+        const bool mid = to_stale | to_pre | to_cand | to_lead | vr_higher | vr_win | vr_late | ack | vq;
+        // the conversion (RaftRoutine.convertTo + RaftMember.<init>), where one happens
+        const bool conv = to_pre | to_cand | vr_higher | vr_win | late_conv | ack | rv_new;
+        const int32_t new_role = (to_cand | win_pre) ? RG_CANDIDATE : (win_rv ? RG_LEADER : RG_FOLLOWER);
+        const int64_t new_term = to_pre ? g_term : (to_cand ? term1 : (vr_win ? T : a));
+        const int32_t new_vote = to_pre ? g_voted : ((to_cand | vr_win) ? (int32_t)self : (rv_new ? (utd ? (int32_t)slot : RG_NO_NODE) : (int32_t)slot));
+        if (to_lead & !g_prep) prepare_replication();                                // a new Leader's first tick (member/Leader.java:30-50)
+        g.elected_epoch = win_rv ? g_repoch : (vr_late ? 0u : el_epoch);             // Candidate.java:75-79 / head.abortRequests()
+        g.elected_term = win_rv ? g_term : el_term;
+        g.role = conv ? new_role : role;
+        g.term = conv ? new_term : g_term;
+        g.voted_for = conv ? new_vote : g_voted;
+        g.role_epoch = g_repoch + (conv ? 1u : 0u);
+        g.td = to_pre | (g_td & !conv);
+        g.leader = conv ? RG_NO_NODE : g.leader;
+        g.votes = conv ? 1 : g_votes;
+        g.prepared = (g.prepared & !conv);
+        if (mid) {
+            const uint32_t emit = to_pre ? RG_EMIT_PREVOTE : (((conv & (new_role == RG_CANDIDATE))) ? RG_EMIT_REQVOTE : (to_lead ? RG_EMIT_HEARTBEAT : RG_EMIT_NONE));
+            const bool replied = vq;
+            const bool success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
+            fx.status = to_stale ? RG_DROPPED_STALE_ROLE : RG_OK;
+            fx.resp_term = rv_new ? a : g_term;
+            fx.log_from = 0;
+            fx.flags = (conv ? (RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER) : 0u) | ((to_lead | pv_judge) ? RG_F_RESET_TIMER : 0u) |
+                       (emit << RG_F_EMIT_SHIFT) | (replied ? RG_F_REPLIED : 0u) | (success ? RG_F_SUCCESS : 0u);
+        }
+        return mid;
+#endif
     }
 
     // ---- one row (tier 2: the general handlers) ---------------------------------------------------

@@ -57,6 +57,12 @@ __device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row,
     t.e2 = *reinterpret_cast<const int64_t *>(base + o2); t.e3 = *reinterpret_cast<const int64_t *>(base + o3);
 }
 
+// every value the 32-bit tier reads from the event is in [0, NARROW_LIMIT)
+__device__ __forceinline__ bool event_narrow(int64_t a, int64_t b, int64_t c, int64_t d, int64_t e0)
+{
+    return ((uint64_t)a | (uint64_t)b | (uint64_t)c | (uint64_t)d | (uint64_t)e0) < NARROW_LIMIT;
+}
+
 // Group state: table -> registers (nine 16-byte coalesced loads), follower columns of a prepared leader -> LDS, and back.
 __device__ __forceinline__ void load_group(const DevTable &t, uint32_t gi, Group &g)
 {
@@ -153,6 +159,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     stage_peers<F>(p.t, gi, g, pe);
 
     Stepper<F> st(p, g, pe);
+    st.refresh_narrow();
     const bool FAST = p.fast_paths != 0;                 // RG_FAST=0 forces every row through the general handlers (tests)
     // decision counters: per-lane 32-bit tallies (no scalar registers tied up across the loop), reduced over the
     // wavefront once at the end
@@ -208,7 +215,8 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
                 st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
             } else {
                 const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
-                                              entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3));
+                                              entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
+                                              event_narrow(cur.a, cur.b, cur.c, cur.d, cur_t.e0));
 #ifdef RG_PROFILE_TIERS
                 tpa = __builtin_amdgcn_s_memtime();
 #endif
@@ -218,7 +226,11 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
                 dbg[6] += st.dbg_reason == 7u; dbg[7] += st.dbg_reason == 8u;
 #endif
 #ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
-                if (!done) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                if (!done) {
+                    if (!st.try_mid(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c))      // (compiled out unless -DRG_TIER15)
+                        st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                    st.refresh_narrow();                  // tier 1.5 and the general handlers work on 64-bit values
+                }
 #endif
 #ifdef RG_PROFILE_TIERS
                 tpb = __builtin_amdgcn_s_memtime();
@@ -315,9 +327,20 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     __shared__ int32_t sh_rej[F * BLOCK];
     __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
     __shared__ uint64_t sh_out[2][OUT_FIELDS][BLOCK];
+#ifdef RG_SPLIT_NARROW
+    __shared__ uint32_t sh_nar[2][BLOCK];                // event_narrow() of the row, worked out by the I/O wavefront
+#endif
 #ifdef RG_PROFILE
     __shared__ uint32_t sh_prof[4];
     uint32_t prof_read = 0, prof_decide = 0, prof_publish = 0;
+#endif
+#ifdef RG_PROFILE2      // experiment build (tools/cyc2.py): where the cycles of a round go, for both wavefronts; replaces six tallies
+    __shared__ uint32_t sh_prof2[8];
+    uint32_t pf_read = 0, pf_t1 = 0, pf_t2 = 0, pf_pub = 0, pf_bar = 0, pf_iobar = 0, pf_iowork = 0;
+#endif
+#ifdef RG_PROFILE3
+    __shared__ uint32_t sh_prof3[4][BLOCK];
+    uint32_t pv_visits = 0, pv_reads = 0, pv_mid = 0, pv_run = 0;
 #endif
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
@@ -338,6 +361,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
             sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0; sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
             sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
+#ifdef RG_SPLIT_NARROW
+            sh_nar[slot][lane] = event_narrow(e.a, e.b, e.c, e.d, t.e0) ? 1u : 0u;
+#endif
         };
         uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
         auto retire = [&](uint32_t r, uint32_t hdr) {      // outcome of round r: LDS -> global, plus the tallies
@@ -363,31 +389,62 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
         };
 
-        EventRow nxt{}, far{};           // rows r+1 (complete with its tail) and r+2 (landed by the top of round r)
-        EventTail nxt_t{};
+        // Five rows in flight. At the top of round r:  n1 = row r+1 and its tail (issued two rounds ago — what is published now),
+        // n2 = row r+2 (its tail was issued last round), n3 = row r+3 (issued two rounds ago: its header is what this round's tail
+        // loads are addressed by), n4 = row r+4 (issued last round). Every value is consumed TWO rounds after its load was issued,
+        // and the vm counter retires in order, so the wait in front of publish() only covers operations older than last round's:
+        // with one round of slack (the first version of this loop) the round could not be shorter than one memory round trip —
+        // measured 1.4 us, i.e. 0.09 ms per 64 rounds whatever the deciding wavefront did (profiles/r02_cycle_breakdown.txt).
+        EventRow n1{}, n2{}, n3{}, n4{};
+        EventTail t1{}, t2{};
         uint32_t hdr_cur, hdr_prev = 0u; // headers of rounds r and r-1 (the tallies need the kind of a retired row)
         {
             EventRow first{};
             EventTail first_t{};
             load_event(p, row_of(0), first);
-            load_event(p, row_of(1), nxt);
-            load_event(p, row_of(2), far);
+            load_event(p, row_of(1), n1);
+            load_event(p, row_of(2), n2);
+            load_event(p, row_of(3), n3);
+            load_event(p, row_of(4), n4);
             load_event_tail(p, row_of(0), first, first_t);
+            load_event_tail(p, row_of(1), n1, t1);
+            load_event_tail(p, row_of(2), n2, t2);
             publish(0u, first, first_t);
-            load_event_tail(p, row_of(1), nxt, nxt_t);
             hdr_cur = first.hdr;
         }
         lds_barrier();                                   // event 0 is visible
+#ifdef RG_PROFILE2
+        uint64_t ti_prev = __builtin_amdgcn_s_memtime();
+#endif
         for (uint32_t r = 0; r < p.rounds; r++) {
-            publish((r + 1u) & 1u, nxt, nxt_t);          // loads issued a full round ago
+            publish((r + 1u) & 1u, n1, t1);
             if (r > 0) retire(r - 1u, hdr_prev);
-            hdr_prev = hdr_cur; hdr_cur = nxt.hdr;
-            nxt = far;
-            load_event(p, row_of(r + 3u), far);
-            load_event_tail(p, row_of(r + 2u), nxt, nxt_t);
+            hdr_prev = hdr_cur; hdr_cur = n1.hdr;
+            n1 = n2; t1 = t2;
+            n2 = n3;
+            n3 = n4;
+            load_event_tail(p, row_of(r + 3u), n2, t2);
+            load_event(p, row_of(r + 5u), n4);
+#ifdef RG_PROFILE2
+            const uint64_t ti0 = __builtin_amdgcn_s_memtime();
+            pf_iowork += (uint32_t)(ti0 - ti_prev);
+#endif
             lds_barrier();
+#ifdef RG_PROFILE2
+            ti_prev = __builtin_amdgcn_s_memtime();
+            pf_iobar += (uint32_t)(ti_prev - ti0);
+#endif
         }
         retire(last_round, hdr_prev);
+#ifdef RG_PROFILE2
+        lds_barrier();
+        c_conv = sh_prof2[0]; c_commit = sh_prof2[1]; c_assert = sh_prof2[2]; c_need = sh_prof2[3]; c_stale = sh_prof2[4]; c_append = pf_iobar;
+        c_replied = pf_iowork;
+        if (lane != 0) { c_conv = 0; c_commit = 0; c_assert = 0; c_need = 0; c_stale = 0; c_append = 0; c_replied = 0; }
+#ifdef RG_PROFILE3
+        c_conv = sh_prof3[0][lane]; c_commit = sh_prof3[1][lane]; c_assert = sh_prof3[2][lane]; c_need = sh_prof3[3][lane];
+#endif
+#endif
 #ifdef RG_PROFILE   // experiment build: the deciding wavefront's cycle sums (LDS-read wait / decide / publish+barrier) replace three tallies
         lds_barrier();
         c_need = sh_prof[0]; c_stale = sh_prof[1]; c_append = sh_prof[2];
@@ -420,6 +477,13 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
     stage_peers<F>(p.t, gi, g, pe);
     Stepper<F> st(p, g, pe);
+#ifndef RG_SPLIT_NARROW
+    // measured (profiles/r02_*): with one deciding wavefront per SIMD the round is a dependent chain, and the 32-bit tier's
+    // entry test (an LDS read, a ballot, a branch) sits at its head: 0.120 ms against 0.112 ms per launch at 65 536 groups.
+    // The single-wavefront kernel (two or more deciding wavefronts per SIMD) gains from it (0.204 -> 0.198 ms at 131 072).
+    st.narrow_tier = false;
+#endif
+    st.refresh_narrow();
     const bool FAST = p.fast_paths != 0;
     bool blocked = false;
     lds_barrier();                                       // event 0 is visible
@@ -430,6 +494,17 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
                       c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
         const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
+#ifdef RG_SPLIT_NARROW
+        const bool ev_narrow = sh_nar[slot][lane] != 0u;
+#else
+        const bool ev_narrow = false;
+#endif
+#ifdef RG_PROFILE2
+        const uint64_t tz0 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const uint64_t tz1 = __builtin_amdgcn_s_memtime();
+        uint64_t tz2 = tz1;
+#endif
 #ifdef RG_PROFILE
         const uint64_t tq0 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -438,13 +513,27 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const uint32_t kind = RG_HDR_KIND(hdr);
         if (blocked && kind != RG_EV_NONE) {
             st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0)) {
+        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow)) {
+#ifdef RG_PROFILE2
+            tz2 = __builtin_amdgcn_s_memtime();
+#endif
             // the general handlers also want the hint and the other prefetched entry terms: read only here
             const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
             const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
                           e3 = (int64_t)sh_ev[slot][EV_E3][lane];
 #ifndef RG_TIER1_ONLY
-            st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+#ifdef RG_PROFILE3      // experiment build: inside a slow-path visit — LDS reads / tier 1.5 / general handlers (lanes that took the visit only)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const uint64_t ty0 = __builtin_amdgcn_s_memtime();
+            const bool mid_done = st.try_mid(FAST, hdr, aux, a, b, c);
+            const uint64_t ty1 = __builtin_amdgcn_s_memtime();
+            if (!mid_done) st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+            const uint64_t ty2 = __builtin_amdgcn_s_memtime();
+            pv_visits += 1u; pv_reads += (uint32_t)(ty0 - tz2); pv_mid += (uint32_t)(ty1 - ty0); pv_run += (uint32_t)(ty2 - ty1);
+#else
+            if (!st.try_mid(FAST, hdr, aux, a, b, c)) st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+#endif
+            st.refresh_narrow();                         // tier 1.5 and the general handlers work on 64-bit values
 #else
             (void)hx; (void)hy; (void)e1; (void)e2; (void)e3;
 #endif
@@ -452,6 +541,10 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const uint32_t status = st.fx.status, flags = st.fx.flags;
 #ifdef RG_PROFILE
         const uint64_t tq2 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef RG_PROFILE2
+        const uint64_t tz3 = __builtin_amdgcn_s_memtime();
+        if (__builtin_amdgcn_ballot_w64(tz2 != tz1) == 0) tz2 = tz3;      // no lane went to the general handlers: all of it was tier 1
 #endif
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
@@ -461,7 +554,15 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         sh_out[slot][OUT_FROM][lane] = (uint64_t)st.fx.log_from;
         sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
         sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
+#ifdef RG_PROFILE2
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const uint64_t tz4 = __builtin_amdgcn_s_memtime();
+#endif
         lds_barrier();
+#ifdef RG_PROFILE2
+        const uint64_t tz5 = __builtin_amdgcn_s_memtime();
+        pf_read += (uint32_t)(tz1 - tz0); pf_t1 += (uint32_t)(tz2 - tz1); pf_t2 += (uint32_t)(tz3 - tz2); pf_pub += (uint32_t)(tz4 - tz3); pf_bar += (uint32_t)(tz5 - tz4);
+#endif
 #ifdef RG_PROFILE
         const uint64_t tq3 = __builtin_amdgcn_s_memtime();
         prof_read += (uint32_t)(tq1 - tq0); prof_decide += (uint32_t)(tq2 - tq1); prof_publish += (uint32_t)(tq3 - tq2);
@@ -469,6 +570,13 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     }
 #ifdef RG_PROFILE
     if (lane == 0) { sh_prof[0] = prof_read; sh_prof[1] = prof_decide; sh_prof[2] = prof_publish; }
+    lds_barrier();
+#endif
+#ifdef RG_PROFILE3      // per-lane sums: the lane that took the visit measured it
+    sh_prof3[0][lane] = pv_visits; sh_prof3[1][lane] = pv_reads; sh_prof3[2][lane] = pv_mid; sh_prof3[3][lane] = pv_run;
+#endif
+#ifdef RG_PROFILE2
+    if (lane == 0) { sh_prof2[0] = pf_read; sh_prof2[1] = pf_t1; sh_prof2[2] = pf_t2; sh_prof2[3] = pf_pub; sh_prof2[4] = pf_bar; }
     lds_barrier();
 #endif
     if (active) store_group<F>(p.t, gi, G, g, pe);

@@ -32,6 +32,19 @@ void encode(unsigned char *out, const StableStore::Record &r, uint32_t seq)
     memcpy(out + 20, &c, 4);
 }
 
+// A new or renamed directory entry is durable only once the DIRECTORY has been synced: fdatasync on the file does not cover it.
+void sync_parent_dir(const std::string &path)
+{
+    const size_t slash = path.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? "." : (slash == 0 ? "/" : path.substr(0, slash));
+    const int dfd = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY);
+    if (dfd < 0) throw std::runtime_error("StableStore open dir " + dir + ": " + strerror(errno));
+    const int rc = ::fsync(dfd);
+    const int err = errno;
+    ::close(dfd);
+    if (rc != 0) throw std::runtime_error("StableStore fsync dir " + dir + ": " + strerror(err));
+}
+
 void write_all(int fd, const unsigned char *p, size_t n)
 {
     while (n) {
@@ -57,6 +70,7 @@ void StableStore::replay()
     if (size == 0) {
         write_all(fd_, (const unsigned char *)MAGIC, sizeof MAGIC);
         if (::fdatasync(fd_) != 0) throw std::runtime_error("StableStore fdatasync");
+        sync_parent_dir(path_);                             // the file's name must survive a crash too
         return;
     }
     std::vector<unsigned char> buf((size_t)size);
@@ -81,12 +95,21 @@ void StableStore::persist(const std::vector<Record> &batch)
 {
     if (batch.empty()) return;
     std::vector<unsigned char> buf(batch.size() * REC);
-    for (size_t i = 0; i < batch.size(); i++) {
-        encode(buf.data() + i * REC, batch[i], ++seq_);
-        latest_[batch[i].gid] = batch[i];
+    uint32_t seq = seq_;
+    for (size_t i = 0; i < batch.size(); i++) encode(buf.data() + i * REC, batch[i], ++seq);
+    const off_t start = ::lseek(fd_, 0, SEEK_CUR);
+    try {
+        write_all(fd_, buf.data(), buf.size());
+        if (::fdatasync(fd_) != 0) throw std::runtime_error(std::string("StableStore fdatasync: ") + strerror(errno));
+    } catch (...) {
+        // nothing of a failed batch may be seen later: cut the file back to where the batch began (a partial record would
+        // otherwise sit in FRONT of the next successful batch and make replay() stop there), and leave latest_/seq_ alone so
+        // that restore() keeps answering with what IS durable
+        if (start >= 0 && ::ftruncate(fd_, start) == 0) ::lseek(fd_, start, SEEK_SET);
+        throw;
     }
-    write_all(fd_, buf.data(), buf.size());
-    if (::fdatasync(fd_) != 0) throw std::runtime_error(std::string("StableStore fdatasync: ") + strerror(errno));
+    seq_ = seq;                                              // the memory image moves only after the bytes are durable
+    for (const Record &r : batch) latest_[r.gid] = r;
     syncs_++;
     records_ += batch.size();
 }
@@ -112,6 +135,7 @@ void StableStore::compact()
     for (const auto &kv : latest_) encode(buf.data() + sizeof MAGIC + (i++) * REC, kv.second, ++seq);
     write_all(fd, buf.data(), buf.size());
     if (::fdatasync(fd) != 0 || ::rename(tmp.c_str(), path_.c_str()) != 0) { ::close(fd); throw std::runtime_error("StableStore compact"); }
+    sync_parent_dir(path_);                                  // make the rename itself durable before the old file's fd goes away
     ::close(fd_);
     fd_ = fd;
     seq_ = seq;
