@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=6, help="batches of the stream the CPU baseline replays")
     ap.add_argument("--copy-bw", action="store_true", help="also measure a plain HBM copy kernel")
+    ap.add_argument("--pcie-batches", type=int, default=12, help="host-memory legs: batches per leg (the first two size the staging buffers)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
     ap.add_argument("--dist-backend", default="gloo", help="how the three result scalars are added up: gloo (default, host sum — the "
                     "data path has no collective) or nccl (= RCCL)")
@@ -146,43 +147,79 @@ def main():
     copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
 
     # ---- the same step with caller-owned HOST buffers (PCIe both ways): reported, never `value` -----------------------------
-    # serial: one rg_submit(RG_MEM_HOST) = H2D, kernel, D2H back to back.  pipelined: rg_submit_async, RG_PIPELINE_DEPTH batches in
-    # flight, the upload of batch k+1 overlapping the kernel and the download of batch k (full-duplex link).
-    pcie = pcie_pipe = pcie_gbps = None
+    # Three ways over the link, each from the same table state with the same FRESH batches of the stream (B0, B1 size the staging
+    # buffers, the rest are timed):  serial = rg_submit(RG_MEM_HOST), H2D -> kernel -> D2H back to back;  pipelined = rg_submit_async,
+    # RG_PIPELINE_DEPTH batches in flight (upload of k+1 over kernel + download of k);  packed = rg_submit_async_packed, the same
+    # pipeline with int32 event fields up and packed logfx / persist lists down. The packed replies must equal the wide ones.
+    pcie = pcie_pipe = pcie_packed = pcie_gbps = packed_gbps = None
+    pcie_bytes = {}
     if rank == 0 and world == 1 and not args.no_pcie:
-        nb_h = 4
-        hbs, houts, owners = [], [], []
-        for k in range(nb_h):
-            hb = gen.next_batch(args.rounds)
+        nb_h, n_size = args.pcie_batches, 2
+        gen_p = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)      # the stream again, from its first round
+        st_p = st0
+        hbs = [gen_p.next_batch(args.rounds) for _ in range(nb_h)]
+        timed = hbs[n_size:]
+        dec_timed = sum(workload.batch_stats(hb, F)[0] for hb in timed)
+        houts, owners = [], []
+        for hb in hbs:
             hout = abi.Outcome(hb.rounds * hb.count)
             hb.entry_terms = np.ascontiguousarray(hb.entry_terms[:max(hb.entry_count, 1)])
+            houts.append(hout)
+        plain = [(np.array(hb.head), np.array(hb.ab), np.array(hb.cd), np.array(hb.entry_terms)) for hb in hbs]   # pageable originals
+        for hb, hout in zip(hbs, houts):
             for obj, names in ((hb, ("head", "ab", "cd", "entry_terms")), (hout, ("reply", "logfx", "persist"))):
                 for nm in names:                      # page-locked caller buffers (rg_host_alloc), as a JNI host would use
                     view, own = engine.pinned_like(table, getattr(obj, nm))
                     setattr(obj, nm, view)
                     owners.append(own)
-            hbs.append(hb)
-            houts.append(hout)
-        for k in range(2):
+        table.load_state(st_p)
+        for k in range(n_size):
             table.submit(hbs[k], houts[k])            # first calls size the staging buffers
         t1 = time.perf_counter()
-        table.submit(hbs[0], houts[0])
+        table.submit(hbs[n_size], houts[n_size])
         dt = time.perf_counter() - t1
-        pcie = workload.batch_stats(hbs[0], F)[0] / dt
-        table.submit_async(hbs[2], houts[2]); table.submit_async(hbs[3], houts[3])      # sizes the pipeline's staging sets
-        table.submit_wait(); table.submit_wait()
-        moved = sum(sum(getattr(o, nm).nbytes for nm in names) for hb, ho in zip(hbs, houts)
+        pcie = workload.batch_stats(hbs[n_size], F)[0] / dt
+        table.load_state(st_p)
+        for k in range(n_size):
+            table.submit_async(hbs[k], houts[k])      # sizes the pipeline's staging sets
+        for k in range(n_size):
+            table.submit_wait()
+        moved = sum(sum(getattr(o, nm).nbytes for nm in names) for hb, ho in zip(timed, houts[n_size:])
                     for o, names in ((hb, ("head", "ab", "cd", "entry_terms")), (ho, ("reply", "logfx", "persist"))))
         t1 = time.perf_counter()
-        for k in range(nb_h):
+        for k in range(n_size, nb_h):
             table.submit_async(hbs[k], houts[k])
-        for k in range(nb_h):
+        for k in range(n_size, nb_h):
             table.submit_wait()
         dt = time.perf_counter() - t1
-        pcie_pipe = sum(workload.batch_stats(hb, F)[0] for hb in hbs) / dt
+        pcie_pipe = dec_timed / dt
         pcie_gbps = moved / dt / 1e9
+        pcie_bytes["wide_bytes_per_decision"] = moved / dec_timed
+        wide_last = np.array(houts[-1].reply)
         for own in owners:
             own.free()
+        for hb, (h_, ab_, cd_, et_) in zip(hbs, plain):
+            hb.head, hb.ab, hb.cd, hb.entry_terms = h_, ab_, cd_, et_
+        pbs = [engine.PackedBatch(table, hb) for hb in hbs]
+        table.load_state(st_p)
+        for k in range(n_size):
+            table.submit_async_packed(pbs[k])
+        for k in range(n_size):
+            table.submit_wait()
+        t1 = time.perf_counter()
+        for k in range(n_size, nb_h):
+            table.submit_async_packed(pbs[k])
+        for k in range(n_size, nb_h):
+            table.submit_wait()
+        dt = time.perf_counter() - t1
+        pcie_packed = dec_timed / dt
+        moved_p = sum(pb.bytes_up + pb.bytes_down for pb in pbs[n_size:])
+        packed_gbps = moved_p / dt / 1e9
+        pcie_bytes["packed_bytes_per_decision"] = moved_p / dec_timed
+        if not np.array_equal(pbs[-1].reply, wide_last):
+            raise SystemExit("bench: the packed pipeline's replies differ from the wide pipeline's on the same batches")
+        for pb in pbs:
+            pb.free()
 
     # ---- CPU baseline + result check on the same stream (rank 0, N=1) ------------------------------
     cpu = None
@@ -270,10 +307,14 @@ def main():
                 "measured_copy_gbps": copy_gbps,
             },
             "cpu_baseline": cpu,
-            "pcie_inclusive_value": pcie_pipe if pcie_pipe is not None else pcie,
-            "pcie_inclusive": {"serial_rg_submit": pcie, "pipelined_rg_submit_async": pcie_pipe, "link_gbytes_per_s_both_ways": pcie_gbps,
-                               "note": "decisions/s with caller-owned page-locked host buffers, H2D + D2H included; repeated rounds of "
-                                       "the stream (their decisions are not 'fresh'): a transport figure, never `value`"},
+            "pcie_inclusive_value": pcie_packed if pcie_packed is not None else (pcie_pipe if pcie_pipe is not None else pcie),
+            "pcie_inclusive": {"serial_rg_submit": pcie, "pipelined_rg_submit_async": pcie_pipe, "pipelined_rg_submit_async_packed": pcie_packed,
+                               "link_gbytes_per_s_both_ways": {"wide": pcie_gbps, "packed": packed_gbps}, **pcie_bytes,
+                               "timed_batches": None if pcie is None else args.pcie_batches - 2,
+                               "note": "decisions/s with caller-owned page-locked host buffers, H2D + D2H included, fresh batches of the "
+                                       "stream from one table state for all three legs; pcie_inclusive_value = the packed pipeline "
+                                       "(int32 event fields up, packed logfx / persist lists down, replies checked equal to the wide "
+                                       "pipeline's): a transport figure, never `value`"},
             "counters": dict(zip(["rows", "replied", "role_conversions", "commit_advances", "asserts", "need_host",
                                   "dropped_stale", "log_appends"], counters)),
             "stage_seconds": t_gen,

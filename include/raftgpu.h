@@ -57,7 +57,7 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async, 48-byte rg_send_head_t */
+#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -292,6 +292,39 @@ int rg_sync(rg_table_t *t);
 #define RG_PIPELINE_DEPTH 2
 int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out);
 int rg_submit_wait(rg_table_t *t);
+
+/* The same pipeline with COMPACT transfer formats: the link, not the kernel, bounds the host-memory path, so what
+ * crosses it is cut to what carries information.
+ *   upload    rg_batch32_t: a, b, c, d and the entry terms as int32 (16 + 4n bytes per row instead of 32 + 8n). Legal only while every
+ *             one of those values is in [0, 2^31) — raft terms and log indices of any deployment younger than 2^31 entries; a host that
+ *             meets a larger value submits that batch through rg_submit_async instead (the two may be mixed freely). Values are
+ *             widened on the device before the step kernel runs: the decisions are the 64-bit ones, bit for bit. No hint column (hints
+ *             answer RG_NEED_HOST rows, which are rare: use the wide format for those batches).
+ *   download  rg_outcome_packed_t: reply stays one row per event; logfx and persist come back PACKED, in row order, one item per row whose
+ *             reply says it has one —  logfx:   flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC), or status RG_NEED_HOST
+ *                                      persist: flags & RG_F_PERSIST
+ *             so a host that walks reply[0 .. rows) takes the next item of a list whenever a row carries the mark. counts[0] / counts[1] =
+ *             items produced (logfx / persist); items beyond the capacity given are dropped, counts still say how many there were.
+ *             reply, logfx, persist and counts MUST be page-locked (rg_host_alloc): the lists are written by the device straight into
+ *             them (their length is not known when the copy would have to be queued). -1 with a message otherwise.
+ * Everything else — depth, ordering, rg_submit_wait — is as for rg_submit_async. */
+typedef struct { int32_t a, b, c, d; } rg_ev_quad32_t;            /* 16 B */
+typedef struct {
+    uint32_t              rounds, count;  /* as rg_batch_t */
+    const uint32_t       *gid;            /* as rg_batch_t */
+    const rg_ev_head_t   *head;           /* [rounds*count] */
+    const rg_ev_quad32_t *abcd;           /* [rounds*count] */
+    const int32_t        *entry_terms;    /* [entry_count], addressed by head.aux */
+    uint64_t              entry_count;
+} rg_batch32_t;
+typedef struct {
+    rg_reply_t   *reply;                  /* [rounds*count] */
+    rg_logfx_t   *logfx;                  /* [logfx_cap] packed */
+    rg_persist_t *persist;                /* [persist_cap] packed */
+    uint32_t     *counts;                 /* [2] */
+    uint32_t      logfx_cap, persist_cap;
+} rg_outcome_packed_t;
+int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
  * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel" */
 const char *rg_step_kernel(rg_table_t *t, uint32_t count);

@@ -96,6 +96,16 @@ class COutcome(C.Structure):
     _fields_ = [("reply", C.c_void_p), ("logfx", C.c_void_p), ("persist", C.c_void_p)]
 
 
+class CBatch32(C.Structure):           # rg_batch32_t
+    _fields_ = [("rounds", C.c_uint32), ("count", C.c_uint32), ("gid", C.c_void_p), ("head", C.c_void_p), ("abcd", C.c_void_p),
+                ("entry_terms", C.c_void_p), ("entry_count", C.c_uint64)]
+
+
+class COutcomePacked(C.Structure):     # rg_outcome_packed_t
+    _fields_ = [("reply", C.c_void_p), ("logfx", C.c_void_p), ("persist", C.c_void_p), ("counts", C.c_void_p),
+                ("logfx_cap", C.c_uint32), ("persist_cap", C.c_uint32)]
+
+
 _STATE_FIELDS = [
     ("current_term", np.int64, 1),
     ("voted_for", np.int32, 1),
@@ -223,6 +233,26 @@ class Batch:
         b.entry_count = self.entry_count
         b.hint = _ptr(self.hint)
         return b
+
+
+QUAD32_DT = np.dtype([("a", np.int32), ("b", np.int32), ("c", np.int32), ("d", np.int32)])
+NARROW_EVENT_LIMIT = 1 << 31
+
+
+def batch_fits_32(batch):
+    """every a, b, c, d and entry term of the batch is in [0, 2^31): the batch may travel as an rg_batch32_t"""
+    cols = [batch.ab["x"], batch.ab["y"], batch.cd["x"], batch.cd["y"], batch.entry_terms[: batch.entry_count]]
+    return batch.hint is None and all(len(c) == 0 or (int(c.min()) >= 0 and int(c.max()) < NARROW_EVENT_LIMIT) for c in cols)
+
+
+def has_logfx(flags):
+    """rows whose reply says a logfx item exists (include/raftgpu.h rg_logfx_t)"""
+    flags = np.asarray(flags)
+    return ((flags & (F_COMMIT | F_LOG_APPEND | F_LOG_TRUNC)) != 0) | (flags_status(flags) == NEED_HOST)
+
+
+def has_persist(flags):
+    return (np.asarray(flags) & F_PERSIST) != 0
 
 
 class Outcome:

@@ -27,6 +27,10 @@ hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
+hipError_t launch_widen(const void *abcd32, I64x2 *ab, I64x2 *cd, uint32_t rows, const int32_t *terms32, int64_t *terms, uint64_t nterms, hipStream_t s);
+hipError_t launch_outcome_count(const rg_reply_t *reply, uint32_t rows, uint32_t *counts, uint32_t *totals, hipStream_t s);
+hipError_t launch_outcome_emit(const rg_reply_t *reply, const I64x2 *logfx, const rg_persist_t *persist, uint32_t rows, const uint32_t *counts,
+                               I64x2 *out_logfx, uint32_t cap_logfx, rg_persist_t *out_persist, uint32_t cap_persist, hipStream_t s);
 }  // namespace rg
 
 using rg::DevTable;
@@ -39,6 +43,7 @@ struct Staging {
 
 struct PipeSlot {                               // one batch in flight on the pipelined host-memory path (rg_submit_async)
     Staging gid, head, ab, cd, hint, terms, reply, logfx, persist;
+    Staging abcd32, terms32, counts;            // rg_submit_async_packed: narrow uploads, per-wavefront list counts
     hipEvent_t up = nullptr, done = nullptr, down = nullptr;
 };
 
@@ -156,7 +161,8 @@ int rg_table_destroy(rg_table_t *t)
     for (void *c : cols) if (c) (void)hipFree(c);
     for (PipeSlot &sl : t->pipe) {
         if (sl.down) (void)hipEventSynchronize(sl.down);
-        for (Staging *st : {&sl.gid, &sl.head, &sl.ab, &sl.cd, &sl.hint, &sl.terms, &sl.reply, &sl.logfx, &sl.persist}) if (st->ptr) (void)hipFree(st->ptr);
+        for (Staging *st : {&sl.gid, &sl.head, &sl.ab, &sl.cd, &sl.hint, &sl.terms, &sl.reply, &sl.logfx, &sl.persist, &sl.abcd32, &sl.terms32, &sl.counts})
+            if (st->ptr) (void)hipFree(st->ptr);
         for (hipEvent_t ev : {sl.up, sl.done, sl.down}) if (ev) (void)hipEventDestroy(ev);
     }
     if (t->s_in) (void)hipStreamDestroy(t->s_in);
@@ -461,6 +467,8 @@ static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
     return p;
 }
 
+static int pipeline_ready(rg_table *t);
+
 /* the pipelined host-memory path: see include/raftgpu.h */
 int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out)
 {
@@ -468,15 +476,7 @@ int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out
     if (int rc = check_batch(t, in, out, true)) return rc;
     if (in->count == 0) return 0;
     if (bind(t, false)) return -2;
-    if (!t->s_in) {
-        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_in, hipStreamNonBlocking));
-        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_out, hipStreamNonBlocking));
-        for (PipeSlot &sl : t->pipe) {
-            HIP_TRY(t, hipEventCreate(&sl.up)); HIP_TRY(t, hipEventCreate(&sl.done)); HIP_TRY(t, hipEventCreate(&sl.down));
-        }
-    }
-    if (t->pipe_head - t->pipe_tail == RG_PIPELINE_DEPTH)
-        if (int rc = wait_oldest(t); rc < 0) return rc;
+    if (int rc = pipeline_ready(t)) return rc;
     PipeSlot &sl = t->pipe[t->pipe_head % RG_PIPELINE_DEPTH];
     const bool sparse = in->gid != nullptr;
     const size_t rows = (size_t)in->rounds * in->count;
@@ -513,6 +513,89 @@ int rg_submit_async(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out
     HIP_TRY(t, hipMemcpyAsync(out->reply, sl.reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, so));
     HIP_TRY(t, hipMemcpyAsync(out->logfx, sl.logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, so));
     HIP_TRY(t, hipMemcpyAsync(out->persist, sl.persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, so));
+    HIP_TRY(t, hipEventRecord(sl.down, so));
+    t->pipe_head += 1;
+    return 0;
+}
+
+static int pipeline_ready(rg_table *t)
+{
+    if (!t->s_in) {
+        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_in, hipStreamNonBlocking));
+        HIP_TRY(t, hipStreamCreateWithFlags(&t->s_out, hipStreamNonBlocking));
+        for (PipeSlot &sl : t->pipe) {
+            HIP_TRY(t, hipEventCreate(&sl.up)); HIP_TRY(t, hipEventCreate(&sl.done)); HIP_TRY(t, hipEventCreate(&sl.down));
+        }
+    }
+    if (t->pipe_head - t->pipe_tail == RG_PIPELINE_DEPTH)
+        if (int rc = wait_oldest(t); rc < 0) return rc;
+    return 0;
+}
+
+/* the pipelined host-memory path with compact transfer formats: see include/raftgpu.h */
+int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out)
+{
+    if (!t) return -1;
+    if (!in || !out) return fail(t, -1, "rg_submit_async_packed: null batch or outcome");
+    if (!in->head || !in->abcd || !out->reply || !out->counts || (out->logfx_cap && !out->logfx) || (out->persist_cap && !out->persist))
+        return fail(t, -1, "rg_submit_async_packed: head, abcd, reply, counts and every list with a capacity are required");
+    if (in->entry_count && !in->entry_terms) return fail(t, -1, "rg_submit_async_packed: entry_count %llu without entry_terms", (unsigned long long)in->entry_count);
+    rg_batch_t wide{};                              // the same shape rules as every other submission (rounds, count, gid list, entry bound)
+    wide.rounds = in->rounds; wide.count = in->count; wide.gid = in->gid; wide.head = in->head;
+    wide.ab = wide.cd = reinterpret_cast<const rg_ev_pair_t *>(in->abcd);      // presence only: check_batch does not read event fields
+    wide.entry_terms = reinterpret_cast<const int64_t *>(in->entry_terms); wide.entry_count = in->entry_count;
+    rg_logfx_t dummy_l; rg_persist_t dummy_p;
+    const rg_outcome_t shape{out->reply, &dummy_l, &dummy_p};
+    if (int rc = check_batch(t, &wide, &shape, true)) return rc;
+    if (in->count == 0) { out->counts[0] = out->counts[1] = 0; return 0; }
+    const size_t rows64 = (size_t)in->rounds * in->count;
+    if (rows64 >= (1ull << 31)) return fail(t, -1, "rg_submit_async_packed: %zu rows in one batch (limit 2^31 - 1)", rows64);
+    if (bind(t, false)) return -2;
+    // the lists are written by the device into the caller's memory: it has to be page-locked and mapped
+    void *d_logfx = nullptr, *d_persist = nullptr, *d_counts = nullptr;
+    if (hipHostGetDevicePointer(&d_counts, out->counts, 0) != hipSuccess ||
+        (out->logfx_cap && hipHostGetDevicePointer(&d_logfx, out->logfx, 0) != hipSuccess) ||
+        (out->persist_cap && hipHostGetDevicePointer(&d_persist, out->persist, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        return fail(t, -1, "rg_submit_async_packed: counts / logfx / persist must be page-locked memory from rg_host_alloc");
+    }
+    if (int rc = pipeline_ready(t)) return rc;
+    PipeSlot &sl = t->pipe[t->pipe_head % RG_PIPELINE_DEPTH];
+    const bool sparse = in->gid != nullptr;
+    const uint32_t rows = (uint32_t)rows64, waves = (rows + 63u) / 64u;
+    rg::StepParams p = step_params(t, &wide);
+    if (reserve(t, sl.head, rows64 * sizeof(rg_ev_head_t)) || reserve(t, sl.abcd32, rows64 * sizeof(rg_ev_quad32_t)) || reserve(t, sl.ab, rows64 * sizeof(I64x2)) ||
+        reserve(t, sl.cd, rows64 * sizeof(I64x2)) || reserve(t, sl.reply, rows64 * sizeof(rg_reply_t)) || reserve(t, sl.logfx, rows64 * sizeof(I64x2)) ||
+        reserve(t, sl.persist, rows64 * sizeof(rg_persist_t)) || reserve(t, sl.counts, (size_t)2 * waves * sizeof(uint32_t)))
+        return -2;
+    hipStream_t si = t->s_in, so = t->s_out;
+    HIP_TRY(t, hipMemcpyAsync(sl.head.ptr, in->head, rows64 * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, si));
+    HIP_TRY(t, hipMemcpyAsync(sl.abcd32.ptr, in->abcd, rows64 * sizeof(rg_ev_quad32_t), hipMemcpyHostToDevice, si));
+    if (sparse) {
+        if (reserve(t, sl.gid, in->count * sizeof(uint32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(sl.gid.ptr, in->gid, in->count * sizeof(uint32_t), hipMemcpyHostToDevice, si));
+        p.gid = (const uint32_t *)sl.gid.ptr;
+    }
+    if (in->entry_count) {
+        if (reserve(t, sl.terms32, in->entry_count * sizeof(int32_t)) || reserve(t, sl.terms, in->entry_count * sizeof(int64_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(sl.terms32.ptr, in->entry_terms, in->entry_count * sizeof(int32_t), hipMemcpyHostToDevice, si));
+    }
+    HIP_TRY(t, hipEventRecord(sl.up, si));
+    HIP_TRY(t, hipStreamWaitEvent(t->stream, sl.up, 0));
+    HIP_TRY(t, rg::launch_widen(sl.abcd32.ptr, (I64x2 *)sl.ab.ptr, (I64x2 *)sl.cd.ptr, rows, (const int32_t *)sl.terms32.ptr, (int64_t *)sl.terms.ptr,
+                                in->entry_count, t->stream));
+    p.head = (const rg_ev_head_t *)sl.head.ptr; p.ab = (const I64x2 *)sl.ab.ptr; p.cd = (const I64x2 *)sl.cd.ptr;
+    p.hint = nullptr;
+    p.entry_terms = in->entry_count ? (const int64_t *)sl.terms.ptr : nullptr;
+    p.reply = (rg_reply_t *)sl.reply.ptr; p.logfx = (I64x2 *)sl.logfx.ptr; p.persist = (rg_persist_t *)sl.persist.ptr;
+    if (int rc = launch(t, p, sparse)) return rc;
+    HIP_TRY(t, rg::launch_outcome_count(p.reply, rows, (uint32_t *)sl.counts.ptr, (uint32_t *)d_counts, t->stream));
+    HIP_TRY(t, hipEventRecord(sl.done, t->stream));
+    HIP_TRY(t, hipStreamWaitEvent(so, sl.done, 0));
+    // the scatter is link-bound (it writes host memory): on the copy-out stream, so the next batch's kernels do not queue behind it
+    HIP_TRY(t, rg::launch_outcome_emit(p.reply, p.logfx, p.persist, rows, (const uint32_t *)sl.counts.ptr, (I64x2 *)d_logfx, out->logfx_cap,
+                                       (rg_persist_t *)d_persist, out->persist_cap, so));
+    HIP_TRY(t, hipMemcpyAsync(out->reply, sl.reply.ptr, rows64 * sizeof(rg_reply_t), hipMemcpyDeviceToHost, so));
     HIP_TRY(t, hipEventRecord(sl.down, so));
     t->pipe_head += 1;
     return 0;

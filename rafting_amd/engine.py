@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit_async", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -90,6 +90,7 @@ def lib():
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_submit_async.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
         L.rg_submit_wait.argtypes = [vp]
+        L.rg_submit_async_packed.argtypes = [vp, vp, vp]
         L.rg_sync.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_step_kernel.restype = C.c_char_p
@@ -155,6 +156,66 @@ def pinned_like(table, array):
                 lib().rg_host_free(table._h, self.ptr)
                 self.ptr = None
     return view, _Owner()
+
+
+class PackedBatch:
+    """An abi.Batch re-laid in the compact transfer formats of rg_submit_async_packed, in page-locked memory: int32 event fields up,
+    dense replies + packed logfx / persist lists down. unpack() rebuilds a dense abi.Outcome (unflagged rows zero) for comparison."""
+
+    def __init__(self, table, batch, logfx_cap=None, persist_cap=None):
+        assert abi.batch_fits_32(batch), "a value outside [0, 2^31) or a hint column: use submit_async for this batch"
+        rows = batch.rounds * batch.count
+        self.rows, self.table, self._owners = rows, table, []
+        q = np.zeros(rows, dtype=abi.QUAD32_DT)
+        q["a"], q["b"], q["c"], q["d"] = batch.ab["x"], batch.ab["y"], batch.cd["x"], batch.cd["y"]
+        self.head, self.abcd = self._pin(batch.head), self._pin(q)
+        self.entry_terms = self._pin(batch.entry_terms[:max(batch.entry_count, 1)].astype(np.int32))
+        self.gid = None if batch.gid is None else self._pin(batch.gid)
+        self.logfx_cap = rows if logfx_cap is None else logfx_cap
+        self.persist_cap = rows if persist_cap is None else persist_cap
+        self.reply = self._pin(np.zeros(rows, dtype=abi.REPLY_DT))
+        self.logfx = self._pin(np.zeros(max(self.logfx_cap, 1), dtype=abi.LOGFX_DT))
+        self.persist = self._pin(np.zeros(max(self.persist_cap, 1), dtype=abi.PERSIST_DT))
+        self.counts = self._pin(np.zeros(2, dtype=np.uint32))
+        b = abi.CBatch32()
+        b.rounds, b.count = batch.rounds, batch.count
+        b.gid = None if self.gid is None else self.gid.ctypes.data
+        b.head, b.abcd = self.head.ctypes.data, self.abcd.ctypes.data
+        b.entry_terms = self.entry_terms.ctypes.data if batch.entry_count else None
+        b.entry_count = batch.entry_count
+        o = abi.COutcomePacked()
+        o.reply, o.logfx, o.persist, o.counts = self.reply.ctypes.data, self.logfx.ctypes.data, self.persist.ctypes.data, self.counts.ctypes.data
+        o.logfx_cap, o.persist_cap = self.logfx_cap, self.persist_cap
+        self.c_in, self.c_out = b, o
+
+    def _pin(self, a):
+        view, own = pinned_like(self.table, a)
+        self._owners.append(own)
+        return view
+
+    @property
+    def bytes_up(self):
+        return self.head.nbytes + self.abcd.nbytes + (self.entry_terms.nbytes if self.c_in.entry_count else 0) + (0 if self.gid is None else self.gid.nbytes)
+
+    @property
+    def bytes_down(self):
+        return self.reply.nbytes + int(self.counts[0]) * abi.LOGFX_DT.itemsize + int(self.counts[1]) * abi.PERSIST_DT.itemsize + self.counts.nbytes
+
+    def unpack(self):
+        out = abi.Outcome(self.rows)
+        out.reply[:] = self.reply
+        nl, npers = int(self.counts[0]), int(self.counts[1])
+        ml, mp = abi.has_logfx(self.reply["flags"]), abi.has_persist(self.reply["flags"])
+        assert nl == int(ml.sum()) and npers == int(mp.sum()), "list lengths disagree with the reply marks"
+        assert nl <= self.logfx_cap and npers <= self.persist_cap, "a list was truncated: raise its capacity"
+        out.logfx[ml] = self.logfx[:nl]
+        out.persist[mp] = self.persist[:npers]
+        return out
+
+    def free(self):
+        for own in self._owners:
+            own.free()
+        self._owners = []
 
 
 class DeviceBuffer:
@@ -284,6 +345,16 @@ class Table:
         self._inflight.append((b, o, batch, out))
         self._check(lib().rg_submit_async(self._h, C.byref(b), C.byref(o)))
         return out
+
+    def submit_async_packed(self, pb):
+        """Pipelined submission with the compact transfer formats (rg_submit_async_packed); `pb` is a PackedBatch, whose page-locked
+        buffers stay valid until submit_wait() has returned for it."""
+        self._inflight = getattr(self, "_inflight", [])
+        if len(self._inflight) >= abi.PIPELINE_DEPTH:
+            self._inflight.pop(0)
+        self._inflight.append((pb.c_in, pb.c_out, pb, pb))
+        self._check(lib().rg_submit_async_packed(self._h, C.byref(pb.c_in), C.byref(pb.c_out)))
+        return pb
 
     def submit_wait(self):
         """Blocks until the oldest batch in flight has landed; returns its Outcome (None when nothing was in flight)."""

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <exception>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -73,6 +74,19 @@ bool waves_mode()
 
 }  // namespace
 
+static std::mutex pinned_m;
+static std::map<uintptr_t, size_t> pinned_ranges;
+void pinned_add(void *p, size_t n) { std::lock_guard<std::mutex> l(pinned_m); pinned_ranges[(uintptr_t)p] = n; }
+void pinned_remove(void *p) { std::lock_guard<std::mutex> l(pinned_m); pinned_ranges.erase((uintptr_t)p); }
+bool pinned_has(const void *p)
+{
+    std::lock_guard<std::mutex> l(pinned_m);
+    auto it = pinned_ranges.upper_bound((uintptr_t)p);
+    if (it == pinned_ranges.begin()) return false;
+    --it;
+    return (uintptr_t)p < it->first + it->second;
+}
+
 unsigned long long wave_ballot(bool p)
 {
     if (!my_wave) return p ? 1ull : 0ull;
@@ -112,7 +126,13 @@ void workgroup_barrier(bool required)
 
 // kernels whose lanes exchange data through LDS behind a __syncthreads (not a required s_barrier): a lane-serial grid would
 // silently compute garbage for them, so they always run with one OS thread per lane
-static bool lanes_must_meet(const char *kernel) { return kernel && strstr(kernel, "replicate_kernel") != nullptr; }
+static bool lanes_must_meet(const char *kernel)
+{
+    if (!kernel) return false;
+    for (const char *name : {"replicate_kernel", "outcome_count_kernel", "outcome_emit_kernel", "timers_scan_kernel"})   // (the last: LDS prefix sum)
+        if (strstr(kernel, name)) return true;
+    return false;
+}
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel)
 {

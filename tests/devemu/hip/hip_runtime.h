@@ -45,6 +45,9 @@ struct uint4 { unsigned x, y, z, w; };
 namespace hipemu {
 extern thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 struct Deadlock {};
+void pinned_add(void *p, size_t n);
+void pinned_remove(void *p);
+bool pinned_has(const void *p);
 unsigned long long wave_ballot(bool p);                    // lane-serial: a wavefront of one lane
 unsigned long long wave_exchange_xor(unsigned long long bits, int lane_xor);   // lane-serial: no partner, 0
 unsigned long long wave_first(unsigned long long v);
@@ -87,8 +90,10 @@ static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipE
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { p->multiProcessorCount = 256; strcpy(p->name, "lane-serial host emulation"); return hipSuccess; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { const hipError_t e = hipMalloc(p, n); if (e == hipSuccess) ::hipemu::pinned_add(*p, n ? n : 1); return e; }
+static inline hipError_t hipHostFree(void *p) { ::hipemu::pinned_remove(p); free(p); return hipSuccess; }
+// page-locked memory is mapped at its own address; anything else is not device-visible (as on the real runtime)
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { if (!::hipemu::pinned_has(h)) return hipErrorInvalidValue; *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }

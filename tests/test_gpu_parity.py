@@ -434,3 +434,77 @@ def test_pipelined_host_submissions_match_the_oracle():
     compare_states(orc.read_state(), gpu.read_state(), "after the pipeline")
     for own in owners:
         own.free()
+
+
+@pytest.mark.gpu
+def test_packed_pipelined_submissions_match_the_oracle():
+    packed_pipeline_case(4096, 6)
+
+
+def packed_pipeline_case(groups, rounds):
+    """rg_submit_async_packed: event fields uploaded as int32 and widened on the device, logfx / persist returned as row-ordered packed
+    lists written by the device into page-locked memory — rebuilt into dense outcomes they equal the oracle's, batch for batch
+    (dense rounds, a sparse batch, a list capacity that is too small, mixed with the wide entry point), and so does the final state."""
+    from rafting_amd import workload
+    cfg = workload.config(5, groups)                     # churn: plenty of persist items as well
+    gen = workload.ReplayGenerator(cfg)
+    st0 = gen.initial_state()
+    gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    batches = [gen.next_batch(rounds) for _ in range(6)]
+    refs = [orc.submit(b) for b in batches]
+    packed = [engine.PackedBatch(gpu, b) for b in batches[:5]]
+    wide_out = abi.Outcome(batches[5].rounds * batches[5].count, 0xAB)
+    for pb in packed[:4]:
+        gpu.submit_async_packed(pb)                      # the third call waits for the first batch by itself
+    gpu.submit_async_packed(packed[4])
+    gpu.submit_async(batches[5], wide_out)               # the two entry points share one pipeline
+    gpu.sync()
+    for k, pb in enumerate(packed):
+        nl, npers = int(pb.counts[0]), int(pb.counts[1])
+        assert 0 < npers < nl < pb.rows                  # the lists really are shorter than the dense columns
+        compare_outcomes(refs[k], pb.unpack(), "packed batch %d" % k)
+    compare_outcomes(refs[5], wide_out, "wide batch after packed ones")
+    compare_states(orc.read_state(), gpu.read_state(), "after the packed pipeline")
+
+    # a sparse batch, and lists that do not fit: counts still report what there was, the items that fit are the first ones
+    gid = np.arange(0, cfg.groups, 3, dtype=np.uint32)
+    sb = abi.Batch(1, len(gid), gid=gid)
+    for i in range(len(gid)):
+        sb.put(0, i, abi.EV_TIMEOUT)
+    made = []
+    for caps in (None, (0, 5)):
+        g2 = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        o2 = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        g2.load_state(st0)
+        o2.load_state(st0)
+        ref = o2.submit(sb)
+        n_per = int(abi.has_persist(ref.reply["flags"]).sum())
+        assert n_per > 8
+        pb = engine.PackedBatch(g2, sb) if caps is None else engine.PackedBatch(g2, sb, logfx_cap=caps[0], persist_cap=caps[1])
+        g2.submit_async_packed(pb)
+        g2.sync()
+        assert int(pb.counts[1]) == n_per and int(pb.counts[0]) == int(abi.has_logfx(ref.reply["flags"]).sum())
+        if caps is None:
+            compare_outcomes(ref, pb.unpack(), "sparse packed batch")
+        else:
+            assert np.array_equal(pb.persist[:5], ref.persist[abi.has_persist(ref.reply["flags"])][:5])
+        compare_states(o2.read_state(), g2.read_state(), "after the sparse packed batch")
+        made.append((pb, g2))
+    for pb in packed:
+        pb.free()
+    for pb, g2 in made:
+        pb.free()
+        g2.close()
+
+    # pageable list memory is refused (the device could not write it), and so is a value the narrow format cannot carry
+    bad = engine.PackedBatch(gpu, batches[0])
+    bad.c_out.counts = np.zeros(2, dtype=np.uint32).ctypes.data
+    with pytest.raises(engine.EngineError, match="page-locked"):
+        gpu.submit_async_packed(bad)
+    bad.free()
+    big = abi.Batch(1, cfg.groups)
+    big.put(0, 0, abi.EV_AE_REQ, slot=1, a=1 << 40, b=1, c=1, d=0)
+    assert not abi.batch_fits_32(big)
