@@ -439,8 +439,8 @@ int rg_timing_read(rg_table_t *t, uint64_t *launches, double *total_ms, int rese
  * rg_timing_end records the stop event, synchronises, and returns the elapsed milliseconds. */
 int rg_timing_begin(rg_table_t *t);
 int rg_timing_end(rg_table_t *t, double *elapsed_ms);
-/* Device-side decision counters accumulated by the step kernel (wave ballot + popcount, one slot
- * per wave): [0]=rows with kind!=NONE, [1]=replied, [2]=role conversions, [3]=commit advances,
+/* Device-side decision counters accumulated by the step kernel (per-lane tallies, summed over the wavefront with a
+ * shuffle butterfly at the end of the launch and added to the wavefront's own slot of a table — no atomics): [0]=rows with kind!=NONE, [1]=replied, [2]=role conversions, [3]=commit advances,
  * [4]=assert statuses, [5]=NEED_HOST, [6]=dropped stale, [7]=log appends. */
 #define RG_NUM_COUNTERS 8
 int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int reset);

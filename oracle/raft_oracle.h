@@ -11,7 +11,7 @@
  * SOURCES: tools/make_ref.py translates Follower / Candidate / Leader / Leadership.State / Membership / RaftMember /
  * TimerTicket / RocksLog / RaftRoutine / RaftContext token by token into C++ (oracle/_ref/libref.so, built by
  * `make -C oracle ref` from /root/reference, sha-pinned source ranges, no hand-edited output), and
- * tests/test_ref_parity.py requires this oracle to answer exactly like that library: all 43 known-answer
+ * tests/test_ref_parity.py requires this oracle to answer exactly like that library: all 47 known-answer
  * scenarios, >= 10^6 random inputs per pure function, the lockstep fuzzer over seven cluster shapes (outcome rows
  * and full state after every round), the BASELINE replay streams; tests/golden/replay_digests.json is generated
  * by that library, not by this oracle.  Hand-derived KATs (tests/test_oracle_kat.py) and the constants extracted
