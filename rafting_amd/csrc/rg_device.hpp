@@ -952,97 +952,126 @@ struct Stepper {
         return fast;
     }
 
-    // ---- tier 1.5: the rows that CHANGE A ROLE, with selects -----------------------------------------------------------
-    // Measured (tools/exp_profile2.sh, profiles/r02_cycle_breakdown.txt): at config 3 only ~0.9 % of the rows miss tier 1, but one such
-    // lane in 64 sends its whole wavefront through the general handlers — ~45 % of the wave-rounds, ~3 500 ticks each, more than a
-    // complete tier-1 round. Those rows are almost all of five shapes whose outcome is "a new participant": an election / heartbeat
-    // timeout (member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126), the vote reply that completes a majority or
-    // carries a higher term (Candidate.java:121-134, Follower.java:258-270), a replication response with a higher term
-    // (Leader.java:224-226), and RequestVote / PreVote at a Follower with a non-empty log (Follower.java:91-127). Under preconditions
-    // that make Membership.isBetter true (or the row a plain refusal) they are decided here in one pass of selects; everything
-    // else — assertion sites, empty logs, Candidate / Leader as voters, conflicts, hints — still goes to run(), the single source of
-    // truth. Only entered for lanes that missed tier 1 (one wave-level branch), so the fast path does not pay for it.
-    // MEASURED AND SWITCHED OFF (build with -DRG_TIER15 to get it back): functionally it takes 98.6 % of config 3's slow rows, but a
-    // slow-path visit usually has ONE active lane, for which the branchy general handlers cost no divergence — a visit came to
-    // ~1 150 ticks in here against ~1 500 in run(), and the larger loop body made every round slower: 0.1229 ms per launch against
-    // 0.1157 ms without it (gpurun_out r02i, profiles/r02_cycle_breakdown.txt).
-    __device__ __forceinline__ bool try_mid(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c)
+    // ---- tier 1.5: the rows that CHANGE A ROLE, with selects, one row class at a time ------------------------------------
+    // At config 3 only ~0.9 % of the rows miss tier 1, but one such lane in 64 sends its whole wavefront into the general handlers in
+    // ~45 % of the rounds, for ~1 700 ticks (profiles/r02_cycle_breakdown.txt). Almost all of those rows have one of four shapes whose
+    // outcome is "a new participant": an election / heartbeat timeout (member/Follower.java:156-168, Candidate.java:82-88,
+    // Leader.java:120-126), the vote reply that completes a majority or carries a higher term (Candidate.java:121-134,
+    // Follower.java:258-270), a replication response with a higher term (Leader.java:224-226), and RequestVote / PreVote at a
+    // Follower with a non-empty log (Follower.java:91-127). Each class sits behind ONE wave-uniform branch (ballot != 0), so a visit
+    // pays for the classes that are present — usually one, ~50 instructions of selects — and under preconditions that make
+    // Membership.isBetter true (or the row a plain refusal) the row is decided here; everything else — assertion sites, empty logs,
+    // Candidate / Leader as voters, conflicts, hints — still goes to run(), the single source of truth.
+    // MUST be called by every lane of the wavefront (converged code): `want` = this lane missed tier 1. Returns "decided here".
+    // MEASURED AND COMPILED OUT (-DRG_TIER15 brings it back; the emulation and GPU suites pass with it): it takes 98.4 % of config 3's
+    // slow rows, yet a visit costs ~900 ticks in here (class tests + one class block, ~125 instructions) against about the same in the
+    // branchy general handlers, which a lone active lane walks without divergence — same-box A/B over four workloads: within
+    // +-0.7 % (profiles/r02_cycle_breakdown.txt section 5). A first version that evaluated all four classes in one straight line of
+    // selects cost ~1 150 ticks per visit. run() stays the only code that decides these rows.
+    __device__ __forceinline__ bool try_mid(bool want, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c)
     {
 #ifndef RG_TIER15
-        (void)allow; (void)hdr; (void)aux; (void)a; (void)b; (void)c;
+        (void)want; (void)hdr; (void)aux; (void)a; (void)b; (void)c;
         return false;
 #else
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr);
         const bool flag = RG_HDR_FLAG(hdr) != 0;
         const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
-        const int64_t g_term = g.term, g_last = g.last, lt = g.last_term(), el_term = g.elected_term;
-        const int32_t role = g.role, g_votes = g.votes, g_voted = g.voted_for;
-        const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
-        const bool has_log = g.rc > 0, g_td = g.td, g_prep = g.prepared;
         const bool peer_ok = (slot < P) & (slot != self);
-        const bool cur_epoch = aux == g_repoch;
-        const int64_t term1 = wadd(g_term, 1);
+        bool done = false;
+        // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv` (everything a new participant resets)
+        auto convert = [&](bool conv, int32_t new_role, int64_t new_term, int32_t new_vote) {
+            g.role = conv ? new_role : g.role;
+            g.term = conv ? new_term : g.term;
+            g.voted_for = conv ? new_vote : g.voted_for;
+            g.role_epoch = g.role_epoch + (conv ? 1u : 0u);
+            g.td = g.td & !conv;
+            g.leader = conv ? RG_NO_NODE : g.leader;
+            g.votes = conv ? 1 : g.votes;
+            g.prepared = g.prepared & !conv;
+        };
+        const uint32_t conv_flags = RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER;
 
-        // (a) RG_EV_TIMEOUT of the live participant (aux 0 = whoever is current)
-        const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
-        const bool to_stale = to_kind & (aux != 0u) & !cur_epoch;                   // context/RaftRoutine.java:70
-        const bool to_live = to_kind & !to_stale;
-        const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);     // refresh + prepareElection
-        const bool bump_ok = term1 > g_term;                                         // currentTerm + 1 did not wrap (else: the general handlers)
-        const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & bump_ok;
-        const bool to_lead = to_live & (role == RG_LEADER);
+        // (a) RG_EV_TIMEOUT (aux 0 = whoever is current)
+        const bool to_kind = want & (kind == RG_EV_TIMEOUT);
+        if (__builtin_amdgcn_ballot_w64(to_kind) != 0) {
+            const int64_t g_term = g.term, term1 = wadd(g_term, 1);
+            const int32_t role = g.role;
+            const bool to_stale = to_kind & (aux != 0u) & (aux != g.role_epoch);             // context/RaftRoutine.java:70
+            const bool to_live = to_kind & !to_stale;
+            const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);          // refresh + prepareElection
+            const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
+            const bool to_lead = to_live & (role == RG_LEADER);
+            const bool mine = to_stale | to_pre | to_cand | to_lead;                          // (currentTerm + 1 wrapped: the general handlers)
+            if (to_lead & !g.prepared) prepare_replication();                                 // a new Leader's first tick (member/Leader.java:30-50)
+            convert(to_pre | to_cand, to_cand ? RG_CANDIDATE : RG_FOLLOWER, to_cand ? term1 : g_term, to_cand ? (int32_t)self : g.voted_for);
+            g.td = g.td | to_pre;
+            if (mine) {
+                fx.status = to_stale ? RG_DROPPED_STALE_ROLE : RG_OK;
+                fx.resp_term = g_term; fx.log_from = 0;
+                fx.flags = ((to_pre | to_cand) ? conv_flags : 0u) | (to_lead ? RG_F_RESET_TIMER : 0u) |
+                           ((to_pre ? RG_EMIT_PREVOTE : (to_cand ? RG_EMIT_REQVOTE : (to_lead ? RG_EMIT_HEARTBEAT : RG_EMIT_NONE))) << RG_F_EMIT_SHIFT);
+            }
+            done = done | mine;
+        }
 
-        // (b) vote replies that end a (pre-)election
-        const bool is_pv = kind == RG_EV_PV_REPLY;
-        const bool vr = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
-        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
-        const int64_t T = is_pv ? term1 : g_term;
-        const bool vr_cur = vr & cur_epoch & sender_ok & (bump_ok | !is_pv);
-        const bool vr_higher = vr_cur & (a > T);                                     // -> Follower(result.term, responder)
-        const bool vr_win = vr_cur & (a <= T) & flag & (g_votes + 1 >= p.majority);
-        const bool win_pre = vr_win & is_pv, win_rv = vr_win & !is_pv;
-        const bool vr_late = vr & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch) & (a > el_term);   // Q13: late higher-term reply
-        const bool late_conv = vr_late & (a >= g_term);                              // Follower is "better" from any role at >= term
+        // (b) vote replies that end a (pre-)election, or arrive late for a won one with a higher term (Q13)
+        const bool vr = want & ((kind == RG_EV_RV_REPLY) | (kind == RG_EV_PV_REPLY)) & peer_ok;
+        if (__builtin_amdgcn_ballot_w64(vr) != 0) {
+            const bool is_pv = kind == RG_EV_PV_REPLY;
+            const int64_t g_term = g.term, term1 = wadd(g_term, 1), el_term = g.elected_term;
+            const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
+            const bool cur_epoch = aux == g_repoch;
+            const bool sender_ok = is_pv ? ((g.role == RG_FOLLOWER) & g.td) : (g.role == RG_CANDIDATE);
+            const int64_t T = is_pv ? term1 : g_term;
+            const bool vr_cur = vr & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);
+            const bool vr_higher = vr_cur & (a > T);                                          // -> Follower(result.term, responder)
+            const bool vr_win = vr_cur & (a <= T) & flag & (g.votes + 1 >= p.majority);
+            const bool win_rv = vr_win & !is_pv;
+            const bool vr_late = vr & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch) & (a > el_term);
+            const bool late_conv = vr_late & (a >= g_term);                                   // Follower is "better" from any role at >= term
+            const bool mine = vr_higher | vr_win | vr_late;
+            const bool conv = vr_higher | vr_win | late_conv;
+            const int32_t new_role = vr_win ? (is_pv ? RG_CANDIDATE : RG_LEADER) : RG_FOLLOWER;
+            g.elected_epoch = win_rv ? g_repoch : (vr_late ? 0u : el_epoch);                  // Candidate.java:75-79 / head.abortRequests()
+            g.elected_term = win_rv ? g_term : el_term;
+            convert(conv, new_role, vr_win ? T : a, vr_win ? (int32_t)self : (int32_t)slot);
+            if (mine) {
+                fx.status = RG_OK; fx.resp_term = g_term; fx.log_from = 0;
+                fx.flags = (conv ? conv_flags : 0u) | (((conv & (new_role == RG_CANDIDATE)) ? RG_EMIT_REQVOTE : RG_EMIT_NONE) << RG_F_EMIT_SHIFT);
+            }
+            done = done | mine;
+        }
 
-        // (c) a replication response with a higher term
-        const bool ack = allow & ((kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK)) & peer_ok & cur_epoch & (role == RG_LEADER) & g_prep & (a > g_term);
+        // (c) a replication response with a higher term: the Leader steps down, votedFor = the responder (Q7)
+        const bool ack = want & ((kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK)) & peer_ok & (aux == g.role_epoch) & (g.role == RG_LEADER) &
+                         g.prepared & (a > g.term);
+        if (__builtin_amdgcn_ballot_w64(ack) != 0) {
+            const int64_t g_term = g.term;
+            convert(ack, RG_FOLLOWER, a, (int32_t)slot);
+            if (ack) { fx.status = RG_OK; fx.resp_term = g_term; fx.log_from = 0; fx.flags = conv_flags; }
+            done = done | ack;
+        }
 
         // (d) RequestVote / PreVote at a Follower that has a log
-        const bool vq = allow & ((kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ)) & (slot < P) & (role == RG_FOLLOWER) & has_log;
-        const bool pvq = vq & (kind == RG_EV_PV_REQ), rvq = vq & (kind == RG_EV_RV_REQ);
-        const bool utd = (c > lt) | ((c == lt) & (b >= g_last));                     // Follower.logUpToDate with a last entry
-        const bool pv_judge = pvq & (a > g_term) & g_td;                             // else failure(currentTerm), no timer touched
-        const bool rv_new = rvq & (a > g_term);                                      // else answered from the current membership
-        const bool rv_same = rvq & (a == g_term);
-
-        const bool mid = to_stale | to_pre | to_cand | to_lead | vr_higher | vr_win | vr_late | ack | vq;
-        // the conversion (RaftRoutine.convertTo + RaftMember.<init>), where one happens
-        const bool conv = to_pre | to_cand | vr_higher | vr_win | late_conv | ack | rv_new;
-        const int32_t new_role = (to_cand | win_pre) ? RG_CANDIDATE : (win_rv ? RG_LEADER : RG_FOLLOWER);
-        const int64_t new_term = to_pre ? g_term : (to_cand ? term1 : (vr_win ? T : a));
-        const int32_t new_vote = to_pre ? g_voted : ((to_cand | vr_win) ? (int32_t)self : (rv_new ? (utd ? (int32_t)slot : RG_NO_NODE) : (int32_t)slot));
-        if (to_lead & !g_prep) prepare_replication();                                // a new Leader's first tick (member/Leader.java:30-50)
-        g.elected_epoch = win_rv ? g_repoch : (vr_late ? 0u : el_epoch);             // Candidate.java:75-79 / head.abortRequests()
-        g.elected_term = win_rv ? g_term : el_term;
-        g.role = conv ? new_role : role;
-        g.term = conv ? new_term : g_term;
-        g.voted_for = conv ? new_vote : g_voted;
-        g.role_epoch = g_repoch + (conv ? 1u : 0u);
-        g.td = to_pre | (g_td & !conv);
-        g.leader = conv ? RG_NO_NODE : g.leader;
-        g.votes = conv ? 1 : g_votes;
-        g.prepared = (g.prepared & !conv);
-        if (mid) {
-            const uint32_t emit = to_pre ? RG_EMIT_PREVOTE : (((conv & (new_role == RG_CANDIDATE))) ? RG_EMIT_REQVOTE : (to_lead ? RG_EMIT_HEARTBEAT : RG_EMIT_NONE));
-            const bool replied = vq;
+        const bool vq = want & ((kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ)) & (slot < P) & (g.role == RG_FOLLOWER) & (g.rc > 0);
+        if (__builtin_amdgcn_ballot_w64(vq) != 0) {
+            const int64_t g_term = g.term, g_last = g.last, lt = g.last_term();
+            const int32_t g_voted = g.voted_for;
+            const bool pvq = vq & (kind == RG_EV_PV_REQ), rvq = vq & (kind == RG_EV_RV_REQ);
+            const bool utd = (c > lt) | ((c == lt) & (b >= g_last));                          // Follower.logUpToDate with a last entry
+            const bool pv_judge = pvq & (a > g_term) & g.td;                                  // else failure(currentTerm), no timer touched
+            const bool rv_new = rvq & (a > g_term);                                           // else answered from the current membership
+            const bool rv_same = rvq & (a == g_term);
             const bool success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
-            fx.status = to_stale ? RG_DROPPED_STALE_ROLE : RG_OK;
-            fx.resp_term = rv_new ? a : g_term;
-            fx.log_from = 0;
-            fx.flags = (conv ? (RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER) : 0u) | ((to_lead | pv_judge) ? RG_F_RESET_TIMER : 0u) |
-                       (emit << RG_F_EMIT_SHIFT) | (replied ? RG_F_REPLIED : 0u) | (success ? RG_F_SUCCESS : 0u);
+            convert(rv_new, RG_FOLLOWER, a, utd ? (int32_t)slot : RG_NO_NODE);
+            if (vq) {
+                fx.status = RG_OK; fx.resp_term = rv_new ? a : g_term; fx.log_from = 0;
+                fx.flags = (rv_new ? conv_flags : 0u) | (pv_judge ? RG_F_RESET_TIMER : 0u) | RG_F_REPLIED | (success ? RG_F_SUCCESS : 0u);
+            }
+            done = done | vq;
         }
-        return mid;
+        return done;
 #endif
     }
 

@@ -211,31 +211,34 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 
         {
             const uint32_t kind = RG_HDR_KIND(cur.hdr);
-            if (blocked && kind != RG_EV_NONE) {
-                st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-            } else {
-                const bool done = st.try_fast(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
-                                              entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
-                                              event_narrow(cur.a, cur.b, cur.c, cur.d, cur_t.e0));
+            // every lane goes through tier 1 and (when any lane of the wavefront needs it) tier 1.5: both contain wave-uniform branches
+            // on ballots and are therefore called from converged code; a lane blocked after a NEED_HOST simply asks for nothing
+            const bool skip = blocked & (kind != RG_EV_NONE);
+            const bool done = st.try_fast(FAST & !skip, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
+                                          entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
+                                          event_narrow(cur.a, cur.b, cur.c, cur.d, cur_t.e0));
 #ifdef RG_PROFILE_TIERS
-                tpa = __builtin_amdgcn_s_memtime();
+            tpa = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef RG_COUNT_SLOW                                   // experiment build: which rows leave tier 1 (reported through three tallies)
-                dbg[0] += !done & (kind == RG_EV_AE_REQ); dbg[1] += st.dbg_reason == 1u; dbg[2] += st.dbg_reason == 2u;
-                dbg[3] += st.dbg_reason == 3u; dbg[4] += (st.dbg_reason == 4u) | (st.dbg_reason == 5u); dbg[5] += st.dbg_reason == 6u;
-                dbg[6] += st.dbg_reason == 7u; dbg[7] += st.dbg_reason == 8u;
+            dbg[0] += !done & !skip & (kind == RG_EV_AE_REQ); dbg[1] += st.dbg_reason == 1u; dbg[2] += st.dbg_reason == 2u;
+            dbg[3] += st.dbg_reason == 3u; dbg[4] += (st.dbg_reason == 4u) | (st.dbg_reason == 5u); dbg[5] += st.dbg_reason == 6u;
+            dbg[6] += st.dbg_reason == 7u; dbg[7] += st.dbg_reason == 8u;
 #endif
+            const bool slow = !done & !skip;
+            if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
 #ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
-                if (!done) {
-                    if (!st.try_mid(FAST, cur.hdr, cur.aux, cur.a, cur.b, cur.c))      // (compiled out unless -DRG_TIER15)
-                        st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
-                    st.refresh_narrow();                  // tier 1.5 and the general handlers work on 64-bit values
-                }
+            if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                const bool mid = st.try_mid(FAST & slow, cur.hdr, cur.aux, cur.a, cur.b, cur.c);
+                if (slow & !mid) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                st.refresh_narrow();                      // tier 1.5 and the general handlers work on 64-bit values
+            }
+#else
+            (void)slow;
 #endif
 #ifdef RG_PROFILE_TIERS
-                tpb = __builtin_amdgcn_s_memtime();
+            tpb = __builtin_amdgcn_s_memtime();
 #endif
-            }
             const uint32_t status = st.fx.status, flags = st.fx.flags;
             if (status == RG_NEED_HOST) blocked = true;
             pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
@@ -511,33 +514,39 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const uint64_t tq1 = __builtin_amdgcn_s_memtime();
 #endif
         const uint32_t kind = RG_HDR_KIND(hdr);
-        if (blocked && kind != RG_EV_NONE) {
-            st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-        } else if (!st.try_fast(FAST, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow)) {
+        // tier 1 and tier 1.5 branch on wavefront ballots: every lane calls them (a lane blocked after a NEED_HOST asks for nothing)
+        const bool skip = blocked & (kind != RG_EV_NONE);
+        const bool done = st.try_fast(FAST & !skip, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow);
+        const bool slow = !done & !skip;
+        if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+#ifndef RG_TIER1_ONLY
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
 #ifdef RG_PROFILE2
             tz2 = __builtin_amdgcn_s_memtime();
 #endif
-            // the general handlers also want the hint and the other prefetched entry terms: read only here
-            const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
-            const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
-                          e3 = (int64_t)sh_ev[slot][EV_E3][lane];
-#ifndef RG_TIER1_ONLY
-#ifdef RG_PROFILE3      // experiment build: inside a slow-path visit — LDS reads / tier 1.5 / general handlers (lanes that took the visit only)
-            __builtin_amdgcn_s_waitcnt(0xC07F);
+#ifdef RG_PROFILE3      // experiment build: inside a slow-path visit — tier 1.5 / LDS reads + general handlers (per wavefront visit, lane 0 reports)
             const uint64_t ty0 = __builtin_amdgcn_s_memtime();
-            const bool mid_done = st.try_mid(FAST, hdr, aux, a, b, c);
-            const uint64_t ty1 = __builtin_amdgcn_s_memtime();
-            if (!mid_done) st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
-            const uint64_t ty2 = __builtin_amdgcn_s_memtime();
-            pv_visits += 1u; pv_reads += (uint32_t)(ty0 - tz2); pv_mid += (uint32_t)(ty1 - ty0); pv_run += (uint32_t)(ty2 - ty1);
-#else
-            if (!st.try_mid(FAST, hdr, aux, a, b, c)) st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
 #endif
+            const bool mid = st.try_mid(FAST & slow, hdr, aux, a, b, c);
+#ifdef RG_PROFILE3
+            const uint64_t ty1 = __builtin_amdgcn_s_memtime();
+#endif
+            if (slow & !mid) {
+                // the general handlers also want the hint and the other prefetched entry terms: read only here
+                const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
+                const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
+                              e3 = (int64_t)sh_ev[slot][EV_E3][lane];
+                st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
+            }
             st.refresh_narrow();                         // tier 1.5 and the general handlers work on 64-bit values
-#else
-            (void)hx; (void)hy; (void)e1; (void)e2; (void)e3;
+#ifdef RG_PROFILE3
+            const uint64_t ty2 = __builtin_amdgcn_s_memtime();
+            pv_visits += 1u; pv_mid += (uint32_t)(ty1 - ty0); pv_run += (uint32_t)(ty2 - ty1); pv_reads += (slow & !mid) ? 1u : 0u;
 #endif
         }
+#else
+        (void)slow;
+#endif
         const uint32_t status = st.fx.status, flags = st.fx.flags;
 #ifdef RG_PROFILE
         const uint64_t tq2 = __builtin_amdgcn_s_memtime();

@@ -94,6 +94,7 @@ void StableStore::replay()
 void StableStore::persist(const std::vector<Record> &batch)
 {
     if (batch.empty()) return;
+    if (broken_) throw std::runtime_error("StableStore: the journal could not be cut back after a failed write; refusing further batches");
     std::vector<unsigned char> buf(batch.size() * REC);
     uint32_t seq = seq_;
     for (size_t i = 0; i < batch.size(); i++) encode(buf.data() + i * REC, batch[i], ++seq);
@@ -106,6 +107,7 @@ void StableStore::persist(const std::vector<Record> &batch)
         // otherwise sit in FRONT of the next successful batch and make replay() stop there), and leave latest_/seq_ alone so
         // that restore() keeps answering with what IS durable
         if (start >= 0 && ::ftruncate(fd_, start) == 0) ::lseek(fd_, start, SEEK_SET);
+        else broken_ = true;                                 // a torn record may sit in the file: fail-stop (replay() would cut there)
         throw;
     }
     seq_ = seq;                                              // the memory image moves only after the bytes are durable
@@ -128,17 +130,24 @@ void StableStore::compact()
     const std::string tmp = path_ + ".tmp";
     int fd = ::open(tmp.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) throw std::runtime_error("StableStore compact open: " + std::string(strerror(errno)));
-    std::vector<unsigned char> buf(sizeof MAGIC + latest_.size() * REC);
-    memcpy(buf.data(), MAGIC, sizeof MAGIC);
-    size_t i = 0;
     uint32_t seq = 0;
-    for (const auto &kv : latest_) encode(buf.data() + sizeof MAGIC + (i++) * REC, kv.second, ++seq);
-    write_all(fd, buf.data(), buf.size());
-    if (::fdatasync(fd) != 0 || ::rename(tmp.c_str(), path_.c_str()) != 0) { ::close(fd); throw std::runtime_error("StableStore compact"); }
-    sync_parent_dir(path_);                                  // make the rename itself durable before the old file's fd goes away
-    ::close(fd_);
+    try {
+        std::vector<unsigned char> buf(sizeof MAGIC + latest_.size() * REC);
+        memcpy(buf.data(), MAGIC, sizeof MAGIC);
+        size_t i = 0;
+        for (const auto &kv : latest_) encode(buf.data() + sizeof MAGIC + (i++) * REC, kv.second, ++seq);
+        write_all(fd, buf.data(), buf.size());
+        if (::fdatasync(fd) != 0) throw std::runtime_error(std::string("StableStore compact fdatasync: ") + strerror(errno));
+        if (::rename(tmp.c_str(), path_.c_str()) != 0) throw std::runtime_error(std::string("StableStore compact rename: ") + strerror(errno));
+    } catch (...) {
+        ::close(fd);                                         // the live journal is untouched: the store keeps working on it
+        ::unlink(tmp.c_str());
+        throw;
+    }
+    ::close(fd_);                                            // the name now means the new file: append there from here on, whatever follows
     fd_ = fd;
     seq_ = seq;
+    sync_parent_dir(path_);                                  // make the rename itself durable before any later batch is acknowledged
     ::lseek(fd_, 0, SEEK_END);
     syncs_++;
 }

@@ -44,6 +44,7 @@ class StableStore {
     int fd_ = -1;
     uint32_t seq_ = 0;
     uint64_t syncs_ = 0, records_ = 0;
+    bool broken_ = false;          // a failed batch could not be removed from the file again
     std::unordered_map<uint32_t, Record> latest_;
 };
 
