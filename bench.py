@@ -251,6 +251,31 @@ def main():
                          "the reference EventLoop path (oracle/raft_oracle.c), in-memory log, no fsync/Netty/Kryo; "
                          "3 threads mirror EventLoopGroup(3), the widest run uses up to 64 host cores; GPU results on this sample verified bit-identical"
                          % (len(keep_host), args.rounds * len(keep_host), gpg, cpu_dec)}
+        # The reference's own decision classes, translated from their Java sources (oracle/_ref/libref.so, tools/make_ref.py), on the first
+        # two rounds of the stream: checked against the GPU's rows, and timed for the record only — that library is built for fidelity
+        # (refcounted object graph, closures, an ordered-map RocksDB stand-in), not speed, and says nothing about a JIT-compiled JVM.
+        try:
+            from tests import ref_lib
+            if ref_lib.available():
+                import copy
+                two = copy.copy(keep_host[0])
+                n2 = 2 * two.count
+                two.rounds = 2
+                two.head, two.ab, two.cd = two.head[:n2], two.ab[:n2], two.cd[:n2]
+                rt = ref_lib.RefTable(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+                rt.load_state(st0)
+                t1 = time.perf_counter()
+                r_out = rt.submit(two)
+                dt = time.perf_counter() - t1
+                g_out = dbatches[0].outcome()
+                for col in ("reply", "logfx", "persist"):
+                    setattr(g_out, col, getattr(g_out, col)[:n2])
+                compare_outcomes(r_out, g_out, "bench stream vs the translated reference")
+                cpu["reference_translated"] = {"value_1_thread": workload.batch_stats(two, F)[0] / dt, "sample": "first 2 rounds of the stream (%d rows), "
+                                               "GPU rows verified bit-identical to it; fidelity build, not a performance baseline" % n2}
+                rt.close()
+        except (ImportError, OSError):
+            pass
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate

@@ -345,9 +345,15 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     __shared__ uint32_t sh_prof3[4][BLOCK];
     uint32_t pv_visits = 0, pv_reads = 0, pv_mid = 0, pv_run = 0;
 #endif
+#ifdef RG_HWID          // experiment build (tools/hwid.py): which SIMD / wave slot the two wavefronts of a workgroup were placed on
+    __shared__ uint32_t sh_hw[2];
+#endif
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
+#ifdef RG_HWID
+    if (lane == 0) sh_hw[io_wave ? 1 : 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: slot 3:0, SIMD 5:4, CU 11:8
+#endif
     const uint32_t i = blockIdx.x * BLOCK + lane;
     const bool active = i < p.count;
     const uint32_t ir = active ? i : p.count - 1u;       // lanes past the end shadow the last row; only their stores are off
@@ -454,6 +460,14 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         if (lane != 0) { c_need = 0; c_stale = 0; c_append = 0; }
 #endif
 
+#ifdef RG_HWID
+        {
+            const uint32_t hd = sh_hw[0], hi = sh_hw[1], sd = (hd >> 4) & 3u, si = (hi >> 4) & 3u;
+            c_replied = sd == 0u; c_conv = sd == 1u; c_commit = sd == 2u; c_assert = sd == 3u;
+            c_need = si == ((sd + 1u) & 3u); c_stale = (hd & 15u) == (hi & 15u); c_append = hd & 15u;
+            if (lane != 0) { c_replied = 0; c_conv = 0; c_commit = 0; c_assert = 0; c_need = 0; c_stale = 0; c_append = 0; }
+        }
+#endif
         uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
 #pragma unroll
         for (int c = 0; c < RG_NUM_COUNTERS; c++) {
