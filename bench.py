@@ -274,8 +274,9 @@ def main():
                 cpu["reference_translated"] = {"value_1_thread": workload.batch_stats(two, F)[0] / dt, "sample": "first 2 rounds of the stream (%d rows), "
                                                "GPU rows verified bit-identical to it; fidelity build, not a performance baseline" % n2}
                 rt.close()
-        except (ImportError, OSError):
-            pass
+        except Exception as e:      # the checker leg must not take the bench line down with it: report, do not raise
+            cpu["reference_translated"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench: translated-reference leg failed: %r" % (e,), file=sys.stderr)
 
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate
