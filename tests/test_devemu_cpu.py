@@ -36,6 +36,30 @@ def test_device_decision_code_on_the_host_matches_the_oracle(emulation_library):
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
+def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
+    """bench.py itself (tests/devemu/bench_dry.py stubs only torch's GPU probes): one JSON line with the contract's keys, roofline and
+    cpu_baseline objects, the three host-memory legs, and the check of the first rounds against the translated reference."""
+    import json
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)
+    env.pop("RG_FAST", None)
+    p = subprocess.run([sys.executable, os.path.join(EMU, "bench_dry.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "pcie_inclusive_value"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "int64"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
+    legs = d["pcie_inclusive"]
+    assert legs["serial_rg_submit"] > 0 and legs["pipelined_rg_submit_async"] > 0 and legs["pipelined_rg_submit_async_packed"] > 0
+    assert legs["packed_bytes_per_decision"] < legs["wide_bytes_per_decision"]
+    rt = d["cpu_baseline"].get("reference_translated")
+    assert rt is None or "error" not in rt, rt
+
+
 def test_compiled_out_tier_between_the_fast_paths_and_the_general_handlers_still_agrees(tmp_path):
     """-DRG_TIER15 (rg_device.hpp try_mid: select-only handlers for timeouts, election-ending vote replies, higher-term acks and
     vote requests at a follower) is measured and switched off in the shipped build; it must keep giving the oracle's answers."""
