@@ -60,6 +60,25 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     assert rt is None or "error" not in rt, rt
 
 
+def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU), on the emulation: config 4's stream, rank r
+    decides block r, nothing but a barrier and three scalars crosses ranks (gloo), rank 0 prints ONE line with the whole-job sum."""
+    import json
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env.pop("RG_FAST", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["config_number"] == 4 and d["config"]["seed"] == "0xc0ffee03"
+    assert d["config"]["groups_per_gpu"] == 256 and d["config"]["groups_total"] == 512
+    assert d["config"]["decisions_per_step_per_gpu"] > 0 and d["value"] > 0
+    assert d["cpu_baseline"] is None and d["pcie_inclusive_value"] is None          # rank-0-at-N=1 legs only
+
+
 def test_compiled_out_tier_between_the_fast_paths_and_the_general_handlers_still_agrees(tmp_path):
     """-DRG_TIER15 (rg_device.hpp try_mid: select-only handlers for timeouts, election-ending vote replies, higher-term acks and
     vote requests at a follower) is measured and switched off in the shipped build; it must keep giving the oracle's answers."""
