@@ -57,6 +57,8 @@ class ReplayConfig:
     grant_prob: float = 0.9
     p_client: float = 0.2         # leader rounds that are client appends rather than acks
     p_reject: float = 0.02
+    p_conflict: float = 0.0       # higher-term AppendEntries (a subset of p_higher_term) whose entries OVERWRITE the last 1-3 uncommitted
+                                  # entries of the follower: prevLogIndex below the tail, conflict -> truncate -> append (general handlers)
     ae_entries: tuple = (0, 1, 2, 4)   # entries per AppendEntries request, equiprobable
     self_slot: int = 0
     pre_vote: bool = True
@@ -133,6 +135,7 @@ class ReplayGenerator:
         lead = self.mode == LEAD
         self.commit[lead] = np.sort(self.match[lead], axis=1)[:, F // 2]
         self.cur_term_start = np.ones(n, dtype=np.int64)         # first log index written in the current term
+        self.tail_run_start = np.ones(n, dtype=np.int64)         # first index of the run of entries that carries last_term
         self.k = np.zeros(n, dtype=np.int64)                     # replies of the running (pre-)election delivered so far
         self.grants = np.zeros(n, dtype=np.int64)
         self.late_k = np.full(n, F, dtype=np.int64)              # next late RequestVote reply of a won election
@@ -208,13 +211,25 @@ class ReplayGenerator:
         kind[ae] = abi.EV_AE_REQ
         slot[ae] = self.leader[ae]
         nn = np.array(cfg.ae_entries, dtype=np.int64)[self._ri(5, len(cfg.ae_entries))]
+        back = np.zeros(n, dtype=np.int64)
+        if cfg.p_conflict > 0.0:
+            assert cfg.p_conflict <= cfg.p_higher_term, "conflicting AppendEntries come from a NEW leader: p_conflict <= p_higher_term"
+            # the new leader's log diverges `back` entries before this follower's tail: it sends prev = last - back and at least one entry
+            # of its own term; the entries being replaced are uncommitted and belong to the follower's last run (so prevLogTerm is known)
+            want = 1 + np.minimum((u3 * 3).astype(np.int64), 2)
+            room = np.minimum(self.last - self.commit, self.last - self.tail_run_start)
+            back = np.where(hi & (u1 < cfg.p_conflict), np.minimum(want, np.maximum(room, 0)), 0)
+            nn = np.where(back > 0, np.maximum(nn, 1), nn)
         nent[ae] = nn[ae]
-        a[ae] = self.term[ae]; bb[ae] = self.last[ae]; c[ae] = self.last_term[ae]
+        prev = self.last - back
+        a[ae] = self.term[ae]; bb[ae] = prev[ae]; c[ae] = self.last_term[ae]
         ent_term[ae] = self.term[ae]
-        new_last = self.last + np.where(ae, nn, 0)
+        new_last = prev + np.where(ae, nn, 0)
         lc = np.maximum(self.commit, new_last - self._ri(6, 4))
         d[ae] = lc[ae]
         grew = ae & (nn > 0)
+        newrun = grew & (self.last_term != self.term)
+        self.tail_run_start[newrun] = prev[newrun] + 1
         self.last_term[grew] = self.term[grew]
         self.last[ae] = new_last[ae]
         self.commit[ae] = np.maximum(self.commit[ae], np.minimum(lc[ae], new_last[ae]))
@@ -234,6 +249,8 @@ class ReplayGenerator:
         nent[cl] = ncmd[cl]
         fresh = cl & self.needs_append
         self.cur_term_start[fresh] = self.last[fresh] + 1
+        newrun_cl = cl & (self.last_term != self.term)
+        self.tail_run_start[newrun_cl] = self.last[newrun_cl] + 1
         self.last[cl] += ncmd[cl]
         self.last_term[cl] = self.term[cl]
         self.needs_append[cl] = False

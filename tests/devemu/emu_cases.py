@@ -52,8 +52,11 @@ def test_multi_round_launch_on_resident_buffers():
 
 
 def test_workload_replay_configs():
-    for number in (3, 5):
-        cfg = workload.config(number, 1000)              # not a multiple of the wavefront size: shadow lanes
+    import dataclasses
+    for number in (3, 5, -3):
+        cfg = workload.config(abs(number), 1000)         # not a multiple of the wavefront size: shadow lanes
+        if number < 0:                                   # config 3 with conflicting AppendEntries: truncate + append in the general handlers
+            cfg = dataclasses.replace(cfg, p_conflict=0.008, name=cfg.name + " + conflicts")
         gen = workload.ReplayGenerator(cfg)
         gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
         orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)

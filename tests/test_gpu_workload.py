@@ -37,6 +37,17 @@ def _replay(cfg, rounds, batches=2, first=0, count=None):
     return gen, fin_g, hist, rows
 
 
+def test_config3_with_conflicting_append_entries():
+    """the stream VERDICT r1 asked about: 0.5 % of the rows are AppendEntries of a new leader that overwrite the follower's last
+    uncommitted entries (conflict -> truncate -> append, none of it in tier 1). Outcomes and state equal the oracle's, the model's
+    independent bookkeeping equals the final state, and the rows really truncate."""
+    import dataclasses
+    cfg = dataclasses.replace(workload.config(3, 16384), p_conflict=0.005, name="config3 + 0.5 % conflicts")
+    gen, fin, hist, rows = _replay(cfg, 48, batches=2)
+    assert hist[abi.OK] == rows
+    assert np.array_equal(fin.current_term, gen.term) and np.array_equal(fin.last_index, gen.last) and np.array_equal(fin.commit_index, gen.commit)
+
+
 def test_kernel_choice_follows_batch_size(monkeypatch):
     """up to one wavefront of groups per SIMD (65 536 rows on MI355X) a batch is decided by the two-wavefront kernel,
     beyond by the single-wavefront one; RG_SPLIT overrides"""

@@ -32,6 +32,30 @@ def test_model_agrees_with_oracle(number):
             assert kinds[k] > 0, k
 
 
+def test_conflicting_append_entries_knob():
+    """p_conflict: a new leader's AppendEntries overwrites the follower's last uncommitted entries — prevLogIndex below the tail, conflict,
+    truncate, append (storage/RocksLog.java:169-225 through member/Follower.java:60-75). Off by default (the BASELINE streams do not
+    change); with it the model still predicts the oracle's final state, and the rows really truncate."""
+    import dataclasses
+    cfg = dataclasses.replace(workload.config(3, 4096), p_conflict=0.005)
+    gen = workload.ReplayGenerator(cfg)
+    orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc.load_state(gen.initial_state())
+    trunc = 0
+    for _ in range(3):
+        b = gen.next_batch(40)
+        out = orc.submit(b)
+        assert np.all(out.status == abi.OK), np.bincount(out.status)
+        trunc += int(np.count_nonzero(out.reply["flags"] & abi.F_LOG_TRUNC))
+    fin = orc.read_state()
+    assert np.array_equal(fin.current_term, gen.term) and np.array_equal(fin.role_epoch.astype(np.int64), gen.epoch)
+    assert np.array_equal(fin.commit_index, gen.commit) and np.array_equal(fin.last_index, gen.last)
+    assert trunc > 500                                     # ~0.4 % of 491 520 rows
+    plain = workload.ReplayGenerator(workload.config(3, 4096)).next_batch(8)
+    again = workload.ReplayGenerator(dataclasses.replace(workload.config(3, 4096), p_conflict=0.0)).next_batch(8)
+    assert np.array_equal(plain.ab, again.ab) and np.array_equal(plain.head, again.head)
+
+
 def test_streams_are_partition_independent():
     cfg = workload.config(3, 8192)
     whole = workload.ReplayGenerator(cfg).next_batch(12)
