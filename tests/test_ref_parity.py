@@ -135,10 +135,14 @@ def test_lockstep_fuzz_oracle_vs_reference_code(cluster, self_slot, pre_vote, se
             abi.DROPPED_STALE_ROLE, abi.NOT_LEADER, abi.BAD_EVENT} <= seen, seen
 
 
-@pytest.mark.parametrize("number,groups,rounds", [(2, 4096, 24), (3, 8192, 24), (5, 8192, 24)])
+@pytest.mark.parametrize("number,groups,rounds", [(2, 4096, 24), (3, 8192, 24), (5, 8192, 24), (-3, 4096, 48)])
 def test_baseline_replays_oracle_vs_reference_code(number, groups, rounds):
-    """BASELINE configs' synthetic RPC streams (the bench workload): outcomes and final state"""
-    cfg = workload.config(number, groups)
+    """BASELINE configs' synthetic RPC streams (the bench workload): outcomes and final state. -3 = config 3 with 1 % of the rows being a new
+    leader's AppendEntries that overwrite uncommitted entries (RocksLog.conflict / truncate / append run in the reference's own code)"""
+    import dataclasses
+    cfg = workload.config(abs(number), groups)
+    if number < 0:
+        cfg = dataclasses.replace(cfg, p_conflict=0.01)
     gen = workload.ReplayGenerator(cfg)
     st0, b = gen.initial_state(), gen.next_batch(rounds)
     orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
