@@ -27,6 +27,17 @@ void FrameSplitter::fail(const std::string &why)
 // ended for lack of bytes, but the same turn goes on to demand STX from the byte after it when five more bytes are there.
 size_t FrameSplitter::feed(const uint8_t *data, size_t n, std::vector<Frame> &out)
 {
+    return feed_views(data, n, [&out](const FrameView &v) {
+        Frame f;
+        f.type = v.type; f.sequence = v.sequence;
+        f.head.assign(v.head, v.head_len);
+        f.body.assign(v.body, v.body_len);
+        out.push_back(std::move(f));
+    });
+}
+
+size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink)
+{
     if (failed_) return 0;
     if (transparent_) { passthrough_.append(reinterpret_cast<const char *>(data), n); return 0; }
     buf_.append(reinterpret_cast<const char *>(data), n);
@@ -41,7 +52,7 @@ size_t FrameSplitter::feed(const uint8_t *data, size_t n, std::vector<Frame> &ou
                 return made;
             }
             if (b != SOH) { fail("frame does not start with SOH"); return made; }
-            cur_ = Frame();
+            cur_.type = NUL; cur_.sequence = 0;
             head_len_ = body_len_ = -1;
             has_seq_ = false;
             open_ = true;
@@ -68,22 +79,26 @@ size_t FrameSplitter::feed(const uint8_t *data, size_t n, std::vector<Frame> &ou
         }
         if (body_len_ == -1) {
             if (!need((size_t)head_len_ + 4)) break;
-            cur_.head.assign(buf_, pos_, (size_t)head_len_);
+            head_at_ = pos_;                                                  // the head stays where it is: buf_ is only compacted between frames
             const int32_t len = be32(pos_ + (size_t)head_len_);
             pos_ += (size_t)head_len_ + 4;
             if (len < 0 || len > MAX_BODY_SIZE) { fail("illegal body length"); return made; }
             body_len_ = len;
         } else {
             if (!need((size_t)body_len_ + 1)) break;
-            cur_.body.assign(buf_, pos_, (size_t)body_len_);
+            FrameView v;
+            v.type = cur_.type; v.sequence = cur_.sequence;
+            v.head = buf_.data() + head_at_; v.head_len = (size_t)head_len_;
+            v.body = buf_.data() + pos_; v.body_len = (size_t)body_len_;
             pos_ += (size_t)body_len_;
             if ((uint8_t)buf_[pos_++] != ETX) { fail("ETX expected"); return made; }
-            out.push_back(std::move(cur_));
+            sink(v);
             made++;
             open_ = false;
         }
     }
-    if (pos_ > (1u << 16) && pos_ * 2 > buf_.size()) { buf_.erase(0, pos_); pos_ = 0; }   // drop what has been consumed
+    // drop what has been consumed — only between frames, so that head_at_ (an offset into buf_) stays valid while a frame is open
+    if (!open_ && pos_ > (1u << 16) && pos_ * 2 > buf_.size()) { buf_.erase(0, pos_); pos_ = 0; }
     return made;
 }
 
@@ -111,53 +126,56 @@ void encode_frame(const Frame &f, bool ending, std::string &out)
 // ---- scopes ---------------------------------------------------------------------------------------------------------
 static const char *const METHOD_NAME[] = {"", "appendEntries", "preVote", "requestVote", "installSnapshot"};
 
-bool parse_scope(const std::string &head, Method &method, std::string &context_id)
+bool parse_scope(const char *head, size_t len, Method &method, std::string &context_id)
 {
     for (int m = M_APPEND_ENTRIES; m <= M_INSTALL_SNAPSHOT; m++) {     // the order NettyNode.parseContextId tests them in
         const size_t n = strlen(METHOD_NAME[m]);
-        if (head.compare(0, n, METHOD_NAME[m]) == 0) {                  // scope.startsWith(name): the separator itself is not checked
+        if (len >= n && memcmp(head, METHOD_NAME[m], n) == 0) {          // scope.startsWith(name): the separator itself is not checked
             method = (Method)m;
-            context_id = head.size() > n ? head.substr(n + 1) : std::string();
+            if (len > n) context_id.assign(head + n + 1, len - n - 1); else context_id.clear();
             return true;
         }
     }
     return false;
 }
+bool parse_scope(const std::string &head, Method &method, std::string &context_id) { return parse_scope(head.data(), head.size(), method, context_id); }
 
 std::string make_scope(Method method, const std::string &context_id) { return std::string(METHOD_NAME[method]) + ":" + context_id; }
 
 // ---- FixedBodyCodec -------------------------------------------------------------------------------------------------
 namespace {
 struct Reader {
-    const std::string &s; size_t at = 0; bool ok = true;
-    explicit Reader(const std::string &x) : s(x) {}
-    int32_t i32() { if (at + 4 > s.size()) { ok = false; return 0; } uint32_t v = 0; for (int k = 0; k < 4; k++) v = (v << 8) | (uint8_t)s[at++]; return (int32_t)v; }
-    int64_t i64() { const uint64_t hi = (uint32_t)i32(), lo = (uint32_t)i32(); return (int64_t)((hi << 32) | lo); }
-    uint8_t u8() { if (at + 1 > s.size()) { ok = false; return 0; } return (uint8_t)s[at++]; }
+    const char *s; size_t n; size_t at = 0; bool ok = true;
+    Reader(const char *p, size_t len) : s(p), n(len) {}
+    size_t size() const { return n; }
+    int32_t i32() { if (at + 4 > n) { ok = false; return 0; } uint32_t v; memcpy(&v, s + at, 4); at += 4; return (int32_t)__builtin_bswap32(v); }
+    int64_t i64() { if (at + 8 > n) { ok = false; at = n; return 0; } uint64_t v; memcpy(&v, s + at, 8); at += 8; return (int64_t)__builtin_bswap64(v); }
+    uint8_t u8() { if (at + 1 > n) { ok = false; return 0; } return (uint8_t)s[at++]; }
 };
 }  // namespace
 
-bool FixedBodyCodec::decode_request(Method m, const std::string &body, Request &out) const
+bool FixedBodyCodec::decode_request(Method m, const char *body, size_t len, Request &out) const
 {
-    Reader r(body);
-    out = Request();
+    Reader r(body, len);
+    out.leader_commit = 0;
+    out.entry_terms.clear();                                           // (keeps its capacity: `out` is reused from frame to frame)
     out.term = r.i64(); out.node = r.i32(); out.x = r.i64(); out.y = r.i64();
     if (m == M_APPEND_ENTRIES) {
         out.leader_commit = r.i64();
         const int32_t n = r.i32();
-        if (!r.ok || n < 0 || (size_t)n > (body.size() - r.at) / 8) return false;
+        if (!r.ok || n < 0 || (size_t)n > (len - r.at) / 8) return false;
         out.entry_terms.resize((size_t)n);
         for (int32_t k = 0; k < n; k++) out.entry_terms[(size_t)k] = r.i64();
     }
-    return r.ok && r.at == body.size();
+    return r.ok && r.at == len;
 }
 
-bool FixedBodyCodec::decode_response(const std::string &body, Response &out) const
+bool FixedBodyCodec::decode_response(const char *body, size_t len, Response &out) const
 {
-    Reader r(body);
+    Reader r(body, len);
     out.term = r.i64();
     out.success = r.u8() != 0;
-    return r.ok && r.at == body.size();
+    return r.ok && r.at == len;
 }
 
 void FixedBodyCodec::encode_request(Method m, const Request &in, std::string &body) const
@@ -180,17 +198,27 @@ void FixedBodyCodec::encode_response(const Response &in, std::string &body) cons
 bool RowWriter::add(const Frame &f, int32_t peer, const BodyCodec &codec, const std::function<bool(const std::string &, uint32_t &)> &gid_of,
                     const std::function<bool(const std::string &, int32_t, Pending &)> &pending_of)
 {
+    FrameView v;
+    v.type = f.type; v.sequence = f.sequence;
+    v.head = f.head.data(); v.head_len = f.head.size();
+    v.body = f.body.data(); v.body_len = f.body.size();
+    return add(v, peer, codec, gid_of, pending_of);
+}
+
+bool RowWriter::add(const FrameView &f, int32_t peer, const BodyCodec &codec, const std::function<bool(const std::string &, uint32_t &)> &gid_of,
+                    const std::function<bool(const std::string &, int32_t, Pending &)> &pending_of)
+{
     if (f.type != ENQ && f.type != ACK) return false;                  // hand-shake / snapshot channel events are not decisions
     Method m;
-    std::string ctx;
+    std::string &ctx = ctx_;
     uint32_t gid = 0;
-    if (!parse_scope(f.head, m, ctx) || !gid_of(ctx, gid) || rows_ >= max_rows_) return false;
+    if (!parse_scope(f.head, f.head_len, m, ctx) || !gid_of(ctx, gid) || rows_ >= max_rows_) return false;
     rg_ev_head_t h{0, 0};
     rg_ev_pair_t ab{0, 0}, cd{0, 0};
     size_t add_terms = 0;
     if (f.type == ENQ) {                                               // a request: NettyNode.prepareLocalInvocation (:109-158)
-        Request q;
-        if (!codec.decode_request(m, f.body, q) || q.node < 0 || q.node > 15) return false;
+        Request &q = q_;
+        if (!codec.decode_request(m, f.body, f.body_len, q) || q.node < 0 || q.node > 15) return false;
         switch (m) {
         case M_APPEND_ENTRIES:
             if (q.entry_terms.size() > RG_MAX_AE_ENTRIES || nterms_ + q.entry_terms.size() > max_terms_) return false;
@@ -209,7 +237,8 @@ bool RowWriter::add(const Frame &f, int32_t peer, const BodyCodec &codec, const 
     } else {                                                           // a response: AsyncService.Invocation by (scope, sequence)
         Response r;
         Pending p;
-        if (!codec.decode_response(f.body, r) || !pending_of(f.head, f.sequence, p) || peer < 0 || peer > 15) return false;
+        scope_.assign(f.head, f.head_len);
+        if (!codec.decode_response(f.body, f.body_len, r) || !pending_of(scope_, f.sequence, p) || peer < 0 || peer > 15) return false;
         switch (m) {
         case M_APPEND_ENTRIES:
             h.hdr = RG_HDR_MAKE(RG_EV_AE_ACK, peer, r.success, 0); h.aux = p.role_epoch;

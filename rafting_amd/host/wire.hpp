@@ -41,6 +41,14 @@ struct Frame {
     std::string body;              // raw bytes (what Serialization.readObject would consume)
 };
 
+// A frame that still lives in the splitter's buffer: valid until the next call into the splitter (no copies on the hot path).
+struct FrameView {
+    uint8_t type = NUL;
+    int32_t sequence = 0;
+    const char *head = nullptr; size_t head_len = 0;
+    const char *body = nullptr; size_t body_len = 0;
+};
+
 // Streaming decoder. feed() consumes what it can and appends complete frames; bytes of an incomplete frame are kept.
 // After a protocol violation the connection is dead (the reference closes the channel, :330-334): failed() stays true and
 // further input is ignored. After an EOT the rest of the stream is handed to passthrough() untouched.
@@ -48,6 +56,9 @@ class FrameSplitter {
 public:
     // returns the number of frames appended
     size_t feed(const uint8_t *data, size_t n, std::vector<Frame> &out);
+    // the same state machine handing every complete frame to `sink` as a view into the internal buffer (nothing is copied or allocated
+    // per frame); feed() above is this plus a copy
+    size_t feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink);
     bool failed() const { return failed_; }
     const std::string &error() const { return error_; }
     bool transparent() const { return transparent_; }
@@ -59,7 +70,8 @@ private:
     int32_t be32(size_t at) const;
     void fail(const std::string &why);
     bool open_ = false, has_seq_ = false;  // a frame is being read / its sequence number is still to come
-    Frame cur_;
+    Frame cur_;                            // type / sequence of the frame being read (head and body stay in buf_ until it is complete)
+    size_t head_at_ = 0;
     int32_t head_len_ = -1, body_len_ = -1;
     std::string buf_;
     size_t pos_ = 0;
@@ -73,6 +85,7 @@ void encode_frame(const Frame &f, bool ending, std::string &out);
 // "<method>:<contextId>" (transport/NettyNode.java:54-73,93-107)
 enum Method { M_NONE = 0, M_APPEND_ENTRIES, M_PRE_VOTE, M_REQUEST_VOTE, M_INSTALL_SNAPSHOT };
 bool parse_scope(const std::string &head, Method &method, std::string &context_id);
+bool parse_scope(const char *head, size_t len, Method &method, std::string &context_id);
 std::string make_scope(Method method, const std::string &context_id);
 
 // ---- bodies ---------------------------------------------------------------------------------------------------------
@@ -88,8 +101,10 @@ struct Response { int64_t term = 0; bool success = false; };   // RaftResponse.j
 class BodyCodec {
 public:
     virtual ~BodyCodec() {}
-    virtual bool decode_request(Method m, const std::string &body, Request &out) const = 0;
-    virtual bool decode_response(const std::string &body, Response &out) const = 0;
+    virtual bool decode_request(Method m, const char *body, size_t len, Request &out) const = 0;   // `out` may be reused: every field is set
+    virtual bool decode_response(const char *body, size_t len, Response &out) const = 0;
+    bool decode_request(Method m, const std::string &body, Request &out) const { return decode_request(m, body.data(), body.size(), out); }
+    bool decode_response(const std::string &body, Response &out) const { return decode_response(body.data(), body.size(), out); }
     virtual void encode_request(Method m, const Request &in, std::string &body) const = 0;
     virtual void encode_response(const Response &in, std::string &body) const = 0;
 };
@@ -100,8 +115,10 @@ public:
 //   response        i64 term, u8 success
 class FixedBodyCodec : public BodyCodec {
 public:
-    bool decode_request(Method m, const std::string &body, Request &out) const override;
-    bool decode_response(const std::string &body, Response &out) const override;
+    using BodyCodec::decode_request;
+    using BodyCodec::decode_response;
+    bool decode_request(Method m, const char *body, size_t len, Request &out) const override;
+    bool decode_response(const char *body, size_t len, Response &out) const override;
     void encode_request(Method m, const Request &in, std::string &body) const override;
     void encode_response(const Response &in, std::string &body) const override;
 };
@@ -124,6 +141,8 @@ public:
     // returns false when the frame is not a raft RPC of a known context, or the buffers are full (nothing is written then)
     bool add(const Frame &f, int32_t peer, const BodyCodec &codec, const std::function<bool(const std::string &, uint32_t &)> &gid_of,
              const std::function<bool(const std::string &, int32_t, Pending &)> &pending_of);
+    bool add(const FrameView &f, int32_t peer, const BodyCodec &codec, const std::function<bool(const std::string &, uint32_t &)> &gid_of,
+             const std::function<bool(const std::string &, int32_t, Pending &)> &pending_of);
     size_t rows() const { return rows_; }
     size_t terms() const { return nterms_; }
     void clear() { rows_ = 0; nterms_ = 0; }
@@ -131,6 +150,8 @@ public:
 private:
     rg_ev_head_t *head_; rg_ev_pair_t *ab_, *cd_; uint32_t *gid_; int64_t *terms_;
     size_t max_rows_, max_terms_, rows_ = 0, nterms_ = 0;
+    Request q_;                            // scratch reused from row to row (no allocation once its vector has grown)
+    std::string scope_, ctx_;
 };
 
 }  // namespace wire

@@ -223,3 +223,13 @@ def test_frames_become_rows(wire):
     assert (int(head["hdr"][4]) >> 12, int(head["aux"][4]), terms[3:5].tolist()) == (2, 3, [7, 7])
     assert (int(head["aux"][2]), int(ab["x"][2]), int(ab["y"][2]), int(cd["x"][2]), (int(head["hdr"][2]) >> 8) & 1) == (6, 9, 50, 120, 1)
     assert (int(head["aux"][3]), int(ab["x"][3])) == (11, 9)
+
+
+def test_zero_copy_stream_path_decodes_every_frame(tmp_path):
+    """FrameSplitter::feed_views + RowWriter::add(FrameView): the allocation-free path a gateway would run (rafting_amd/host/wire_bench.cpp
+    checks that every frame of a 200 000-frame stream, fed in 64 KiB reads, comes out as a row)."""
+    exe = str(tmp_path / "wire_bench")
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(host, "wire_bench.cpp"), os.path.join(host, "wire.cpp")], check=True)
+    p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "split+rows 200000 rows" in p.stdout, p.stdout + p.stderr
