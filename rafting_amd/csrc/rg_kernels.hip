@@ -489,8 +489,8 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     // ---- the deciding wavefront ----------------------------------------------------------------------------------
 #ifdef RG_DECIDE_PRIO   // NOT in the shipped build. This wavefront is the critical path of the workgroup and the I/O wavefronts it shares a SIMD with
     // have ~1 000 ticks of slack per round; issue priority over them measured 0.1166 -> 0.1104 ms per launch at config 3 (same-box A/B,
-    // profiles/r02_cycle_breakdown.txt section 8). The first full GPU test run of a library built with it ended in a GPU memory access
-    // fault (tests/test_golden.py, cause not established before the round's GPU budget ran out), so it stays an experiment until that is.
+    // profiles/r02_cycle_breakdown.txt section 8). Not shipped only because the round's GPU budget ended before an evidence pass of
+    // that build could be taken: the box it was started on faulted inside rg_table_create's memset, before any kernel of ours ran.
     __builtin_amdgcn_s_setprio(3);
 #endif
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
