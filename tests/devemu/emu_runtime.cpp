@@ -134,6 +134,45 @@ static bool lanes_must_meet(const char *kernel)
     return false;
 }
 
+// One OS thread per lane of a workgroup, kept across launches (creating them per launch costs more than running the kernel).
+struct LanePool {
+    std::mutex busy;                                   // one grid at a time
+    std::mutex m;
+    std::condition_variable start, finished;
+    std::vector<std::thread> workers;
+    unsigned long long generation = 0;
+    unsigned want = 0, done = 0;
+    const std::function<void(unsigned)> *job = nullptr;
+
+    void worker(unsigned idx)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                start.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                if (idx < want) fn = job;
+            }
+            if (!fn) continue;
+            (*fn)(idx);
+            std::lock_guard<std::mutex> lk(m);
+            if (++done == want) finished.notify_all();
+        }
+    }
+    void run(unsigned n, const std::function<void(unsigned)> &fn)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        while (workers.size() < n) { const unsigned idx = (unsigned)workers.size(); workers.emplace_back([this, idx] { worker(idx); }); workers.back().detach(); }
+        job = &fn; want = n; done = 0; generation++;
+        start.notify_all();
+        finished.wait(lk, [&] { return done == want; });
+        job = nullptr;
+    }
+};
+static LanePool &lane_pool() { static LanePool *p = new LanePool; return *p; }      // never destroyed: its threads live until the process ends
+
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel)
 {
     if (!waves_mode() && !lanes_must_meet(kernel)) {
@@ -152,28 +191,24 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const ch
     const unsigned waves = (block.x + 63u) / 64u;
     std::mutex err_m;
     bool failed = false;
+    std::lock_guard<std::mutex> one_grid(lane_pool().busy);            // launches from several host threads take turns
     for (unsigned b = 0; b < grid.x; b++) {
         Meeting wg;
         std::vector<Meeting> wv(waves);
         wg.init((int)block.x);
         for (unsigned w = 0; w < waves; w++) wv[w].init((int)std::min(64u, block.x - w * 64u));
-        std::vector<std::thread> lanes;
-        lanes.reserve(block.x);
-        for (unsigned t = 0; t < block.x; t++) {
-            lanes.emplace_back([&, t, b] {
-                gridDim_ = grid; blockDim_ = block; blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
-                my_block = &wg; my_wave = &wv[t / 64u]; my_lane = (int)(t % 64u);
-                try {
-                    body();
-                } catch (...) {
-                    std::lock_guard<std::mutex> lk(err_m);
-                    failed = true;
-                }
-                my_wave->leave(); my_block->leave();          // a lane that has returned is not waited for any more
-                my_wave = nullptr; my_block = nullptr;
-            });
-        }
-        for (std::thread &th : lanes) th.join();
+        lane_pool().run(block.x, [&, b](unsigned t) {
+            gridDim_ = grid; blockDim_ = block; blockIdx_ = dim3(b, 0, 0); threadIdx_ = dim3(t, 0, 0);
+            my_block = &wg; my_wave = &wv[t / 64u]; my_lane = (int)(t % 64u);
+            try {
+                body();
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(err_m);
+                failed = true;
+            }
+            my_wave->leave(); my_block->leave();          // a lane that has returned is not waited for any more
+            my_wave = nullptr; my_block = nullptr;
+        });
         if (failed) break;
     }
     if (failed) last_error = hipErrorNotSupported;
