@@ -323,9 +323,31 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_s_barrier();
 }
 
+// -DRG_FLAG_SYNC (experiment build, not shipped): the per-round hand-over between the two wavefronts through three LDS counters that each side polls,
+// instead of the workgroup's one hardware barrier — the prerequisite for a third wavefront that is NOT waited for every round.
+//   sync[0] = events published (I/O)   sync[1] = rounds decided (deciding)   sync[2] = outcomes retired (I/O)
+// A wavefront's LDS operations complete in order, so a counter written after the data it announces is never seen before that data.
+__device__ __forceinline__ void flag_set(volatile uint32_t *f, uint32_t v, uint32_t lane)
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();                 // (free on the GPU, where a wavefront's lanes move together; the host emulation's lanes are threads)
+    if (lane == 0) *f = v;
+}
+__device__ __forceinline__ void flag_wait(volatile uint32_t *f, uint32_t at_least)
+{
+    for (;;) {
+        const uint32_t seen = *f;
+        if (__builtin_amdgcn_readfirstlane(seen) >= at_least) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 template <int F, bool SPARSE>
 __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
 {
+#ifdef RG_FLAG_SYNC
+    __shared__ uint32_t sh_sync[3];
+#endif
     __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
     __shared__ int32_t sh_rej[F * BLOCK];
     __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
@@ -421,13 +443,23 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             publish(0u, first, first_t);
             hdr_cur = first.hdr;
         }
+#ifdef RG_FLAG_SYNC
+        if (lane == 0) { sh_sync[0] = 1u; sh_sync[1] = 0u; sh_sync[2] = 0u; }
+#endif
         lds_barrier();                                   // event 0 is visible
 #ifdef RG_PROFILE2
         uint64_t ti_prev = __builtin_amdgcn_s_memtime();
 #endif
         for (uint32_t r = 0; r < p.rounds; r++) {
+#ifdef RG_FLAG_SYNC
+            flag_wait(&sh_sync[1], r);                   // round r-1 is decided: its event slot is free, its outcome is there
+            publish((r + 1u) & 1u, n1, t1);
+            flag_set(&sh_sync[0], r + 2u, lane);
+            if (r > 0) { retire(r - 1u, hdr_prev); flag_set(&sh_sync[2], r, lane); }
+#else
             publish((r + 1u) & 1u, n1, t1);
             if (r > 0) retire(r - 1u, hdr_prev);
+#endif
             hdr_prev = hdr_cur; hdr_cur = n1.hdr;
             n1 = n2; t1 = t2;
             n2 = n3;
@@ -438,12 +470,17 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             const uint64_t ti0 = __builtin_amdgcn_s_memtime();
             pf_iowork += (uint32_t)(ti0 - ti_prev);
 #endif
+#ifndef RG_FLAG_SYNC
             lds_barrier();
+#endif
 #ifdef RG_PROFILE2
             ti_prev = __builtin_amdgcn_s_memtime();
             pf_iobar += (uint32_t)(ti_prev - ti0);
 #endif
         }
+#ifdef RG_FLAG_SYNC
+        flag_wait(&sh_sync[1], p.rounds);
+#endif
         retire(last_round, hdr_prev);
 #ifdef RG_PROFILE2
         lds_barrier();
@@ -512,6 +549,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     lds_barrier();                                       // event 0 is visible
     for (uint32_t r = 0; r < p.rounds; r++) {
         const uint32_t slot = r & 1u;
+#ifdef RG_FLAG_SYNC
+        flag_wait(&sh_sync[0], r + 1u);                  // event r is published
+#endif
         const uint64_t head = sh_ev[slot][EV_HEAD][lane];
         const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
@@ -577,6 +617,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 #endif
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+#ifdef RG_FLAG_SYNC
+        if (r >= 2u) flag_wait(&sh_sync[2], r - 1u);     // outcome r-2, which lived in this slot, has been read
+#endif
         sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
         sh_out[slot][OUT_FLAGS][lane] = (uint64_t)flags_all | ((uint64_t)g.role_epoch << 32);
         sh_out[slot][OUT_COMMIT][lane] = (uint64_t)g.commit;
@@ -587,7 +630,11 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         __builtin_amdgcn_s_waitcnt(0xC07F);
         const uint64_t tz4 = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RG_FLAG_SYNC
+        flag_set(&sh_sync[1], r + 1u, lane);
+#else
         lds_barrier();
+#endif
 #ifdef RG_PROFILE2
         const uint64_t tz5 = __builtin_amdgcn_s_memtime();
         pf_read += (uint32_t)(tz1 - tz0); pf_t1 += (uint32_t)(tz2 - tz1); pf_t2 += (uint32_t)(tz3 - tz2); pf_pub += (uint32_t)(tz4 - tz3); pf_bar += (uint32_t)(tz5 - tz4);

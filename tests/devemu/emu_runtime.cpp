@@ -87,6 +87,8 @@ bool pinned_has(const void *p)
     return (uintptr_t)p < it->first + it->second;
 }
 
+void lane_yield() { std::this_thread::yield(); }
+
 unsigned long long wave_ballot(bool p)
 {
     if (!my_wave) return p ? 1ull : 0ull;

@@ -48,6 +48,7 @@ struct Deadlock {};
 void pinned_add(void *p, size_t n);
 void pinned_remove(void *p);
 bool pinned_has(const void *p);
+void lane_yield();
 unsigned long long wave_ballot(bool p);                    // lane-serial: a wavefront of one lane
 unsigned long long wave_exchange_xor(unsigned long long bits, int lane_xor);   // lane-serial: no partner, 0
 unsigned long long wave_first(unsigned long long v);
@@ -65,6 +66,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const ch
 #define __builtin_amdgcn_readfirstlane(x) ((decltype(x))::hipemu::wave_first((unsigned long long)(x)))
 #define __builtin_amdgcn_ballot_w64(x) (::hipemu::wave_ballot(x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) (::hipemu::lane_yield())
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
 #define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))      /* g++ has no such builtin; vectors via ext_vector_type are clang-only: */
