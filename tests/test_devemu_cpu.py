@@ -64,10 +64,14 @@ def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per GPU), on the emulation: config 4's stream, rank r
     decides block r, nothing but a barrier and three scalars crosses ranks (gloo), rank 0 prints ONE line with the whole-job sum."""
     import json
+    import socket
+    with socket.socket() as sk:                            # a port nobody is listening on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     env.pop("RG_FAST", None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"],
+                        "--master-port", str(port), os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
