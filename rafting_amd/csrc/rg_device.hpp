@@ -764,19 +764,11 @@ struct Stepper {
     // is left untouched and goes to run().
     // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
     // into exec-mask branches, which is exactly what this tier exists to avoid.
-#ifdef RG_COUNT_SLOW
-    uint32_t dbg_reason = 0u;
-#endif
     // pe0 = the first carried entry term; entries_ok / same = entries_readable() / entries_same_term() of the row;
     // ev_narrow = a, b, c, d, pe0 are all in [0, NARROW_LIMIT) (worked out where the event is loaded)
     __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
                                              int64_t d, int64_t pe0, bool entries_ok, bool same, bool ev_narrow)
     {
-#if defined(RG_EXP_ONLY_NARROW)      // analysis builds (tools/isa_stats.sh): one instantiation only, to count its instructions
-        (void)ev_narrow; return try_fast_v<int32_t>(allow, hdr, aux, (int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d, (int32_t)pe0, entries_ok, same);
-#elif defined(RG_EXP_ONLY_WIDE)
-        (void)ev_narrow; return try_fast_v<int64_t>(allow, hdr, aux, a, b, c, d, pe0, entries_ok, same);
-#endif
         if (narrow_tier && __builtin_amdgcn_ballot_w64(!(ev_narrow & g.narrow)) == 0)       // wave-uniform: all 64 rows fit the 32-bit tier
             return try_fast_v<int32_t>(allow, hdr, aux, (int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d, (int32_t)pe0, entries_ok, same);
         const bool done = try_fast_v<int64_t>(allow, hdr, aux, a, b, c, d, pe0, entries_ok, same);
@@ -825,14 +817,10 @@ struct Stepper {
         const V ae_last = contains ? vadd(b, (V)n) : g_last;
         const bool want_commit = contains & (d > g_epoch);
         const V ae_x = vmin(d, ae_last);
-#ifdef RG_EXP_NO_AE      // experiment build (tools/exp_class_split.sh): the instruction stream of a wavefront that never decides AppendEntries
-        const bool fa = false;
-#else
         const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a >= g_term) &
                         (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
                         (b > g_epoch) & (c != 0) & entries_ok & (!contains | (n == 0) | same) &
                         !(want_commit & (ae_x < g_commit));
-#endif
         const bool ae_refresh = fa & refresh;
         const bool ae_commit = fa & want_commit & (ae_x > g_commit);
         const bool ae_append = fa & contains & (n > 0);
@@ -840,11 +828,7 @@ struct Stepper {
 
         // ---- AppendEntries ack at a leader ----------------------------------------------------------
         const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
-#ifdef RG_EXP_NO_ACK     // experiment build: the instruction stream of a wavefront that never decides acks / client appends
-        const bool ack_shape = false;
-#else
         const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
-#endif
         const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
         const V s_epoch = (V)pe.last_epoch[j * BLOCK], s_next = (V)pe.next_index[j * BLOCK], s_match = (V)pe.match_index[j * BLOCK];
         const int32_t s_rej = pe.rejection[j * BLOCK];
@@ -873,11 +857,7 @@ struct Stepper {
         const bool ack_drop = allow & ack_kind & peer_ok & (aux != g_repoch);       // AsyncHead aborted: response dropped
 
         // ---- client append at a leader ----------------------------------------------------------------
-#ifdef RG_EXP_NO_ACK
-        const bool fc = false;
-#else
         const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
-#endif
         const bool fc_newrun = fc & (lt != g_term);
         const bool fc_prepare = fc & !g_prep;
 
@@ -898,13 +878,6 @@ struct Stepper {
         const bool fv = count_only | late_noop | vote_drop;
 
         const bool fast = fa | fk | fc | fv | ack_drop;
-#ifdef RG_COUNT_SLOW   // experiment build: why an ack row leaves tier 1 (first failing precondition)
-        dbg_reason = 0u;
-        if (ack_shape & !fk & !ack_drop) {
-            dbg_reason = !((role == RG_LEADER) & g_prep) ? 1u : (a > g_term) ? 2u : (b != s_epoch) ? 3u : s_pend ? 4u :
-                         (c < s_match) ? 5u : !(flag | (s_match != 0)) ? 6u : (lookup & !major_ok) ? 7u : 8u;
-        }
-#endif
         if (fk) {
             pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
             if constexpr (NARROW) {                       // the high words in LDS are zero already
@@ -970,109 +943,8 @@ struct Stepper {
     // selects cost ~1 150 ticks per visit. run() stays the only code that decides these rows.
     __device__ __forceinline__ bool try_mid(bool want, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c)
     {
-#ifndef RG_TIER15
         (void)want; (void)hdr; (void)aux; (void)a; (void)b; (void)c;
         return false;
-#else
-        const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr);
-        const bool flag = RG_HDR_FLAG(hdr) != 0;
-        const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
-        const bool peer_ok = (slot < P) & (slot != self);
-        bool done = false;
-        // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv` (everything a new participant resets)
-        auto convert = [&](bool conv, int32_t new_role, int64_t new_term, int32_t new_vote) {
-            g.role = conv ? new_role : g.role;
-            g.term = conv ? new_term : g.term;
-            g.voted_for = conv ? new_vote : g.voted_for;
-            g.role_epoch = g.role_epoch + (conv ? 1u : 0u);
-            g.td = g.td & !conv;
-            g.leader = conv ? RG_NO_NODE : g.leader;
-            g.votes = conv ? 1 : g.votes;
-            g.prepared = g.prepared & !conv;
-        };
-        const uint32_t conv_flags = RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER;
-
-        // (a) RG_EV_TIMEOUT (aux 0 = whoever is current)
-        const bool to_kind = want & (kind == RG_EV_TIMEOUT);
-        if (__builtin_amdgcn_ballot_w64(to_kind) != 0) {
-            const int64_t g_term = g.term, term1 = wadd(g_term, 1);
-            const int32_t role = g.role;
-            const bool to_stale = to_kind & (aux != 0u) & (aux != g.role_epoch);             // context/RaftRoutine.java:70
-            const bool to_live = to_kind & !to_stale;
-            const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);          // refresh + prepareElection
-            const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
-            const bool to_lead = to_live & (role == RG_LEADER);
-            const bool mine = to_stale | to_pre | to_cand | to_lead;                          // (currentTerm + 1 wrapped: the general handlers)
-            if (to_lead & !g.prepared) prepare_replication();                                 // a new Leader's first tick (member/Leader.java:30-50)
-            convert(to_pre | to_cand, to_cand ? RG_CANDIDATE : RG_FOLLOWER, to_cand ? term1 : g_term, to_cand ? (int32_t)self : g.voted_for);
-            g.td = g.td | to_pre;
-            if (mine) {
-                fx.status = to_stale ? RG_DROPPED_STALE_ROLE : RG_OK;
-                fx.resp_term = g_term; fx.log_from = 0;
-                fx.flags = ((to_pre | to_cand) ? conv_flags : 0u) | (to_lead ? RG_F_RESET_TIMER : 0u) |
-                           ((to_pre ? RG_EMIT_PREVOTE : (to_cand ? RG_EMIT_REQVOTE : (to_lead ? RG_EMIT_HEARTBEAT : RG_EMIT_NONE))) << RG_F_EMIT_SHIFT);
-            }
-            done = done | mine;
-        }
-
-        // (b) vote replies that end a (pre-)election, or arrive late for a won one with a higher term (Q13)
-        const bool vr = want & ((kind == RG_EV_RV_REPLY) | (kind == RG_EV_PV_REPLY)) & peer_ok;
-        if (__builtin_amdgcn_ballot_w64(vr) != 0) {
-            const bool is_pv = kind == RG_EV_PV_REPLY;
-            const int64_t g_term = g.term, term1 = wadd(g_term, 1), el_term = g.elected_term;
-            const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
-            const bool cur_epoch = aux == g_repoch;
-            const bool sender_ok = is_pv ? ((g.role == RG_FOLLOWER) & g.td) : (g.role == RG_CANDIDATE);
-            const int64_t T = is_pv ? term1 : g_term;
-            const bool vr_cur = vr & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);
-            const bool vr_higher = vr_cur & (a > T);                                          // -> Follower(result.term, responder)
-            const bool vr_win = vr_cur & (a <= T) & flag & (g.votes + 1 >= p.majority);
-            const bool win_rv = vr_win & !is_pv;
-            const bool vr_late = vr & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch) & (a > el_term);
-            const bool late_conv = vr_late & (a >= g_term);                                   // Follower is "better" from any role at >= term
-            const bool mine = vr_higher | vr_win | vr_late;
-            const bool conv = vr_higher | vr_win | late_conv;
-            const int32_t new_role = vr_win ? (is_pv ? RG_CANDIDATE : RG_LEADER) : RG_FOLLOWER;
-            g.elected_epoch = win_rv ? g_repoch : (vr_late ? 0u : el_epoch);                  // Candidate.java:75-79 / head.abortRequests()
-            g.elected_term = win_rv ? g_term : el_term;
-            convert(conv, new_role, vr_win ? T : a, vr_win ? (int32_t)self : (int32_t)slot);
-            if (mine) {
-                fx.status = RG_OK; fx.resp_term = g_term; fx.log_from = 0;
-                fx.flags = (conv ? conv_flags : 0u) | (((conv & (new_role == RG_CANDIDATE)) ? RG_EMIT_REQVOTE : RG_EMIT_NONE) << RG_F_EMIT_SHIFT);
-            }
-            done = done | mine;
-        }
-
-        // (c) a replication response with a higher term: the Leader steps down, votedFor = the responder (Q7)
-        const bool ack = want & ((kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK)) & peer_ok & (aux == g.role_epoch) & (g.role == RG_LEADER) &
-                         g.prepared & (a > g.term);
-        if (__builtin_amdgcn_ballot_w64(ack) != 0) {
-            const int64_t g_term = g.term;
-            convert(ack, RG_FOLLOWER, a, (int32_t)slot);
-            if (ack) { fx.status = RG_OK; fx.resp_term = g_term; fx.log_from = 0; fx.flags = conv_flags; }
-            done = done | ack;
-        }
-
-        // (d) RequestVote / PreVote at a Follower that has a log
-        const bool vq = want & ((kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ)) & (slot < P) & (g.role == RG_FOLLOWER) & (g.rc > 0);
-        if (__builtin_amdgcn_ballot_w64(vq) != 0) {
-            const int64_t g_term = g.term, g_last = g.last, lt = g.last_term();
-            const int32_t g_voted = g.voted_for;
-            const bool pvq = vq & (kind == RG_EV_PV_REQ), rvq = vq & (kind == RG_EV_RV_REQ);
-            const bool utd = (c > lt) | ((c == lt) & (b >= g_last));                          // Follower.logUpToDate with a last entry
-            const bool pv_judge = pvq & (a > g_term) & g.td;                                  // else failure(currentTerm), no timer touched
-            const bool rv_new = rvq & (a > g_term);                                           // else answered from the current membership
-            const bool rv_same = rvq & (a == g_term);
-            const bool success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
-            convert(rv_new, RG_FOLLOWER, a, utd ? (int32_t)slot : RG_NO_NODE);
-            if (vq) {
-                fx.status = RG_OK; fx.resp_term = rv_new ? a : g_term; fx.log_from = 0;
-                fx.flags = (rv_new ? conv_flags : 0u) | (pv_judge ? RG_F_RESET_TIMER : 0u) | RG_F_REPLIED | (success ? RG_F_SUCCESS : 0u);
-            }
-            done = done | vq;
-        }
-        return done;
-#endif
     }
 
     // ---- one row (tier 2: the general handlers) ---------------------------------------------------

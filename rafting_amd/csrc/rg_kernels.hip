@@ -165,9 +165,6 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // wavefront once at the end
     uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
     bool blocked = false;
-#ifdef RG_COUNT_SLOW
-    uint32_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};    // [0] slow AppendEntries; [1..7] first failing precondition of a slow ack
-#endif
 
     // outcome of the previous round, stored one round late (see the drain below)
     rg_reply_t pend_rep{0, 0u, 0u};
@@ -186,13 +183,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         // vmcnt(0) and also wait for the loads issued below, and (b) draining right after the outcome stores
         // would expose the full store latency every round. Hence: loads AND the previous round's stores are
         // issued right after this point and get a whole round of decision work to complete.
-#ifdef RG_PROFILE
-        const uint64_t tp0 = __builtin_amdgcn_s_memtime();
-#endif
         __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) expcnt(7) lgkmcnt(15)
-#ifdef RG_PROFILE
-        const uint64_t tp1 = __builtin_amdgcn_s_memtime();
-#endif
         if (r > 0) {
             if (active) p.reply[row - p.count] = pend_rep;
             if (pend_w_lfx) p.logfx[row - p.count] = pend_lfx;
@@ -202,12 +193,6 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
         const uint32_t r1 = r + 1u < p.rounds ? r + 1u : last_round, r2 = r + 2u < p.rounds ? r + 2u : last_round;
         load_event(p, (size_t)r2 * p.count + ir, far);
         load_event_tail(p, (size_t)r1 * p.count + ir, near, near_t);
-#ifdef RG_PROFILE
-        const uint64_t tp2 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RG_PROFILE_TIERS
-        uint64_t tpa = tp2, tpb = tp2;                  // -DRG_PROFILE -DRG_PROFILE_TIERS: split "decide" into tier 1 / tier 2 / epilogue
-#endif
 
         {
             const uint32_t kind = RG_HDR_KIND(cur.hdr);
@@ -217,28 +202,13 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             const bool done = st.try_fast(FAST & !skip, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
                                           entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
                                           event_narrow(cur.a, cur.b, cur.c, cur.d, cur_t.e0));
-#ifdef RG_PROFILE_TIERS
-            tpa = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RG_COUNT_SLOW                                   // experiment build: which rows leave tier 1 (reported through three tallies)
-            dbg[0] += !done & !skip & (kind == RG_EV_AE_REQ); dbg[1] += st.dbg_reason == 1u; dbg[2] += st.dbg_reason == 2u;
-            dbg[3] += st.dbg_reason == 3u; dbg[4] += (st.dbg_reason == 4u) | (st.dbg_reason == 5u); dbg[5] += st.dbg_reason == 6u;
-            dbg[6] += st.dbg_reason == 7u; dbg[7] += st.dbg_reason == 8u;
-#endif
             const bool slow = !done & !skip;
             if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-#ifndef RG_TIER1_ONLY                                  // analysis-only build (tools/isa_stats.sh): the loop body without tier 2
             if (__builtin_amdgcn_ballot_w64(slow) != 0) {
                 const bool mid = st.try_mid(FAST & slow, cur.hdr, cur.aux, cur.a, cur.b, cur.c);
                 if (slow & !mid) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
                 st.refresh_narrow();                      // tier 1.5 and the general handlers work on 64-bit values
             }
-#else
-            (void)slow;
-#endif
-#ifdef RG_PROFILE_TIERS
-            tpb = __builtin_amdgcn_s_memtime();
-#endif
             const uint32_t status = st.fx.status, flags = st.fx.flags;
             if (status == RG_NEED_HOST) blocked = true;
             pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
@@ -258,16 +228,6 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             c_need += status == RG_NEED_HOST ? 1u : 0u;
             c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
         }
-#ifdef RG_PROFILE
-        {   // experiment build only: cycles spent draining / issuing / deciding, reported through the tallies
-            const uint64_t tp3 = __builtin_amdgcn_s_memtime();
-#ifdef RG_PROFILE_TIERS
-            if (lane == 0) { c_need += (uint32_t)(tpa - tp2); c_stale += (uint32_t)(tpb - tpa); c_append += (uint32_t)(tp3 - tpb); }
-#else
-            if (lane == 0) { c_need += (uint32_t)(tp1 - tp0); c_stale += (uint32_t)(tp2 - tp1); c_append += (uint32_t)(tp3 - tp2); }
-#endif
-        }
-#endif
         cur = near; cur_t = near_t;
         near = far;
     }
@@ -282,11 +242,7 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
     // Wavefront reduction of the tallies: butterfly over the 64 lanes, then each wave adds into its own
     // 64-byte slot of the counter table with a plain read-modify-write (8 atomics per wave onto 8 shared
     // words cost ~60 us per launch at 1024 waves). rg_counters_read sums the slots.
-#ifdef RG_COUNT_SLOW
-    uint32_t tally[RG_NUM_COUNTERS] = {dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7]};
-#else
     uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
-#endif
 #pragma unroll
     for (int c = 0; c < RG_NUM_COUNTERS; c++) {
         uint32_t v = active ? tally[c] : 0u;
@@ -345,37 +301,13 @@ __device__ __forceinline__ void flag_wait(volatile uint32_t *f, uint32_t at_leas
 template <int F, bool SPARSE>
 __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
 {
-#ifdef RG_FLAG_SYNC
-    __shared__ uint32_t sh_sync[3];
-#endif
     __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
     __shared__ int32_t sh_rej[F * BLOCK];
     __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
     __shared__ uint64_t sh_out[2][OUT_FIELDS][BLOCK];
-#ifdef RG_SPLIT_NARROW
-    __shared__ uint32_t sh_nar[2][BLOCK];                // event_narrow() of the row, worked out by the I/O wavefront
-#endif
-#ifdef RG_PROFILE
-    __shared__ uint32_t sh_prof[4];
-    uint32_t prof_read = 0, prof_decide = 0, prof_publish = 0;
-#endif
-#ifdef RG_PROFILE2      // experiment build (tools/cyc2.py): where the cycles of a round go, for both wavefronts; replaces six tallies
-    __shared__ uint32_t sh_prof2[8];
-    uint32_t pf_read = 0, pf_t1 = 0, pf_t2 = 0, pf_pub = 0, pf_bar = 0, pf_iobar = 0, pf_iowork = 0;
-#endif
-#ifdef RG_PROFILE3
-    __shared__ uint32_t sh_prof3[4][BLOCK];
-    uint32_t pv_visits = 0, pv_reads = 0, pv_mid = 0, pv_run = 0;
-#endif
-#ifdef RG_HWID          // experiment build (tools/hwid.py): which SIMD / wave slot the two wavefronts of a workgroup were placed on
-    __shared__ uint32_t sh_hw[2];
-#endif
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
-#ifdef RG_HWID
-    if (lane == 0) sh_hw[io_wave ? 1 : 0] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID: slot 3:0, SIMD 5:4, CU 11:8
-#endif
     const uint32_t i = blockIdx.x * BLOCK + lane;
     const bool active = i < p.count;
     const uint32_t ir = active ? i : p.count - 1u;       // lanes past the end shadow the last row; only their stores are off
@@ -392,9 +324,6 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
             sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0; sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
             sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
-#ifdef RG_SPLIT_NARROW
-            sh_nar[slot][lane] = event_narrow(e.a, e.b, e.c, e.d, t.e0) ? 1u : 0u;
-#endif
         };
         uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
         auto retire = [&](uint32_t r, uint32_t hdr) {      // outcome of round r: LDS -> global, plus the tallies
@@ -443,68 +372,20 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
             publish(0u, first, first_t);
             hdr_cur = first.hdr;
         }
-#ifdef RG_FLAG_SYNC
-        if (lane == 0) { sh_sync[0] = 1u; sh_sync[1] = 0u; sh_sync[2] = 0u; }
-#endif
         lds_barrier();                                   // event 0 is visible
-#ifdef RG_PROFILE2
-        uint64_t ti_prev = __builtin_amdgcn_s_memtime();
-#endif
         for (uint32_t r = 0; r < p.rounds; r++) {
-#ifdef RG_FLAG_SYNC
-            flag_wait(&sh_sync[1], r);                   // round r-1 is decided: its event slot is free, its outcome is there
-            publish((r + 1u) & 1u, n1, t1);
-            flag_set(&sh_sync[0], r + 2u, lane);
-            if (r > 0) { retire(r - 1u, hdr_prev); flag_set(&sh_sync[2], r, lane); }
-#else
             publish((r + 1u) & 1u, n1, t1);
             if (r > 0) retire(r - 1u, hdr_prev);
-#endif
             hdr_prev = hdr_cur; hdr_cur = n1.hdr;
             n1 = n2; t1 = t2;
             n2 = n3;
             n3 = n4;
             load_event_tail(p, row_of(r + 3u), n2, t2);
             load_event(p, row_of(r + 5u), n4);
-#ifdef RG_PROFILE2
-            const uint64_t ti0 = __builtin_amdgcn_s_memtime();
-            pf_iowork += (uint32_t)(ti0 - ti_prev);
-#endif
-#ifndef RG_FLAG_SYNC
             lds_barrier();
-#endif
-#ifdef RG_PROFILE2
-            ti_prev = __builtin_amdgcn_s_memtime();
-            pf_iobar += (uint32_t)(ti_prev - ti0);
-#endif
         }
-#ifdef RG_FLAG_SYNC
-        flag_wait(&sh_sync[1], p.rounds);
-#endif
         retire(last_round, hdr_prev);
-#ifdef RG_PROFILE2
-        lds_barrier();
-        c_conv = sh_prof2[0]; c_commit = sh_prof2[1]; c_assert = sh_prof2[2]; c_need = sh_prof2[3]; c_stale = sh_prof2[4]; c_append = pf_iobar;
-        c_replied = pf_iowork;
-        if (lane != 0) { c_conv = 0; c_commit = 0; c_assert = 0; c_need = 0; c_stale = 0; c_append = 0; c_replied = 0; }
-#ifdef RG_PROFILE3
-        c_conv = sh_prof3[0][lane]; c_commit = sh_prof3[1][lane]; c_assert = sh_prof3[2][lane]; c_need = sh_prof3[3][lane];
-#endif
-#endif
-#ifdef RG_PROFILE   // experiment build: the deciding wavefront's cycle sums (LDS-read wait / decide / publish+barrier) replace three tallies
-        lds_barrier();
-        c_need = sh_prof[0]; c_stale = sh_prof[1]; c_append = sh_prof[2];
-        if (lane != 0) { c_need = 0; c_stale = 0; c_append = 0; }
-#endif
 
-#ifdef RG_HWID
-        {
-            const uint32_t hd = sh_hw[0], hi = sh_hw[1], sd = (hd >> 4) & 3u, si = (hi >> 4) & 3u;
-            c_replied = sd == 0u; c_conv = sd == 1u; c_commit = sd == 2u; c_assert = sd == 3u;
-            c_need = si == ((sd + 1u) & 3u); c_stale = (hd & 15u) == (hi & 15u); c_append = hd & 15u;
-            if (lane != 0) { c_replied = 0; c_conv = 0; c_commit = 0; c_assert = 0; c_need = 0; c_stale = 0; c_append = 0; }
-        }
-#endif
         uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
 #pragma unroll
         for (int c = 0; c < RG_NUM_COUNTERS; c++) {
@@ -537,60 +418,30 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
     stage_peers<F>(p.t, gi, g, pe);
     Stepper<F> st(p, g, pe);
-#ifndef RG_SPLIT_NARROW
     // measured (profiles/r02_*): with one deciding wavefront per SIMD the round is a dependent chain, and the 32-bit tier's
     // entry test (an LDS read, a ballot, a branch) sits at its head: 0.120 ms against 0.112 ms per launch at 65 536 groups.
     // The single-wavefront kernel (two or more deciding wavefronts per SIMD) gains from it (0.204 -> 0.198 ms at 131 072).
     st.narrow_tier = false;
-#endif
     st.refresh_narrow();
     const bool FAST = p.fast_paths != 0;
     bool blocked = false;
     lds_barrier();                                       // event 0 is visible
     for (uint32_t r = 0; r < p.rounds; r++) {
         const uint32_t slot = r & 1u;
-#ifdef RG_FLAG_SYNC
-        flag_wait(&sh_sync[0], r + 1u);                  // event r is published
-#endif
         const uint64_t head = sh_ev[slot][EV_HEAD][lane];
         const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
                       c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
         const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
-#ifdef RG_SPLIT_NARROW
-        const bool ev_narrow = sh_nar[slot][lane] != 0u;
-#else
         const bool ev_narrow = false;
-#endif
-#ifdef RG_PROFILE2
-        const uint64_t tz0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const uint64_t tz1 = __builtin_amdgcn_s_memtime();
-        uint64_t tz2 = tz1;
-#endif
-#ifdef RG_PROFILE
-        const uint64_t tq0 = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const uint64_t tq1 = __builtin_amdgcn_s_memtime();
-#endif
         const uint32_t kind = RG_HDR_KIND(hdr);
         // tier 1 and tier 1.5 branch on wavefront ballots: every lane calls them (a lane blocked after a NEED_HOST asks for nothing)
         const bool skip = blocked & (kind != RG_EV_NONE);
         const bool done = st.try_fast(FAST & !skip, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow);
         const bool slow = !done & !skip;
         if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-#ifndef RG_TIER1_ONLY
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-#ifdef RG_PROFILE2
-            tz2 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RG_PROFILE3      // experiment build: inside a slow-path visit — tier 1.5 / LDS reads + general handlers (per wavefront visit, lane 0 reports)
-            const uint64_t ty0 = __builtin_amdgcn_s_memtime();
-#endif
             const bool mid = st.try_mid(FAST & slow, hdr, aux, a, b, c);
-#ifdef RG_PROFILE3
-            const uint64_t ty1 = __builtin_amdgcn_s_memtime();
-#endif
             if (slow & !mid) {
                 // the general handlers also want the hint and the other prefetched entry terms: read only here
                 const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
@@ -599,62 +450,18 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
                 st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
             }
             st.refresh_narrow();                         // tier 1.5 and the general handlers work on 64-bit values
-#ifdef RG_PROFILE3
-            const uint64_t ty2 = __builtin_amdgcn_s_memtime();
-            pv_visits += 1u; pv_mid += (uint32_t)(ty1 - ty0); pv_run += (uint32_t)(ty2 - ty1); pv_reads += (slow & !mid) ? 1u : 0u;
-#endif
         }
-#else
-        (void)slow;
-#endif
         const uint32_t status = st.fx.status, flags = st.fx.flags;
-#ifdef RG_PROFILE
-        const uint64_t tq2 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RG_PROFILE2
-        const uint64_t tz3 = __builtin_amdgcn_s_memtime();
-        if (__builtin_amdgcn_ballot_w64(tz2 != tz1) == 0) tz2 = tz3;      // no lane went to the general handlers: all of it was tier 1
-#endif
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
-#ifdef RG_FLAG_SYNC
-        if (r >= 2u) flag_wait(&sh_sync[2], r - 1u);     // outcome r-2, which lived in this slot, has been read
-#endif
         sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
         sh_out[slot][OUT_FLAGS][lane] = (uint64_t)flags_all | ((uint64_t)g.role_epoch << 32);
         sh_out[slot][OUT_COMMIT][lane] = (uint64_t)g.commit;
         sh_out[slot][OUT_FROM][lane] = (uint64_t)st.fx.log_from;
         sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
         sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
-#ifdef RG_PROFILE2
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        const uint64_t tz4 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef RG_FLAG_SYNC
-        flag_set(&sh_sync[1], r + 1u, lane);
-#else
         lds_barrier();
-#endif
-#ifdef RG_PROFILE2
-        const uint64_t tz5 = __builtin_amdgcn_s_memtime();
-        pf_read += (uint32_t)(tz1 - tz0); pf_t1 += (uint32_t)(tz2 - tz1); pf_t2 += (uint32_t)(tz3 - tz2); pf_pub += (uint32_t)(tz4 - tz3); pf_bar += (uint32_t)(tz5 - tz4);
-#endif
-#ifdef RG_PROFILE
-        const uint64_t tq3 = __builtin_amdgcn_s_memtime();
-        prof_read += (uint32_t)(tq1 - tq0); prof_decide += (uint32_t)(tq2 - tq1); prof_publish += (uint32_t)(tq3 - tq2);
-#endif
     }
-#ifdef RG_PROFILE
-    if (lane == 0) { sh_prof[0] = prof_read; sh_prof[1] = prof_decide; sh_prof[2] = prof_publish; }
-    lds_barrier();
-#endif
-#ifdef RG_PROFILE3      // per-lane sums: the lane that took the visit measured it
-    sh_prof3[0][lane] = pv_visits; sh_prof3[1][lane] = pv_reads; sh_prof3[2][lane] = pv_mid; sh_prof3[3][lane] = pv_run;
-#endif
-#ifdef RG_PROFILE2
-    if (lane == 0) { sh_prof2[0] = pf_read; sh_prof2[1] = pf_t1; sh_prof2[2] = pf_t2; sh_prof2[3] = pf_pub; sh_prof2[4] = pf_bar; }
-    lds_barrier();
-#endif
     if (active) store_group<F>(p.t, gi, G, g, pe);
 }
 
