@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5), help="default: 3 at N=1, 4 at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=6, help="batches of the stream the CPU baseline replays")
-    ap.add_argument("--copy-bw", action="store_true", help="also measure a plain HBM copy kernel")
+    ap.add_argument("--copy-bw", action="store_true", help="(default now) measure a plain HBM copy kernel in the same run")
+    ap.add_argument("--no-copy-bw", action="store_true", help="skip the plain-copy bandwidth measurement")
     ap.add_argument("--pcie-batches", type=int, default=12, help="host-memory legs: batches per leg (the first two size the staging buffers)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
     ap.add_argument("--dist-backend", default="gloo", help="how the three result scalars are added up: gloo (default, host sum — the "
@@ -144,7 +145,7 @@ def main():
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
     elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device=red_dev if world > 1 else None)
 
-    copy_gbps = table.copy_bandwidth(1 << 30, 10) if args.copy_bw else None
+    copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(1 << 30, 10)     # the measured-copy yardstick, same run, same device
 
     # ---- the same step with caller-owned HOST buffers (PCIe both ways): reported, never `value` -----------------------------
     # Three ways over the link, each from the same table state with the same FRESH batches of the stream (B0, B1 size the staging

@@ -56,7 +56,7 @@ struct rg_table {
     unsigned long long *counters = nullptr;     // [counter_slots][RG_NUM_COUNTERS], one slot per wave of a dense launch
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
-    int lanes = -1;                             // -1: pick per launch; 0: split kernel; 8/16/32/64: single-wave kernel (RG_LANES / RG_SPLIT env)
+    int lanes = -1;                             // -1: pick per launch; 0: split kernel; 64: single-wavefront kernel (RG_SPLIT env forces one)
     uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
     bool timing = false;
@@ -217,13 +217,9 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
         t->simds = (uint32_t)prop.multiProcessorCount * 4u;
     }
     t->lanes = -1;
-    if (const char *e = getenv("RG_LANES")) {
-        const int v = atoi(e);
-        if (v == 8 || v == 16 || v == 32 || v == 64) t->lanes = v;
-    }
-    if (const char *e = getenv("RG_SPLIT")) t->lanes = atoi(e) != 0 ? 0 : (t->lanes > 0 ? t->lanes : 64);   // force either kernel
+    if (const char *e = getenv("RG_SPLIT")) t->lanes = atoi(e) != 0 ? 0 : 64;   // force either kernel
     if (const char *e = getenv("RG_FAST")) t->fast_paths = atoi(e) != 0;
-    t->counter_slots = (G + 7) / 8;             // enough for the narrowest wavefronts
+    t->counter_slots = (G + 63) / 64 + 1;       // one slot per workgroup of a dense launch
     CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
     t->dt.groups = groups;
     CREATE_TRY(hipMalloc((void **)&t->timer_deadline, G * sizeof(int64_t)));

@@ -925,28 +925,6 @@ struct Stepper {
         return fast;
     }
 
-    // ---- tier 1.5: the rows that CHANGE A ROLE, with selects, one row class at a time ------------------------------------
-    // At config 3 only ~0.9 % of the rows miss tier 1, but one such lane in 64 sends its whole wavefront into the general handlers in
-    // ~45 % of the rounds, for ~1 700 ticks (profiles/r02_cycle_breakdown.txt). Almost all of those rows have one of four shapes whose
-    // outcome is "a new participant": an election / heartbeat timeout (member/Follower.java:156-168, Candidate.java:82-88,
-    // Leader.java:120-126), the vote reply that completes a majority or carries a higher term (Candidate.java:121-134,
-    // Follower.java:258-270), a replication response with a higher term (Leader.java:224-226), and RequestVote / PreVote at a
-    // Follower with a non-empty log (Follower.java:91-127). Each class sits behind ONE wave-uniform branch (ballot != 0), so a visit
-    // pays for the classes that are present — usually one, ~50 instructions of selects — and under preconditions that make
-    // Membership.isBetter true (or the row a plain refusal) the row is decided here; everything else — assertion sites, empty logs,
-    // Candidate / Leader as voters, conflicts, hints — still goes to run(), the single source of truth.
-    // MUST be called by every lane of the wavefront (converged code): `want` = this lane missed tier 1. Returns "decided here".
-    // MEASURED AND COMPILED OUT (-DRG_TIER15 brings it back; the emulation and GPU suites pass with it): it takes 98.4 % of config 3's
-    // slow rows, yet a visit costs ~900 ticks in here (class tests + one class block, ~125 instructions) against about the same in the
-    // branchy general handlers, which a lone active lane walks without divergence — same-box A/B over four workloads: within
-    // +-0.7 % (profiles/r02_cycle_breakdown.txt section 5). A first version that evaluated all four classes in one straight line of
-    // selects cost ~1 150 ticks per visit. run() stays the only code that decides these rows.
-    __device__ __forceinline__ bool try_mid(bool want, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c)
-    {
-        (void)want; (void)hdr; (void)aux; (void)a; (void)b; (void)c;
-        return false;
-    }
-
     // ---- one row (tier 2: the general handlers) ---------------------------------------------------
     __device__ __forceinline__ void run(uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
                                         int64_t hx, int64_t hy, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)

@@ -127,19 +127,17 @@ __device__ __forceinline__ void store_group(const DevTable &t, uint32_t gi, uint
     }
 }
 
-// LANES = raft groups per wavefront (the upper lanes are simply masked off). Measured at 64 / 32 / 16 / 8 on
-// 65 536 groups: 0.193 / 0.204 / 0.358 / 0.527 ms — a half-masked wavefront still costs both passes of a wave64
-// instruction, so narrower wavefronts buy more instruction streams per SIMD but no throughput. 64 is the default;
-// the knob (RG_LANES) stays for experiments.
-template <int F, bool SPARSE, int LANES>
+// (Fewer groups per wavefront — upper lanes masked off — was measured in round 1 at 64 / 32 / 16 / 8 lanes on 65 536 groups:
+// 0.193 / 0.204 / 0.358 / 0.527 ms. A half-masked wavefront still costs both passes of a wave64 instruction; the knob is gone.)
+template <int F, bool SPARSE>
 __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 {
     __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
     __shared__ int32_t sh_rej[F * BLOCK];
 
     const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * LANES + lane;
-    const bool active = lane < (uint32_t)LANES && i < p.count;
+    const uint32_t i = blockIdx.x * BLOCK + lane;
+    const bool active = i < p.count;
     // Lanes past the end of the batch (tail wavefront, or the masked half of a narrow one) shadow the batch's last row:
     // they load and decide like everybody else — so the round loop has no divergent control flow around it — and only
     // their stores are switched off.
@@ -196,8 +194,8 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 
         {
             const uint32_t kind = RG_HDR_KIND(cur.hdr);
-            // every lane goes through tier 1 and (when any lane of the wavefront needs it) tier 1.5: both contain wave-uniform branches
-            // on ballots and are therefore called from converged code; a lane blocked after a NEED_HOST simply asks for nothing
+            // every lane goes through tier 1: it contains wave-uniform branches on ballots and is therefore called from converged
+            // code; a lane blocked after a NEED_HOST simply asks for nothing
             const bool skip = blocked & (kind != RG_EV_NONE);
             const bool done = st.try_fast(FAST & !skip, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
                                           entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
@@ -205,9 +203,8 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             const bool slow = !done & !skip;
             if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
             if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-                const bool mid = st.try_mid(FAST & slow, cur.hdr, cur.aux, cur.a, cur.b, cur.c);
-                if (slow & !mid) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
-                st.refresh_narrow();                      // tier 1.5 and the general handlers work on 64-bit values
+                if (slow) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                st.refresh_narrow();                      // the general handlers work on 64-bit values
             }
             const uint32_t status = st.fx.status, flags = st.fx.flags;
             if (status == RG_NEED_HOST) blocked = true;
@@ -277,25 +274,6 @@ __device__ __forceinline__ void lds_barrier()
 {
     __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt/expcnt untouched: my LDS writes have landed
     __builtin_amdgcn_s_barrier();
-}
-
-// -DRG_FLAG_SYNC (experiment build, not shipped): the per-round hand-over between the two wavefronts through three LDS counters that each side polls,
-// instead of the workgroup's one hardware barrier — the prerequisite for a third wavefront that is NOT waited for every round.
-//   sync[0] = events published (I/O)   sync[1] = rounds decided (deciding)   sync[2] = outcomes retired (I/O)
-// A wavefront's LDS operations complete in order, so a counter written after the data it announces is never seen before that data.
-__device__ __forceinline__ void flag_set(volatile uint32_t *f, uint32_t v, uint32_t lane)
-{
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();                 // (free on the GPU, where a wavefront's lanes move together; the host emulation's lanes are threads)
-    if (lane == 0) *f = v;
-}
-__device__ __forceinline__ void flag_wait(volatile uint32_t *f, uint32_t at_least)
-{
-    for (;;) {
-        const uint32_t seen = *f;
-        if (__builtin_amdgcn_readfirstlane(seen) >= at_least) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
 }
 
 template <int F, bool SPARSE>
@@ -405,12 +383,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
     }
 
     // ---- the deciding wavefront ----------------------------------------------------------------------------------
-#ifdef RG_DECIDE_PRIO   // NOT in the shipped build. This wavefront is the critical path of the workgroup and the I/O wavefronts it shares a SIMD with
-    // have ~1 000 ticks of slack per round; issue priority over them measured 0.1166 -> 0.1104 ms per launch at config 3 (same-box A/B,
-    // profiles/r02_cycle_breakdown.txt section 8). Not shipped only because the round's GPU budget ended before an evidence pass of
-    // that build could be taken: the box it was started on faulted inside rg_table_create's memset, before any kernel of ours ran.
+    // This wavefront is the critical path of the workgroup and the I/O wavefronts it shares a SIMD with have ~1 000 ticks of slack per
+    // round: issue priority over them. Same-box A/B at config 3: 0.1166 -> 0.1104 ms per launch (profiles/r02_cycle_breakdown.txt section 8).
     __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     const uint32_t G = p.t.groups;
     Group g;
@@ -435,21 +410,20 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
         const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
         const bool ev_narrow = false;
         const uint32_t kind = RG_HDR_KIND(hdr);
-        // tier 1 and tier 1.5 branch on wavefront ballots: every lane calls them (a lane blocked after a NEED_HOST asks for nothing)
+        // tier 1 branches on wavefront ballots: every lane calls it (a lane blocked after a NEED_HOST asks for nothing)
         const bool skip = blocked & (kind != RG_EV_NONE);
         const bool done = st.try_fast(FAST & !skip, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow);
         const bool slow = !done & !skip;
         if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-            const bool mid = st.try_mid(FAST & slow, hdr, aux, a, b, c);
-            if (slow & !mid) {
+            if (slow) {
                 // the general handlers also want the hint and the other prefetched entry terms: read only here
                 const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
                 const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
                               e3 = (int64_t)sh_ev[slot][EV_E3][lane];
                 st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
             }
-            st.refresh_narrow();                         // tier 1.5 and the general handlers work on 64-bit values
+            st.refresh_narrow();                         // the general handlers work on 64-bit values
         }
         const uint32_t status = st.fx.status, flags = st.fx.flags;
         if (status == RG_NEED_HOST) blocked = true;
@@ -829,10 +803,21 @@ hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t 
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+// Plain streaming copy, the yardstick `roofline.measured_copy_gbps` is read from: four independent 16-byte non-temporal loads per lane in
+// flight, then their four non-temporal stores (neither side is read again: keep the caches out of it); the grid covers the buffer once.
+constexpr int COPY_UNROLL = 4;
+__global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (COPY_UNROLL - 1) * stride < n; i += COPY_UNROLL * stride) {
+        u32x4 v[COPY_UNROLL];
+#pragma unroll
+        for (int k = 0; k < COPY_UNROLL; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < COPY_UNROLL; k++) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 // ---- compact transfer formats of the pipelined host path (rg_submit_async_packed, include/raftgpu.h) ---------------------------
@@ -911,13 +896,13 @@ hipError_t launch_outcome_emit(const rg_reply_t *reply, const I64x2 *logfx, cons
     return hipGetLastError();
 }
 
-template <int F, int LANES>
-static hipError_t launch_fl(const StepParams &p, bool sparse, hipStream_t s)
+template <int F>
+static hipError_t launch_single(const StepParams &p, bool sparse, hipStream_t s)
 {
-    const uint32_t blocks = (p.count + LANES - 1) / LANES;
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
     if (blocks == 0) return hipSuccess;
-    if (sparse) hipLaunchKernelGGL((step_kernel<F, true, LANES>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else        hipLaunchKernelGGL((step_kernel<F, false, LANES>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    if (sparse) hipLaunchKernelGGL((step_kernel<F, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step_kernel<F, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
     return hipGetLastError();
 }
 
@@ -936,10 +921,7 @@ static hipError_t launch_f(const StepParams &p, bool sparse, int lanes, hipStrea
 {
     switch (lanes) {
     case 0:  return launch_split<F>(p, sparse, s);      // two wavefronts (decide + I/O) per 64 groups
-    case 64: return launch_fl<F, 64>(p, sparse, s);
-    case 32: return launch_fl<F, 32>(p, sparse, s);
-    case 16: return launch_fl<F, 16>(p, sparse, s);
-    case 8:  return launch_fl<F, 8>(p, sparse, s);
+    case 64: return launch_single<F>(p, sparse, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -959,7 +941,7 @@ hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lane
 
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, s, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+    hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, s, (const u32x4 *)src, (u32x4 *)dst, bytes / 16);
     return hipGetLastError();
 }
 

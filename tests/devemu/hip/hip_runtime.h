@@ -69,6 +69,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const ch
 #define __builtin_amdgcn_s_sleep(x) (::hipemu::lane_yield())
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
 #define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */
+#define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))      /* g++ has no such builtin; vectors via ext_vector_type are clang-only: */
 #define __syncthreads() (::hipemu::workgroup_barrier(false))
 #define __ballot(x) (::hipemu::wave_ballot(x))

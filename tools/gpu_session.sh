@@ -1,0 +1,29 @@
+#!/bin/bash
+# One gpurun call = one session: everything it prints lands in gpurun_out/<tag>/ (merged back by gpurun).
+#   gpurun --timeout 1500 -- 'bash tools/gpu_session.sh s1 membench tests ab rounds'
+TAG=$1; shift
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+B="python bench.py --no-cpu-baseline --no-pcie"
+line() { python -c "
+import json,sys
+for l in sys.stdin:
+    l=l.strip()
+    if not l.startswith('{'): continue
+    d=json.loads(l); r=d['roofline']
+    print('%-34s %.4f ms  frac %.3f  copy %s  %s  value %.3e' % ('$1', r['avg_kernel_ms'], r['frac'], r.get('measured_copy_gbps'), r['kernel'], d['value']))"; }
+for step in "$@"; do
+  case $step in
+    membench) timeout 300 build/membench > $OUT/membench.txt 2>&1; tail -50 $OUT/membench.txt ;;
+    tests) timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -5 $OUT/pytest_gpu.log ;;
+    ab) for i in 1 2 3; do for L in ${LIBS:-rafting_amd/libraftgpu_r02.so rafting_amd/libraftgpu.so}; do
+          RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 ${AB_ARGS} 2>>$OUT/ab.err | tee -a $OUT/ab.jsonl | line $L; done; done ;;
+    rounds) for R in 1 4 16 64; do $B --steps 20 --warmup 3 --rounds $R 2>>$OUT/rounds.err | tee -a $OUT/rounds.jsonl | line rounds=$R; done ;;
+    conflict) $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/conflict.err | tee -a $OUT/conflict.jsonl | line p_conflict=0.005 ;;
+    c5) $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c5_65536
+        $B --steps 10 --warmup 2 --config 5 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c5_131072
+        $B --steps 10 --warmup 2 --config 4 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c4_131072 ;;
+    bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
