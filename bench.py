@@ -56,6 +56,8 @@ def parse():
                     "data path has no collective) or nccl (= RCCL)")
     ap.add_argument("--device", type=int, default=None, help="test only: HIP device for every rank (default LOCAL_RANK)")
     ap.add_argument("--override", default="", help="experiment only: workload overrides, e.g. leader_frac=0,p_timeout=0")
+    ap.add_argument("--wide-rows", action="store_true", help="stage the batches as rg_batch_t (40 B + 8n per row, 64-bit fields) and decide them with the "
+                    "wide-row kernels instead of the default compact rows (rg_batch32_t, 24 B per row) / rg::step32_kernel")
     return ap.parse_args()
 
 
@@ -119,7 +121,7 @@ def main():
     for i in range(nb):
         b = gen.next_batch(args.rounds)
         stats.append(workload.batch_stats(b, F)[:2])
-        dbatches.append(engine.DeviceBatch(table, b))
+        dbatches.append(engine.DeviceBatch(table, b) if args.wide_rows else engine.DeviceBatch32(table, b))
         if rank == 0 and world == 1 and not args.no_cpu_baseline and i < args.cpu_batches:
             keep_host.append(b)
     t_gen = time.time() - t_gen
@@ -284,7 +286,7 @@ def main():
         # passes, gfx950 x2 fetch correction applied; tools/prof.sh writes profiles/traffic.json) — quoted only when the entry
         # describes this very workload, kernel and library build
         traffic = traffic_src = None
-        kernel_name = "%s<%d,false>" % (table.step_kernel(), F)
+        kernel_name = "%s<%d,false>" % (table.step_kernel() if args.wide_rows else "rg::step32_kernel", F)
         try:
             for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
                 if (tr["config"], tr["groups_per_gpu"], tr["rounds"], tr["kernel"]) == (args.config, gpg, args.rounds, kernel_name) \
@@ -316,6 +318,11 @@ def main():
                 "rounds_per_step": args.rounds, "decisions_per_step_per_gpu": decisions // max(args.steps, 1),
                 "parallelism": "groups block-partitioned over %d GPU(s), no RCCL on the data path" % world,
                 "inputs": "HBM-resident event/outcome buffers (RG_MEM_DEVICE); every step consumes fresh rounds",
+                "rows": "rg_batch_t (wide: 8 + 16 + 16 B per row + 8 B per entry term)" if args.wide_rows else
+                        "rg_batch32_t (compact: 8 + 16 B per row, the term shared by a row's entries in the row; rg_submit32)",
+                "arithmetic": "Java long (int64) semantics throughout; the compact-row kernel decides a workgroup's 64 groups with 32-bit instruction forms "
+                              "while every value of those groups and of their rows is below 2^30 and redoes the workgroup in 64-bit forms otherwise "
+                              "(tests/test_gpu_parity.py::test_compact_multi_round_launch_and_domain_exits) - results are bit-identical either way",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -57,7 +57,8 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      2     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t */
+#define RG_ABI_VERSION      3     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
+                                     3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -101,6 +102,9 @@ enum {
 #define RG_HDR_MAKE(kind, slot, flag, n) \
     (((uint32_t)(kind) & 0xFu) | (((uint32_t)(slot) & 0xFu) << 4) | (((uint32_t)(flag) & 1u) << 8) | ((uint32_t)(n) << 12))
 #define RG_HDR_HINT_BIT       (1u << 9)
+#define RG_HDR_SAME_TERM      (1u << 10)  /* rg_batch32_t rows only, RG_EV_AE_REQ with n >= 1: ALL n carried entries have the term held in `aux`
+                                             (what a leader replicating its own term sends); entry_terms is not consulted for the row.
+                                             Must be 0 in rg_batch_t rows. Bit 11 is reserved (0). */
 #define RG_MAX_ENTRIES        ((1u << 20) - 1)   /* what the header field can carry */
 #define RG_MAX_AE_ENTRIES     200u               /* what a row may carry: 4 x REPLICATE_LIMIT (member/Leadership.java:10; the reference never
                                                     ships more than REPLICATE_LIMIT per request, member/Leader.java:194). Larger -> RG_BAD_EVENT:
@@ -295,10 +299,11 @@ int rg_submit_wait(rg_table_t *t);
 
 /* The same pipeline with COMPACT transfer formats: the link, not the kernel, bounds the host-memory path, so what
  * crosses it is cut to what carries information.
- *   upload    rg_batch32_t: a, b, c, d and the entry terms as int32 (16 + 4n bytes per row instead of 32 + 8n). Legal only while every
- *             one of those values is in [0, 2^31) — raft terms and log indices of any deployment younger than 2^31 entries; a host that
- *             meets a larger value submits that batch through rg_submit_async instead (the two may be mixed freely). Values are
- *             widened on the device before the step kernel runs: the decisions are the 64-bit ones, bit for bit. No hint column (hints
+ *   upload    rg_batch32_t: a, b, c, d and the entry terms as int32 (16 + 4n bytes per row instead of 32 + 8n; 16 bytes flat for the
+ *             AppendEntries rows whose entries share one term, RG_HDR_SAME_TERM). Legal only while every one of those values is in
+ *             [0, 2^31) — raft terms and log indices of any deployment younger than 2^31 entries; a host that meets a larger value
+ *             submits that batch through rg_submit_async instead (the two may be mixed freely). The rows are decided as they arrive by
+ *             the compact-format step kernel: the decisions are the 64-bit ones, bit for bit (rg_submit32 below). No hint column (hints
  *             answer RG_NEED_HOST rows, which are rare: use the wide format for those batches).
  *   download  rg_outcome_packed_t: reply stays one row per event; logfx and persist come back PACKED, in row order, one item per row whose
  *             reply says it has one —  logfx:   flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC), or status RG_NEED_HOST
@@ -325,8 +330,22 @@ typedef struct {
     uint32_t      logfx_cap, persist_cap;
 } rg_outcome_packed_t;
 int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out);
+
+/* The compact rows as a batch format of their own — what a host that keeps its batches in HBM (or builds them there) hands over:
+ * 24 bytes per event instead of 40 + 8n, no gathered entry-term loads. Same contract as rg_submit (memspace, dense / sparse, rounds,
+ * outcome columns, per-row status), same results: the kernel decides a workgroup's 64 groups on 32-bit values while every value of
+ * those groups and of their rows is below 2^30 and restarts that workgroup's rounds in 64-bit arithmetic at the first value that is
+ * not — nothing was written to the table by then, outcome rows are written again — so a table may hold any int64 state.
+ * Rows whose values do not fit int32 cannot be expressed in this format at all: submit those batches through rg_submit. */
+int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, int memspace);
+/* Host-side packer (no device involved): rewrites a wide batch into caller buffers head[rows], abcd[rows], entry_terms[<= in->entry_count].
+ * AppendEntries rows whose entries all have one term get RG_HDR_SAME_TERM and carry it in aux; the others keep their terms, renumbered.
+ * Returns the entry_count of the compact batch, or < 0: -1 missing column, -2 the batch has hints, -3 a value outside [0, 2^31),
+ * -4 entry_terms needed but NULL. rounds / count / gid are the wide batch's. */
+int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
- * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel" */
+ * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel";
+ * compact batches (rg_submit32, rg_submit_async_packed) are always decided by "rg::step32_kernel" */
 const char *rg_step_kernel(rg_table_t *t, uint32_t count);
 
 /* ---- N1: the leader's send side ---------------------------------------------------------------- */

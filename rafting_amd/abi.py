@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MIN_CLUSTER, MAX_CLUSTER = 2, 7
 TERM_RUNS = 4
 NO_NODE = -1
@@ -20,6 +20,7 @@ EV_RV_REPLY, EV_PV_REPLY, EV_TIMEOUT, EV_CLIENT_APPEND, EV_LOG_FLUSH, EV_IS_REQ 
 MAX_AE_ENTRIES = 200
 PIPELINE_DEPTH = 2
 HDR_HINT_BIT = 1 << 9
+HDR_SAME_TERM = 1 << 10     # rg_batch32_t rows only: every carried entry of the AppendEntries row has the term held in aux
 
 F_SUCCESS, F_REPLIED, F_PERSIST, F_ROLE_CHANGED = 1 << 0, 1 << 1, 1 << 2, 1 << 3
 F_RESET_TIMER, F_COMMIT, F_LOG_TRUNC, F_LOG_APPEND = 1 << 4, 1 << 5, 1 << 6, 1 << 7
@@ -243,6 +244,25 @@ def batch_fits_32(batch):
     """every a, b, c, d and entry term of the batch is in [0, 2^31): the batch may travel as an rg_batch32_t"""
     cols = [batch.ab["x"], batch.ab["y"], batch.cd["x"], batch.cd["y"], batch.entry_terms[: batch.entry_count]]
     return batch.hint is None and all(len(c) == 0 or (int(c.min()) >= 0 and int(c.max()) < NARROW_EVENT_LIMIT) for c in cols)
+
+
+class Batch32:
+    """Host image of an rg_batch32_t (compact rows): head + int32 a, b, c, d + int32 entry terms of the rows without RG_HDR_SAME_TERM.
+    Built from a Batch by rafting_amd.engine.pack32 (the library's rg_batch32_pack) or tests' own packers."""
+
+    def __init__(self, rounds, count, gid, head, abcd, entry_terms, entry_count):
+        self.rounds, self.count, self.gid = rounds, count, gid
+        self.head, self.abcd = head, abcd
+        self.entry_terms, self.entry_count = entry_terms, int(entry_count)
+
+    def as_struct(self):
+        b = CBatch32()
+        b.rounds, b.count = self.rounds, self.count
+        b.gid = _ptr(self.gid)
+        b.head, b.abcd = _ptr(self.head), _ptr(self.abcd)
+        b.entry_terms = _ptr(self.entry_terms) if self.entry_count else None
+        b.entry_count = self.entry_count
+        return b
 
 
 def has_logfx(flags):

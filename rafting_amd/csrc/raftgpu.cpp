@@ -17,7 +17,7 @@
 #include "rg_device.hpp"
 
 namespace rg {
-hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s);
+hipError_t launch_step(const StepParams &p, int followers, bool sparse, int shape, hipStream_t s);
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s);
 hipError_t launch_health_update(const HealthParams &p, hipStream_t s);
@@ -27,7 +27,6 @@ hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
-hipError_t launch_widen(const void *abcd32, I64x2 *ab, I64x2 *cd, uint32_t rows, const int32_t *terms32, int64_t *terms, uint64_t nterms, hipStream_t s);
 hipError_t launch_outcome_count(const rg_reply_t *reply, uint32_t rows, uint32_t *counts, uint32_t *totals, hipStream_t s);
 hipError_t launch_outcome_emit(const rg_reply_t *reply, const I64x2 *logfx, const rg_persist_t *persist, uint32_t rows, const uint32_t *counts,
                                I64x2 *out_logfx, uint32_t cap_logfx, rg_persist_t *out_persist, uint32_t cap_persist, hipStream_t s);
@@ -56,6 +55,8 @@ struct rg_table {
     unsigned long long *counters = nullptr;     // [counter_slots][RG_NUM_COUNTERS], one slot per wave of a dense launch
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
+    int force_wide = 0;                         // RG_FORCE_WIDE=1: the compact-format kernel skips its 32-bit body (differential tests)
+    Staging st_abcd32, st_terms32;
     int lanes = -1;                             // -1: pick per launch; 0: split kernel; 64: single-wavefront kernel (RG_SPLIT env forces one)
     uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
@@ -219,6 +220,7 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     t->lanes = -1;
     if (const char *e = getenv("RG_SPLIT")) t->lanes = atoi(e) != 0 ? 0 : 64;   // force either kernel
     if (const char *e = getenv("RG_FAST")) t->fast_paths = atoi(e) != 0;
+    if (const char *e = getenv("RG_FORCE_WIDE")) t->force_wide = atoi(e) != 0;
     t->counter_slots = (G + 63) / 64 + 1;       // one slot per workgroup of a dense launch
     CREATE_TRY(hipMalloc((void **)&t->counters, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long)));
     t->dt.groups = groups;
@@ -419,7 +421,7 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
     // Up to one wavefront of groups per SIMD, a lone deciding wavefront leaves half of its SIMD's issue slots empty:
     // give it an I/O partner (step_split_kernel). With more groups the SIMDs are shared by several deciding
     // wavefronts anyway and the single-wavefront kernel is the faster one.
-    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, step_lanes(t, p.count), t->stream));
+    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, p.abcd32 ? 32 : step_lanes(t, p.count), t->stream));
     if (t->timing) {
         HIP_TRY(t, hipEventRecord(e1, t->stream));
         t->ev_used += 1;
@@ -460,6 +462,7 @@ static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
     p.counters = t->counters;
     p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
     p.fast_paths = t->fast_paths;
+    p.force_wide = t->force_wide;
     return p;
 }
 
@@ -560,8 +563,8 @@ int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outco
     const bool sparse = in->gid != nullptr;
     const uint32_t rows = (uint32_t)rows64, waves = (rows + 63u) / 64u;
     rg::StepParams p = step_params(t, &wide);
-    if (reserve(t, sl.head, rows64 * sizeof(rg_ev_head_t)) || reserve(t, sl.abcd32, rows64 * sizeof(rg_ev_quad32_t)) || reserve(t, sl.ab, rows64 * sizeof(I64x2)) ||
-        reserve(t, sl.cd, rows64 * sizeof(I64x2)) || reserve(t, sl.reply, rows64 * sizeof(rg_reply_t)) || reserve(t, sl.logfx, rows64 * sizeof(I64x2)) ||
+    if (reserve(t, sl.head, rows64 * sizeof(rg_ev_head_t)) || reserve(t, sl.abcd32, rows64 * sizeof(rg_ev_quad32_t)) ||
+        reserve(t, sl.reply, rows64 * sizeof(rg_reply_t)) || reserve(t, sl.logfx, rows64 * sizeof(I64x2)) ||
         reserve(t, sl.persist, rows64 * sizeof(rg_persist_t)) || reserve(t, sl.counts, (size_t)2 * waves * sizeof(uint32_t)))
         return -2;
     hipStream_t si = t->s_in, so = t->s_out;
@@ -573,16 +576,15 @@ int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outco
         p.gid = (const uint32_t *)sl.gid.ptr;
     }
     if (in->entry_count) {
-        if (reserve(t, sl.terms32, in->entry_count * sizeof(int32_t)) || reserve(t, sl.terms, in->entry_count * sizeof(int64_t))) return -2;
+        if (reserve(t, sl.terms32, in->entry_count * sizeof(int32_t))) return -2;
         HIP_TRY(t, hipMemcpyAsync(sl.terms32.ptr, in->entry_terms, in->entry_count * sizeof(int32_t), hipMemcpyHostToDevice, si));
     }
     HIP_TRY(t, hipEventRecord(sl.up, si));
     HIP_TRY(t, hipStreamWaitEvent(t->stream, sl.up, 0));
-    HIP_TRY(t, rg::launch_widen(sl.abcd32.ptr, (I64x2 *)sl.ab.ptr, (I64x2 *)sl.cd.ptr, rows, (const int32_t *)sl.terms32.ptr, (int64_t *)sl.terms.ptr,
-                                in->entry_count, t->stream));
-    p.head = (const rg_ev_head_t *)sl.head.ptr; p.ab = (const I64x2 *)sl.ab.ptr; p.cd = (const I64x2 *)sl.cd.ptr;
+    // the compact-format kernel reads the rows as they arrived: no widening pass
+    p.head = (const rg_ev_head_t *)sl.head.ptr; p.abcd32 = (const rg::I32x4 *)sl.abcd32.ptr;
     p.hint = nullptr;
-    p.entry_terms = in->entry_count ? (const int64_t *)sl.terms.ptr : nullptr;
+    p.entry_terms32 = in->entry_count ? (const int32_t *)sl.terms32.ptr : nullptr;
     p.reply = (rg_reply_t *)sl.reply.ptr; p.logfx = (I64x2 *)sl.logfx.ptr; p.persist = (rg_persist_t *)sl.persist.ptr;
     if (int rc = launch(t, p, sparse)) return rc;
     HIP_TRY(t, rg::launch_outcome_count(p.reply, rows, (uint32_t *)sl.counts.ptr, (uint32_t *)d_counts, t->stream));
@@ -659,6 +661,90 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
     HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
     return 0;
+}
+
+/* compact rows, HBM-resident or host: see include/raftgpu.h */
+int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, int memspace)
+{
+    if (!t) return -1;
+    if (!in || !out) return fail(t, -1, "rg_submit32: NULL batch or outcome");
+    if (!in->head || !in->abcd) return fail(t, -1, "rg_submit32: head and abcd are required");
+    rg_batch_t wide{};                              // the same shape rules as every other submission (rounds, count, gid list, entry bound)
+    wide.rounds = in->rounds; wide.count = in->count; wide.gid = in->gid; wide.head = in->head;
+    wide.ab = wide.cd = reinterpret_cast<const rg_ev_pair_t *>(in->abcd);      // presence only: check_batch does not read event fields
+    wide.entry_terms = reinterpret_cast<const int64_t *>(in->entry_terms); wide.entry_count = in->entry_count;
+    if (int rc = check_batch(t, &wide, out, memspace == RG_MEM_HOST)) return rc;
+    if (in->count == 0) return 0;
+    if (bind(t)) return -2;
+    const bool sparse = in->gid != nullptr;
+    const size_t rows = (size_t)in->rounds * in->count;
+    rg::StepParams p = step_params(t, &wide);
+    if (memspace == RG_MEM_DEVICE) {
+        p.gid = in->gid; p.head = in->head; p.abcd32 = (const rg::I32x4 *)in->abcd;
+        p.entry_terms32 = in->entry_count ? in->entry_terms : nullptr;
+        p.reply = out->reply; p.logfx = (I64x2 *)out->logfx; p.persist = out->persist;
+        return launch(t, p, sparse);
+    }
+    if (memspace != RG_MEM_HOST) return fail(t, -1, "rg_submit32: unknown memspace %d", memspace);
+    hipStream_t s = t->stream;
+    if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_abcd32, rows * sizeof(rg_ev_quad32_t)) ||
+        reserve(t, t->st_reply, rows * sizeof(rg_reply_t)) || reserve(t, t->st_logfx, rows * sizeof(I64x2)) ||
+        reserve(t, t->st_persist, rows * sizeof(rg_persist_t)))
+        return -2;
+    HIP_TRY(t, hipMemcpyAsync(t->st_head.ptr, in->head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_abcd32.ptr, in->abcd, rows * sizeof(rg_ev_quad32_t), hipMemcpyHostToDevice, s));
+    p.head = (const rg_ev_head_t *)t->st_head.ptr; p.abcd32 = (const rg::I32x4 *)t->st_abcd32.ptr;
+    if (sparse) {
+        if (reserve(t, t->st_gid, in->count * sizeof(uint32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_gid.ptr, in->gid, in->count * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        p.gid = (const uint32_t *)t->st_gid.ptr;
+    }
+    if (in->entry_count) {
+        if (reserve(t, t->st_terms32, in->entry_count * sizeof(int32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_terms32.ptr, in->entry_terms, in->entry_count * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        p.entry_terms32 = (const int32_t *)t->st_terms32.ptr;
+    }
+    p.reply = (rg_reply_t *)t->st_reply.ptr; p.logfx = (I64x2 *)t->st_logfx.ptr; p.persist = (rg_persist_t *)t->st_persist.ptr;
+    HIP_TRY(t, hipMemsetAsync(t->st_logfx.ptr, 0, rows * sizeof(I64x2), s));
+    HIP_TRY(t, hipMemsetAsync(t->st_persist.ptr, 0, rows * sizeof(rg_persist_t), s));
+    if (int rc = launch(t, p, sparse)) return rc;
+    HIP_TRY(t, hipMemcpyAsync(out->reply, t->st_reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(out->logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+/* host-side packer: rg_batch_t -> rg_batch32_t (no device involved) */
+int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms)
+{
+    if (!in || !in->head || !in->ab || !in->cd || !head || !abcd) return -1;
+    if (in->hint) return -2;                                    // hints answer RG_NEED_HOST rows: those batches stay wide
+    const size_t rows = (size_t)in->rounds * in->count;
+    auto fits = [](int64_t v) { return v >= 0 && v < (int64_t)1 << 31; };
+    uint64_t out_terms = 0;
+    for (size_t r = 0; r < rows; r++) {
+        const uint32_t hdr = in->head[r].hdr & ~(RG_HDR_HINT_BIT | RG_HDR_SAME_TERM | (1u << 11)), aux = in->head[r].aux;
+        const int64_t a = in->ab[r].x, b = in->ab[r].y, c = in->cd[r].x, d = in->cd[r].y;
+        if (!fits(a) || !fits(b) || !fits(c) || !fits(d)) return -3;
+        abcd[r] = rg_ev_quad32_t{(int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d};
+        head[r].hdr = hdr; head[r].aux = aux;
+        const uint32_t n = RG_HDR_N(hdr);
+        if (RG_HDR_KIND(hdr) != RG_EV_AE_REQ || n == 0) continue;
+        if (!in->entry_terms || (uint64_t)aux + n > in->entry_count) { head[r].aux = 0xFFFFFFFFu; continue; }   // unreadable stays unreadable (RG_BAD_EVENT): aux + n exceeds any entry_count
+        const int64_t *e = in->entry_terms + aux;
+        bool same = true;
+        for (uint32_t k = 0; k < n; k++) { if (!fits(e[k])) return -3; same = same && e[k] == e[0]; }
+        if (same) {
+            head[r].hdr = hdr | RG_HDR_SAME_TERM; head[r].aux = (uint32_t)e[0];
+        } else {
+            if (!entry_terms) return -4;
+            head[r].aux = (uint32_t)out_terms;
+            for (uint32_t k = 0; k < n; k++) entry_terms[out_terms + k] = (int32_t)e[k];
+            out_terms += n;
+        }
+    }
+    return (int64_t)out_terms;
 }
 
 int rg_replicate(rg_table_t *t, uint32_t count, const uint32_t *gid, const uint8_t *heartbeat, const uint16_t *in_flight,

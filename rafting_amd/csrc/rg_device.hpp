@@ -1,9 +1,9 @@
 // rg_device.hpp — device-side decision logic of the batched multi-Raft engine (gfx950 / CDNA4).
 //
 // One LANE owns one raft group for the whole launch: the group's scalar state lives in VGPRs, its
-// per-follower replication state (Leadership.State) is staged in LDS as [follower][lane] columns so
-// the responder slot of an ack — a runtime value — indexes LDS instead of forcing the register file
-// through scratch.  Integer work only; no MFMA.
+// per-follower replication state (Leadership.State) is staged in LDS so the responder slot of an ack —
+// a runtime value — indexes LDS instead of forcing the register file through scratch.  Integer work
+// only; no MFMA.
 //
 // What is decided here, and the reference code it stands in for (paths relative to
 // /root/reference/src/main/java/io/lubricant/consensus/raft/):
@@ -23,6 +23,16 @@
 // equal-term runs of it, which answers RaftLog.get(i).term() exactly for every index at or above the
 // oldest cached run.  A lookup below that is a cache miss: the row is left unapplied
 // (RG_NEED_HOST) unless the host attached the answer as a hint.
+//
+// Two tiers decide a row:
+//   tier 2  Stepper::run — the general handlers, one function per reference method, branchy, 64-bit: the single
+//           source of truth;
+//   tier 1  tier1<V> — the rows a cluster produces in operation (AppendEntries at a follower whose prevLog is the log tail,
+//           acks at a prepared leader, client appends, the whole election traffic: timeouts, vote requests at a follower,
+//           vote replies that count / win / carry a higher term / arrive late, a leader stepping down on a higher-term ack)
+//           with selects only, under preconditions that make every one of them a strict special case of tier 2.
+//           V = int64_t: any values. V = int32_t: the same statements on 32-bit values, used by the compact-format kernel
+//           while every value of a workgroup's groups and rows is below 2^30 (rg_kernels.hip: step32_kernel).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -34,9 +44,11 @@
 namespace rg {
 
 constexpr int K = RG_TERM_RUNS;
-constexpr int BLOCK = 64;          // one wavefront per workgroup: lanes never share LDS columns, no barriers
+constexpr int BLOCK = 64;          // raft groups per workgroup = lanes of a wavefront
 
 struct alignas(16) I64x2 { int64_t x, y; };
+struct alignas(16) I32x4 { int32_t x, y, z, w; };
+struct alignas(8) U32x2 { uint32_t x, y; };
 struct alignas(16) Ident { int32_t voted_for, leader; uint32_t role_epoch, meta; };
 struct alignas(16) Elect { int64_t elected_term; uint32_t elected_epoch; int32_t votes; };
 struct alignas(16) Match { int64_t match_index; int32_t rejection; int32_t pad; };
@@ -64,15 +76,18 @@ struct StepParams {
     uint32_t rounds, count;
     const uint32_t *gid;            // sparse only
     const rg_ev_head_t *head;
-    const I64x2 *ab, *cd, *hint;
+    const I64x2 *ab, *cd, *hint;    // wide rows (rg_batch_t)
     const int64_t *entry_terms;
+    const I32x4 *abcd32;            // compact rows (rg_batch32_t): a, b, c, d as int32; entry_terms32 instead of entry_terms
+    const int32_t *entry_terms32;
     uint64_t entry_count;
     rg_reply_t *reply;
     I64x2 *logfx;
     rg_persist_t *persist;
-    unsigned long long *counters;   // [RG_NUM_COUNTERS]
+    unsigned long long *counters;   // [workgroups][RG_NUM_COUNTERS]
     int32_t self, cluster, majority, pre_vote;
     int32_t fast_paths;             // 0: general handlers only
+    int32_t force_wide;             // compact-format kernel: skip the 32-bit body (tests)
 };
 
 struct ReplicateParams {             // N1: Leader.replicateLog for many groups (rg_kernels.hip: replicate_kernel)
@@ -111,20 +126,35 @@ __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int64_t min64(int64_t a, int64_t b) { return a < b ? a : b; }
+// two's-complement add in the width of V (Java long arithmetic wraps; the 32-bit tier never gets near its limit)
+template <class V> __device__ __forceinline__ V vadd(V x, V y) { typedef typename std::make_unsigned<V>::type U; return (V)((U)x + (U)y); }
+template <class V> __device__ __forceinline__ V vmin(V x, V y) { return x < y ? x : y; }
+template <class V> __device__ __forceinline__ V vmax(V x, V y) { return x > y ? x : y; }
+
+// The 32-bit tier's domain. Event fields must lie in [0, EV_LIMIT), group state in [0, STATE_LIMIT): tier 1 adds at most
+// RG_MAX_ENTRIES (< 2^20) to a value per row, so nothing it computes from such inputs can reach 2^31, and every sum it forms equals
+// the 64-bit one. A row or a state outside the domain sends its WORKGROUP back to the 64-bit body (step32_kernel).
+constexpr uint32_t EV_LIMIT = 1u << 30;
+constexpr uint32_t STATE_LIMIT = (1u << 30) + (1u << 29);
 
 // State.majorIndices (member/Leadership.java:116-130): sorted[0] ("full") and sorted[F/2] ("major") of the F follower
 // matchIndex values. One 64-bit compare per compare-exchange; for F = 4 (five nodes) only the two order statistics
 // that are used get completed: pairs, then min of the minima / max of the maxima, then the larger of the middle two.
-__device__ __forceinline__ void cmp_exchange(int64_t &a, int64_t &b)
+template <class V>
+__device__ __forceinline__ void cmp_exchange(V &a, V &b)
 {
     const bool sw = a > b;
-    const int64_t lo = sw ? b : a, hi = sw ? a : b;
+    const V lo = sw ? b : a, hi = sw ? a : b;
     a = lo; b = hi;
 }
-template <int F>
-__device__ __forceinline__ void major_indices(int64_t (&m)[F], int64_t &full, int64_t &major)
+template <int F, class V>
+__device__ __forceinline__ void major_indices(V (&m)[F], V &full, V &major)
 {
-    if constexpr (F == 4) {
+    if constexpr (F == 4 && sizeof(V) == 4) {                           // 32-bit: the ISA has integer min / max / max3
+        const V lo1 = vmin(m[0], m[1]), hi1 = vmax(m[0], m[1]), lo2 = vmin(m[2], m[3]), hi2 = vmax(m[2], m[3]);
+        full = vmin(lo1, lo2);
+        major = vmax(vmax(lo1, lo2), vmin(hi1, hi2));                   // second largest of four
+    } else if constexpr (F == 4) {
         cmp_exchange(m[0], m[1]); cmp_exchange(m[2], m[3]);
         cmp_exchange(m[0], m[2]); cmp_exchange(m[1], m[3]);
         full = m[0]; major = m[1] > m[2] ? m[1] : m[2];
@@ -135,27 +165,6 @@ __device__ __forceinline__ void major_indices(int64_t (&m)[F], int64_t &full, in
             for (int b = a; b > 0; b--) cmp_exchange(m[b - 1], m[b]);
         }
         full = m[0]; major = m[F / 2];
-    }
-}
-
-template <int F, class V>
-__device__ __forceinline__ void major_indices_v(V (&m)[F], V &full, V &major)
-{
-    if constexpr (sizeof(V) == 8) {
-        major_indices<F>(reinterpret_cast<int64_t (&)[F]>(m), reinterpret_cast<int64_t &>(full), reinterpret_cast<int64_t &>(major));
-    } else {                                                            // 32-bit: the ISA has integer min / max
-        auto cx = [](V &x, V &y) { const V lo = x < y ? x : y, hi = x < y ? y : x; x = lo; y = hi; };
-        if constexpr (F == 4) {
-            cx(m[0], m[1]); cx(m[2], m[3]); cx(m[0], m[2]); cx(m[1], m[3]);
-            full = m[0]; major = m[1] > m[2] ? m[1] : m[2];
-        } else {
-#pragma unroll
-            for (int x = 1; x < F; x++) {
-#pragma unroll
-                for (int y = x; y > 0; y--) cx(m[y - 1], m[y]);
-            }
-            full = m[0]; major = m[F / 2];
-        }
     }
 }
 
@@ -171,56 +180,37 @@ __device__ __forceinline__ int64_t rejection_step(int32_t r)
     return s;
 }
 
-// The 32-bit tier. Raft terms and log indices are Java longs, but a group whose values all fit in 30 bits — every real
-// deployment for years — can be decided with 32-bit compares, selects and adds: half the VALU instructions of the 64-bit
-// forms (a 64-bit select is two v_cndmask, a 64-bit min/max a compare plus two, an add two). try_fast therefore exists in
-// two instantiations; the narrow one runs when EVERY lane of the wavefront has a narrow event and a narrow group (one
-// ballot), writes only the low words back (the high words are zero and stay zero: inputs below 2^30 plus increments below
-// 2^21 cannot reach 2^31), and is bit-for-bit the wide one on that domain — the differential tests run both.
-constexpr uint64_t NARROW_LIMIT = 1ull << 30;
-__device__ __forceinline__ bool is_narrow(int64_t v) { return (uint64_t)v < NARROW_LIMIT; }
-__device__ __forceinline__ int64_t with_lo(int64_t old, uint32_t lo) { return (int64_t)(((uint64_t)old & 0xFFFFFFFF00000000ull) | lo); }
-
 // effects of one row
-struct Fx {
+template <class V>
+struct FxT {
     uint32_t flags;
     uint32_t status;
-    int64_t resp_term;
-    int64_t log_from;
+    V resp_term;
+    V log_from;
 };
+typedef FxT<int64_t> Fx;
 
-// Two facts about an AppendEntries request that do not depend on the group's state — "the carried entry terms are
-// readable" and "the first min(n, 4) entry terms are all equal" — are worked out where the event is loaded. The
-// two-wavefront kernel hands them to the deciding wavefront in the two unused bits of its LDS copy of the header.
-constexpr uint32_t HDR_SAME = 1u << 10, HDR_ENTRIES_OK = 1u << 11;
-__device__ __forceinline__ bool entries_readable(const StepParams &p, uint32_t hdr, uint32_t aux)
-{
-    const uint32_t n = RG_HDR_N(hdr);
-    return (n == 0) | ((n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)aux + n <= p.entry_count));
-}
-__device__ __forceinline__ bool entries_same_term(uint32_t hdr, int64_t e0, int64_t e1, int64_t e2, int64_t e3)
-{
-    const uint32_t n = RG_HDR_N(hdr);
-    return ((n < 2u) | (e1 == e0)) & ((n < 3u) | (e2 == e0)) & ((n < 4u) | (e3 == e0));
-}
+// Facts about a row that do not depend on the group's state are worked out where the event is loaded (the I/O wavefront of the
+// two-wavefront kernels) and handed over in header bits 10, 11 of the LDS / register copy (on the wire bit 10 is RG_HDR_SAME_TERM,
+// bit 11 is unused; the loader consumes and replaces them):
+//   HDR_AE_OK    AppendEntries request that tier 1 may decide: leader slot in range, prevLogTerm != 0, and either no entries or
+//                <= RG_MAX_AE_ENTRIES entries that are readable and all of one term (the term itself travels as `pe0`)
+//   HDR_PEER_OK  slot names a remote peer (slot < P, slot != self)
+//   HDR_WIDE     compact rows only (they carry no hints, so the copy reuses the hint bit): a field lies outside [0, EV_LIMIT)
+constexpr uint32_t HDR_AE_OK = 1u << 10, HDR_PEER_OK = 1u << 11, HDR_WIDE = 1u << 9;
 
-template <int F>
-struct Peers {                       // LDS columns of this lane
-    int64_t *last_epoch, *next_index, *match_index;
-    int32_t *rejection;
-};
-
-// Register image of one group.  The K=4 cached term runs are SCALAR members on purpose: with arrays the
-// optimiser folds the select chains below back into dynamically indexed accesses, which pins the whole
-// struct in scratch memory (measured: 168 B/lane of scratch, every field access a scratch_load).
-struct Group {
-    int64_t term, commit, epoch_index, epoch_term, first, last, elected_term;
-    int64_t s0, s1, s2, s3;          // run starts, ascending; valid [0, rc)
-    int64_t t0, t1, t2, t3;          // run terms
+// Register image of one group, in the width V of its terms and indices.  The K=4 cached term runs are SCALAR members on
+// purpose: with arrays the optimiser folds the select chains below back into dynamically indexed accesses, which pins the
+// whole struct in scratch memory (measured: 168 B/lane of scratch, every field access a scratch_load).
+template <class V>
+struct GroupT {
+    V term, commit, epoch_index, epoch_term, first, last, elected_term;
+    V s0, s1, s2, s3;                // run starts, ascending; valid [0, rc)
+    V t0, t1, t2, t3;                // run terms
+    V lt, top;                       // term / start of the NEWEST run (== t[rc-1], s[rc-1]); kept by push / truncate / flush, meaningless while rc == 0
     int32_t voted_for, leader, votes, role, rc;
     uint32_t role_epoch, elected_epoch, pending;
     bool td, prepared, log_dirty, peers_dirty;
-    bool narrow;                     // every 64-bit value of the group (and of its LDS follower columns) is in [0, NARROW_LIMIT): see try_fast
     static_assert(K == 4, "run cache is hand-unrolled for 4 runs");
 
     // NOTE on style: every method first copies the fields it needs into locals, computes with value
@@ -228,43 +218,40 @@ struct Group {
     // into the kernel, while `this` is still an opaque pointer; a load inside a conditional arm there is
     // folded into "load of a selected address", which later defeats scalar replacement of the struct.
     __device__ __forceinline__ bool has_log() const { return rc > 0; }
-    __device__ __forceinline__ bool present(int64_t i) const
+    __device__ __forceinline__ bool present(V i) const
     {
-        const int n = rc; const int64_t f = first, l = last;
+        const int n = rc; const V f = first, l = last;
         return n > 0 && i >= f && i <= l;
     }
-    __device__ __forceinline__ bool cached(int64_t i) const { return i >= s0; }
-    __device__ __forceinline__ int64_t last_term() const
+    __device__ __forceinline__ bool cached(V i) const { return i >= s0; }
+    __device__ __forceinline__ V last_term() const { return lt; }
+    __device__ __forceinline__ void refresh_tail()
     {
-        const int n = rc; const int64_t a0 = t0, a1 = t1, a2 = t2, a3 = t3;
-        int64_t t = a0;
-        t = n > 1 ? a1 : t;
-        t = n > 2 ? a2 : t;
-        t = n > 3 ? a3 : t;
-        return t;
+        const int n = rc; const V a0 = t0, a1 = t1, a2 = t2, a3 = t3, b0 = s0, b1 = s1, b2 = s2, b3 = s3;
+        V t = a0, s = b0;
+        t = n > 1 ? a1 : t; s = n > 1 ? b1 : s;
+        t = n > 2 ? a2 : t; s = n > 2 ? b2 : s;
+        t = n > 3 ? a3 : t; s = n > 3 ? b3 : s;
+        lt = t; top = s;
     }
     // term of a PRESENT and CACHED index
-    __device__ __forceinline__ int64_t term_at(int64_t i) const
+    __device__ __forceinline__ V term_at(V i) const
     {
-        const int n = rc; const int64_t a0 = t0, a1 = t1, a2 = t2, a3 = t3, b1 = s1, b2 = s2, b3 = s3;
-        int64_t t = a0;
+        const int n = rc; const V a0 = t0, a1 = t1, a2 = t2, a3 = t3, b1 = s1, b2 = s2, b3 = s3;
+        V t = a0;
         t = (n > 1 && b1 <= i) ? a1 : t;
         t = (n > 2 && b2 <= i) ? a2 : t;
         t = (n > 3 && b3 <= i) ? a3 : t;
         return t;
     }
     // db.put(last+1, t) — or the first key of an empty log
-    __device__ __forceinline__ void push(int64_t index, int64_t t)
+    __device__ __forceinline__ void push(V index, V t)
     {
         int n = rc;
-        int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
-        const int64_t f = first;
-        int64_t lt = y0;
-        lt = n > 1 ? y1 : lt;
-        lt = n > 2 ? y2 : lt;
-        lt = n > 3 ? y3 : lt;
+        V x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
+        const V f = first, cur_lt = lt, cur_top = top;
         const bool empty = n == 0;
-        const bool newrun = empty || lt != t;
+        const bool newrun = empty || cur_lt != t;
         const bool shift = newrun && n == K;     // cache full: forget the oldest run (lookups into it become misses)
         x0 = shift ? x1 : x0; y0 = shift ? y1 : y0;
         x1 = shift ? x2 : x1; y1 = shift ? y2 : y1;
@@ -277,6 +264,7 @@ struct Group {
         x3 = w3 ? index : x3; y3 = w3 ? t : y3;
         n += newrun ? 1 : 0;
         s0 = x0; s1 = x1; s2 = x2; s3 = x3; t0 = y0; t1 = y1; t2 = y2; t3 = y3;
+        lt = t; top = newrun ? index : cur_top;
         rc = n;
         first = empty ? index : f;
         last = index;
@@ -284,10 +272,10 @@ struct Group {
     }
     // RaftLog.truncate(index): storage/RocksLog.java:219-225. `keep_term` = term of index-1, used only when
     // the cut lands below the cached runs (hint-resolved conflict) and the cache must be re-seeded.
-    __device__ __forceinline__ void truncate(int64_t index, int64_t keep_term)
+    __device__ __forceinline__ void truncate(V index, V keep_term)
     {
         const int n0 = rc;
-        const int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, f = first, l = last;
+        const V x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, f = first, l = last;
         const bool dirty0 = log_dirty;
         const bool act = n0 != 0 && l >= index;
         const bool wipe = act && index <= f;
@@ -300,13 +288,14 @@ struct Group {
         rc = act ? (wipe ? 0 : n) : n0;
         last = (act && !wipe) ? index - 1 : l;
         log_dirty = dirty0 || act;
+        refresh_tail();
     }
     // RaftLog.flush(index, term): storage/RocksLog.java:228-242
-    __device__ __forceinline__ uint32_t flush(int64_t index, int64_t term_)
+    __device__ __forceinline__ uint32_t flush(V index, V term_)
     {
         int n = rc;
-        int64_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
-        const int64_t f = first, l = last, ei = epoch_index;
+        V x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
+        const V f = first, l = last, ei = epoch_index;
         const bool dirty0 = log_dirty;
         if (index < ei) return RG_FLUSH_OUT_OF_BOUNDS;
         const bool have = n != 0;
@@ -330,19 +319,166 @@ struct Group {
         log_dirty = dirty0 || wipe || trim;
         epoch_index = index;
         epoch_term = term_;
+        refresh_tail();
         return RG_OK;
+    }
+};
+typedef GroupT<int64_t> Group;
+typedef GroupT<int32_t> Group32;
+
+// 32-bit image <-> 64-bit image (the general handlers always work on the 64-bit one)
+__device__ __forceinline__ Group widen(const Group32 &n)
+{
+    Group g;
+    g.term = n.term; g.commit = n.commit; g.epoch_index = n.epoch_index; g.epoch_term = n.epoch_term; g.first = n.first; g.last = n.last;
+    g.elected_term = n.elected_term;
+    g.s0 = n.s0; g.s1 = n.s1; g.s2 = n.s2; g.s3 = n.s3; g.t0 = n.t0; g.t1 = n.t1; g.t2 = n.t2; g.t3 = n.t3; g.lt = n.lt; g.top = n.top;
+    g.voted_for = n.voted_for; g.leader = n.leader; g.votes = n.votes; g.role = n.role; g.rc = n.rc;
+    g.role_epoch = n.role_epoch; g.elected_epoch = n.elected_epoch; g.pending = n.pending;
+    g.td = n.td; g.prepared = n.prepared; g.log_dirty = n.log_dirty; g.peers_dirty = n.peers_dirty;
+    return g;
+}
+// every term / index of the image is in [0, limit)
+__device__ __forceinline__ bool fits32(const Group &g, uint32_t limit)
+{
+    // a value is in range iff it is non-negative and below the limit; the maximum of the unsigned images tells both at once
+    auto mx = [](uint64_t x, uint64_t y) { return x > y ? x : y; };
+    uint64_t w = mx(mx(mx((uint64_t)g.term, (uint64_t)g.commit), mx((uint64_t)g.epoch_index, (uint64_t)g.epoch_term)),
+                    mx(mx((uint64_t)g.first, (uint64_t)g.last), (uint64_t)g.elected_term));
+    w = mx(w, mx(mx(mx((uint64_t)g.s0, (uint64_t)g.s1), mx((uint64_t)g.s2, (uint64_t)g.s3)), mx(mx((uint64_t)g.t0, (uint64_t)g.t1), mx((uint64_t)g.t2, (uint64_t)g.t3))));
+    return w < (uint64_t)limit;
+}
+__device__ __forceinline__ Group32 narrow(const Group &g)
+{
+    Group32 n;
+    n.term = (int32_t)g.term; n.commit = (int32_t)g.commit; n.epoch_index = (int32_t)g.epoch_index; n.epoch_term = (int32_t)g.epoch_term;
+    n.first = (int32_t)g.first; n.last = (int32_t)g.last; n.elected_term = (int32_t)g.elected_term;
+    n.s0 = (int32_t)g.s0; n.s1 = (int32_t)g.s1; n.s2 = (int32_t)g.s2; n.s3 = (int32_t)g.s3;
+    n.t0 = (int32_t)g.t0; n.t1 = (int32_t)g.t1; n.t2 = (int32_t)g.t2; n.t3 = (int32_t)g.t3; n.lt = (int32_t)g.lt; n.top = (int32_t)g.top;
+    n.voted_for = g.voted_for; n.leader = g.leader; n.votes = g.votes; n.role = g.role; n.rc = g.rc;
+    n.role_epoch = g.role_epoch; n.elected_epoch = g.elected_epoch; n.pending = g.pending;
+    n.td = g.td; n.prepared = g.prepared; n.log_dirty = g.log_dirty; n.peers_dirty = g.peers_dirty;
+    return n;
+}
+
+// ---- Leadership.State of this lane's group in LDS -------------------------------------------------------------------
+// Wide: four [follower][lane] columns of 64-bit values. Narrow (32-bit body): one 16-byte record {lastEpoch, nextIndex, matchIndex,
+// recentRejection} per follower as [follower][lane], plus the F matchIndex values again as one [lane] row of 16 (F <= 4) or 32
+// bytes, so that the quorum select reads them with one or two ds_read_b128 instead of F. The general handlers use the scalar
+// accessors; tier 1 the bulk ones.
+template <int F>
+struct PeersWide {
+    int64_t *e, *n, *m;              // + lane already applied
+    int32_t *r;
+    bool overflow;                   // (narrow only; kept so both have the same shape)
+    __device__ __forceinline__ int64_t last_epoch(int j) const { return e[j * BLOCK]; }
+    __device__ __forceinline__ int64_t next_index(int j) const { return n[j * BLOCK]; }
+    __device__ __forceinline__ int64_t match_index(int j) const { return m[j * BLOCK]; }
+    __device__ __forceinline__ int32_t rejection(int j) const { return r[j * BLOCK]; }
+    __device__ __forceinline__ void set_last_epoch(int j, int64_t v) { e[j * BLOCK] = v; }
+    __device__ __forceinline__ void set_next_index(int j, int64_t v) { n[j * BLOCK] = v; }
+    __device__ __forceinline__ void set_match_index(int j, int64_t v) { m[j * BLOCK] = v; }
+    __device__ __forceinline__ void set_rejection(int j, int32_t v) { r[j * BLOCK] = v; }
+    // tier 1
+    __device__ __forceinline__ void load_state(uint32_t j, int64_t &ep, int64_t &nx, int64_t &mt, int32_t &rj) const
+    {
+        ep = e[j * BLOCK]; nx = n[j * BLOCK]; mt = m[j * BLOCK]; rj = r[j * BLOCK];
+    }
+    __device__ __forceinline__ void load_matches(int64_t (&mm)[F]) const
+    {
+#pragma unroll
+        for (int i = 0; i < F; i++) mm[i] = m[i * BLOCK];
+    }
+    __device__ __forceinline__ void store_ack(uint32_t j, int64_t ep, int64_t nx, int64_t mt, int32_t rj)
+    {
+        (void)ep; n[j * BLOCK] = nx; m[j * BLOCK] = mt; r[j * BLOCK] = rj;
+    }
+    __device__ __forceinline__ void store_prepare(int64_t ep, int64_t nx)
+    {
+#pragma unroll
+        for (int i = 0; i < F; i++) { e[i * BLOCK] = ep; n[i * BLOCK] = nx; m[i * BLOCK] = 0; r[i * BLOCK] = 0; }
     }
 };
 
 template <int F>
+struct PeersNarrow {
+    static constexpr int MV = (F + 3) / 4;      // 16-byte pieces of the matchIndex row
+    I32x4 *rec;                                 // [F][BLOCK], + lane applied
+    int32_t *mv;                                // [MV][BLOCK][4], + lane * 4 applied; element i at mv[(i / 4) * BLOCK * 4 + (i % 4)]
+    bool overflow;                              // a general handler stored a value that does not fit: the workgroup redoes the launch in 64 bits
+    __device__ __forceinline__ int32_t *mslot(int i) const { return mv + (i >> 2) * (BLOCK * 4) + (i & 3); }
+    __device__ __forceinline__ int64_t last_epoch(int j) const { return rec[j * BLOCK].x; }
+    __device__ __forceinline__ int64_t next_index(int j) const { return rec[j * BLOCK].y; }
+    __device__ __forceinline__ int64_t match_index(int j) const { return rec[j * BLOCK].z; }
+    __device__ __forceinline__ int32_t rejection(int j) const { return rec[j * BLOCK].w; }
+    __device__ __forceinline__ int32_t fit(int64_t v) { overflow = overflow | ((uint64_t)v >= (uint64_t)STATE_LIMIT); return (int32_t)v; }
+    __device__ __forceinline__ void set_last_epoch(int j, int64_t v) { rec[j * BLOCK].x = fit(v); }
+    __device__ __forceinline__ void set_next_index(int j, int64_t v) { rec[j * BLOCK].y = fit(v); }
+    __device__ __forceinline__ void set_match_index(int j, int64_t v) { const int32_t w = fit(v); rec[j * BLOCK].z = w; *mslot(j) = w; }
+    __device__ __forceinline__ void set_rejection(int j, int32_t v) { rec[j * BLOCK].w = v; }
+    // tier 1
+    __device__ __forceinline__ void load_state(uint32_t j, int32_t &ep, int32_t &nx, int32_t &mt, int32_t &rj) const
+    {
+        const I32x4 v = rec[j * BLOCK];
+        ep = v.x; nx = v.y; mt = v.z; rj = v.w;
+    }
+    __device__ __forceinline__ void load_matches(int32_t (&mm)[F]) const
+    {
+#pragma unroll
+        for (int q = 0; q < MV; q++) {
+            const I32x4 v = *reinterpret_cast<const I32x4 *>(mv + q * (BLOCK * 4));
+            if (q * 4 + 0 < F) mm[q * 4 + 0] = v.x;
+            if (q * 4 + 1 < F) mm[q * 4 + 1] = v.y;
+            if (q * 4 + 2 < F) mm[q * 4 + 2] = v.z;
+            if (q * 4 + 3 < F) mm[q * 4 + 3] = v.w;
+        }
+    }
+    __device__ __forceinline__ void store_ack(uint32_t j, int32_t ep, int32_t nx, int32_t mt, int32_t rj)
+    {
+        rec[j * BLOCK] = I32x4{ep, nx, mt, rj};
+        *mslot((int)j) = mt;
+    }
+    __device__ __forceinline__ void store_prepare(int32_t ep, int32_t nx)
+    {
+#pragma unroll
+        for (int i = 0; i < F; i++) rec[i * BLOCK] = I32x4{ep, nx, 0, 0};
+#pragma unroll
+        for (int q = 0; q < MV; q++) *reinterpret_cast<I32x4 *>(mv + q * (BLOCK * 4)) = I32x4{0, 0, 0, 0};
+    }
+};
+
+// entry terms of an AppendEntries request as the general handlers read them: `same` = every carried entry has term e0 (nothing else is
+// read); otherwise the first four may have been prefetched with the event (wide rows) and the rest is read from the batch's entry stream,
+// 64-bit (rg_batch_t) or 32-bit (rg_batch32_t)
+struct Entries {
+    const int64_t *t64;
+    const int32_t *t32;
+    int64_t e0, e1, e2, e3;          // scalars, not an array: see the note in GroupT
+    bool same, prefetched;
+    __device__ __forceinline__ int64_t term(uint64_t k) const
+    {
+        // fields to locals first, value selects after (the note in GroupT: a select between member loads becomes an indexed load of `this`)
+        const int64_t a0 = e0, a1 = e1, a2 = e2, a3 = e3;
+        const int64_t *p64 = t64;
+        const int32_t *p32 = t32;
+        const bool sm = same, pf = prefetched;
+        int64_t t = a0;
+        t = k == 1 ? a1 : t;
+        t = k == 2 ? a2 : t;
+        t = k == 3 ? a3 : t;
+        if (!sm && !(pf && k < 4)) t = p64 ? p64[k] : (int64_t)p32[k];
+        return sm ? a0 : t;
+    }
+};
+
+template <int F, class PE>
 struct Stepper {
     const StepParams &p;
     Group &g;
-    Peers<F> pe;
+    PE &pe;
     Fx fx;
-    bool narrow_tier = true;             // false: this kernel never takes the 32-bit tier (a compile-time constant after inlining)
 
-    __device__ __forceinline__ Stepper(const StepParams &p_, Group &g_, const Peers<F> &pe_) : p(p_), g(g_), pe(pe_) {}
+    __device__ __forceinline__ Stepper(const StepParams &p_, Group &g_, PE &pe_) : p(p_), g(g_), pe(pe_) {}
 
     __device__ __forceinline__ void reply(int64_t term, bool success)
     {
@@ -388,10 +524,10 @@ struct Stepper {
         const int64_t next = wadd(g.rc > 0 ? l_ : e_, 1);
 #pragma unroll
         for (int j = 0; j < F; j++) {
-            pe.last_epoch[j * BLOCK] = g.epoch_index;
-            pe.next_index[j * BLOCK] = next;
-            pe.match_index[j * BLOCK] = 0;
-            pe.rejection[j * BLOCK] = 0;
+            pe.set_last_epoch(j, g.epoch_index);
+            pe.set_next_index(j, next);
+            pe.set_match_index(j, 0);
+            pe.set_rejection(j, 0);
         }
         g.pending = 0;
         g.prepared = true;
@@ -406,22 +542,8 @@ struct Stepper {
     }
 
     // ---- appendEntries --------------------------------------------------------------------------
-    // entry term k of the request: the first PREFETCHED_ENTRIES arrive in registers with the event
-    // (loaded one round ahead), the rest is read from the entry stream on demand
-    struct Pre { int64_t e0, e1, e2, e3; };          // scalars, not an array: see the note in Group
-    __device__ __forceinline__ int64_t entry_term(const int64_t *terms, const Pre pre, uint64_t k) const
-    {
-        int64_t t = pre.e0;
-        t = k == 1 ? pre.e1 : t;
-        t = k == 2 ? pre.e2 : t;
-        t = k == 3 ? pre.e3 : t;
-        if (k >= 4) t = terms[k];
-        return t;
-    }
-
     __device__ __forceinline__ void on_append_entries(int64_t term, int32_t leader, int64_t prev_index,
-                                                      int64_t prev_term, uint32_t n, const int64_t *terms,
-                                                      const Pre pre,
+                                                      int64_t prev_term, uint32_t n, const Entries en,
                                                       int64_t leader_commit, bool hinted, int64_t hint_prev_term,
                                                       int64_t hint_conflict)
     {
@@ -495,7 +617,7 @@ struct Stepper {
             } else if (g.has_log() && e0 <= g.last) {
                 const int64_t stop = min64(e_last, g.last);
                 for (int64_t idx = e0; idx <= stop; idx++) {
-                    if (g.term_at(idx) != entry_term(terms, pre, (uint64_t)(idx - e_first))) { conflict = idx; break; }
+                    if (g.term_at(idx) != en.term((uint64_t)(idx - e_first))) { conflict = idx; break; }
                 }
             }
             if (conflict) {
@@ -504,7 +626,7 @@ struct Stepper {
                 int64_t keep = 0;
                 if (g.has_log() && conflict > g.first && conflict <= g.s0)
                     keep = (conflict == e0) ? (purged ? g.epoch_term : prev_term)
-                                            : entry_term(terms, pre, (uint64_t)(conflict - 1 - e_first));
+                                            : en.term((uint64_t)(conflict - 1 - e_first));
                 g.truncate(conflict, keep);
                 fx.flags |= RG_F_LOG_TRUNC;
             }
@@ -521,7 +643,7 @@ struct Stepper {
                 fx.log_from = conflict ? conflict : from;
                 fx.flags |= RG_F_LOG_APPEND;
             }
-            for (int64_t idx = from; idx <= e_last; idx++) g.push(idx, entry_term(terms, pre, (uint64_t)(idx - e_first)));
+            for (int64_t idx = from; idx <= e_last; idx++) g.push(idx, en.term((uint64_t)(idx - e_first)));
         }
         if (leader_commit > g.epoch_index && g.has_log()) {
             const uint32_t st = mark_committed(min64(leader_commit, g.last));
@@ -595,8 +717,8 @@ struct Stepper {
         const int j = (int)(slot < (uint32_t)p.self ? slot : slot - 1u);
 
         // work on a register copy of this follower's State; committed to LDS only if the row applies
-        int64_t s_epoch = pe.last_epoch[j * BLOCK], s_next = pe.next_index[j * BLOCK], s_match = pe.match_index[j * BLOCK];
-        int32_t s_rej = pe.rejection[j * BLOCK];
+        int64_t s_epoch = pe.last_epoch(j), s_next = pe.next_index(j), s_match = pe.match_index(j);
+        int32_t s_rej = pe.rejection(j);
         bool s_pend = (g.pending >> j) & 1u;
 
         s_rej = success ? 0 : (int32_t)((uint32_t)s_rej + 1u);          // statSuccess runs before updateIndex
@@ -625,9 +747,9 @@ struct Stepper {
         if (!rollback && !snapshot && success) {
             int64_t m[F];
 #pragma unroll
-            for (int i = 0; i < F; i++) m[i] = (i == j) ? s_match : pe.match_index[i * BLOCK];
+            for (int i = 0; i < F; i++) m[i] = (i == j) ? s_match : pe.match_index(i);
             int64_t full, major;
-            major_indices<F>(m, full, major);
+            major_indices<F, int64_t>(m, full, major);
             if (major != 0) {
                 if (!g.present(major)) {
                     commit_status = RG_NPE_MAJOR_NULL;
@@ -645,12 +767,12 @@ struct Stepper {
             }
         }
 
-        pe.rejection[j * BLOCK] = s_rej;
+        pe.set_rejection(j, s_rej);
         g.peers_dirty = true;
         if (rollback) { fx.status = RG_A_MATCH_ROLLBACK; return; }
-        pe.last_epoch[j * BLOCK] = s_epoch;
-        pe.next_index[j * BLOCK] = s_next;
-        pe.match_index[j * BLOCK] = s_match;
+        pe.set_last_epoch(j, s_epoch);
+        pe.set_next_index(j, s_next);
+        pe.set_match_index(j, s_match);
         g.pending = (g.pending & ~(1u << j)) | ((s_pend ? 1u : 0u) << j);
         if (commit_status) { fx.status = commit_status; return; }
         if (commit_to != 0 && commit_to != g.commit) {
@@ -746,201 +868,23 @@ struct Stepper {
         fx.flags |= RG_F_LOG_APPEND | (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT);
     }
 
-    // ---- tier 1: branch-free fast paths -----------------------------------------------------------
-    // A lone wavefront per SIMD pays ~40 cycles for every divergent branch of the general handlers below
-    // (measured: ~3000 cycles for a plain heartbeat), so the common rows are decided here with selects only,
-    // under explicit preconditions that make them a strict special case of the general code (which stays the
-    // single source of truth for everything else):
-    //   * AppendEntries at a Follower (term >= currentTerm; a higher term or a pending pre-vote refreshes the
-    //     Follower first, member/Follower.java:45-47) whose prevLog is the log tail: no conflict, no purge,
-    //     entries of one term (member/Follower.java:35-88);
-    //   * AppendEntries ack at a prepared Leader: same role epoch, no term change, no epoch move, not pending
-    //     (member/Leader.java:218-237, member/Leadership.java:75-114, member/Leader.java:247-280);
-    //   * client append at a Leader with a non-empty log (member/Leader.java:128-140);
-    //   * vote replies that only count (member/Candidate.java:127-128, member/Follower.java:264-265), late
-    //     replies to a won election that change nothing (Q13), and responses to a fenced participant.
-    // The two rare sub-cases that need more than selects (a new term run at the log tail, the first
-    // prepareReplication of a new Leader) sit behind ONE wave-level branch. Any row that misses a precondition
-    // is left untouched and goes to run().
-    // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
-    // into exec-mask branches, which is exactly what this tier exists to avoid.
-    // pe0 = the first carried entry term; entries_ok / same = entries_readable() / entries_same_term() of the row;
-    // ev_narrow = a, b, c, d, pe0 are all in [0, NARROW_LIMIT) (worked out where the event is loaded)
-    __device__ __forceinline__ bool try_fast(bool allow, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c,
-                                             int64_t d, int64_t pe0, bool entries_ok, bool same, bool ev_narrow)
-    {
-        if (narrow_tier && __builtin_amdgcn_ballot_w64(!(ev_narrow & g.narrow)) == 0)       // wave-uniform: all 64 rows fit the 32-bit tier
-            return try_fast_v<int32_t>(allow, hdr, aux, (int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d, (int32_t)pe0, entries_ok, same);
-        const bool done = try_fast_v<int64_t>(allow, hdr, aux, a, b, c, d, pe0, entries_ok, same);
-        refresh_narrow();                                                    // 64-bit values went in: the group may have left the domain
-        return done;
-    }
-
-    // is every 64-bit value of the group (registers and LDS follower columns) in [0, NARROW_LIMIT)?
-    __device__ __forceinline__ void refresh_narrow()
-    {
-        if (!narrow_tier) return;
-        uint64_t w = (uint64_t)g.term | (uint64_t)g.commit | (uint64_t)g.epoch_index | (uint64_t)g.epoch_term | (uint64_t)g.first | (uint64_t)g.last |
-                     (uint64_t)g.elected_term | (uint64_t)g.s0 | (uint64_t)g.s1 | (uint64_t)g.s2 | (uint64_t)g.s3 | (uint64_t)g.t0 | (uint64_t)g.t1 |
-                     (uint64_t)g.t2 | (uint64_t)g.t3;
-        if (g.prepared) {
-#pragma unroll
-            for (int i = 0; i < F; i++) w |= (uint64_t)pe.last_epoch[i * BLOCK] | (uint64_t)pe.next_index[i * BLOCK] | (uint64_t)pe.match_index[i * BLOCK];
-        }
-        g.narrow = w < NARROW_LIMIT;
-    }
-
-    // V = int64_t: any values. V = int32_t: the narrow tier (see NARROW_LIMIT) — same statements, 32-bit arithmetic.
-    template <class V>
-    __device__ __forceinline__ bool try_fast_v(bool allow, uint32_t hdr, uint32_t aux, V a, V b, V c, V d, V pe0, bool entries_ok, bool same)
-    {
-        constexpr bool NARROW = sizeof(V) == 4;
-        auto vadd = [](V x, V y) -> V { typedef typename std::make_unsigned<V>::type U; return (V)((U)x + (U)y); };
-        auto vmin = [](V x, V y) -> V { return x < y ? x : y; };
-        auto keep = [](int64_t old, V v) -> int64_t { if constexpr (sizeof(V) == 4) return with_lo(old, (uint32_t)v); else return (int64_t)v; };
-        const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
-        const bool flag = RG_HDR_FLAG(hdr) != 0;
-        const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
-        const V g_term = (V)g.term, g_last = (V)g.last, g_commit = (V)g.commit, g_epoch = (V)g.epoch_index, g_first = (V)g.first;
-        const V g_s0 = (V)g.s0, el_term = (V)g.elected_term;
-        const V q0 = (V)g.t0, q1 = (V)g.t1, q2 = (V)g.t2, q3 = (V)g.t3, b1 = (V)g.s1, b2 = (V)g.s2, b3 = (V)g.s3;
-        V lt = q0;                                                       // Group::last_term()
-        lt = g.rc > 1 ? q1 : lt; lt = g.rc > 2 ? q2 : lt; lt = g.rc > 3 ? q3 : lt;
-        const int32_t rc = g.rc, role = g.role, g_leader = g.leader, g_votes = g.votes;
-        const uint32_t g_repoch = g.role_epoch, el_epoch = g.elected_epoch;
-        const bool has_log = rc > 0, g_td = g.td, g_prep = g.prepared;
-        const bool peer_ok = (slot < P) & (slot != self);
-
-        // ---- AppendEntries request at a follower --------------------------------------------------
-        const bool contains = c == lt;                                   // prevLogTerm == term of the tail
-        const bool refresh = (a > g_term) | g_td;                        // switchTo(Follower, term, lastCandidate)
-        const V ae_last = contains ? vadd(b, (V)n) : g_last;
-        const bool want_commit = contains & (d > g_epoch);
-        const V ae_x = vmin(d, ae_last);
-        const bool fa = allow & (kind == RG_EV_AE_REQ) & (slot < P) & (role == RG_FOLLOWER) & (a >= g_term) &
-                        (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
-                        (b > g_epoch) & (c != 0) & entries_ok & (!contains | (n == 0) | same) &
-                        !(want_commit & (ae_x < g_commit));
-        const bool ae_refresh = fa & refresh;
-        const bool ae_commit = fa & want_commit & (ae_x > g_commit);
-        const bool ae_append = fa & contains & (n > 0);
-        const bool ae_newrun = ae_append & (pe0 != lt);
-
-        // ---- AppendEntries ack at a leader ----------------------------------------------------------
-        const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
-        const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
-        const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
-        const V s_epoch = (V)pe.last_epoch[j * BLOCK], s_next = (V)pe.next_index[j * BLOCK], s_match = (V)pe.match_index[j * BLOCK];
-        const int32_t s_rej = pe.rejection[j * BLOCK];
-        const bool s_pend = ((g.pending >> j) & 1u) != 0;
-        const bool adv = flag & (c > s_match);
-        const V n_match = adv ? c : s_match;
-        const V n_next = adv ? vadd(c, 1) : s_next;
-        V m[F];
-#pragma unroll
-        for (int i = 0; i < F; i++) {
-            const V mi = (V)pe.match_index[i * BLOCK];
-            m[i] = ((uint32_t)i == j) ? n_match : mi;
-        }
-        V full, major;
-        major_indices_v<F, V>(m, full, major);
-        const bool lookup = flag & (major != 0);
-        const bool major_ok = has_log & (major >= g_first) & (major <= g_last) & (major >= g_s0);   // present and cached
-        V mt = q0;                                                       // Group::term_at(major)
-        mt = ((rc > 1) & (b1 <= major)) ? q1 : mt; mt = ((rc > 2) & (b2 <= major)) ? q2 : mt; mt = ((rc > 3) & (b3 <= major)) ? q3 : mt;
-        const V commit_to = lookup ? (mt == g_term ? major : full) : (V)0;
-        const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
-        const bool fk = ack_shape & (aux == g_repoch) & (role == RG_LEADER) & g_prep & (a <= g_term) &
-                        (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
-                        (!lookup | major_ok) & !(do_commit & (commit_to < g_commit));
-        const bool ack_commit = fk & do_commit;
-        const bool ack_drop = allow & ack_kind & peer_ok & (aux != g_repoch);       // AsyncHead aborted: response dropped
-
-        // ---- client append at a leader ----------------------------------------------------------------
-        const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
-        const bool fc_newrun = fc & (lt != g_term);
-        const bool fc_prepare = fc & !g_prep;
-
-        // ---- vote replies that only count, change nothing, or reach a fenced participant --------------
-        const bool is_pv = kind == RG_EV_PV_REPLY;
-        const bool vr_shape = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
-        bool count_only = false, late_noop = false, vote_drop = false;
-        if (__builtin_amdgcn_ballot_w64(vr_shape) != 0) {                // wave-uniform: steady replication carries no vote replies
-            const bool cur_epoch = aux == g_repoch;
-            const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
-            const V T = is_pv ? vadd(g_term, 1) : g_term;
-            count_only = vr_shape & cur_epoch & sender_ok & (a <= T) & (!flag | (g_votes + 1 < p.majority));
-            const bool late = !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
-            late_noop = vr_shape & late & (a <= el_term) &
-                        (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
-            vote_drop = vr_shape & !cur_epoch & !late;
-        }
-        const bool fv = count_only | late_noop | vote_drop;
-
-        const bool fast = fa | fk | fc | fv | ack_drop;
-        if (fk) {
-            pe.rejection[j * BLOCK] = flag ? 0 : (int32_t)((uint32_t)s_rej + 1u);
-            if constexpr (NARROW) {                       // the high words in LDS are zero already
-                reinterpret_cast<int32_t *>(&pe.next_index[j * BLOCK])[0] = n_next;
-                reinterpret_cast<int32_t *>(&pe.match_index[j * BLOCK])[0] = n_match;
-            } else {
-                pe.next_index[j * BLOCK] = n_next;
-                pe.match_index[j * BLOCK] = n_match;
-            }
-        }
-        if (ae_newrun | fc_newrun | fc_prepare) {          // rare: one wave-level branch for both
-            if (ae_newrun | fc_newrun) g.push((int64_t)vadd(g_last, 1), (int64_t)(ae_newrun ? pe0 : g_term));
-            if (fc_prepare) {                             // Leader.prepareReplication after the FIRST new entry
-                const int64_t next = (int64_t)vadd(g_last, 2);
-#pragma unroll
-                for (int i = 0; i < F; i++) {
-                    pe.last_epoch[i * BLOCK] = (int64_t)g_epoch; pe.next_index[i * BLOCK] = next;
-                    pe.match_index[i * BLOCK] = 0; pe.rejection[i * BLOCK] = 0;
-                }
-                g.pending = 0;
-            }
-        }
-        g.prepared = g_prep | fc_prepare;
-        g.peers_dirty = g.peers_dirty | fk | fc_prepare;
-        g.term = keep(g.term, ae_refresh ? a : g_term);
-        g.role_epoch = g_repoch + (ae_refresh ? 1u : 0u);
-        g.td = g_td & !ae_refresh;
-        g.votes = ae_refresh ? 1 : (g_votes + ((count_only & flag) ? 1 : 0));
-        g.leader = fa ? (int32_t)slot : g_leader;
-        {
-            const V cur_last = (V)g.last;                 // (a new run pushed above has already moved it)
-            g.last = keep(g.last, ae_append ? ae_last : (fc ? vadd(g_last, (V)n) : cur_last));
-        }
-        g.log_dirty = g.log_dirty | ae_append | fc;
-        g.commit = keep(g.commit, ae_commit ? ae_x : (ack_commit ? commit_to : g_commit));
-        if (fast) {
-            fx.status = (ack_drop | vote_drop) ? RG_DROPPED_STALE_ROLE : RG_OK;
-            fx.resp_term = (int64_t)a;                   // only read for AppendEntries: the request term (== currentTerm by now)
-            fx.log_from = (int64_t)vadd(g_last, 1);
-            fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
-                       (ae_refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) |
-                       ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
-                       (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
-        }
-        return fast;
-    }
-
     // ---- one row (tier 2: the general handlers) ---------------------------------------------------
+    // hdr: kind / slot / flag / n as on the wire (other bits are not looked at); en: how this row's entry terms are read
     __device__ __forceinline__ void run(uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
-                                        int64_t hx, int64_t hy, int64_t pe0, int64_t pe1, int64_t pe2, int64_t pe3)
+                                        bool hinted, int64_t hx, int64_t hy, const Entries en, bool entries_readable)
     {
         fx = Fx{0u, RG_OK, 0, 0};
         const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
-        const bool flag = RG_HDR_FLAG(hdr) != 0, hinted = (RG_HDR_HINT(hdr) != 0) & (p.hint != nullptr);   // no hint column: the bit means nothing
+        const bool flag = RG_HDR_FLAG(hdr) != 0;
         const uint32_t P = (uint32_t)p.cluster;
         switch (kind) {
         case RG_EV_NONE:
             break;
         case RG_EV_AE_REQ:
-            if (slot >= P || n > RG_MAX_AE_ENTRIES || (n > 0 && (p.entry_terms == nullptr || (uint64_t)aux + n > p.entry_count))) {
+            if (slot >= P || n > RG_MAX_AE_ENTRIES || (n > 0 && !entries_readable)) {
                 fx.status = RG_BAD_EVENT; break;
             }
-            on_append_entries(a, (int32_t)slot, b, c, n, p.entry_terms + aux, Pre{pe0, pe1, pe2, pe3}, d, hinted, hx, hy);
+            on_append_entries(a, (int32_t)slot, b, c, n, en, d, hinted, hx, hy);
             break;
         case RG_EV_AE_ACK:
         case RG_EV_IS_ACK:
@@ -978,5 +922,189 @@ struct Stepper {
         }
     }
 };
+
+// ---- tier 1: the rows of a cluster in operation, with selects only ----------------------------------------------------------
+// A lone wavefront per SIMD pays ~40 cycles for every taken branch of the general handlers (measured in round 2: ~1 700 ticks for a
+// visit by ONE lane, which its 63 neighbours wait for), so every row class a healthy or an electing cluster produces is decided here
+// under explicit preconditions that make it a strict special case of the general code:
+//   * AppendEntries at a Follower (term >= currentTerm; a higher term or a pending pre-vote refreshes the Follower first,
+//     member/Follower.java:45-47) whose prevLog is the log tail: no conflict, no purge, entries of one term (member/Follower.java:35-88);
+//   * AppendEntries ack at a prepared Leader: same role epoch, no term change, no epoch move, not pending, the quorum index inside the
+//     newest term run (member/Leader.java:218-237, member/Leadership.java:75-114, member/Leader.java:247-280);
+//   * client append at a Leader with a non-empty log (member/Leader.java:128-140);
+//   * responses to a fenced participant (transport/rpc/Async.java:157-171);
+//   and, behind ONE wave-uniform branch that steady replication never takes (`election`):
+//   * vote replies: counted, winning (-> Candidate / Leader), carrying a higher term (-> Follower, votedFor = responder), late for a won
+//     election (Q13) (member/Candidate.java:121-134, member/Follower.java:258-270);
+//   * election / heartbeat timeouts of the three roles (member/Follower.java:156-168, Candidate.java:82-88, Leader.java:120-126);
+//   * RequestVote / PreVote at a Follower that has a log (member/Follower.java:91-127, 193-207);
+//   * a Leader stepping down on a higher-term replication response (member/Leader.java:224-226, 178-181).
+// Every conversion these rows make is one application of RaftRoutine.convertTo + RaftMember.<init> at the end (`conv_all`).
+// The two rare sub-cases that need more than selects (a new term run at the log tail, prepareReplication of a new Leader) sit behind one
+// more wave-level branch. Any row that misses a precondition is left untouched — `false` — and goes to Stepper::run().
+// MUST be called by every lane of the wavefront (converged code).
+// NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
+// into exec-mask branches, which is exactly what this tier exists to avoid.
+// hdr: header with HDR_AE_OK / HDR_PEER_OK worked out by the loader; pe0: the term shared by the carried entries (if any)
+template <int F, class V, class PE>
+__device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe, FxT<V> &fx, bool allow, uint32_t hdr, uint32_t aux,
+                                      V a, V b, V c, V d, V pe0)
+{
+    constexpr bool NARROW = sizeof(V) == 4;
+    const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+    const bool flag = RG_HDR_FLAG(hdr) != 0;
+    const uint32_t self = (uint32_t)p.self;
+    const V g_term = g.term, g_last = g.last, g_commit = g.commit, g_epoch = g.epoch_index, lt = g.lt, top = g.top;
+    const int32_t rc = g.rc, role = g.role, g_leader = g.leader, g_votes = g.votes, g_voted = g.voted_for;
+    const uint32_t g_repoch = g.role_epoch;
+    const bool has_log = rc > 0, g_td = g.td, g_prep = g.prepared;
+    const bool peer_ok = (hdr & HDR_PEER_OK) != 0;
+
+    // ---- AppendEntries request at a follower --------------------------------------------------
+    const bool contains = c == lt;                                   // prevLogTerm == term of the tail
+    const bool refresh = (a > g_term) | g_td;                        // switchTo(Follower, term, lastCandidate)
+    const V ae_last = contains ? vadd<V>(b, (V)n) : g_last;
+    const bool want_commit = contains & (d > g_epoch);
+    const V ae_x = vmin<V>(d, ae_last);
+    const bool fa = allow & ((hdr & HDR_AE_OK) != 0) & (role == RG_FOLLOWER) & (a >= g_term) &
+                    (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
+                    (b > g_epoch) & !(want_commit & (ae_x < g_commit));
+    const bool ae_refresh = fa & refresh;
+    const bool ae_commit = fa & want_commit & (ae_x > g_commit);
+    const bool ae_append = fa & contains & (n > 0);
+    const bool ae_newrun = ae_append & (pe0 != lt);
+
+    // ---- AppendEntries ack at a leader ----------------------------------------------------------
+    const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
+    const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
+    const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
+    V s_epoch, s_next, s_match;
+    int32_t s_rej;
+    pe.load_state(j, s_epoch, s_next, s_match, s_rej);
+    const bool s_pend = ((g.pending >> j) & 1u) != 0;
+    const bool adv = flag & (c > s_match);
+    const V n_match = adv ? c : s_match;
+    const V n_next = adv ? vadd<V>(c, 1) : s_next;
+    V m[F];
+    pe.load_matches(m);
+#pragma unroll
+    for (int i = 0; i < F; i++) m[i] = ((uint32_t)i == j) ? n_match : m[i];
+    V full, major;
+    major_indices<F, V>(m, full, major);
+    const bool lookup = flag & (major != 0);
+    const bool major_ok = has_log & (major >= top) & (major <= g_last);     // inside the newest run: present, cached, its term is lt
+    const V commit_to = lookup ? (lt == g_term ? major : full) : (V)0;
+    const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
+    const bool lead_ok = (aux == g_repoch) & (role == RG_LEADER) & g_prep;
+    const bool fk = ack_shape & lead_ok & (a <= g_term) &
+                    (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
+                    (!lookup | major_ok) & !(do_commit & (commit_to < g_commit));
+    const bool ack_commit = fk & do_commit;
+    const bool ack_any = allow & ack_kind & peer_ok;
+    const bool ack_drop = ack_any & (aux != g_repoch);               // AsyncHead aborted: response dropped
+
+    // ---- client append at a leader ----------------------------------------------------------------
+    bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
+    if constexpr (NARROW) fc = fc & ((uint32_t)g_last + n < STATE_LIMIT);     // (n < 2^20: the sum cannot wrap)
+    const bool fc_newrun = fc & (lt != g_term);
+    const bool fc_prepare = fc & !g_prep;
+
+    // ---- election traffic -----------------------------------------------------------------------------
+    // defaults = what the AppendEntries refresh converts to: Follower(request term, lastCandidate)
+    bool conv = false, to_pre = false, to_lead = false, count_grant = false, el_fast = false, el_drop = false, vq = false, vq_success = false,
+         vq_timer = false, el_reqvote = false;
+    int32_t new_role = RG_FOLLOWER, new_vote = g_voted;
+    V new_term = a;
+    const bool ack_down = ack_any & lead_ok & (a > g_term);          // Leader -> Follower(result.term, responder)
+    const bool election = (allow & (kind - (uint32_t)RG_EV_RV_REQ <= (uint32_t)(RG_EV_TIMEOUT - RG_EV_RV_REQ))) | ack_down;
+    if (__builtin_amdgcn_ballot_w64(election) != 0) {               // wave-uniform: steady replication carries no such rows
+        const V term1 = vadd<V>(g_term, 1), el_term = g.elected_term;
+        const uint32_t el_epoch = g.elected_epoch;
+        const bool cur_epoch = aux == g_repoch;
+        // vote replies
+        const bool is_pv = kind == RG_EV_PV_REPLY;
+        const bool vr_shape = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
+        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
+        const V T = is_pv ? term1 : g_term;
+        const bool vr_cur = vr_shape & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);     // (currentTerm + 1 wrapped: the general handlers)
+        const bool vr_higher = vr_cur & (a > T);
+        const bool vr_grant = vr_cur & (a <= T) & flag;
+        const bool vr_win = vr_grant & (g_votes + 1 >= p.majority);
+        const bool win_rv = vr_win & !is_pv;
+        const bool vr_quiet = vr_cur & (a <= T) & !vr_win;            // counted, or refused: nothing else changes
+        const bool late = vr_shape & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
+        const bool late_higher = late & (a > el_term);                // head.abortRequests(); Follower if that is "better"
+        const bool late_noop = late & (a <= el_term) & (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
+        const bool vote_drop = vr_shape & !cur_epoch & !late;
+        // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
+        const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
+        const bool to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
+        const bool to_live = to_kind & !to_stale;
+        to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
+        const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
+        to_lead = to_live & (role == RG_LEADER);
+        // RequestVote / PreVote at a Follower that has a log
+        const bool is_pvq = kind == RG_EV_PV_REQ;
+        vq = allow & ((kind == RG_EV_RV_REQ) | is_pvq) & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
+        const bool utd = (c > lt) | ((c == lt) & (b >= g_last));      // Follower.logUpToDate with a last entry
+        const bool pv_judge = vq & is_pvq & (a > g_term) & g_td;      // else failure(currentTerm), no timer touched
+        const bool rv_new = vq & !is_pvq & (a > g_term);
+        const bool rv_same = vq & !is_pvq & (a == g_term);
+        vq_success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
+        vq_timer = pv_judge | rv_new;
+
+        const bool conv_self = vr_win | to_cand;                      // ballot = self
+        conv = vr_higher | conv_self | (late_higher & (a >= g_term)) | to_pre | rv_new | ack_down;
+        // (lanes this block converts nothing for keep the defaults: their AppendEntries refresh, if any, needs them)
+        new_role = vr_win ? (is_pv ? RG_CANDIDATE : RG_LEADER) : (to_cand ? RG_CANDIDATE : RG_FOLLOWER);
+        new_term = (to_cand | (vr_win & is_pv)) ? term1 : ((win_rv | to_pre) ? g_term : a);
+        new_vote = conv_self ? (int32_t)self : ((to_pre | !conv) ? g_voted : ((rv_new & !utd) ? RG_NO_NODE : (int32_t)slot));
+        el_reqvote = conv & (new_role == RG_CANDIDATE);
+        count_grant = vr_grant & !vr_win;
+        el_drop = vote_drop | to_stale;
+        el_fast = vr_higher | vr_win | vr_quiet | late_higher | late_noop | el_drop | to_pre | to_cand | to_lead | vq | ack_down;
+        g.elected_epoch = win_rv ? g_repoch : (late_higher ? 0u : el_epoch);      // Candidate.java:75-79 / head.abortRequests()
+        g.elected_term = win_rv ? g_term : el_term;
+    }
+
+    const bool fast = fa | fk | fc | ack_drop | el_fast;
+    if (fk) pe.store_ack(j, s_epoch, n_next, n_match, flag ? 0 : (int32_t)((uint32_t)s_rej + 1u));
+    const bool lead_prepare = fc_prepare | (to_lead & !g_prep);      // Leader.prepareReplication (member/Leader.java:30-50)
+    if (ae_newrun | fc_newrun | lead_prepare) {                      // rare: one wave-level branch for both
+        if (ae_newrun | fc_newrun) g.push(vadd<V>(g_last, 1), ae_newrun ? pe0 : g_term);
+        if (lead_prepare) {                                          // a client append prepares after its FIRST new entry: nextIndex = that entry + 1
+            pe.store_prepare(g_epoch, vadd<V>(has_log ? g_last : g_epoch, fc_prepare ? 2 : 1));
+            g.pending = 0;
+        }
+    }
+    const bool conv_all = conv | ae_refresh;
+    g.prepared = (g_prep & !conv_all) | lead_prepare;
+    g.peers_dirty = g.peers_dirty | fk | lead_prepare;
+    g.term = conv_all ? new_term : g_term;
+    g.role = conv_all ? new_role : role;
+    g.voted_for = conv_all ? new_vote : g_voted;
+    g.role_epoch = g_repoch + (conv_all ? 1u : 0u);
+    g.td = (g_td & !conv_all) | to_pre;
+    g.votes = conv_all ? 1 : (g_votes + (count_grant ? 1 : 0));
+    g.leader = fa ? (int32_t)slot : (conv_all ? RG_NO_NODE : g_leader);
+    {
+        const V cur_last = g.last;                                   // (a new run pushed above has already moved it)
+        g.last = ae_append ? ae_last : (fc ? vadd<V>(g_last, (V)n) : cur_last);
+    }
+    g.log_dirty = g.log_dirty | ae_append | fc;
+    g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
+    if (fast) {
+        fx.status = (ack_drop | el_drop) ? RG_DROPPED_STALE_ROLE : RG_OK;
+        fx.resp_term = (fa | conv) ? a : g_term;                     // only read for requests: AppendEntries (== currentTerm by now), vote requests
+        fx.log_from = vadd<V>(g_last, 1);                            // only read with RG_F_LOG_APPEND
+        fx.flags = ((fa | vq) ? RG_F_REPLIED : 0u) | (((fa & contains) | vq_success) ? RG_F_SUCCESS : 0u) |
+                   ((fa | vq_timer | to_lead) ? RG_F_RESET_TIMER : 0u) |
+                   (conv_all ? (RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER) : 0u) |
+                   ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
+                   ((fc | to_lead) ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u) |
+                   (to_pre ? (RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT) : 0u) | (el_reqvote ? (RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT) : 0u);
+    }
+    return fast;
+}
 
 }  // namespace rg

@@ -1,443 +1,10 @@
-// rg_kernels.hip — gfx950 kernels of the batched multi-Raft decision engine.
-//
-// step_kernel<F, SPARSE, LANES> / step_split_kernel<F, SPARSE>: the replacement of the reference EventLoop drain
-// (support/EventLoopGroup.java:32-46).  One lane = one raft group for the whole launch:
-//   * group state is read ONCE (16-byte coalesced loads from the structure-of-structs table),
-//     kept in VGPRs across all `rounds` of the batch, and written back once;
-//   * the per-follower Leadership.State columns are staged in LDS ([follower][lane]) only for groups
-//     that lead, so the runtime responder slot indexes LDS, not registers;
-//   * per round every lane loads its 40-byte event as 8+16+16 B, two rounds ahead of its use (software
-//     prefetch) — the event/outcome streams are what HBM sees;
-//   * outcomes: the 16-byte reply is always stored; log/commit effects and the durable
-//     (term, votedFor) pair are stored only for rows that have them;
-//   * decision counters are per-lane tallies, reduced over the wavefront once and added to the wave's own
-//     slot of a counter table at the end (no atomics).
-// step_kernel: workgroup = one wavefront that does all of it (lanes never share LDS columns, no barrier anywhere).
-// step_split_kernel: workgroup = a deciding and an I/O wavefront for the same 64 groups, one LDS-only barrier per
-// round (see its header comment). The host picks per launch (raftgpu.cpp: step_lanes).
+// rg_kernels.hip — gfx950 kernels of the batched multi-Raft decision engine: the step kernels (rg_step.hpp: the replacement of the
+// reference EventLoop drain) and, below, the send side (N1), the timers and the health / readiness gate (N4), the measured-copy
+// yardstick and the compact transfer formats of the pipelined host path.
 #include "rg_device.hpp"
+#include "rg_step.hpp"
 
 namespace rg {
-
-struct EventRow {                   // what the row index addresses: 8 + 16 + 16 bytes
-    uint32_t hdr, aux;
-    int64_t a, b, c, d;
-};
-struct EventTail {                  // what the header addresses
-    int64_t hx, hy;                 // hint (only meaningful when the header carries RG_HDR_HINT_BIT)
-    int64_t e0, e1, e2, e3;         // first entry terms of an AppendEntries request
-};
-
-// Stage 1 of the event pipeline: the three row-addressed loads (8 + 16 + 16 B per lane). Nothing here
-// depends on loaded data, so the loads are issued two rounds ahead of their use.
-__device__ __forceinline__ void load_event(const StepParams &p, size_t row, EventRow &e)
-{
-    const rg_ev_head_t h = p.head[row];
-    const I64x2 ab = p.ab[row], cd = p.cd[row];
-    e.hdr = h.hdr; e.aux = h.aux;
-    e.a = ab.x; e.b = ab.y; e.c = cd.x; e.d = cd.y;
-}
-
-// Stage 2, one round later (the header has landed by now): loads whose ADDRESS comes from the header —
-// the first entry terms of an AppendEntries request and the optional hint. Issued one round ahead of use.
-__device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, const EventRow &e, EventTail &t)
-{
-    if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; t.hx = hh.x; t.hy = hh.y; }
-    // four unconditional 8-byte loads at 32-bit offsets from one uniform base: lanes without a k-th entry read the
-    // word at offset 0 (always readable) instead of branching around the load. The host keeps entry_count <= 2^29,
-    // so (aux + k) * 8 cannot wrap.
-    const uint32_t n = RG_HDR_N(e.hdr);
-    const bool have_terms = (p.entry_terms != nullptr) & (p.entry_count != 0);
-    const char *base = have_terms ? reinterpret_cast<const char *>(p.entry_terms) : reinterpret_cast<const char *>(p.head);
-    const bool ae = (RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ) & (n > 0) & have_terms & ((uint64_t)e.aux + n <= p.entry_count);
-    const uint32_t o = e.aux * 8u;
-    const uint32_t o0 = ae ? o : 0u, o1 = (ae & (n > 1u)) ? o + 8u : 0u, o2 = (ae & (n > 2u)) ? o + 16u : 0u,
-                   o3 = (ae & (n > 3u)) ? o + 24u : 0u;
-    t.e0 = *reinterpret_cast<const int64_t *>(base + o0); t.e1 = *reinterpret_cast<const int64_t *>(base + o1);
-    t.e2 = *reinterpret_cast<const int64_t *>(base + o2); t.e3 = *reinterpret_cast<const int64_t *>(base + o3);
-}
-
-// every value the 32-bit tier reads from the event is in [0, NARROW_LIMIT)
-__device__ __forceinline__ bool event_narrow(int64_t a, int64_t b, int64_t c, int64_t d, int64_t e0)
-{
-    return ((uint64_t)a | (uint64_t)b | (uint64_t)c | (uint64_t)d | (uint64_t)e0) < NARROW_LIMIT;
-}
-
-// Group state: table -> registers (nine 16-byte coalesced loads), follower columns of a prepared leader -> LDS, and back.
-__device__ __forceinline__ void load_group(const DevTable &t, uint32_t gi, Group &g)
-{
-    const uint32_t G = t.groups;
-    const I64x2 tc = t.term_commit[gi], ep = t.epoch[gi], w = t.window[gi];
-    const Ident id = t.ident[gi];
-    const Elect el = t.elect[gi];
-    g.term = tc.x; g.commit = tc.y; g.epoch_index = ep.x; g.epoch_term = ep.y; g.first = w.x; g.last = w.y;
-    g.voted_for = id.voted_for; g.leader = id.leader; g.role_epoch = id.role_epoch;
-    g.role = (int32_t)(id.meta & META_ROLE);
-    g.td = (id.meta & META_TD) != 0; g.prepared = (id.meta & META_PREP) != 0;
-    g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
-    g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
-    g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
-    const I64x2 r0 = t.runs[gi], r1 = t.runs[(size_t)G + gi], r2 = t.runs[(size_t)2 * G + gi], r3 = t.runs[(size_t)3 * G + gi];
-    g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
-    g.log_dirty = false; g.peers_dirty = false;
-}
-
-template <int F>
-__device__ __forceinline__ void stage_peers(const DevTable &t, uint32_t gi, const Group &g, Peers<F> &pe)
-{
-    if (!g.prepared) return;
-    const uint32_t G = t.groups;
-#pragma unroll
-    for (int j = 0; j < F; j++) {
-        const I64x2 en = t.peer_en[(size_t)j * G + gi];
-        const Match m = t.peer_m[(size_t)j * G + gi];
-        pe.last_epoch[j * BLOCK] = en.x; pe.next_index[j * BLOCK] = en.y;
-        pe.match_index[j * BLOCK] = m.match_index; pe.rejection[j * BLOCK] = m.rejection;
-    }
-}
-
-template <int F>
-__device__ __forceinline__ void store_group(const DevTable &t, uint32_t gi, uint32_t G, const Group &g, const Peers<F> &pe)
-{
-    t.term_commit[gi] = I64x2{g.term, g.commit};
-    t.epoch[gi] = I64x2{g.epoch_index, g.epoch_term};
-    t.window[gi] = I64x2{g.first, g.last};
-    Ident id;
-    id.voted_for = g.voted_for; id.leader = g.leader; id.role_epoch = g.role_epoch;
-    id.meta = (uint32_t)g.role | (g.td ? META_TD : 0u) | (g.prepared ? META_PREP : 0u) |
-              ((uint32_t)g.rc << META_RC_SHIFT) | (g.pending << META_PEND_SHIFT);
-    t.ident[gi] = id;
-    Elect el;
-    el.elected_term = g.elected_term; el.elected_epoch = g.elected_epoch; el.votes = g.votes;
-    t.elect[gi] = el;
-    if (g.log_dirty) {
-        t.runs[gi] = I64x2{g.s0, g.t0};
-        t.runs[(size_t)G + gi] = I64x2{g.s1, g.t1};
-        t.runs[(size_t)2 * G + gi] = I64x2{g.s2, g.t2};
-        t.runs[(size_t)3 * G + gi] = I64x2{g.s3, g.t3};
-    }
-    if (g.peers_dirty) {
-#pragma unroll
-        for (int j = 0; j < F; j++) {
-            t.peer_en[(size_t)j * G + gi] = I64x2{pe.last_epoch[j * BLOCK], pe.next_index[j * BLOCK]};
-            Match m;
-            m.match_index = pe.match_index[j * BLOCK]; m.rejection = pe.rejection[j * BLOCK]; m.pad = 0;
-            t.peer_m[(size_t)j * G + gi] = m;
-        }
-    }
-}
-
-// (Fewer groups per wavefront — upper lanes masked off — was measured in round 1 at 64 / 32 / 16 / 8 lanes on 65 536 groups:
-// 0.193 / 0.204 / 0.358 / 0.527 ms. A half-masked wavefront still costs both passes of a wave64 instruction; the knob is gone.)
-template <int F, bool SPARSE>
-__global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
-{
-    __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
-    __shared__ int32_t sh_rej[F * BLOCK];
-
-    const uint32_t lane = threadIdx.x;
-    const uint32_t i = blockIdx.x * BLOCK + lane;
-    const bool active = i < p.count;
-    // Lanes past the end of the batch (tail wavefront, or the masked half of a narrow one) shadow the batch's last row:
-    // they load and decide like everybody else — so the round loop has no divergent control flow around it — and only
-    // their stores are switched off.
-    const uint32_t ir = active ? i : p.count - 1u;
-    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
-    const uint32_t G = p.t.groups;
-
-    Group g;
-    load_group(p.t, gi, g);
-    // start the event pipeline before anything that has to wait for the state loads above
-    EventRow cur{}, near{}, far{};
-    EventTail cur_t{}, near_t{};
-    const uint32_t last_round = p.rounds - 1u;            // the host never launches with rounds == 0
-    load_event(p, ir, cur);
-    load_event(p, (size_t)(last_round < 1u ? last_round : 1u) * p.count + ir, near);
-    Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
-    stage_peers<F>(p.t, gi, g, pe);
-
-    Stepper<F> st(p, g, pe);
-    st.refresh_narrow();
-    const bool FAST = p.fast_paths != 0;                 // RG_FAST=0 forces every row through the general handlers (tests)
-    // decision counters: per-lane 32-bit tallies (no scalar registers tied up across the loop), reduced over the
-    // wavefront once at the end
-    uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
-    bool blocked = false;
-
-    // outcome of the previous round, stored one round late (see the drain below)
-    rg_reply_t pend_rep{0, 0u, 0u};
-    I64x2 pend_lfx{0, 0};
-    rg_persist_t pend_per{0, 0, 0};
-    bool pend_w_lfx = false, pend_w_per = false;
-
-    // three-deep event pipeline: `far` = round r+2 (row loads in flight), `near` = round r+1 (header landed,
-    // header-addressed loads in flight), `cur` = round r (complete). Every wait falls at the top of a
-    // round, for memory operations issued a full round earlier, so their latency overlaps decision work.
-    load_event_tail(p, ir, cur, cur_t);
-    for (uint32_t r = 0; r < p.rounds; r++) {
-        const size_t row = (size_t)r * p.count + ir;
-        // Drain HERE, before issuing anything new: the vm counter retires in order and (on gfx9-class ISAs)
-        // counts stores too, so (a) a wait placed lazily inside the divergent decision code would degrade to
-        // vmcnt(0) and also wait for the loads issued below, and (b) draining right after the outcome stores
-        // would expose the full store latency every round. Hence: loads AND the previous round's stores are
-        // issued right after this point and get a whole round of decision work to complete.
-        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) expcnt(7) lgkmcnt(15)
-        if (r > 0) {
-            if (active) p.reply[row - p.count] = pend_rep;
-            if (pend_w_lfx) p.logfx[row - p.count] = pend_lfx;
-            if (pend_w_per) p.persist[row - p.count] = pend_per;
-        }
-        // prefetch without conditions: past the last round the pipeline simply re-reads the last round's rows
-        const uint32_t r1 = r + 1u < p.rounds ? r + 1u : last_round, r2 = r + 2u < p.rounds ? r + 2u : last_round;
-        load_event(p, (size_t)r2 * p.count + ir, far);
-        load_event_tail(p, (size_t)r1 * p.count + ir, near, near_t);
-
-        {
-            const uint32_t kind = RG_HDR_KIND(cur.hdr);
-            // every lane goes through tier 1: it contains wave-uniform branches on ballots and is therefore called from converged
-            // code; a lane blocked after a NEED_HOST simply asks for nothing
-            const bool skip = blocked & (kind != RG_EV_NONE);
-            const bool done = st.try_fast(FAST & !skip, cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0, entries_readable(p, cur.hdr, cur.aux),
-                                          entries_same_term(cur.hdr, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3),
-                                          event_narrow(cur.a, cur.b, cur.c, cur.d, cur_t.e0));
-            const bool slow = !done & !skip;
-            if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-            if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-                if (slow) st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.hx, cur_t.hy, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
-                st.refresh_narrow();                      // the general handlers work on 64-bit values
-            }
-            const uint32_t status = st.fx.status, flags = st.fx.flags;
-            if (status == RG_NEED_HOST) blocked = true;
-            pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
-            pend_rep.flags = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
-            pend_rep.role_epoch = g.role_epoch;
-            pend_w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-            pend_lfx = I64x2{g.commit, st.fx.log_from};
-            pend_w_per = active & ((flags & RG_F_PERSIST) != 0);
-            pend_per.term = g.term; pend_per.voted_for = g.voted_for; pend_per.role = g.role;
-
-            c_rows += kind != RG_EV_NONE ? 1u : 0u;
-            c_replied += (flags >> 1) & 1u;             // RG_F_REPLIED
-            c_conv += (flags >> 3) & 1u;                // RG_F_ROLE_CHANGED
-            c_commit += (flags >> 5) & 1u;              // RG_F_COMMIT
-            c_append += (flags >> 7) & 1u;              // RG_F_LOG_APPEND
-            c_assert += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
-            c_need += status == RG_NEED_HOST ? 1u : 0u;
-            c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
-        }
-        cur = near; cur_t = near_t;
-        near = far;
-    }
-    if (active && p.rounds > 0) {
-        const size_t row = (size_t)(p.rounds - 1) * p.count + ir;
-        p.reply[row] = pend_rep;
-        if (pend_w_lfx) p.logfx[row] = pend_lfx;
-        if (pend_w_per) p.persist[row] = pend_per;
-    }
-
-    if (active) store_group<F>(p.t, gi, G, g, pe);
-    // Wavefront reduction of the tallies: butterfly over the 64 lanes, then each wave adds into its own
-    // 64-byte slot of the counter table with a plain read-modify-write (8 atomics per wave onto 8 shared
-    // words cost ~60 us per launch at 1024 waves). rg_counters_read sums the slots.
-    uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
-#pragma unroll
-    for (int c = 0; c < RG_NUM_COUNTERS; c++) {
-        uint32_t v = active ? tally[c] : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        tally[c] = v;
-    }
-    if (lane < RG_NUM_COUNTERS) {
-        uint32_t v = tally[0];
-#pragma unroll
-        for (int c = 1; c < RG_NUM_COUNTERS; c++) v = (lane == (uint32_t)c) ? tally[c] : v;
-        unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
-        *slot += v;
-    }
-}
-
-// ---- step_split_kernel: the same decisions, two instruction streams per 64 groups -----------------------------
-// One wavefront per SIMD gets one issue slot every ~4 cycles and leaves half of the SIMD's VALU slots empty (DESIGN.md
-// §6). This variant gives every 64 groups a workgroup of TWO wavefronts with different jobs:
-//   wave 1 (I/O)     row addressing, the event loads (same three-stage prefetch as above), the outcome stores and the
-//                    decision counters — everything that does not need the group's state;
-//   wave 0 (decide)  group state in registers, follower state in LDS, tier 1 / tier 2 — and nothing else.
-// They meet once per round at an LDS-only barrier. Events travel through a two-slot LDS ring written one round ahead,
-// outcomes through a two-slot ring read one round behind, so neither wave ever waits for the other's memory traffic:
-//   round r:  I/O    writes event r+1 -> ev[(r+1)&1], reads outcome r-1 <- out[(r-1)&1] and stores it, issues next loads
-//             decide reads event r <- ev[r&1], decides, writes outcome r -> out[r&1]
-//   barrier   (s_waitcnt lgkmcnt(0) + s_barrier: LDS traffic only — global loads/stores stay in flight across it)
-enum { EV_HEAD = 0, EV_A, EV_B, EV_C, EV_D, EV_HX, EV_HY, EV_E0, EV_E1, EV_E2, EV_E3, EV_FIELDS };
-enum { OUT_RESP = 0, OUT_FLAGS, OUT_COMMIT, OUT_FROM, OUT_TERM, OUT_VOTE, OUT_FIELDS };
-
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt/expcnt untouched: my LDS writes have landed
-    __builtin_amdgcn_s_barrier();
-}
-
-template <int F, bool SPARSE>
-__global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
-{
-    __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
-    __shared__ int32_t sh_rej[F * BLOCK];
-    __shared__ uint64_t sh_ev[2][EV_FIELDS][BLOCK];
-    __shared__ uint64_t sh_out[2][OUT_FIELDS][BLOCK];
-
-    const uint32_t lane = threadIdx.x & (BLOCK - 1);
-    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
-    const uint32_t i = blockIdx.x * BLOCK + lane;
-    const bool active = i < p.count;
-    const uint32_t ir = active ? i : p.count - 1u;       // lanes past the end shadow the last row; only their stores are off
-    const uint32_t last_round = p.rounds - 1u;
-
-    if (io_wave) {
-        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
-        auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
-            const uint32_t hdr = (e.hdr & ~(HDR_SAME | HDR_ENTRIES_OK)) | (entries_readable(p, e.hdr, e.aux) ? HDR_ENTRIES_OK : 0u) |
-                                 (entries_same_term(e.hdr, t.e0, t.e1, t.e2, t.e3) ? HDR_SAME : 0u);
-            sh_ev[slot][EV_HEAD][lane] = (uint64_t)hdr | ((uint64_t)e.aux << 32);
-            sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
-            sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
-            sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
-            sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0; sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
-            sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
-        };
-        uint32_t c_rows = 0, c_replied = 0, c_conv = 0, c_commit = 0, c_assert = 0, c_need = 0, c_stale = 0, c_append = 0;
-        auto retire = [&](uint32_t r, uint32_t hdr) {      // outcome of round r: LDS -> global, plus the tallies
-            const uint32_t slot = r & 1u;
-            const size_t row = (size_t)r * p.count + ir;
-            const uint64_t fe = sh_out[slot][OUT_FLAGS][lane];
-            const uint32_t flags_all = (uint32_t)fe, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
-            rg_reply_t rep;
-            rep.resp_term = (int64_t)sh_out[slot][OUT_RESP][lane]; rep.flags = flags_all; rep.role_epoch = (uint32_t)(fe >> 32);
-            if (active) p.reply[row] = rep;
-            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-            if (w_lfx) p.logfx[row] = I64x2{(int64_t)sh_out[slot][OUT_COMMIT][lane], (int64_t)sh_out[slot][OUT_FROM][lane]};
-            if (active & ((flags & RG_F_PERSIST) != 0)) {
-                const uint64_t v = sh_out[slot][OUT_VOTE][lane];
-                rg_persist_t per;
-                per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
-                p.persist[row] = per;
-            }
-            c_rows += RG_HDR_KIND(hdr) != RG_EV_NONE ? 1u : 0u;
-            c_replied += (flags >> 1) & 1u; c_conv += (flags >> 3) & 1u; c_commit += (flags >> 5) & 1u; c_append += (flags >> 7) & 1u;
-            c_assert += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
-            c_need += status == RG_NEED_HOST ? 1u : 0u;
-            c_stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
-        };
-
-        // Five rows in flight. At the top of round r:  n1 = row r+1 and its tail (issued two rounds ago — what is published now),
-        // n2 = row r+2 (its tail was issued last round), n3 = row r+3 (issued two rounds ago: its header is what this round's tail
-        // loads are addressed by), n4 = row r+4 (issued last round). Every value is consumed TWO rounds after its load was issued,
-        // and the vm counter retires in order, so the wait in front of publish() only covers operations older than last round's:
-        // with one round of slack (the first version of this loop) the round could not be shorter than one memory round trip —
-        // measured 1.4 us, i.e. 0.09 ms per 64 rounds whatever the deciding wavefront did (profiles/r02_cycle_breakdown.txt).
-        EventRow n1{}, n2{}, n3{}, n4{};
-        EventTail t1{}, t2{};
-        uint32_t hdr_cur, hdr_prev = 0u; // headers of rounds r and r-1 (the tallies need the kind of a retired row)
-        {
-            EventRow first{};
-            EventTail first_t{};
-            load_event(p, row_of(0), first);
-            load_event(p, row_of(1), n1);
-            load_event(p, row_of(2), n2);
-            load_event(p, row_of(3), n3);
-            load_event(p, row_of(4), n4);
-            load_event_tail(p, row_of(0), first, first_t);
-            load_event_tail(p, row_of(1), n1, t1);
-            load_event_tail(p, row_of(2), n2, t2);
-            publish(0u, first, first_t);
-            hdr_cur = first.hdr;
-        }
-        lds_barrier();                                   // event 0 is visible
-        for (uint32_t r = 0; r < p.rounds; r++) {
-            publish((r + 1u) & 1u, n1, t1);
-            if (r > 0) retire(r - 1u, hdr_prev);
-            hdr_prev = hdr_cur; hdr_cur = n1.hdr;
-            n1 = n2; t1 = t2;
-            n2 = n3;
-            n3 = n4;
-            load_event_tail(p, row_of(r + 3u), n2, t2);
-            load_event(p, row_of(r + 5u), n4);
-            lds_barrier();
-        }
-        retire(last_round, hdr_prev);
-
-        uint32_t tally[RG_NUM_COUNTERS] = {c_rows, c_replied, c_conv, c_commit, c_assert, c_need, c_stale, c_append};
-#pragma unroll
-        for (int c = 0; c < RG_NUM_COUNTERS; c++) {
-            uint32_t v = active ? tally[c] : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            tally[c] = v;
-        }
-        if (lane < RG_NUM_COUNTERS) {
-            uint32_t v = tally[0];
-#pragma unroll
-            for (int c = 1; c < RG_NUM_COUNTERS; c++) v = (lane == (uint32_t)c) ? tally[c] : v;
-            unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
-            *slot += v;
-        }
-        return;
-    }
-
-    // ---- the deciding wavefront ----------------------------------------------------------------------------------
-    // This wavefront is the critical path of the workgroup and the I/O wavefronts it shares a SIMD with have ~1 000 ticks of slack per
-    // round: issue priority over them. Same-box A/B at config 3: 0.1166 -> 0.1104 ms per launch (profiles/r02_cycle_breakdown.txt section 8).
-    __builtin_amdgcn_s_setprio(3);
-    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
-    const uint32_t G = p.t.groups;
-    Group g;
-    load_group(p.t, gi, g);
-    Peers<F> pe{sh_epoch + lane, sh_next + lane, sh_match + lane, sh_rej + lane};
-    stage_peers<F>(p.t, gi, g, pe);
-    Stepper<F> st(p, g, pe);
-    // measured (profiles/r02_*): with one deciding wavefront per SIMD the round is a dependent chain, and the 32-bit tier's
-    // entry test (an LDS read, a ballot, a branch) sits at its head: 0.120 ms against 0.112 ms per launch at 65 536 groups.
-    // The single-wavefront kernel (two or more deciding wavefronts per SIMD) gains from it (0.204 -> 0.198 ms at 131 072).
-    st.narrow_tier = false;
-    st.refresh_narrow();
-    const bool FAST = p.fast_paths != 0;
-    bool blocked = false;
-    lds_barrier();                                       // event 0 is visible
-    for (uint32_t r = 0; r < p.rounds; r++) {
-        const uint32_t slot = r & 1u;
-        const uint64_t head = sh_ev[slot][EV_HEAD][lane];
-        const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
-        const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
-                      c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
-        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
-        const bool ev_narrow = false;
-        const uint32_t kind = RG_HDR_KIND(hdr);
-        // tier 1 branches on wavefront ballots: every lane calls it (a lane blocked after a NEED_HOST asks for nothing)
-        const bool skip = blocked & (kind != RG_EV_NONE);
-        const bool done = st.try_fast(FAST & !skip, hdr, aux, a, b, c, d, e0, (hdr & HDR_ENTRIES_OK) != 0, (hdr & HDR_SAME) != 0, ev_narrow);
-        const bool slow = !done & !skip;
-        if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
-        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
-            if (slow) {
-                // the general handlers also want the hint and the other prefetched entry terms: read only here
-                const int64_t hx = (int64_t)sh_ev[slot][EV_HX][lane], hy = (int64_t)sh_ev[slot][EV_HY][lane];
-                const int64_t e1 = (int64_t)sh_ev[slot][EV_E1][lane], e2 = (int64_t)sh_ev[slot][EV_E2][lane],
-                              e3 = (int64_t)sh_ev[slot][EV_E3][lane];
-                st.run(hdr, aux, a, b, c, d, hx, hy, e0, e1, e2, e3);
-            }
-            st.refresh_narrow();                         // the general handlers work on 64-bit values
-        }
-        const uint32_t status = st.fx.status, flags = st.fx.flags;
-        if (status == RG_NEED_HOST) blocked = true;
-        const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
-        sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
-        sh_out[slot][OUT_FLAGS][lane] = (uint64_t)flags_all | ((uint64_t)g.role_epoch << 32);
-        sh_out[slot][OUT_COMMIT][lane] = (uint64_t)g.commit;
-        sh_out[slot][OUT_FROM][lane] = (uint64_t)st.fx.log_from;
-        sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
-        sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
-        lds_barrier();
-    }
-    if (active) store_group<F>(p.t, gi, G, g, pe);
-}
 
 // this wavefront's earlier LDS writes are visible to its later LDS reads (other wavefronts are not involved)
 __device__ __forceinline__ void wave_lds_sync()
@@ -446,7 +13,6 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 // outputs nobody on the device reads again: write-through, do not keep them in the caches
-typedef uint32_t u32x4 __attribute__((vector_size(16)));
 __device__ __forceinline__ void stream_store(uint4 *dst, const uint4 v)
 {
     const u32x4 q = {v.x, v.y, v.z, v.w};
@@ -821,23 +387,7 @@ __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src
 }
 
 // ---- compact transfer formats of the pipelined host path (rg_submit_async_packed, include/raftgpu.h) ---------------------------
-// Upload: a, b, c, d and the entry terms arrive as int32 and are widened into the 64-bit columns the step kernels read — an extra
-// HBM pass of 56 B per row (~0.06 ms for 4.2 M rows) that saves 16 + 4n bytes per row on a link forty times slower than HBM.
-struct alignas(16) Quad32 { int32_t a, b, c, d; };
-__global__ __launch_bounds__(256) void widen_events_kernel(const Quad32 *__restrict__ q, I64x2 *__restrict__ ab, I64x2 *__restrict__ cd, uint32_t rows)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= rows) return;
-    const Quad32 v = q[i];
-    ab[i] = I64x2{(int64_t)v.a, (int64_t)v.b};
-    cd[i] = I64x2{(int64_t)v.c, (int64_t)v.d};
-}
-__global__ __launch_bounds__(256) void widen_terms_kernel(const int32_t *__restrict__ src, int64_t *__restrict__ dst, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i < n) dst[i] = (int64_t)src[i];
-}
-
+// Upload: a, b, c, d and the entry terms arrive as int32 and are read as such by step32_kernel (rg_step.hpp) — no widening pass.
 // Download: logfx / persist rows that the reply marks as present, packed in row order (same three passes as the expired-timer
 // list: per-wavefront ballot counts, one-block prefix sum, scatter). The scatter writes straight into the caller's page-locked
 // buffers — the length of the lists is not known on the host when a copy would have to be queued.
@@ -872,12 +422,6 @@ __global__ __launch_bounds__(256) void outcome_emit_kernel(const rg_reply_t *__r
     }
 }
 
-hipError_t launch_widen(const void *abcd32, I64x2 *ab, I64x2 *cd, uint32_t rows, const int32_t *terms32, int64_t *terms, uint64_t nterms, hipStream_t s)
-{
-    if (rows) hipLaunchKernelGGL(widen_events_kernel, dim3((rows + 255u) / 256u), dim3(256), 0, s, (const Quad32 *)abcd32, ab, cd, rows);
-    if (nterms) hipLaunchKernelGGL(widen_terms_kernel, dim3((uint32_t)((nterms + 255u) / 256u)), dim3(256), 0, s, terms32, terms, nterms);
-    return hipGetLastError();
-}
 // counts: [2][waves] scratch; totals: [2] (device-visible page-locked host memory)
 hipError_t launch_outcome_count(const rg_reply_t *reply, uint32_t rows, uint32_t *counts, uint32_t *totals, hipStream_t s)
 {
@@ -894,49 +438,6 @@ hipError_t launch_outcome_emit(const rg_reply_t *reply, const I64x2 *logfx, cons
     hipLaunchKernelGGL(outcome_emit_kernel, dim3(blocks), dim3(256), 0, s, reply, logfx, persist, rows, counts, counts + waves, out_logfx, cap_logfx,
                        out_persist, cap_persist);
     return hipGetLastError();
-}
-
-template <int F>
-static hipError_t launch_single(const StepParams &p, bool sparse, hipStream_t s)
-{
-    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
-    if (blocks == 0) return hipSuccess;
-    if (sparse) hipLaunchKernelGGL((step_kernel<F, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    else        hipLaunchKernelGGL((step_kernel<F, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
-    return hipGetLastError();
-}
-
-template <int F>
-static hipError_t launch_split(const StepParams &p, bool sparse, hipStream_t s)
-{
-    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
-    if (blocks == 0) return hipSuccess;
-    if (sparse) hipLaunchKernelGGL((step_split_kernel<F, true>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-    else        hipLaunchKernelGGL((step_split_kernel<F, false>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-    return hipGetLastError();
-}
-
-template <int F>
-static hipError_t launch_f(const StepParams &p, bool sparse, int lanes, hipStream_t s)
-{
-    switch (lanes) {
-    case 0:  return launch_split<F>(p, sparse, s);      // two wavefronts (decide + I/O) per 64 groups
-    case 64: return launch_single<F>(p, sparse, s);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t launch_step(const StepParams &p, int followers, bool sparse, int lanes, hipStream_t s)
-{
-    switch (followers) {
-    case 1: return launch_f<1>(p, sparse, lanes, s);
-    case 2: return launch_f<2>(p, sparse, lanes, s);
-    case 3: return launch_f<3>(p, sparse, lanes, s);
-    case 4: return launch_f<4>(p, sparse, lanes, s);
-    case 5: return launch_f<5>(p, sparse, lanes, s);
-    case 6: return launch_f<6>(p, sparse, lanes, s);
-    default: return hipErrorInvalidValue;
-    }
 }
 
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s)

@@ -1,0 +1,791 @@
+// rg_step.hpp — the step kernels: the replacement of the reference EventLoop drain (support/EventLoopGroup.java:32-46).
+// Included by rg_kernels.hip only.
+//
+// One lane = one raft group for the whole launch:
+//   * group state is read ONCE (16-byte coalesced loads from the structure-of-structs table), kept in VGPRs across all
+//     `rounds` of the batch, and written back once;
+//   * the per-follower Leadership.State of groups that lead is staged in LDS, so the runtime responder slot indexes LDS,
+//     not registers;
+//   * per round every lane loads its event row several rounds ahead of its use (software prefetch) — the event / outcome
+//     streams are what HBM sees, and they are read and written with non-temporal accesses (nobody reads them twice);
+//   * outcomes: the 16-byte reply is always stored; log/commit effects and the durable (term, votedFor) pair only for rows
+//     that have them;
+//   * decision counters are per-lane tallies, reduced over the wavefront once and added to the workgroup's own slot of a
+//     counter table at the end (no atomics).
+// Three kernels share the decision code of rg_device.hpp (tier 1 + Stepper):
+//   step_kernel<F, SPARSE>        wide rows (rg_batch_t), workgroup = ONE wavefront that does all of it; chosen when a launch
+//                                 has more than one wavefront of groups per SIMD
+//   step_split_kernel<F, SPARSE>  wide rows, workgroup = a deciding and an I/O wavefront for the same 64 groups, one LDS-only
+//                                 barrier per round (split_body)
+//   step32_kernel<F, SPARSE>      compact rows (rg_batch32_t), the same two wavefronts; while every value of the workgroup's 64
+//                                 groups and of their rows is below 2^30 the deciding wavefront works on a 32-bit image
+//                                 (narrow_body); the first value outside that domain sends THE WORKGROUP back to round 0 in
+//                                 64-bit arithmetic (split_body on the compact rows) — nothing was written to the table yet and
+//                                 outcome rows are simply written again, so the results are the 64-bit ones, bit for bit.
+#pragma once
+#include "rg_device.hpp"
+
+namespace rg {
+
+typedef uint32_t u32x2 __attribute__((vector_size(8)));
+typedef uint32_t u32x4 __attribute__((vector_size(16)));
+
+// event and outcome rows are touched once: keep them out of the caches
+template <class T> __device__ __forceinline__ T nt_load16(const T *p)
+{
+    static_assert(sizeof(T) == 16, "16-byte row");
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    T r; __builtin_memcpy(&r, &v, 16); return r;
+}
+template <class T> __device__ __forceinline__ T nt_load8(const T *p)
+{
+    static_assert(sizeof(T) == 8, "8-byte row");
+    const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p));
+    T r; __builtin_memcpy(&r, &v, 8); return r;
+}
+template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
+{
+    static_assert(sizeof(T) == 16, "16-byte row");
+    u32x4 v; __builtin_memcpy(&v, &x, 16);
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
+constexpr uint32_t KIND_OUT_OF_DOMAIN = 15u;      // LDS copy of a compact row whose fields leave [0, EV_LIMIT): no event kind has this code
+constexpr uint32_t HDR_SAME_IN = 1u << 9;         // compact rows, LDS / register copy: RG_HDR_SAME_TERM of the wire header (wide rows keep the hint bit here)
+
+struct EventRow {                   // wide: what the row index addresses, 8 + 16 + 16 bytes; compact: 8 + 16 bytes widened
+    uint32_t hdr, aux;
+    int64_t a, b, c, d;
+};
+struct EventTail {                  // wide rows: what the header addresses
+    int64_t hx, hy;                 // hint (only meaningful when the header carries RG_HDR_HINT_BIT)
+    int64_t e0, e1, e2, e3;         // first entry terms of an AppendEntries request
+};
+
+// Stage 1 of the event pipeline: the row-addressed loads. Nothing here depends on loaded data, so the loads are issued
+// rounds ahead of their use.
+template <bool EV32>
+__device__ __forceinline__ void load_event(const StepParams &p, size_t row, EventRow &e)
+{
+    const rg_ev_head_t h = nt_load8(p.head + row);
+    e.hdr = h.hdr; e.aux = h.aux;
+    if constexpr (EV32) {
+        const I32x4 q = nt_load16(p.abcd32 + row);
+        e.a = q.x; e.b = q.y; e.c = q.z; e.d = q.w;
+    } else {
+        const I64x2 ab = nt_load16(p.ab + row), cd = nt_load16(p.cd + row);
+        e.a = ab.x; e.b = ab.y; e.c = cd.x; e.d = cd.y;
+    }
+}
+
+// Stage 2 (wide rows), one round later (the header has landed by now): loads whose ADDRESS comes from the header —
+// the first entry terms of an AppendEntries request and the optional hint. Compact rows have neither: the term shared by
+// the entries travels in the row, anything else is read by the general handlers on demand.
+template <bool EV32>
+__device__ __forceinline__ void load_event_tail(const StepParams &p, size_t row, const EventRow &e, EventTail &t)
+{
+    if constexpr (EV32) {
+        t.hx = 0; t.hy = 0;
+        t.e0 = (int64_t)(int32_t)e.aux; t.e1 = t.e0; t.e2 = t.e0; t.e3 = t.e0;
+    } else {
+        if (p.hint != nullptr && RG_HDR_HINT(e.hdr)) { const I64x2 hh = p.hint[row]; t.hx = hh.x; t.hy = hh.y; }
+        // four unconditional 8-byte loads at 32-bit offsets from one uniform base: lanes without a k-th entry read the
+        // word at offset 0 (always readable) instead of branching around the load. The host keeps entry_count <= 2^29,
+        // so (aux + k) * 8 cannot wrap.
+        const uint32_t n = RG_HDR_N(e.hdr);
+        const bool have_terms = (p.entry_terms != nullptr) & (p.entry_count != 0);
+        const char *base = have_terms ? reinterpret_cast<const char *>(p.entry_terms) : reinterpret_cast<const char *>(p.head);
+        const bool ae = (RG_HDR_KIND(e.hdr) == RG_EV_AE_REQ) & (n > 0) & have_terms & ((uint64_t)e.aux + n <= p.entry_count);
+        const uint32_t o = e.aux * 8u;
+        const uint32_t o0 = ae ? o : 0u, o1 = (ae & (n > 1u)) ? o + 8u : 0u, o2 = (ae & (n > 2u)) ? o + 16u : 0u,
+                       o3 = (ae & (n > 3u)) ? o + 24u : 0u;
+        t.e0 = *reinterpret_cast<const int64_t *>(base + o0); t.e1 = *reinterpret_cast<const int64_t *>(base + o1);
+        t.e2 = *reinterpret_cast<const int64_t *>(base + o2); t.e3 = *reinterpret_cast<const int64_t *>(base + o3);
+    }
+}
+
+// The state-independent facts of a row, folded into header bits 10, 11 (rg_device.hpp: HDR_AE_OK, HDR_PEER_OK). Compact rows also get
+// their RG_HDR_SAME_TERM bit moved to bit 9 and, when a field lies outside the 32-bit tier's domain, the kind KIND_OUT_OF_DOMAIN.
+template <bool EV32>
+__device__ __forceinline__ uint32_t decorate(const StepParams &p, const EventRow &e, const EventTail &t, bool mark_out_of_domain)
+{
+    const uint32_t hdr = e.hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+    const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
+    const bool peer_ok = (slot < P) & (slot != self);
+    bool one_term;                   // no entries, or entries that tier 1 knows to be readable and of one term
+    uint32_t keep;
+    if constexpr (EV32) {
+        const bool same = (hdr & RG_HDR_SAME_TERM) != 0;
+        one_term = (n == 0) | same;
+        keep = (hdr & ~(7u << 9)) | (same ? HDR_SAME_IN : 0u);
+    } else {
+        const bool readable = (n <= 4u) & (p.entry_terms != nullptr) & ((uint64_t)e.aux + n <= p.entry_count);
+        const bool same = ((n < 2u) | (t.e1 == t.e0)) & ((n < 3u) | (t.e2 == t.e0)) & ((n < 4u) | (t.e3 == t.e0));
+        one_term = (n == 0) | (readable & same);
+        keep = hdr & ~(3u << 10);
+    }
+    const bool ae_ok = (kind == RG_EV_AE_REQ) & (slot < P) & (e.c != 0) & (n <= RG_MAX_AE_ENTRIES) & one_term;
+    uint32_t out = keep | (ae_ok ? HDR_AE_OK : 0u) | (peer_ok ? HDR_PEER_OK : 0u);
+    if constexpr (EV32) {
+        if (mark_out_of_domain) {
+            const uint32_t w = (uint32_t)(int32_t)e.a | (uint32_t)(int32_t)e.b | (uint32_t)(int32_t)e.c | (uint32_t)(int32_t)e.d |
+                               (((kind == RG_EV_AE_REQ) & ((hdr & RG_HDR_SAME_TERM) != 0)) ? e.aux : 0u);
+            out = (w >= EV_LIMIT) ? (out | KIND_OUT_OF_DOMAIN) : out;
+        }
+    }
+    return out;
+}
+
+// how the general handlers read the entry terms of this row
+template <bool EV32>
+__device__ __forceinline__ Entries entries_of(const StepParams &p, uint32_t hdr_in, uint32_t aux, int64_t e0, int64_t e1, int64_t e2, int64_t e3)
+{
+    Entries en;
+    if constexpr (EV32) {
+        en.t64 = nullptr;
+        en.t32 = p.entry_terms32 ? p.entry_terms32 + aux : nullptr;
+        en.same = ((hdr_in & HDR_SAME_IN) != 0) & (RG_HDR_KIND(hdr_in) == RG_EV_AE_REQ);
+        en.prefetched = false;
+        en.e0 = (int64_t)(int32_t)aux; en.e1 = en.e0; en.e2 = en.e0; en.e3 = en.e0;
+    } else {
+        en.t64 = p.entry_terms ? p.entry_terms + aux : nullptr;
+        en.t32 = nullptr;
+        en.same = false;
+        en.prefetched = true;
+        en.e0 = e0; en.e1 = e1; en.e2 = e2; en.e3 = e3;
+    }
+    return en;
+}
+// RG_BAD_EVENT check of an AppendEntries row that carries entries: are they readable at all
+__device__ __forceinline__ bool entries_readable(const StepParams &p, const Entries &en, uint32_t aux, uint32_t n)
+{
+    return en.same | (((en.t64 != nullptr) | (en.t32 != nullptr)) & ((uint64_t)aux + n <= p.entry_count));
+}
+
+// Group state: table -> registers (nine 16-byte coalesced loads), follower state of a prepared leader -> LDS, and back.
+__device__ __forceinline__ void load_group(const DevTable &t, uint32_t gi, Group &g)
+{
+    const uint32_t G = t.groups;
+    const I64x2 tc = t.term_commit[gi], ep = t.epoch[gi], w = t.window[gi];
+    const Ident id = t.ident[gi];
+    const Elect el = t.elect[gi];
+    g.term = tc.x; g.commit = tc.y; g.epoch_index = ep.x; g.epoch_term = ep.y; g.first = w.x; g.last = w.y;
+    g.voted_for = id.voted_for; g.leader = id.leader; g.role_epoch = id.role_epoch;
+    g.role = (int32_t)(id.meta & META_ROLE);
+    g.td = (id.meta & META_TD) != 0; g.prepared = (id.meta & META_PREP) != 0;
+    g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
+    g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+    g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
+    const I64x2 r0 = t.runs[gi], r1 = t.runs[(size_t)G + gi], r2 = t.runs[(size_t)2 * G + gi], r3 = t.runs[(size_t)3 * G + gi];
+    g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
+    g.log_dirty = false; g.peers_dirty = false;
+    g.refresh_tail();
+}
+
+template <int F>
+__device__ __forceinline__ void stage_peers(const DevTable &t, uint32_t gi, const Group &g, PeersWide<F> &pe)
+{
+    if (!g.prepared) return;
+    const uint32_t G = t.groups;
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const I64x2 en = t.peer_en[(size_t)j * G + gi];
+        const Match m = t.peer_m[(size_t)j * G + gi];
+        pe.set_last_epoch(j, en.x); pe.set_next_index(j, en.y);
+        pe.set_match_index(j, m.match_index); pe.set_rejection(j, m.rejection);
+    }
+}
+// the same into the 32-bit records; false when a value lies outside [0, EV_LIMIT)
+template <int F>
+__device__ __forceinline__ bool stage_peers(const DevTable &t, uint32_t gi, bool prepared, PeersNarrow<F> &pe)
+{
+    if (!prepared) return true;
+    const uint32_t G = t.groups;
+    uint64_t w = 0;
+#pragma unroll
+    for (int j = 0; j < F; j++) {
+        const I64x2 en = t.peer_en[(size_t)j * G + gi];
+        const Match m = t.peer_m[(size_t)j * G + gi];
+        w |= (uint64_t)en.x | (uint64_t)en.y | (uint64_t)m.match_index;
+        pe.rec[j * BLOCK] = I32x4{(int32_t)en.x, (int32_t)en.y, (int32_t)m.match_index, m.rejection};
+        *pe.mslot(j) = (int32_t)m.match_index;
+    }
+    return w < (uint64_t)EV_LIMIT;
+}
+
+template <class PE>
+__device__ __forceinline__ void store_group(const DevTable &t, uint32_t gi, const Group &g, const PE &pe, int followers)
+{
+    const uint32_t G = t.groups;
+    t.term_commit[gi] = I64x2{g.term, g.commit};
+    t.epoch[gi] = I64x2{g.epoch_index, g.epoch_term};
+    t.window[gi] = I64x2{g.first, g.last};
+    Ident id;
+    id.voted_for = g.voted_for; id.leader = g.leader; id.role_epoch = g.role_epoch;
+    id.meta = (uint32_t)g.role | (g.td ? META_TD : 0u) | (g.prepared ? META_PREP : 0u) |
+              ((uint32_t)g.rc << META_RC_SHIFT) | (g.pending << META_PEND_SHIFT);
+    t.ident[gi] = id;
+    Elect el;
+    el.elected_term = g.elected_term; el.elected_epoch = g.elected_epoch; el.votes = g.votes;
+    t.elect[gi] = el;
+    if (g.log_dirty) {
+        t.runs[gi] = I64x2{g.s0, g.t0};
+        t.runs[(size_t)G + gi] = I64x2{g.s1, g.t1};
+        t.runs[(size_t)2 * G + gi] = I64x2{g.s2, g.t2};
+        t.runs[(size_t)3 * G + gi] = I64x2{g.s3, g.t3};
+    }
+    if (g.peers_dirty) {
+        for (int j = 0; j < followers; j++) {
+            t.peer_en[(size_t)j * G + gi] = I64x2{pe.last_epoch(j), pe.next_index(j)};
+            Match m;
+            m.match_index = pe.match_index(j); m.rejection = pe.rejection(j); m.pad = 0;
+            t.peer_m[(size_t)j * G + gi] = m;
+        }
+    }
+}
+
+// the eight decision counters of include/raftgpu.h, kept per lane by whoever sees the outcome rows
+struct Tally {
+    uint32_t rows = 0, replied = 0, conv = 0, commit = 0, asserts = 0, need = 0, stale = 0, append = 0;
+    __device__ __forceinline__ void add(uint32_t kind, uint32_t flags, uint32_t status)
+    {
+        rows += kind != RG_EV_NONE ? 1u : 0u;
+        replied += (flags >> 1) & 1u;               // RG_F_REPLIED
+        conv += (flags >> 3) & 1u;                  // RG_F_ROLE_CHANGED
+        commit += (flags >> 5) & 1u;                // RG_F_COMMIT
+        append += (flags >> 7) & 1u;                // RG_F_LOG_APPEND
+        asserts += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
+        need += status == RG_NEED_HOST ? 1u : 0u;
+        stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
+    }
+    // Wavefront reduction: butterfly over the 64 lanes, then the wave adds into its workgroup's own 64-byte slot of the counter
+    // table with a plain read-modify-write (8 atomics per wave onto 8 shared words cost ~60 us per launch at 1024 waves).
+    __device__ __forceinline__ void flush(const StepParams &p, uint32_t lane, bool active) const
+    {
+        uint32_t tally[RG_NUM_COUNTERS] = {rows, replied, conv, commit, asserts, need, stale, append};
+#pragma unroll
+        for (int c = 0; c < RG_NUM_COUNTERS; c++) {
+            uint32_t v = active ? tally[c] : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            tally[c] = v;
+        }
+        if (lane < RG_NUM_COUNTERS) {
+            uint32_t v = tally[0];
+#pragma unroll
+            for (int c = 1; c < RG_NUM_COUNTERS; c++) v = (lane == (uint32_t)c) ? tally[c] : v;
+            unsigned long long *slot = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS + lane;
+            *slot += v;
+        }
+    }
+};
+
+// ---- step_kernel: one wavefront per 64 groups ----------------------------------------------------------------------------
+template <int F, bool SPARSE>
+__global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
+{
+    __shared__ int64_t sh_epoch[F * BLOCK], sh_next[F * BLOCK], sh_match[F * BLOCK];
+    __shared__ int32_t sh_rej[F * BLOCK];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t i = blockIdx.x * BLOCK + lane;
+    const bool active = i < p.count;
+    // Lanes past the end of the batch shadow the batch's last row: they load and decide like everybody else — so the round
+    // loop has no divergent control flow around it — and only their stores are switched off.
+    const uint32_t ir = active ? i : p.count - 1u;
+    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
+
+    Group g;
+    load_group(p.t, gi, g);
+    // start the event pipeline before anything that has to wait for the state loads above
+    EventRow cur{}, near{}, far{};
+    EventTail cur_t{}, near_t{};
+    const uint32_t last_round = p.rounds - 1u;            // the host never launches with rounds == 0
+    load_event<false>(p, ir, cur);
+    load_event<false>(p, (size_t)(last_round < 1u ? last_round : 1u) * p.count + ir, near);
+    PeersWide<F> pe;
+    pe.e = sh_epoch + lane; pe.n = sh_next + lane; pe.m = sh_match + lane; pe.r = sh_rej + lane; pe.overflow = false;
+    stage_peers<F>(p.t, gi, g, pe);
+
+    Stepper<F, PeersWide<F>> st(p, g, pe);
+    const bool FAST = p.fast_paths != 0;                 // RG_FAST=0 forces every row through the general handlers (tests)
+    Tally tally;
+    bool blocked = false;
+
+    // outcome of the previous round, stored one round late (see the drain below)
+    rg_reply_t pend_rep{0, 0u, 0u};
+    I64x2 pend_lfx{0, 0};
+    rg_persist_t pend_per{0, 0, 0};
+    bool pend_w_lfx = false, pend_w_per = false;
+
+    // three-deep event pipeline: `far` = round r+2 (row loads in flight), `near` = round r+1 (header landed,
+    // header-addressed loads in flight), `cur` = round r (complete). Every wait falls at the top of a
+    // round, for memory operations issued a full round earlier, so their latency overlaps decision work.
+    load_event_tail<false>(p, ir, cur, cur_t);
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const size_t row = (size_t)r * p.count + ir;
+        // Drain HERE, before issuing anything new: the vm counter retires in order and (on gfx9-class ISAs)
+        // counts stores too, so (a) a wait placed lazily inside the divergent decision code would degrade to
+        // vmcnt(0) and also wait for the loads issued below, and (b) draining right after the outcome stores
+        // would expose the full store latency every round. Hence: loads AND the previous round's stores are
+        // issued right after this point and get a whole round of decision work to complete.
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0) expcnt(7) lgkmcnt(15)
+        if (r > 0) {
+            if (active) nt_store16(p.reply + (row - p.count), pend_rep);
+            if (pend_w_lfx) nt_store16(p.logfx + (row - p.count), pend_lfx);
+            if (pend_w_per) nt_store16(p.persist + (row - p.count), pend_per);
+        }
+        // prefetch without conditions: past the last round the pipeline simply re-reads the last round's rows
+        const uint32_t r1 = r + 1u < p.rounds ? r + 1u : last_round, r2 = r + 2u < p.rounds ? r + 2u : last_round;
+        load_event<false>(p, (size_t)r2 * p.count + ir, far);
+        load_event_tail<false>(p, (size_t)r1 * p.count + ir, near, near_t);
+
+        {
+            const uint32_t kind = RG_HDR_KIND(cur.hdr);
+            // every lane goes through tier 1: it contains wave-uniform branches on ballots and is therefore called from converged
+            // code; a lane blocked after a NEED_HOST simply asks for nothing
+            const bool skip = blocked & (kind != RG_EV_NONE);
+            const uint32_t hdr = decorate<false>(p, cur, cur_t, false);
+            const bool done = tier1<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST & !skip, hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0);
+            const bool slow = !done & !skip;
+            if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+            if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                if (slow) {
+                    const Entries en = entries_of<false>(p, cur.hdr, cur.aux, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
+                    st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, (RG_HDR_HINT(cur.hdr) != 0) & (p.hint != nullptr), cur_t.hx, cur_t.hy, en,
+                           entries_readable(p, en, cur.aux, RG_HDR_N(cur.hdr)));
+                }
+            }
+            const uint32_t status = st.fx.status, flags = st.fx.flags;
+            if (status == RG_NEED_HOST) blocked = true;
+            pend_rep.resp_term = (flags & RG_F_REPLIED) ? st.fx.resp_term : 0;
+            pend_rep.flags = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+            pend_rep.role_epoch = g.role_epoch;
+            pend_w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
+            pend_lfx = I64x2{g.commit, st.fx.log_from};
+            pend_w_per = active & ((flags & RG_F_PERSIST) != 0);
+            pend_per.term = g.term; pend_per.voted_for = g.voted_for; pend_per.role = g.role;
+            tally.add(kind, flags, status);
+        }
+        cur = near; cur_t = near_t;
+        near = far;
+    }
+    if (active) {
+        const size_t row = (size_t)(p.rounds - 1) * p.count + ir;
+        nt_store16(p.reply + row, pend_rep);
+        if (pend_w_lfx) nt_store16(p.logfx + row, pend_lfx);
+        if (pend_w_per) nt_store16(p.persist + row, pend_per);
+    }
+
+    if (active) store_group(p.t, gi, g, pe, F);
+    tally.flush(p, lane, active);
+}
+
+// ---- two instruction streams per 64 groups ------------------------------------------------------------------------------------
+// One wavefront per SIMD gets one issue slot every ~4 cycles and leaves half of the SIMD's VALU slots empty (DESIGN.md
+// §6). These bodies give every 64 groups a workgroup of TWO wavefronts with different jobs:
+//   wave 1 (I/O)     row addressing, the event loads, the state-independent facts of a row (decorate), the outcome stores and the
+//                    decision counters — everything that does not need the group's state;
+//   wave 0 (decide)  group state in registers, follower state in LDS, tier 1 / tier 2 — and nothing else; it runs at raised issue
+//                    priority (s_setprio 3): it is the critical path, its I/O neighbours on the SIMD have slack
+//                    (same-box A/B at config 3: 0.1167 -> 0.1102 ms per launch, profiles/r03a_prio_ab.jsonl).
+// They meet once per round at an LDS-only barrier. Events travel through a two-slot LDS ring written one round ahead,
+// outcomes through a two-slot ring read one round behind, so neither wave ever waits for the other's memory traffic:
+//   round r:  I/O    writes event r+1 -> ev[(r+1)&1], reads outcome r-1 <- out[(r-1)&1] and stores it, issues next loads
+//             decide reads event r <- ev[r&1], decides, writes outcome r -> out[r&1]
+//   barrier   (s_waitcnt lgkmcnt(0) + s_barrier: LDS traffic only — global loads/stores stay in flight across it)
+enum { EV_HEAD = 0, EV_A, EV_B, EV_C, EV_D, EV_HX, EV_HY, EV_E0, EV_E1, EV_E2, EV_E3, EV_FIELDS };
+enum { OUT_RESP = 0, OUT_FLAGS, OUT_COMMIT, OUT_FROM, OUT_TERM, OUT_VOTE, OUT_FIELDS };
+
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt/expcnt untouched: my LDS writes have landed
+    __builtin_amdgcn_s_barrier();
+}
+
+// LDS of a two-wavefront workgroup. The 64-bit body and the 32-bit body never run at the same time: one buffer, two layouts.
+template <int F>
+struct SplitLds {
+    // 64-bit body
+    static constexpr size_t W_EPOCH = 0, W_NEXT = W_EPOCH + F * BLOCK * 8, W_MATCH = W_NEXT + F * BLOCK * 8, W_REJ = W_MATCH + F * BLOCK * 8,
+                            W_EV = W_REJ + F * BLOCK * 4, W_OUT = W_EV + 2 * EV_FIELDS * BLOCK * 8, W_END = W_OUT + 2 * OUT_FIELDS * BLOCK * 8;
+    // 32-bit body
+    static constexpr int MV = (F + 3) / 4;
+    static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + 2 * BLOCK * 8,
+                            N_O0 = N_EVQ + 2 * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16, N_END = N_BAIL + 16;
+    static constexpr size_t BYTES = W_END > N_END ? W_END : N_END;
+};
+
+// The 64-bit body of a two-wavefront workgroup, on wide (EV32 = false) or compact (EV32 = true) rows.
+template <int F, bool SPARSE, bool EV32>
+__device__ __forceinline__ void split_body(const StepParams &p, unsigned char *smem)
+{
+    typedef SplitLds<F> L;
+    int64_t *sh_epoch = reinterpret_cast<int64_t *>(smem + L::W_EPOCH), *sh_next = reinterpret_cast<int64_t *>(smem + L::W_NEXT),
+            *sh_match = reinterpret_cast<int64_t *>(smem + L::W_MATCH);
+    int32_t *sh_rej = reinterpret_cast<int32_t *>(smem + L::W_REJ);
+    uint64_t (*sh_ev)[EV_FIELDS][BLOCK] = reinterpret_cast<uint64_t (*)[EV_FIELDS][BLOCK]>(smem + L::W_EV);
+    uint64_t (*sh_out)[OUT_FIELDS][BLOCK] = reinterpret_cast<uint64_t (*)[OUT_FIELDS][BLOCK]>(smem + L::W_OUT);
+
+    const uint32_t lane = threadIdx.x & (BLOCK - 1);
+    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
+    const uint32_t i = blockIdx.x * BLOCK + lane;
+    const bool active = i < p.count;
+    const uint32_t ir = active ? i : p.count - 1u;       // lanes past the end shadow the last row; only their stores are off
+    const uint32_t last_round = p.rounds - 1u;
+
+    if (io_wave) {
+        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
+            sh_ev[slot][EV_HEAD][lane] = (uint64_t)decorate<EV32>(p, e, t, false) | ((uint64_t)e.aux << 32);
+            sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
+            sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
+            sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0;
+            if constexpr (!EV32) {
+                sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
+                sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
+                sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
+            }
+        };
+        Tally tally;
+        auto retire = [&](uint32_t r, uint32_t hdr) {      // outcome of round r: LDS -> global, plus the tallies
+            const uint32_t slot = r & 1u;
+            const size_t row = (size_t)r * p.count + ir;
+            const uint64_t fe = sh_out[slot][OUT_FLAGS][lane];
+            const uint32_t flags_all = (uint32_t)fe, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
+            rg_reply_t rep;
+            rep.resp_term = (int64_t)sh_out[slot][OUT_RESP][lane]; rep.flags = flags_all; rep.role_epoch = (uint32_t)(fe >> 32);
+            if (active) nt_store16(p.reply + row, rep);
+            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
+            if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)sh_out[slot][OUT_COMMIT][lane], (int64_t)sh_out[slot][OUT_FROM][lane]});
+            if (active & ((flags & RG_F_PERSIST) != 0)) {
+                const uint64_t v = sh_out[slot][OUT_VOTE][lane];
+                rg_persist_t per;
+                per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
+                nt_store16(p.persist + row, per);
+            }
+            tally.add(RG_HDR_KIND(hdr), flags, status);
+        };
+
+        // Five rows in flight. At the top of round r:  n1 = row r+1 and its tail (issued two rounds ago — what is published now),
+        // n2 = row r+2 (its tail was issued last round), n3 = row r+3 (issued two rounds ago: its header is what this round's tail
+        // loads are addressed by), n4 = row r+4 (issued last round). Every value is consumed TWO rounds after its load was issued,
+        // and the vm counter retires in order, so the wait in front of publish() only covers operations older than last round's:
+        // with one round of slack (the first version of this loop) the round could not be shorter than one memory round trip —
+        // measured 1.4 us, i.e. 0.09 ms per 64 rounds whatever the deciding wavefront did (profiles/r02_cycle_breakdown.txt).
+        EventRow n1{}, n2{}, n3{}, n4{};
+        EventTail t1{}, t2{};
+        uint32_t hdr_cur, hdr_prev = 0u; // headers of rounds r and r-1 (the tallies need the kind of a retired row)
+        {
+            EventRow first{};
+            EventTail first_t{};
+            load_event<EV32>(p, row_of(0), first);
+            load_event<EV32>(p, row_of(1), n1);
+            load_event<EV32>(p, row_of(2), n2);
+            load_event<EV32>(p, row_of(3), n3);
+            load_event<EV32>(p, row_of(4), n4);
+            load_event_tail<EV32>(p, row_of(0), first, first_t);
+            load_event_tail<EV32>(p, row_of(1), n1, t1);
+            load_event_tail<EV32>(p, row_of(2), n2, t2);
+            publish(0u, first, first_t);
+            hdr_cur = first.hdr;
+        }
+        lds_barrier();                                   // event 0 is visible
+        for (uint32_t r = 0; r < p.rounds; r++) {
+            publish((r + 1u) & 1u, n1, t1);
+            if (r > 0) retire(r - 1u, hdr_prev);
+            hdr_prev = hdr_cur; hdr_cur = n1.hdr;
+            n1 = n2; t1 = t2;
+            n2 = n3;
+            n3 = n4;
+            load_event_tail<EV32>(p, row_of(r + 3u), n2, t2);
+            load_event<EV32>(p, row_of(r + 5u), n4);
+            lds_barrier();
+        }
+        retire(last_round, hdr_prev);
+        tally.flush(p, lane, active);
+        return;
+    }
+
+    // ---- the deciding wavefront ----------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
+    Group g;
+    load_group(p.t, gi, g);
+    PeersWide<F> pe;
+    pe.e = sh_epoch + lane; pe.n = sh_next + lane; pe.m = sh_match + lane; pe.r = sh_rej + lane; pe.overflow = false;
+    stage_peers<F>(p.t, gi, g, pe);
+    Stepper<F, PeersWide<F>> st(p, g, pe);
+    const bool FAST = p.fast_paths != 0;
+    bool blocked = false;
+    lds_barrier();                                       // event 0 is visible
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const uint32_t slot = r & 1u;
+        const uint64_t head = sh_ev[slot][EV_HEAD][lane];
+        const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
+        const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
+                      c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
+        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
+        const uint32_t kind = RG_HDR_KIND(hdr);
+        // tier 1 branches on wavefront ballots: every lane calls it (a lane blocked after a NEED_HOST asks for nothing)
+        const bool skip = blocked & (kind != RG_EV_NONE);
+        const bool done = tier1<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST & !skip, hdr, aux, a, b, c, d, e0);
+        const bool slow = !done & !skip;
+        if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+            if (slow) {
+                // the general handlers also want the hint and the other prefetched entry terms: read only here
+                int64_t hx = 0, hy = 0, e1 = e0, e2 = e0, e3 = e0;
+                if constexpr (!EV32) {
+                    hx = (int64_t)sh_ev[slot][EV_HX][lane]; hy = (int64_t)sh_ev[slot][EV_HY][lane];
+                    e1 = (int64_t)sh_ev[slot][EV_E1][lane]; e2 = (int64_t)sh_ev[slot][EV_E2][lane]; e3 = (int64_t)sh_ev[slot][EV_E3][lane];
+                }
+                const Entries en = entries_of<EV32>(p, hdr, aux, e0, e1, e2, e3);
+                const bool hinted = EV32 ? false : ((RG_HDR_HINT(hdr) != 0) & (p.hint != nullptr));
+                st.run(hdr, aux, a, b, c, d, hinted, hx, hy, en, entries_readable(p, en, aux, RG_HDR_N(hdr)));
+            }
+        }
+        const uint32_t status = st.fx.status, flags = st.fx.flags;
+        if (status == RG_NEED_HOST) blocked = true;
+        const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+        sh_out[slot][OUT_RESP][lane] = (flags & RG_F_REPLIED) ? (uint64_t)st.fx.resp_term : 0ull;
+        sh_out[slot][OUT_FLAGS][lane] = (uint64_t)flags_all | ((uint64_t)g.role_epoch << 32);
+        sh_out[slot][OUT_COMMIT][lane] = (uint64_t)g.commit;
+        sh_out[slot][OUT_FROM][lane] = (uint64_t)st.fx.log_from;
+        sh_out[slot][OUT_TERM][lane] = (uint64_t)g.term;
+        sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
+        lds_barrier();
+    }
+    if (active) store_group(p.t, gi, g, pe, F);
+}
+
+template <int F, bool SPARSE>
+__global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
+{
+    __shared__ alignas(16) unsigned char smem[SplitLds<F>::W_END];
+    split_body<F, SPARSE, false>(p, smem);
+}
+
+// ---- the 32-bit body on compact rows ------------------------------------------------------------------------------------------
+// Same protocol as split_body, with everything that crosses LDS half as wide:
+//   event  r+1 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store (instead of eleven 8-byte ones)
+//   outcome r-1: {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows
+// and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O
+// wavefront's stream is two loads per row, four rows ahead. The deciding wavefront keeps a GroupT<int32_t>; a row that tier 1 does not
+// decide is handed to the general handlers on a widened copy of the image and the result is narrowed back.
+// Returns false when the workgroup left the 32-bit domain (a group or a Leadership.State value at or above 2^30 at load, a row field
+// outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
+template <int F, bool SPARSE>
+__device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
+{
+    typedef SplitLds<F> L;
+    I32x4 *sh_rec = reinterpret_cast<I32x4 *>(smem + L::N_REC);
+    int32_t *sh_mv = reinterpret_cast<int32_t *>(smem + L::N_MV);
+    U32x2 (*sh_evh)[BLOCK] = reinterpret_cast<U32x2 (*)[BLOCK]>(smem + L::N_EVH);
+    I32x4 (*sh_evq)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVQ);
+    I32x4 (*sh_o0)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O0);
+    I32x4 (*sh_o1)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O1);
+    volatile uint32_t *sh_bail = reinterpret_cast<volatile uint32_t *>(smem + L::N_BAIL);
+
+    const uint32_t lane = threadIdx.x & (BLOCK - 1);
+    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
+    const uint32_t i = blockIdx.x * BLOCK + lane;
+    const bool active = i < p.count;
+    const uint32_t ir = active ? i : p.count - 1u;
+    const uint32_t last_round = p.rounds - 1u;
+
+    if (io_wave) {
+        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        struct Row32 { U32x2 h; I32x4 q; };
+        auto fetch = [&](uint32_t r, Row32 &x) {
+            const size_t row = row_of(r);
+            x.h = nt_load8(reinterpret_cast<const U32x2 *>(p.head) + row);
+            x.q = nt_load16(p.abcd32 + row);
+        };
+        auto publish = [&](uint32_t slot, const Row32 &x) {
+            EventRow e;
+            e.hdr = x.h.x; e.aux = x.h.y; e.a = x.q.x; e.b = x.q.y; e.c = x.q.z; e.d = x.q.w;
+            sh_evh[slot][lane] = U32x2{decorate<true>(p, e, EventTail{}, true), x.h.y};
+            sh_evq[slot][lane] = x.q;
+        };
+        Tally tally;
+        auto retire = [&](uint32_t r, uint32_t hdr) {
+            const uint32_t slot = r & 1u;
+            const size_t row = (size_t)r * p.count + ir;
+            const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
+            const uint32_t flags_all = (uint32_t)o0.y, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
+            rg_reply_t rep;
+            rep.resp_term = (int64_t)o0.x; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
+            if (active) nt_store16(p.reply + row, rep);
+            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
+            if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)o0.w, (int64_t)o1.x});
+            if (active & ((flags & RG_F_PERSIST) != 0)) {
+                rg_persist_t per;
+                per.term = (int64_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
+                nt_store16(p.persist + row, per);
+            }
+            tally.add(RG_HDR_KIND(hdr), flags, status);
+        };
+        // four rows in flight: n1 = row r+1 (published now), ... n4 = row r+4 (issued last round)
+        Row32 n1, n2, n3, n4;
+        uint32_t hdr_cur, hdr_prev = 0u;
+        {
+            Row32 first;
+            fetch(0, first); fetch(1, n1); fetch(2, n2); fetch(3, n3); fetch(4, n4);
+            publish(0u, first);
+            hdr_cur = first.h.x;
+        }
+        // The bail flag holds 0, 1 (the state load left the domain) or r + 2 (round r did). The deciding wavefront may already be one round
+        // further and have written a LATER round's mark when this wavefront looks: only a mark that is due makes it leave, so both
+        // always pass the same number of barriers.
+        lds_barrier();                                   // event 0 and the mark of the state load are visible
+        { const uint32_t mark0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(mark0) == 1u) return false; }
+        bool bailed = false;
+        for (uint32_t r = 0; r < p.rounds; r++) {
+            publish((r + 1u) & 1u, n1);
+            if (r > 0) retire(r - 1u, hdr_prev);
+            hdr_prev = hdr_cur; hdr_cur = n1.h.x;
+            n1 = n2; n2 = n3; n3 = n4;
+            fetch(r + 5u, n4);
+            lds_barrier();
+            const uint32_t seen = *sh_bail;
+            const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
+            if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
+        }
+        if (bailed) return false;
+        retire(last_round, hdr_prev);
+        tally.flush(p, lane, active);
+        return true;
+    }
+
+    // ---- the deciding wavefront ----------------------------------------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t gi = SPARSE ? p.gid[ir] : ir;
+    Group32 g;
+    PeersNarrow<F> pe;
+    pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false;
+    bool in_domain;
+    {
+        Group g64;
+        load_group(p.t, gi, g64);
+        in_domain = fits32(g64, EV_LIMIT) & (p.force_wide == 0);
+        g = narrow(g64);
+        in_domain = in_domain & stage_peers<F>(p.t, gi, g.prepared, pe);
+    }
+    bool bailed = __builtin_amdgcn_ballot_w64(!in_domain) != 0;
+    if (lane == 0) *sh_bail = bailed ? 1u : 0u;
+    const bool FAST = p.fast_paths != 0;
+    bool blocked = false;
+    lds_barrier();
+    if (bailed) return false;
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const uint32_t slot = r & 1u;
+        const U32x2 h = sh_evh[slot][lane];
+        const I32x4 q = sh_evq[slot][lane];
+        const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
+        const bool skip = blocked & (kind != RG_EV_NONE);
+        FxT<int32_t> fx{0u, RG_OK, 0, 0};
+        const bool done = tier1<F, int32_t, PeersNarrow<F>>(p, g, pe, fx, FAST & !skip, hdr, aux, q.x, q.y, q.z, q.w, (int32_t)aux);
+        const bool slow = !done & !skip;
+        if (skip) fx = FxT<int32_t>{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+            bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
+            if (slow & !bail) {
+                Group g64 = widen(g);
+                Stepper<F, PeersNarrow<F>> st(p, g64, pe);
+                const Entries en = entries_of<true>(p, hdr, aux, 0, 0, 0, 0);
+                st.run(hdr, aux, (int64_t)q.x, (int64_t)q.y, (int64_t)q.z, (int64_t)q.w, false, 0, 0, en, entries_readable(p, en, aux, RG_HDR_N(hdr)));
+                bail = !fits32(g64, STATE_LIMIT) | pe.overflow | (((uint64_t)st.fx.resp_term | (uint64_t)st.fx.log_from) >= (uint64_t)STATE_LIMIT);
+                g = narrow(g64);
+                fx = FxT<int32_t>{st.fx.flags, st.fx.status, (int32_t)st.fx.resp_term, (int32_t)st.fx.log_from};
+            }
+            if (__builtin_amdgcn_ballot_w64(bail) != 0) {
+                if (lane == 0) *sh_bail = r + 2u;
+                bailed = true;
+            }
+        }
+        const uint32_t status = fx.status, flags = fx.flags;
+        if (status == RG_NEED_HOST) blocked = true;
+        const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+        sh_o0[slot][lane] = I32x4{(flags & RG_F_REPLIED) ? fx.resp_term : 0, (int32_t)flags_all, (int32_t)g.role_epoch, g.commit};
+        sh_o1[slot][lane] = I32x4{fx.log_from, g.term, g.voted_for, g.role};
+        lds_barrier();
+        if (bailed) return false;
+    }
+    if (active) {
+        const Group g64 = widen(g);
+        store_group(p.t, gi, g64, pe, F);
+    }
+    return true;
+}
+
+#ifndef RG_NOTE_FALLBACK            // the host emulation (tests/devemu) counts the workgroups that take the 64-bit body; nothing on the GPU
+#define RG_NOTE_FALLBACK() ((void)0)
+#endif
+
+template <int F, bool SPARSE>
+__global__ __launch_bounds__(2 * BLOCK) void step32_kernel(const StepParams p)
+{
+    __shared__ alignas(16) unsigned char smem[SplitLds<F>::BYTES];
+    if (narrow_body<F, SPARSE>(p, smem)) return;
+    if (threadIdx.x == 0) RG_NOTE_FALLBACK();
+    // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic
+    split_body<F, SPARSE, true>(p, smem);
+}
+
+template <int F>
+static hipError_t launch_single(const StepParams &p, bool sparse, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    if (blocks == 0) return hipSuccess;
+    if (sparse) hipLaunchKernelGGL((step_kernel<F, true>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step_kernel<F, false>), dim3(blocks), dim3(BLOCK), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int F>
+static hipError_t launch_split(const StepParams &p, bool sparse, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    if (blocks == 0) return hipSuccess;
+    if (sparse) hipLaunchKernelGGL((step_split_kernel<F, true>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step_split_kernel<F, false>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    return hipGetLastError();
+}
+
+template <int F>
+static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    if (blocks == 0) return hipSuccess;
+    if (sparse) hipLaunchKernelGGL((step32_kernel<F, true>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    else        hipLaunchKernelGGL((step32_kernel<F, false>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    return hipGetLastError();
+}
+
+// shape: 0 = step_split_kernel, 64 = step_kernel (wide rows); 32 = step32_kernel (compact rows: p.abcd32 set)
+template <int F>
+static hipError_t launch_f(const StepParams &p, bool sparse, int shape, hipStream_t s)
+{
+    switch (shape) {
+    case 0:  return launch_split<F>(p, sparse, s);
+    case 64: return launch_single<F>(p, sparse, s);
+    case 32: return launch_compact<F>(p, sparse, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_step(const StepParams &p, int followers, bool sparse, int shape, hipStream_t s)
+{
+    switch (followers) {
+    case 1: return launch_f<1>(p, sparse, shape, s);
+    case 2: return launch_f<2>(p, sparse, shape, s);
+    case 3: return launch_f<3>(p, sparse, shape, s);
+    case 4: return launch_f<4>(p, sparse, shape, s);
+    case 5: return launch_f<5>(p, sparse, shape, s);
+    case 6: return launch_f<6>(p, sparse, shape, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rg

@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -88,6 +88,9 @@ def lib():
         L.rg_load_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_read_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
+        L.rg_submit32.argtypes = [vp, C.POINTER(abi.CBatch32), C.POINTER(abi.COutcome), i32]
+        L.rg_batch32_pack.restype = C.c_int64
+        L.rg_batch32_pack.argtypes = [C.POINTER(abi.CBatch), vp, vp, vp]
         L.rg_submit_async.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
         L.rg_submit_wait.argtypes = [vp]
         L.rg_submit_async_packed.argtypes = [vp, vp, vp]
@@ -139,6 +142,21 @@ def _replicate(call, groups, cluster, gid, heartbeat, in_flight):
     return head, np.ascontiguousarray(send.reshape(F, count).T)
 
 
+def pack32(batch):
+    """abi.Batch -> abi.Batch32 through the library's host-side packer (rg_batch32_pack): AppendEntries rows whose entries share one term
+    carry it in the row (RG_HDR_SAME_TERM). Raises when the batch cannot travel in the compact format (hints, a value outside [0, 2^31))."""
+    rows = batch.rounds * batch.count
+    head = np.zeros(rows, dtype=abi.HEAD_DT)
+    abcd = np.zeros(rows, dtype=abi.QUAD32_DT)
+    terms = np.zeros(max(batch.entry_count, 1), dtype=np.int32)
+    b = batch.as_struct()
+    n = lib().rg_batch32_pack(C.byref(b), head.ctypes.data, abcd.ctypes.data, terms.ctypes.data)
+    if n < 0:
+        raise EngineError("rg_batch32_pack: %d (%s)" % (n, {-1: "missing column", -2: "the batch carries hints", -3: "a value outside [0, 2^31)",
+                                                             -4: "entry_terms needed"}.get(n, "?")))
+    return abi.Batch32(batch.rounds, batch.count, batch.gid, head, abcd, terms, n)
+
+
 def pinned_like(table, array):
     """A page-locked copy of `array` (rg_host_alloc) as a numpy view; keep the returned owner alive, free with .free()."""
     a = np.ascontiguousarray(array)
@@ -166,10 +184,9 @@ class PackedBatch:
         assert abi.batch_fits_32(batch), "a value outside [0, 2^31) or a hint column: use submit_async for this batch"
         rows = batch.rounds * batch.count
         self.rows, self.table, self._owners = rows, table, []
-        q = np.zeros(rows, dtype=abi.QUAD32_DT)
-        q["a"], q["b"], q["c"], q["d"] = batch.ab["x"], batch.ab["y"], batch.cd["x"], batch.cd["y"]
-        self.head, self.abcd = self._pin(batch.head), self._pin(q)
-        self.entry_terms = self._pin(batch.entry_terms[:max(batch.entry_count, 1)].astype(np.int32))
+        b32 = pack32(batch)
+        self.head, self.abcd = self._pin(b32.head), self._pin(b32.abcd)
+        self.entry_terms = self._pin(b32.entry_terms[:max(b32.entry_count, 1)])
         self.gid = None if batch.gid is None else self._pin(batch.gid)
         self.logfx_cap = rows if logfx_cap is None else logfx_cap
         self.persist_cap = rows if persist_cap is None else persist_cap
@@ -181,8 +198,8 @@ class PackedBatch:
         b.rounds, b.count = batch.rounds, batch.count
         b.gid = None if self.gid is None else self.gid.ctypes.data
         b.head, b.abcd = self.head.ctypes.data, self.abcd.ctypes.data
-        b.entry_terms = self.entry_terms.ctypes.data if batch.entry_count else None
-        b.entry_count = batch.entry_count
+        b.entry_terms = self.entry_terms.ctypes.data if b32.entry_count else None
+        b.entry_count = b32.entry_count
         o = abi.COutcomePacked()
         o.reply, o.logfx, o.persist, o.counts = self.reply.ctypes.data, self.logfx.ctypes.data, self.persist.ctypes.data, self.counts.ctypes.data
         o.logfx_cap, o.persist_cap = self.logfx_cap, self.persist_cap
@@ -287,6 +304,46 @@ class DeviceBatch:
                 b.free()
 
 
+class DeviceBatch32:
+    """An rg_batch32_t + rg_outcome_t resident in HBM (rg_submit32, RG_MEM_DEVICE): built once from an abi.Batch, submitted many times."""
+
+    def __init__(self, table, batch):
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
+        self.table, self.rounds, self.count = table, b32.rounds, b32.count
+        rows = b32.rounds * b32.count
+        self.rows = rows
+        mk = lambda a: DeviceBuffer.from_host(table, a)   # noqa: E731
+        self.gid = None if b32.gid is None else mk(b32.gid)
+        self.head, self.abcd = mk(b32.head), mk(b32.abcd)
+        self.entry_count = b32.entry_count
+        self.entry_terms = mk(b32.entry_terms[: b32.entry_count]) if b32.entry_count else None
+        self.reply = DeviceBuffer(table, rows * abi.REPLY_DT.itemsize)
+        self.logfx = DeviceBuffer(table, rows * abi.LOGFX_DT.itemsize)
+        self.persist = DeviceBuffer(table, rows * abi.PERSIST_DT.itemsize)
+        b = abi.CBatch32()
+        b.rounds, b.count = b32.rounds, b32.count
+        b.gid = self.gid.ptr if self.gid else None
+        b.head, b.abcd = self.head.ptr, self.abcd.ptr
+        b.entry_terms = self.entry_terms.ptr if self.entry_terms else None
+        b.entry_count = self.entry_count
+        o = abi.COutcome()
+        o.reply, o.logfx, o.persist = self.reply.ptr, self.logfx.ptr, self.persist.ptr
+        self.c_batch, self.c_out = b, o
+        self.bytes_in = b32.head.nbytes + b32.abcd.nbytes + 4 * b32.entry_count
+
+    def outcome(self):
+        out = abi.Outcome(self.rows)
+        out.reply = self.reply.to_host(abi.REPLY_DT, self.rows)
+        out.logfx = self.logfx.to_host(abi.LOGFX_DT, self.rows)
+        out.persist = self.persist.to_host(abi.PERSIST_DT, self.rows)
+        return out
+
+    def free(self):
+        for b in (self.gid, self.head, self.abcd, self.entry_terms, self.reply, self.logfx, self.persist):
+            if b is not None:
+                b.free()
+
+
 class Table:
     """G raft groups resident on one MI355X. Mirrors ContextManager for the decision path: the host
     keeps RaftLog / StableLock / timers / Netty, this object answers what every RaftParticipant would
@@ -335,6 +392,14 @@ class Table:
         self._check(lib().rg_submit(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
         return out
 
+    def submit32(self, batch, out=None, fill=0):
+        """Host-buffer submission of COMPACT rows (rg_submit32, RG_MEM_HOST); `batch` is an abi.Batch32 (or an abi.Batch, packed here)."""
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
+        out = abi.Outcome(b32.rounds * b32.count, fill) if out is None else out
+        b, o = b32.as_struct(), out.as_struct()
+        self._check(lib().rg_submit32(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
+        return out
+
     def submit_async(self, batch, out):
         """Pipelined host-buffer submission (rg_submit_async): returns at once; `batch` and `out` must stay alive and untouched
         until submit_wait() has returned for them. Keeps the ctypes structs alive itself."""
@@ -366,8 +431,11 @@ class Table:
         return self._inflight.pop(0)[3]
 
     def submit_device(self, dbatch):
-        """HBM-resident submission (RG_MEM_DEVICE): asynchronous on the table's stream."""
-        self._check(lib().rg_submit(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
+        """HBM-resident submission (RG_MEM_DEVICE): asynchronous on the table's stream. DeviceBatch -> rg_submit, DeviceBatch32 -> rg_submit32."""
+        if isinstance(dbatch, DeviceBatch32):
+            self._check(lib().rg_submit32(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
+        else:
+            self._check(lib().rg_submit(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
 
     def sync(self):
         self._check(lib().rg_sync(self._h))

@@ -133,9 +133,3 @@ def test_split_kernel_is_refused_not_hung(monkeypatch):
     t = engine.Table(64, 3, 0, True)
     with pytest.raises(engine.EngineError):
         t.submit(abi.Batch(1, 64))
-
-
-def test_packed_pipeline_formats():
-    """rg_submit_async_packed end to end (narrow uploads widened on the device, row-ordered packed lists written into page-locked
-    memory, capacity overflow, refusal of pageable list memory). The count / scan / scatter kernels always run with one OS thread per lane."""
-    T.packed_pipeline_case(320, 3)

@@ -66,3 +66,45 @@ def test_expired_timers_are_compacted_in_order():
         eo, no = orc.timers_expired(now, capacity=G if now != 2300 else 17)
         assert ng == no and np.array_equal(eg, eo)
         assert np.array_equal(gpu.timers_read(), orc.timers_read())
+
+
+def test_packed_pipeline_formats():
+    """rg_submit_async_packed end to end (compact uploads decided as they arrive by step32_kernel, row-ordered packed lists written into
+    page-locked memory, capacity overflow, refusal of pageable list memory)."""
+    T.packed_pipeline_case(320, 3)
+
+
+# ---- compact rows (rg_batch32_t) through step32_kernel: the 32-bit body, and the 64-bit body it falls back to ------------------------
+@pytest.fixture(params=["narrow", "forced-wide"])
+def compact_route(request, monkeypatch):
+    """Table.submit packs every batch that fits (no hints, values < 2^31) and sends it through rg_submit32"""
+    if request.param == "forced-wide":
+        monkeypatch.setenv("RG_FORCE_WIDE", "1")
+    T.route_through_compact(monkeypatch)
+    return request.param
+
+
+@pytest.mark.parametrize("scenario", kat_scenarios.SCENARIOS, ids=lambda f: f.__name__)
+def test_kat_on_compact_rows(scenario, compact_route):
+    scenario(T.mk_gpu)
+
+
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (5, 4, False, 13), (2, 1, True, 14),
+                                                             (7, 3, True, 16)])
+def test_fuzz_lockstep_on_compact_rows(cluster, self_slot, pre_vote, seed, compact_route):
+    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 40, seed, allow_miss=True)
+    assert hist[abi.OK] > 0
+
+
+def test_fuzz_general_handlers_only_on_compact_rows(monkeypatch, compact_route):
+    monkeypatch.setenv("RG_FAST", "0")
+    _, _, _, hist, _, _ = T._lockstep(128, 5, 0, True, 40, 41, allow_miss=True)
+    assert hist[abi.OK] > 0
+
+
+def test_compact_multi_round_launch_and_domain_exits():
+    T.compact_multi_round_case(192, 5, 24)
+
+
+def test_compact_workload_replays():
+    T.compact_workload_case(groups=200, rounds=12)

@@ -1,6 +1,7 @@
 // tests/devemu/emu_runtime.cpp — the two grid executors of the host emulation (see hip/hip_runtime.h). TEST INFRASTRUCTURE.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <exception>
@@ -12,6 +13,10 @@
 // The marker rafting_amd/engine.py looks for: a library that exports it is refused unless the caller says, through
 // RG_ALLOW_HOST_EMULATION=1 (only tests/test_devemu_cpu.py does), that it knows it is not talking to a GPU.
 extern "C" int rg_is_host_emulation() { return 1; }
+// test hook: workgroups of step32_kernel that fell back to the 64-bit body since the last read
+static std::atomic<long> g_fallbacks{0};
+extern "C" void rg_emu_note_fallback() { g_fallbacks.fetch_add(1); }
+extern "C" long rg_emu_fallbacks(int reset) { return reset ? g_fallbacks.exchange(0) : g_fallbacks.load(); }
 
 namespace hipemu {
 

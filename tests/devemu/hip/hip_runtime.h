@@ -55,6 +55,8 @@ unsigned long long wave_first(unsigned long long v);
 void workgroup_barrier(bool required);                      // required (s_barrier) throws Deadlock on a lane-serial grid
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel);
 }
+extern "C" void rg_emu_note_fallback();                    // step32_kernel: a workgroup left the 32-bit domain (emu_runtime.cpp counts them)
+#define RG_NOTE_FALLBACK() rg_emu_note_fallback()
 #define threadIdx (::hipemu::threadIdx_)
 #define blockIdx (::hipemu::blockIdx_)
 #define blockDim (::hipemu::blockDim_)

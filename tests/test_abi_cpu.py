@@ -15,7 +15,7 @@ HEADER = open(os.path.join(ROOT, "include", "raftgpu.h")).read()
 
 
 def test_library_exports_every_declared_symbol():
-    declared = set(re.findall(r"\b(rg_[a-z_]+)\s*\(", HEADER))
+    declared = set(re.findall(r"\b(rg_[a-z_0-9]+)\s*\(", HEADER))
     declared -= {"rg_table_t"}
     assert declared == set(engine.exported_symbols()), declared ^ set(engine.exported_symbols())
     L = C.CDLL(engine.LIB_PATH)

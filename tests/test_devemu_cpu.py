@@ -13,7 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "devemu")
 LIB = os.path.join(EMU, "libraftgpu_emu.so")
-SOURCES = [os.path.join(ROOT, "rafting_amd", "csrc", f) for f in ("rg_kernels.hip", "raftgpu.cpp", "rg_device.hpp")] + [
+SOURCES = [os.path.join(ROOT, "rafting_amd", "csrc", f) for f in ("rg_kernels.hip", "raftgpu.cpp", "rg_device.hpp", "rg_step.hpp")] + [
     os.path.join(EMU, "emu_runtime.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "raftgpu.h")]
 
 
@@ -23,7 +23,7 @@ def emulation_library():
         pytest.skip("no g++")
     if not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in SOURCES):
         subprocess.run(["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-w", "-pthread", "-I" + EMU, "-I" + os.path.join(ROOT, "include"),
-                        "-x", "c++", SOURCES[0], SOURCES[1], SOURCES[3], "-o", LIB], check=True, cwd=EMU)
+                        "-x", "c++", SOURCES[0], SOURCES[1], os.path.join(EMU, "emu_runtime.cpp"), "-o", LIB], check=True, cwd=EMU)
     return LIB
 
 
@@ -40,8 +40,8 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     """bench.py itself (tests/devemu/bench_dry.py stubs only torch's GPU probes): one JSON line with the contract's keys, roofline and
     cpu_baseline objects, the three host-memory legs, and the check of the first rounds against the translated reference."""
     import json
-    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)
-    env.pop("RG_FAST", None)
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)   # wavefront mode: bench.py's
+    env.pop("RG_FAST", None)                                                    # default path is the two-wavefront compact-format kernel
     p = subprocess.run([sys.executable, os.path.join(EMU, "bench_dry.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -68,7 +68,7 @@ def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):
     with socket.socket() as sk:                            # a port nobody is listening on right now
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="0", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     env.pop("RG_FAST", None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"],

@@ -3,6 +3,8 @@ Everything here needs a real MI355X: run with `pytest -m gpu`.
 
 Bar: bit-exact — every reply row, every conditional effect row that is flagged valid, and the final
 state of every group (term, votedFor, role, commitIndex, matchIndex[], log tail ...)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,11 +15,29 @@ from tests.helpers import compare_outcomes, compare_states, make_state, simple_l
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["split", "single"])
+def route_through_compact(monkeypatch):
+    """Table.submit packs every batch that can travel as compact rows (no hint column, every value in [0, 2^31)) with the library's
+    rg_batch32_pack and hands it to rg_submit32 — so whatever a test does through submit() is decided by step32_kernel."""
+    wide_submit = engine.Table.submit
+
+    def submit(self, batch, out=None, fill=0):
+        if batch.hint is None and abi.batch_fits_32(batch):
+            return self.submit32(batch, out, fill)
+        return wide_submit(self, batch, out, fill)
+    monkeypatch.setattr(engine.Table, "submit", submit)
+
+
+@pytest.fixture(autouse=True, params=["split", "single", "compact", "compact-forced-wide"])
 def step_kernel_variant(request, monkeypatch):
-    """Every test of this module runs against both step kernels: `split` = decide + I/O wavefront per 64 groups (what the
-    library picks up to one wavefront of groups per SIMD), `single` = one wavefront does both (picked beyond that)."""
-    monkeypatch.setenv("RG_SPLIT", "1" if request.param == "split" else "0")
+    """Every test of this module runs against every step kernel: `split` = decide + I/O wavefront per 64 groups on wide rows (what the
+    library picks up to one wavefront of groups per SIMD), `single` = one wavefront does both (picked beyond that), `compact` = the
+    compact-format kernel (32-bit body wherever the values allow it), `compact-forced-wide` = the same kernel made to take its 64-bit
+    body from the start (RG_FORCE_WIDE=1)."""
+    monkeypatch.setenv("RG_SPLIT", "0" if request.param == "single" else "1")
+    if request.param.startswith("compact"):
+        route_through_compact(monkeypatch)
+        if request.param == "compact-forced-wide":
+            monkeypatch.setenv("RG_FORCE_WIDE", "1")
 
 
 def mk_gpu(groups, cluster, self_slot, pre_vote):
@@ -508,3 +528,169 @@ def packed_pipeline_case(groups, rounds):
     big = abi.Batch(1, cfg.groups)
     big.put(0, 0, abi.EV_AE_REQ, slot=1, a=1 << 40, b=1, c=1, d=0)
     assert not abi.batch_fits_32(big)
+
+
+# ---- compact rows (rg_batch32_t / rg_submit32 / step32_kernel) ---------------------------------------------------------------------
+def numpy_pack32(batch):
+    """what rg_batch32_pack must produce, written independently (numpy + a python loop over the AppendEntries rows)"""
+    rows = batch.rounds * batch.count
+    head = batch.head.copy()
+    head["hdr"] &= np.uint32(~(abi.HDR_HINT_BIT | abi.HDR_SAME_TERM | (1 << 11)) & 0xFFFFFFFF)
+    q = np.zeros(rows, dtype=abi.QUAD32_DT)
+    q["a"], q["b"], q["c"], q["d"] = batch.ab["x"], batch.ab["y"], batch.cd["x"], batch.cd["y"]
+    terms = []
+    kind, n = head["hdr"] & 0xF, head["hdr"] >> 12
+    for r in np.flatnonzero((kind == abi.EV_AE_REQ) & (n > 0)):
+        aux, k = int(head["aux"][r]), int(n[r])
+        if aux + k > batch.entry_count:
+            head["aux"][r] = 0xFFFFFFFF
+            continue
+        e = batch.entry_terms[aux:aux + k]
+        if np.all(e == e[0]):
+            head["hdr"][r] |= abi.HDR_SAME_TERM
+            head["aux"][r] = int(e[0])
+        else:
+            head["aux"][r] = len(terms)
+            terms.extend(int(x) for x in e)
+    return head, q, np.array(terms, dtype=np.int32)
+
+
+def compact_multi_round_case(G, P, rounds):
+    """ONE multi-round launch of step32_kernel on HBM-resident compact rows against the oracle (outcomes, final state, counters); then the
+    ways a workgroup leaves the 32-bit domain — a group state at 2^30 when the launch starts, a row field reaching 2^30 in the middle of
+    the launch, a state value pushed towards 2^31 by client appends — each compared with the oracle and with neighbours that stay inside."""
+    st0, batches, outs, _, misses, _ = _lockstep(G, P, 1, True, rounds, 21, allow_miss=False)
+    assert misses == 0
+    big, ref = fuzz.concat_batches(batches), fuzz.concat_outcomes(outs)
+    gpu = engine.Table(G, P, 1, True)
+    gpu.load_state(st0)
+    db = engine.DeviceBatch32(gpu, big)
+    emu_fallbacks()
+    gpu.submit_device(db)
+    gpu.sync()
+    fb = emu_fallbacks()
+    assert fb in (None, 0) or os.environ.get("RG_FORCE_WIDE"), "a fuzz stream of small values must stay in the 32-bit body (%r fallbacks)" % fb
+    compare_outcomes(ref, db.outcome(), "compact multi-round")
+    orc = oracle_lib.OracleTable(G, P, 1, True)
+    orc.load_state(st0)
+    orc.submit(big)
+    compare_states(orc.read_state(), gpu.read_state(), "compact multi-round final")
+    c = gpu.counters()
+    assert c[0] == int(np.count_nonzero(big.head["hdr"] & 0xF))
+    assert c[1] == int(np.count_nonzero(ref.reply["flags"] & abi.F_REPLIED))
+    assert c[2] == int(np.count_nonzero(ref.reply["flags"] & abi.F_ROLE_CHANGED))
+    assert c[3] == int(np.count_nonzero(ref.reply["flags"] & abi.F_COMMIT))
+    db.free()
+    gpu.close()
+
+    # followers whose log tail sits just below / far below / above 2^30, fed AppendEntries with 4 entries per round: the groups of the
+    # second workgroup cross 2^30 in round 3 (their rows leave the domain), one group of the third starts beyond it, the first never does
+    G2, R2, LIM = 192, 8, 1 << 30
+    base = np.full(G2, 1000, dtype=np.int64)
+    base[64:128] = LIM - 10 - np.arange(64)
+    base[130] = LIM + 12345
+    st = abi.GroupState(G2, 3)
+    for g in range(G2):
+        set_state_follower(st, g, term=5, leader=1, last=int(base[g]))
+    b = abi.Batch(R2, G2)
+    last = base.copy()
+    for r in range(R2):
+        for g in range(G2):
+            n = 4 if (g + r) % 3 else 0
+            b.put(r, g, abi.EV_AE_REQ, slot=1, a=5 + (1 if (r == 4 and g % 7 == 0) else 0), b=int(last[g]), c=5 if r < 5 or g % 7 else 5,
+                  d=int(last[g]) - 1, entries=[5] * n if n else None)
+            last[g] += n
+    _compact_vs_oracle(G2, 3, 0, st, b, "tails crossing 2^30", expect_fallbacks=2)
+
+    # a leader appending 2^20 - 1 commands per round from just below 2^30: state grows past the row limit and on towards 2^31
+    G3, R3 = 64, 640
+    st = abi.GroupState(G3, 3)
+    for g in range(G3):
+        set_state_follower(st, g, term=3, leader=abi.NO_NODE, last=1000 + g)
+        st.role[g], st.voted_for[g] = abi.LEADER, 0
+    st.last_index[7] = LIM - (1 << 21)
+    b = abi.Batch(R3, G3)
+    for r in range(R3):
+        for g in range(G3):
+            if g == 7:
+                b.put(r, g, abi.EV_CLIENT_APPEND, n=(1 << 20) - 1)
+            elif r % 2 == 0:
+                b.put(r, g, abi.EV_CLIENT_APPEND, n=1 + (g % 3))
+            else:
+                b.put(r, g, abi.EV_TIMEOUT)
+    _compact_vs_oracle(G3, 3, 0, st, b, "client appends towards 2^31", expect_fallbacks=1)
+
+
+def set_state_follower(st, g, term, leader, last):
+    st.role[g], st.current_term[g], st.voted_for[g], st.current_leader[g] = abi.FOLLOWER, term, leader, leader
+    st.commit_index[g] = max(last - 2, 0)
+    st.set_log(g, 1, [(1, term)], last)
+
+
+def emu_fallbacks():
+    """host emulation only: workgroups of step32_kernel that took the 64-bit body since the last call (None on the GPU)"""
+    L = engine.lib()
+    if not hasattr(L, "rg_emu_fallbacks"):
+        return None
+    L.rg_emu_fallbacks.restype = __import__("ctypes").c_long
+    return int(L.rg_emu_fallbacks(1))
+
+
+def _compact_vs_oracle(G, P, self_slot, st, batch, where, expect_fallbacks=None):
+    emu_fallbacks()
+    gpu = engine.Table(G, P, self_slot, True)
+    orc = oracle_lib.OracleTable(G, P, self_slot, True)
+    gpu.load_state(st)
+    orc.load_state(st)
+    ref = orc.submit(batch)
+    db = engine.DeviceBatch32(gpu, batch)
+    gpu.submit_device(db)
+    gpu.sync()
+    compare_outcomes(ref, db.outcome(), where)
+    compare_states(orc.read_state(), gpu.read_state(), where + " final")
+    fb = emu_fallbacks()
+    if fb is not None and expect_fallbacks is not None and not os.environ.get("RG_FORCE_WIDE"):
+        assert fb == expect_fallbacks, "%s: %d workgroups fell back to 64-bit arithmetic, expected %d" % (where, fb, expect_fallbacks)
+    db.free()
+    gpu.close()
+    orc.close()
+
+
+def compact_workload_case(groups, rounds):
+    """BASELINE streams (config 3, config 5, config 3 with conflicting AppendEntries) as compact rows: C packer == numpy packer, and
+    step32_kernel == oracle on outcomes and final state, two launches in a row"""
+    import dataclasses
+    from rafting_amd import workload
+    for number in (3, 5, -3):
+        cfg = workload.config(abs(number), groups)
+        if number < 0:
+            cfg = dataclasses.replace(cfg, p_conflict=0.008, name=cfg.name + " + conflicts")
+        gen = workload.ReplayGenerator(cfg)
+        st0 = gen.initial_state()
+        gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+        gpu.load_state(st0)
+        orc.load_state(st0)
+        for k in range(2):
+            b = gen.next_batch(rounds)
+            b32 = engine.pack32(b)
+            h, q, t = numpy_pack32(b)
+            assert np.array_equal(b32.head, h) and np.array_equal(b32.abcd, q) and np.array_equal(b32.entry_terms[:b32.entry_count], t)
+            assert b32.entry_count < max(b.entry_count, 1)          # most entries share their row's term
+            ref = orc.submit(b)
+            db = engine.DeviceBatch32(gpu, b32)
+            gpu.submit_device(db)
+            gpu.sync()
+            compare_outcomes(ref, db.outcome(), "%s batch %d (compact)" % (cfg.name, k))
+            db.free()
+        compare_states(orc.read_state(), gpu.read_state(), cfg.name + " final (compact)")
+        gpu.close()
+        orc.close()
+
+
+def test_compact_multi_round_launch_and_domain_exits():
+    compact_multi_round_case(1024, 5, 48)
+
+
+def test_compact_workload_replays():
+    compact_workload_case(groups=5000, rounds=24)
