@@ -288,9 +288,9 @@ int rg_sync(rg_table_t *t);
  * and the download of batch k — PCIe is full duplex. Batches apply in submission order (their kernels share one stream).
  *   - caller buffers (in->*, out->*) must stay valid and untouched until the batch has been waited for, and should be page-locked
  *     (rg_host_alloc): pageable memory makes every copy synchronous;
- *   - out->reply is written for every row; out->logfx / out->persist only for rows whose flags say so (other rows keep their previous
- *     content — unlike rg_submit, nothing is zeroed: that is 32 B per row that need not cross the link... the rows are still copied
- *     densely);
+ *   - out->reply is written for every row; out->logfx / out->persist rows are meaningful only where the reply's flags say so. The
+ *     CONTENT OF THE OTHER ROWS IS UNDEFINED (the columns are copied back densely from staging memory that is not cleared between
+ *     batches — unlike rg_submit, which zeroes them): read a logfx / persist row only after checking its reply;
  *   - rg_submit_wait blocks until the OLDEST batch in flight has landed in its buffers; returns 1 when nothing is in flight;
  *   - every other entry point that touches the table first drains the pipeline. */
 #define RG_PIPELINE_DEPTH 2

@@ -50,6 +50,18 @@ template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
 }
 
+// -DRG_PROBE (experiment build, tools/probe.py): s_memtime deltas per section of a round, summed per wavefront and reported through the
+// workgroup's counter slot INSTEAD of the decision counters (words 0-3: I/O wavefront, 4-7: deciding wavefront). Nothing in the default build.
+#ifdef RG_PROBE
+#define RG_PROBE_BEGIN() uint64_t pb_t_ = __builtin_amdgcn_s_memtime(); uint32_t pb_[4] = {0u, 0u, 0u, 0u}
+#define RG_PROBE_MARK(i) do { __builtin_amdgcn_s_waitcnt(0xC07F); const uint64_t n_ = __builtin_amdgcn_s_memtime(); pb_[i] += (uint32_t)(n_ - pb_t_); pb_t_ = n_; } while (0)
+#define RG_PROBE_FLUSH(base) do { if ((threadIdx.x & 63u) == 0u) for (int q_ = 0; q_ < 4; q_++) p.counters[(size_t)blockIdx.x * RG_NUM_COUNTERS + (base) + q_] += pb_[q_]; } while (0)
+#else
+#define RG_PROBE_BEGIN() ((void)0)
+#define RG_PROBE_MARK(i) ((void)0)
+#define RG_PROBE_FLUSH(base) ((void)0)
+#endif
+
 constexpr uint32_t KIND_OUT_OF_DOMAIN = 15u;      // LDS copy of a compact row whose fields leave [0, EV_LIMIT): no event kind has this code
 constexpr uint32_t HDR_SAME_IN = 1u << 9;         // compact rows, LDS / register copy: RG_HDR_SAME_TERM of the wire header (wide rows keep the hint bit here)
 
@@ -394,37 +406,42 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
 //   round r:  I/O    writes event r+1 -> ev[(r+1)&1], reads outcome r-1 <- out[(r-1)&1] and stores it, issues next loads
 //             decide reads event r <- ev[r&1], decides, writes outcome r -> out[r&1]
 //   barrier   (s_waitcnt lgkmcnt(0) + s_barrier: LDS traffic only — global loads/stores stay in flight across it)
-enum { EV_HEAD = 0, EV_A, EV_B, EV_C, EV_D, EV_HX, EV_HY, EV_E0, EV_E1, EV_E2, EV_E3, EV_FIELDS };
+enum { EV_HEAD = 0, EV_A, EV_B, EV_C, EV_D, EV_E0, EV_HX, EV_HY, EV_E1, EV_E2, EV_E3, EV_FIELDS };
 enum { OUT_RESP = 0, OUT_FLAGS, OUT_COMMIT, OUT_FROM, OUT_TERM, OUT_VOTE, OUT_FIELDS };
 
 __device__ __forceinline__ void lds_barrier()
 {
     __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), vmcnt/expcnt untouched: my LDS writes have landed
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");              // (compiler only: no LDS access of this wavefront moves across the hand-over)
 }
 
-// LDS of a two-wavefront workgroup. The 64-bit body and the 32-bit body never run at the same time: one buffer, two layouts.
-template <int F>
+// LDS of a two-wavefront workgroup. The 64-bit body and the 32-bit body never run at the same time: one buffer, two layouts. On compact rows
+// (EV32) the 64-bit body's event ring carries five fields instead of eleven (no hint, the entry term is `aux`): 18 KB per workgroup at F = 4,
+// eight workgroups per CU instead of six.
+template <int F, bool EV32>
 struct SplitLds {
     // 64-bit body
+    static constexpr int EVF = EV32 ? (int)EV_D + 1 : (int)EV_FIELDS;
     static constexpr size_t W_EPOCH = 0, W_NEXT = W_EPOCH + F * BLOCK * 8, W_MATCH = W_NEXT + F * BLOCK * 8, W_REJ = W_MATCH + F * BLOCK * 8,
-                            W_EV = W_REJ + F * BLOCK * 4, W_OUT = W_EV + 2 * EV_FIELDS * BLOCK * 8, W_END = W_OUT + 2 * OUT_FIELDS * BLOCK * 8;
-    // 32-bit body
+                            W_EV = W_REJ + F * BLOCK * 4, W_OUT = W_EV + 2 * EVF * BLOCK * 8, W_END = W_OUT + 2 * OUT_FIELDS * BLOCK * 8;
+    // 32-bit body: follower records, their matchIndex row, a four-slot event ring (written two rounds ahead), a two-slot outcome ring
     static constexpr int MV = (F + 3) / 4;
-    static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + 2 * BLOCK * 8,
-                            N_O0 = N_EVQ + 2 * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16, N_END = N_BAIL + 16;
-    static constexpr size_t BYTES = W_END > N_END ? W_END : N_END;
+    static constexpr int NEV = 4;
+    static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 8,
+                            N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16, N_END = N_BAIL + 16;
+    static constexpr size_t BYTES = EV32 ? (W_END > N_END ? W_END : N_END) : W_END;
 };
 
 // The 64-bit body of a two-wavefront workgroup, on wide (EV32 = false) or compact (EV32 = true) rows.
 template <int F, bool SPARSE, bool EV32>
 __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *smem)
 {
-    typedef SplitLds<F> L;
+    typedef SplitLds<F, EV32> L;
     int64_t *sh_epoch = reinterpret_cast<int64_t *>(smem + L::W_EPOCH), *sh_next = reinterpret_cast<int64_t *>(smem + L::W_NEXT),
             *sh_match = reinterpret_cast<int64_t *>(smem + L::W_MATCH);
     int32_t *sh_rej = reinterpret_cast<int32_t *>(smem + L::W_REJ);
-    uint64_t (*sh_ev)[EV_FIELDS][BLOCK] = reinterpret_cast<uint64_t (*)[EV_FIELDS][BLOCK]>(smem + L::W_EV);
+    uint64_t (*sh_ev)[L::EVF][BLOCK] = reinterpret_cast<uint64_t (*)[L::EVF][BLOCK]>(smem + L::W_EV);
     uint64_t (*sh_out)[OUT_FIELDS][BLOCK] = reinterpret_cast<uint64_t (*)[OUT_FIELDS][BLOCK]>(smem + L::W_OUT);
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
@@ -440,8 +457,8 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
             sh_ev[slot][EV_HEAD][lane] = (uint64_t)decorate<EV32>(p, e, t, false) | ((uint64_t)e.aux << 32);
             sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
             sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
-            sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0;
             if constexpr (!EV32) {
+                sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0;
                 sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
                 sh_ev[slot][EV_E1][lane] = (uint64_t)t.e1;
                 sh_ev[slot][EV_E2][lane] = (uint64_t)t.e2; sh_ev[slot][EV_E3][lane] = (uint64_t)t.e3;
@@ -525,7 +542,8 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
         const uint32_t hdr = (uint32_t)head, aux = (uint32_t)(head >> 32);
         const int64_t a = (int64_t)sh_ev[slot][EV_A][lane], b = (int64_t)sh_ev[slot][EV_B][lane],
                       c = (int64_t)sh_ev[slot][EV_C][lane], d = (int64_t)sh_ev[slot][EV_D][lane];
-        const int64_t e0 = (int64_t)sh_ev[slot][EV_E0][lane];
+        int64_t e0 = (int64_t)(int32_t)aux;              // compact rows: the term shared by the carried entries travels in aux
+        if constexpr (!EV32) e0 = (int64_t)sh_ev[slot][EV_E0][lane];
         const uint32_t kind = RG_HDR_KIND(hdr);
         // tier 1 branches on wavefront ballots: every lane calls it (a lane blocked after a NEED_HOST asks for nothing)
         const bool skip = blocked & (kind != RG_EV_NONE);
@@ -562,30 +580,51 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
 template <int F, bool SPARSE>
 __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams p)
 {
-    __shared__ alignas(16) unsigned char smem[SplitLds<F>::W_END];
+    __shared__ alignas(16) unsigned char smem[SplitLds<F, false>::BYTES];
     split_body<F, SPARSE, false>(p, smem);
 }
 
 // ---- the 32-bit body on compact rows ------------------------------------------------------------------------------------------
-// Same protocol as split_body, with everything that crosses LDS half as wide:
-//   event  r+1 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store (instead of eleven 8-byte ones)
-//   outcome r-1: {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows
-// and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O
-// wavefront's stream is two loads per row, four rows ahead. The deciding wavefront keeps a GroupT<int32_t>; a row that tier 1 does not
-// decide is handed to the general handlers on a widened copy of the image and the result is narrowed back.
+// Same protocol as split_body, with everything that crosses LDS half as wide and one round more of slack:
+//   event   r+2 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store into a FOUR-slot ring, written two rounds ahead, so
+//                 that the deciding wavefront reads event r+1 at the top of round r and its LDS latency hides behind the decision of r
+//   outcome r-1 : {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows (two-slot ring)
+// and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O wavefront's
+// stream is two loads per row, issued six rounds ahead of the decision, four rows in registers (the loop is unrolled by four: no copies).
+// The deciding wavefront keeps a GroupT<int32_t>; a row that tier 1 does not decide is handed to the general handlers on a widened copy
+// of the image and the result is narrowed back.
 // Returns false when the workgroup left the 32-bit domain (a group or a Leadership.State value at or above 2^30 at load, a row field
 // outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
+struct Row32 { U32x2 h; I32x4 q; };
+
+// decorate<true> for the 32-bit body, on the row as loaded: the same header bits, plus KIND_OUT_OF_DOMAIN when a field leaves [0, EV_LIMIT)
+__device__ __forceinline__ uint32_t decorate_narrow(const StepParams &p, const Row32 &x)
+{
+    const uint32_t hdr = x.h.x, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+    const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
+    const bool same = (hdr & RG_HDR_SAME_TERM) != 0, ae = kind == RG_EV_AE_REQ;
+    const bool ae_ok = ae & (slot < P) & (x.q.z != 0) & (n <= RG_MAX_AE_ENTRIES) & ((n == 0) | same);
+    const bool peer_ok = (slot < P) & (slot != self);
+    const uint32_t w = (uint32_t)x.q.x | (uint32_t)x.q.y | (uint32_t)x.q.z | (uint32_t)x.q.w | ((ae & same) ? x.h.y : 0u);
+    const uint32_t out = (hdr & ~(7u << 9)) | (same ? HDR_SAME_IN : 0u) | (ae_ok ? HDR_AE_OK : 0u) | (peer_ok ? HDR_PEER_OK : 0u);
+    return (w >= EV_LIMIT) ? (out | KIND_OUT_OF_DOMAIN) : out;
+}
+
 template <int F, bool SPARSE>
 __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
-    typedef SplitLds<F> L;
+    typedef SplitLds<F, true> L;
     I32x4 *sh_rec = reinterpret_cast<I32x4 *>(smem + L::N_REC);
     int32_t *sh_mv = reinterpret_cast<int32_t *>(smem + L::N_MV);
     U32x2 (*sh_evh)[BLOCK] = reinterpret_cast<U32x2 (*)[BLOCK]>(smem + L::N_EVH);
     I32x4 (*sh_evq)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVQ);
     I32x4 (*sh_o0)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O0);
     I32x4 (*sh_o1)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O1);
-    volatile uint32_t *sh_bail = reinterpret_cast<volatile uint32_t *>(smem + L::N_BAIL);
+    // The bail mark: 0, 1 (the state load left the domain) or r + 2 (round r did). Written by the deciding wavefront before a barrier, read by
+    // the I/O wavefront after it — a plain LDS word (a `volatile` generic pointer would become a FLAT load whose vmcnt(0) drains the I/O
+    // wavefront's whole prefetch every round). The deciding wavefront may already be one round further and have written a LATER round's
+    // mark when the I/O wavefront looks: only a mark that is due makes it leave, so both always pass the same number of barriers.
+    uint32_t *sh_bail = reinterpret_cast<uint32_t *>(smem + L::N_BAIL);
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
@@ -596,16 +635,13 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 
     if (io_wave) {
         auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
-        struct Row32 { U32x2 h; I32x4 q; };
         auto fetch = [&](uint32_t r, Row32 &x) {
             const size_t row = row_of(r);
             x.h = nt_load8(reinterpret_cast<const U32x2 *>(p.head) + row);
             x.q = nt_load16(p.abcd32 + row);
         };
         auto publish = [&](uint32_t slot, const Row32 &x) {
-            EventRow e;
-            e.hdr = x.h.x; e.aux = x.h.y; e.a = x.q.x; e.b = x.q.y; e.c = x.q.z; e.d = x.q.w;
-            sh_evh[slot][lane] = U32x2{decorate<true>(p, e, EventTail{}, true), x.h.y};
+            sh_evh[slot][lane] = U32x2{decorate_narrow(p, x), x.h.y};
             sh_evq[slot][lane] = x.q;
         };
         Tally tally;
@@ -626,35 +662,46 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             }
             tally.add(RG_HDR_KIND(hdr), flags, status);
         };
-        // four rows in flight: n1 = row r+1 (published now), ... n4 = row r+4 (issued last round)
-        Row32 n1, n2, n3, n4;
-        uint32_t hdr_cur, hdr_prev = 0u;
+        // Rows r+2 .. r+5 are in registers at the top of round r, row k in buf[k & 3]; the loop is unrolled by four so that the indices are
+        // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
+        Row32 buf[4];
+        uint32_t hdr_m1 = 0u, hdr_0, hdr_1;              // headers of rounds r-1, r, r+1 (the tallies need the kind of a retired row)
         {
-            Row32 first;
-            fetch(0, first); fetch(1, n1); fetch(2, n2); fetch(3, n3); fetch(4, n4);
-            publish(0u, first);
-            hdr_cur = first.h.x;
+            Row32 e0, e1;
+            fetch(0, e0); fetch(1, e1); fetch(2, buf[2]); fetch(3, buf[3]); fetch(4, buf[0]); fetch(5, buf[1]);
+            publish(0u, e0); publish(1u, e1);
+            hdr_0 = e0.h.x; hdr_1 = e1.h.x;
         }
-        // The bail flag holds 0, 1 (the state load left the domain) or r + 2 (round r did). The deciding wavefront may already be one round
-        // further and have written a LATER round's mark when this wavefront looks: only a mark that is due makes it leave, so both
-        // always pass the same number of barriers.
-        lds_barrier();                                   // event 0 and the mark of the state load are visible
-        { const uint32_t mark0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(mark0) == 1u) return false; }
+        lds_barrier();                                   // events 0, 1 and the mark of the state load are visible
+        { const uint32_t seen0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(seen0) == 1u) return false; }
         bool bailed = false;
-        for (uint32_t r = 0; r < p.rounds; r++) {
-            publish((r + 1u) & 1u, n1);
-            if (r > 0) retire(r - 1u, hdr_prev);
-            hdr_prev = hdr_cur; hdr_cur = n1.h.x;
-            n1 = n2; n2 = n3; n3 = n4;
-            fetch(r + 5u, n4);
-            lds_barrier();
-            const uint32_t seen = *sh_bail;
-            const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
-            if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
+        RG_PROBE_BEGIN();
+        for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t r = r0 + (uint32_t)k;
+                if (r >= p.rounds) break;
+                Row32 &x = buf[(k + 2) & 3];
+                publish((r + 2u) & 3u, x);
+                RG_PROBE_MARK(0);
+                if (r > 0) retire(r - 1u, hdr_m1);
+                hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
+                fetch(r + 6u, x);
+                RG_PROBE_MARK(1);
+                lds_barrier();
+                RG_PROBE_MARK(2);
+                const uint32_t seen = *sh_bail;
+                const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
+                if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
+            }
         }
         if (bailed) return false;
-        retire(last_round, hdr_prev);
+        retire(last_round, hdr_m1);
+#ifdef RG_PROBE
+        RG_PROBE_FLUSH(0);
+#else
         tally.flush(p, lane, active);
+#endif
         return true;
     }
 
@@ -678,16 +725,20 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     bool blocked = false;
     lds_barrier();
     if (bailed) return false;
+    U32x2 h = sh_evh[0][lane];                           // event 0; from here on event r+1 is read at the top of round r
+    I32x4 q = sh_evq[0][lane];
+    RG_PROBE_BEGIN();
     for (uint32_t r = 0; r < p.rounds; r++) {
-        const uint32_t slot = r & 1u;
-        const U32x2 h = sh_evh[slot][lane];
-        const I32x4 q = sh_evq[slot][lane];
+        const U32x2 h_next = sh_evh[(r + 1u) & 3u][lane];
+        const I32x4 q_next = sh_evq[(r + 1u) & 3u][lane];
+        RG_PROBE_MARK(0);
         const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
         const bool skip = blocked & (kind != RG_EV_NONE);
         FxT<int32_t> fx{0u, RG_OK, 0, 0};
         const bool done = tier1<F, int32_t, PeersNarrow<F>>(p, g, pe, fx, FAST & !skip, hdr, aux, q.x, q.y, q.z, q.w, (int32_t)aux);
         const bool slow = !done & !skip;
         if (skip) fx = FxT<int32_t>{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+        RG_PROBE_MARK(1);
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {
@@ -707,11 +758,16 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         const uint32_t status = fx.status, flags = fx.flags;
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
+        const uint32_t slot = r & 1u;
         sh_o0[slot][lane] = I32x4{(flags & RG_F_REPLIED) ? fx.resp_term : 0, (int32_t)flags_all, (int32_t)g.role_epoch, g.commit};
         sh_o1[slot][lane] = I32x4{fx.log_from, g.term, g.voted_for, g.role};
+        RG_PROBE_MARK(2);
         lds_barrier();
+        RG_PROBE_MARK(3);
         if (bailed) return false;
+        h = h_next; q = q_next;
     }
+    RG_PROBE_FLUSH(4);
     if (active) {
         const Group g64 = widen(g);
         store_group(p.t, gi, g64, pe, F);
@@ -723,10 +779,13 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 #define RG_NOTE_FALLBACK() ((void)0)
 #endif
 
+#ifndef RG_STEP32_MIN_WAVES         // experiment knob: waves per SIMD the register allocation must leave room for
+#define RG_STEP32_MIN_WAVES 1
+#endif
 template <int F, bool SPARSE>
-__global__ __launch_bounds__(2 * BLOCK) void step32_kernel(const StepParams p)
+__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(RG_STEP32_MIN_WAVES, 8))) void step32_kernel(const StepParams p)
 {
-    __shared__ alignas(16) unsigned char smem[SplitLds<F>::BYTES];
+    __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
     if (narrow_body<F, SPARSE>(p, smem)) return;
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
     // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic

@@ -83,7 +83,8 @@ static void fail(const char *what, uint32_t gid) { fprintf(stderr, "INVARIANT VI
 static std::string line_of(const Entry &e) { return "t" + std::to_string(e.term) + "-cmd" + std::to_string(e.index); }
 
 // ---- SIM_WIRE=1: every message crosses the "network" as an encoded frame of the reference's wire protocol ---------------
-// (transport/EventCodec.java): the sender encodes (FixedBodyCodec stand-in for the Kryo body), the bytes sit in a per-connection
+// (transport/EventCodec.java): the sender encodes (bodies in the reference's Kryo format, KryoBodyCodec; SIM_WIRE=2 takes the fixed-layout
+// test codec instead), the bytes sit in a per-connection
 // stream, the receiver's FrameSplitter gets them in random pieces and the decoded frame is turned back into the message.
 // A response carries only (scope, sequence, term, success): what the requester needs beyond that — the role epoch it sent
 // under and Leader.replicateLog's closure state — comes from ITS OWN table of pending invocations, as in AsyncService.
@@ -100,9 +101,18 @@ static std::mt19937_64 chunk_rng(20240921);                   // piece sizes: th
 static std::string ctx_name(uint32_t groups, uint32_t gid) { return groups == 1 ? "root" : "ctx-" + std::to_string(gid); }
 static uint32_t g_groups = 1;
 
+// the demo cluster of src/test/resources/raft{1,2,3}.xml: 127.0.0.1:6001-6003 (slots 0..2; further slots continue the ports)
+static const rw::BodyCodec &body_codec()
+{
+    static const rw::FixedBodyCodec fixed;
+    static const rw::KryoBodyCodec kryo([] { std::vector<rw::KryoBodyCodec::Node> n; for (int i = 0; i < 8; i++) n.push_back({"127.0.0.1", 6001 + i}); return n; }());
+    static const bool use_fixed = getenv("SIM_WIRE") && atoi(getenv("SIM_WIRE")) == 2;
+    return use_fixed ? static_cast<const rw::BodyCodec &>(fixed) : kryo;
+}
+
 static void encode_msg(Msg &m)
 {
-    const rw::FixedBodyCodec codec;
+    const rw::BodyCodec &codec = body_codec();
     rw::Frame f;
     const bool request = m.type == AE || m.type == PV || m.type == RV || m.type == IS;
     const rw::Method method = (m.type == AE || m.type == AE_RESP) ? rw::M_APPEND_ENTRIES : (m.type == PV || m.type == PV_RESP) ? rw::M_PRE_VOTE
@@ -131,7 +141,7 @@ static void encode_msg(Msg &m)
 // one tick of the network: every connection delivers what was written to it, in arbitrary pieces
 static void deliver_frames(std::vector<Msg> &out)
 {
-    const rw::FixedBodyCodec codec;
+    const rw::BodyCodec &codec = body_codec();
     std::deque<std::pair<bool, Msg>> arrived[8][8];             // per connection, in order; false = decoded but dropped
     for (int from = 0; from < P; from++)
         for (int to = 0; to < P; to++) {
@@ -441,7 +451,7 @@ int main(int argc, char **argv)
                 fail("journal does not hold the participant's (term, votedFor)", g.ctx->gid());
         }
     }
-    if (use_wire) fprintf(stderr, "wire: %llu frames, %llu bytes through FrameSplitter / FixedBodyCodec\n", (unsigned long long)wire_frames, (unsigned long long)wire_bytes);
+    if (use_wire) fprintf(stderr, "wire: %llu frames, %llu bytes through FrameSplitter / %s\n", (unsigned long long)wire_frames, (unsigned long long)wire_bytes, (getenv("SIM_WIRE") && atoi(getenv("SIM_WIRE")) == 2) ? "FixedBodyCodec" : "KryoBodyCodec");
     fprintf(stderr, "readiness gate: %llu commands refused (NotReadyException), %llu RPC timeouts\n", (unsigned long long)not_ready,
             (unsigned long long)rpc_timeouts);
     fprintf(stderr, "durability: %llu (term, votedFor) records in %llu fdatasyncs\n", (unsigned long long)persisted, (unsigned long long)syncs);

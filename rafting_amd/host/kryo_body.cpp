@@ -1,0 +1,235 @@
+// kryo_body.cpp — KryoBodyCodec (wire.hpp): the RPC bodies of the reference in the byte format of Kryo 4.0.2.
+//
+// Kryo is a third-party JVM library (com.esotericsoftware:kryo:4.0.2, pom.xml:25-29) that is NOT vendored in /root/reference and cannot
+// run here. This file restates the part of its format the reference's RPC bodies use, from Kryo's published sources (class / method named
+// at every rule). STATUS: unverified against a JVM — see tests/golden/kryo_bodies.json and INTEGRATION.md §"Checking the Kryo format".
+//
+// How the reference configures it (support/serial/Serialization.java:21-26): `new Kryo()` with an instantiator strategy — i.e. every default:
+// registrationRequired = false, references = true, default serializer FieldSerializer, ten pre-registered types with ids 0..9
+// (Kryo.<init>: int, String, float, boolean, byte, char, short, long, double, void — a wrapper class resolves to its primitive's
+// registration, DefaultClassResolver.register). Bodies are written by kryo.writeClassAndObject (Serialization.java:47-62, 98-111).
+//
+// Rules used (all from the Kryo 4.0.2 sources):
+//  R1 varint       Output.writeVarInt(value, optimizePositive): 7 bits per byte, low group first, bit 7 = "more"; optimizePositive = false
+//                  zig-zags first ((v << 1) ^ (v >> 31)). Output.writeVarLong the same on 64 bits, up to 9 bytes (the 9th holds 8 bits).
+//  R2 class        DefaultClassResolver.writeClass: null -> varint 0; registered type -> varint id + 2; unregistered -> varint 1 (NAME + 2), then
+//                  varint nameId, and — the FIRST time this class appears in the object graph — its Class.getName() as a string (writeName).
+//                  nameIds count up from 0 per top-level write (Kryo.reset -> ClassResolver.reset).
+//  R3 string       Output.writeString: null -> 0x80; "" -> 0x81; 2..63 chars, all ASCII -> the chars, bit 7 set on the LAST one (writeAscii);
+//                  anything else -> writeUtf8Length(charCount + 1) (first byte carries 6 bits with bit 7 set and bit 6 = "more", later bytes 7
+//                  bits + "more") followed by the chars as UTF-8 (1 byte for c <= 0x7F, 2 for <= 0x7FF, else 3).
+//  R4 references   Kryo.writeReferenceOrNull (references = true): for an object whose class MapReferenceResolver.useReferences accepts — every
+//                  class except the eight primitive wrappers (Util.isWrapperClass) — varint 1 (NOT_NULL) in front of its first occurrence, varint
+//                  id + 2 for a repeated one (ids count first occurrences from 0); where null is possible (writeObjectOrNull) null is varint 0.
+//                  Wrappers (Long ...) get no marker under writeClassAndObject.
+//  R5 Long         DefaultSerializers.LongSerializer.write: writeLong(value, false) = zig-zag varlong.
+//  R6 Object[]     DefaultArraySerializers.ObjectArraySerializer.write: varint length + 1 (optimizePositive); the component type of Object[] and
+//                  of RaftLog.Entry[] is not final, so every element is written with kryo.writeClassAndObject (R2 + R4 + its serializer).
+//  R7 byte[]       DefaultArraySerializers.ByteArraySerializer.write: varint length + 1, then the bytes.
+//  R8 fields       FieldSerializer: the non-static, non-transient fields of the class (and its superclasses), sorted by NAME
+//                  (FieldSerializer.rebuildCachedFields: Collections.sort(cachedFields, this) — compare = field name); a primitive field is
+//                  written raw — boolean 1 byte, int writeInt(v, false), long writeLong(v, false) (zig-zag varints, varIntsEnabled default) — an
+//                  object field whose declared class is final (String, byte[]) by kryo.writeObjectOrNull with that class's serializer (R4
+//                  marker with null possible, then the value; no class), any other by writeClassAndObject.
+//       NodeID      {hostname: String, port: int}            RocksEntry {data: byte[], index: long, term: long}
+//       RaftResponse{success: boolean, term: long}
+// Decoding reads exactly this shape; a back-reference (R4, id + 2) where a value is needed is answered with `false` — nothing in these bodies
+// repeats an object (a request holds one NodeID, every entry its own byte[]).
+#include <cstring>
+
+#include "wire.hpp"
+
+namespace rafting {
+namespace wire {
+
+namespace {
+
+const char *const N_OBJECT_ARRAY = "[Ljava.lang.Object;";
+const char *const N_NODE_ID = "io.lubricant.consensus.raft.transport.event.NodeID";
+const char *const N_ENTRY_ARRAY = "[Lio.lubricant.consensus.raft.command.RaftLog$Entry;";
+const char *const N_ROCKS_ENTRY = "io.lubricant.consensus.raft.command.storage.RocksEntry";
+const char *const N_RESPONSE = "io.lubricant.consensus.raft.RaftResponse";
+constexpr uint32_t ID_LONG = 7;                 // Kryo.<init>: register(long.class) is the eighth call
+
+struct Out {
+    std::string &o;
+    std::vector<const char *> names;            // classes already written by name (identity = pointer of the constants above)
+    explicit Out(std::string &out) : o(out) {}
+    void u8(uint8_t b) { o.push_back((char)b); }
+    void varint(uint32_t v) { while (v >> 7) { u8((uint8_t)(v & 0x7F) | 0x80); v >>= 7; } u8((uint8_t)v); }                 // R1, optimizePositive
+    void varint_zz(int32_t v) { varint(((uint32_t)v << 1) ^ (uint32_t)(v >> 31)); }
+    void varlong_zz(int64_t v)                                                                                              // R1 / R5
+    {
+        uint64_t u = ((uint64_t)v << 1) ^ (uint64_t)(v >> 63);
+        for (int i = 0; i < 8 && (u >> 7); i++) { u8((uint8_t)(u & 0x7F) | 0x80); u >>= 7; }
+        u8((uint8_t)u);                         // the ninth byte, if it comes to that, carries the remaining 8 bits
+    }
+    void string(const std::string &s)                                                                                       // R3
+    {
+        const size_t n = s.size();
+        if (n == 0) { u8(0x81); return; }
+        bool ascii = n > 1 && n < 64;
+        for (size_t i = 0; ascii && i < n; i++) ascii = (uint8_t)s[i] <= 127;
+        if (ascii) { o.append(s); o.back() = (char)((uint8_t)o.back() | 0x80); return; }
+        // (callers only pass ASCII host names and class names; a non-ASCII or long string takes the length-prefixed form, chars <= 0x7F)
+        uint32_t v = (uint32_t)n + 1;
+        if (v >> 6 == 0) { u8((uint8_t)(v | 0x80)); }
+        else { u8((uint8_t)((v & 0x3F) | 0x40 | 0x80)); v >>= 6; while (v >> 7) { u8((uint8_t)(v & 0x7F) | 0x80); v >>= 7; } u8((uint8_t)v); }
+        o.append(s);
+    }
+    void class_by_name(const char *name)                                                                                    // R2
+    {
+        varint(1);
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == name) { varint((uint32_t)i); return; }
+        varint((uint32_t)names.size());
+        names.push_back(name);
+        string(name);
+    }
+    void boxed_long(int64_t v) { varint(ID_LONG + 2); varlong_zz(v); }                                                      // R2 + R5 (no R4 marker)
+};
+
+struct In {
+    const uint8_t *p, *end;
+    bool ok = true;
+    std::vector<std::string> names;
+    explicit In(const char *s, size_t n) : p(reinterpret_cast<const uint8_t *>(s)), end(p + n) {}
+    uint8_t u8() { if (p >= end) { ok = false; return 0; } return *p++; }
+    uint32_t varint()
+    {
+        uint32_t v = 0;
+        for (int shift = 0; shift < 35; shift += 7) { const uint8_t b = u8(); v |= (uint32_t)(b & 0x7F) << shift; if (!(b & 0x80)) return v; }
+        ok = false; return 0;
+    }
+    int32_t varint_zz() { const uint32_t u = varint(); return (int32_t)((u >> 1) ^ (~(u & 1) + 1)); }
+    int64_t varlong_zz()
+    {
+        uint64_t u = 0;
+        int shift = 0;
+        for (int i = 0; i < 8; i++, shift += 7) { const uint8_t b = u8(); u |= (uint64_t)(b & 0x7F) << shift; if (!(b & 0x80)) goto done; }
+        u |= (uint64_t)u8() << 56;
+    done:
+        return (int64_t)((u >> 1) ^ (~(u & 1) + 1));
+    }
+    bool string(std::string &s)                                                                                             // R3 (never null here)
+    {
+        s.clear();
+        if (p >= end) { ok = false; return false; }
+        const uint8_t b = *p;
+        if (!(b & 0x80)) {                                   // ASCII run ending at the first byte with bit 7 set
+            while (true) { const uint8_t c = u8(); if (!ok) return false; s.push_back((char)(c & 0x7F)); if (c & 0x80) return true; }
+        }
+        p++;
+        uint32_t v = b & 0x3F;                               // writeUtf8Length
+        if (b & 0x40) { int shift = 6; while (true) { const uint8_t c = u8(); if (!ok) return false; v |= (uint32_t)(c & 0x7F) << shift; if (!(c & 0x80)) break; shift += 7; if (shift > 34) { ok = false; return false; } } }
+        if (v == 0) { ok = false; return false; }            // null
+        for (uint32_t i = 1; i < v; i++) {                   // v - 1 chars as UTF-8
+            const uint8_t c = u8();
+            if (!ok) return false;
+            s.push_back((char)c);
+            if (c >= 0xE0) { s.push_back((char)u8()); s.push_back((char)u8()); }
+            else if (c >= 0xC0) s.push_back((char)u8());
+        }
+        return ok;
+    }
+    // R2: 0 = null, 1 = by name (returned through `name`), else registered id + 2
+    uint32_t klass(std::string &name)
+    {
+        const uint32_t c = varint();
+        if (c != 1) return c;
+        const uint32_t id = varint();
+        if (id < names.size()) { name = names[id]; return 1; }
+        if (id != names.size() || !string(name)) { ok = false; return 1; }
+        names.push_back(name);
+        return 1;
+    }
+    bool first_occurrence() { if (varint() != 1) { ok = false; return false; } return ok; }                                  // R4: NOT_NULL, not a back-reference
+    bool boxed_long(int64_t &v) { std::string nm; if (klass(nm) != ID_LONG + 2) { ok = false; return false; } v = varlong_zz(); return ok; }
+};
+
+}  // namespace
+
+void KryoBodyCodec::encode_request(Method m, const Request &in, std::string &body) const
+{
+    Out w(body);
+    const bool ae = m == M_APPEND_ENTRIES;
+    w.class_by_name(N_OBJECT_ARRAY); w.varint(1);                                  // Object[] (R2, R4)
+    w.varint((ae ? 6u : 4u) + 1u);                                                 // R6
+    w.boxed_long(in.term);
+    const Node none{"", 0};
+    const Node &id = (in.node >= 0 && (size_t)in.node < nodes_.size()) ? nodes_[(size_t)in.node] : none;
+    w.class_by_name(N_NODE_ID); w.varint(1);                                       // NodeID: fields by name — hostname, port (R8)
+    w.varint(1); w.string(id.hostname);                                            //   String field: writeObjectOrNull (R4 marker, R3)
+    w.varint_zz(id.port);
+    w.boxed_long(in.x);
+    w.boxed_long(in.y);
+    if (ae) {
+        w.class_by_name(N_ENTRY_ARRAY); w.varint(1);
+        w.varint((uint32_t)in.entry_terms.size() + 1u);
+        for (size_t k = 0; k < in.entry_terms.size(); k++) {
+            w.class_by_name(N_ROCKS_ENTRY); w.varint(1);                           // RocksEntry: data, index, term (R8)
+            w.varint(1); w.varint(8u + 1u);                                        //   byte[] field: R4 marker, R7; the stored value starts with the term
+            const uint64_t t = (uint64_t)in.entry_terms[k];
+            for (int s = 56; s >= 0; s -= 8) w.u8((uint8_t)(t >> s));
+            w.varlong_zz((int64_t)((uint64_t)in.x + 1u + k));
+            w.varlong_zz(in.entry_terms[k]);
+        }
+        w.boxed_long(in.leader_commit);
+    }
+}
+
+void KryoBodyCodec::encode_response(const Response &in, std::string &body) const
+{
+    Out w(body);
+    w.class_by_name(N_RESPONSE); w.varint(1);
+    w.u8(in.success ? 1 : 0);                                                      // success before term (R8)
+    w.varlong_zz(in.term);
+}
+
+bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Request &out) const
+{
+    In r(body, len);
+    std::string nm, host;
+    out.leader_commit = 0;
+    out.entry_terms.clear();
+    out.node = RG_NO_NODE;
+    if (r.klass(nm) != 1 || nm != N_OBJECT_ARRAY || !r.first_occurrence()) return false;
+    const uint32_t n1 = r.varint();
+    const bool ae = m == M_APPEND_ENTRIES;
+    if (!r.ok || n1 != (ae ? 7u : 5u)) return false;                               // NettyNode.prepareLocalInvocation: params.length != 6 / 4 throws
+    if (!r.boxed_long(out.term)) return false;
+    if (r.klass(nm) != 1 || nm != N_NODE_ID || !r.first_occurrence()) return false;
+    if (!r.first_occurrence() || !r.string(host)) return false;
+    const int32_t port = r.varint_zz();
+    for (size_t i = 0; i < nodes_.size(); i++) if (nodes_[i].port == port && nodes_[i].hostname == host) out.node = (int32_t)i;
+    if (!r.boxed_long(out.x) || !r.boxed_long(out.y)) return false;
+    if (ae) {
+        if (r.klass(nm) != 1 || nm != N_ENTRY_ARRAY || !r.first_occurrence()) return false;
+        const uint32_t e1 = r.varint();
+        if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p)) return false;
+        for (uint32_t k = 0; k + 1 < e1; k++) {
+            if (r.klass(nm) != 1 || nm != N_ROCKS_ENTRY || !r.first_occurrence()) return false;
+            if (!r.first_occurrence()) return false;                               // data (never null: RocksLog.get builds entries from stored values)
+            const uint32_t d1 = r.varint();
+            if (!r.ok || d1 == 0 || (size_t)(d1 - 1) > (size_t)(r.end - r.p)) return false;
+            r.p += d1 - 1;                                                         // the payload never reaches a decision row
+            const int64_t index = r.varlong_zz(), term = r.varlong_zz();
+            if (!r.ok || index != (int64_t)((uint64_t)out.x + 1u + k)) return false;   // the C-ABI's rows carry implicit indices
+            out.entry_terms.push_back(term);
+        }
+        if (!r.boxed_long(out.leader_commit)) return false;
+    }
+    return r.ok && r.p == r.end && out.node != RG_NO_NODE;
+}
+
+bool KryoBodyCodec::decode_response(const char *body, size_t len, Response &out) const
+{
+    In r(body, len);
+    std::string nm;
+    if (r.klass(nm) != 1 || nm != N_RESPONSE || !r.first_occurrence()) return false;
+    out.success = r.u8() != 0;
+    out.term = r.varlong_zz();
+    return r.ok && r.p == r.end;
+}
+
+}  // namespace wire
+}  // namespace rafting

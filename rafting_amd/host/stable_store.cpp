@@ -147,8 +147,15 @@ void StableStore::compact()
     ::close(fd_);                                            // the name now means the new file: append there from here on, whatever follows
     fd_ = fd;
     seq_ = seq;
-    sync_parent_dir(path_);                                  // make the rename itself durable before any later batch is acknowledged
     ::lseek(fd_, 0, SEEK_END);
+    try {
+        sync_parent_dir(path_);                              // make the rename itself durable before any later batch is acknowledged
+    } catch (...) {
+        // the directory entry of the new journal may not be durable: after a crash the OLD file could reappear under path_ without the
+        // batches acknowledged from now on. Fail-stop like a failed persist(): nothing more is acknowledged through this object.
+        broken_ = true;
+        throw;
+    }
     syncs_++;
 }
 

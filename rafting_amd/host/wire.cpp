@@ -79,7 +79,7 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
         }
         if (body_len_ == -1) {
             if (!need((size_t)head_len_ + 4)) break;
-            head_at_ = pos_;                                                  // the head stays where it is: buf_ is only compacted between frames
+            head_at_ = pos_;                                                  // the head stays in buf_ (compaction rebases this offset)
             const int32_t len = be32(pos_ + (size_t)head_len_);
             pos_ += (size_t)head_len_ + 4;
             if (len < 0 || len > MAX_BODY_SIZE) { fail("illegal body length"); return made; }
@@ -97,8 +97,15 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
             open_ = false;
         }
     }
-    // drop what has been consumed — only between frames, so that head_at_ (an offset into buf_) stays valid while a frame is open
-    if (!open_ && pos_ > (1u << 16) && pos_ * 2 > buf_.size()) { buf_.erase(0, pos_); pos_ = 0; }
+    // Drop what has been consumed. A read normally ENDS inside a frame (the loop has already eaten the next SOH), so waiting for a
+    // moment between frames would let a busy connection grow buf_ without bound: while a frame is open everything before
+    // the bytes it still needs goes — its head once that has been located (head_at_ is rebased), else the parse position.
+    const size_t keep_from = (open_ && body_len_ != -1) ? head_at_ : pos_;
+    if (keep_from > (1u << 16) && keep_from * 2 > buf_.size()) {
+        buf_.erase(0, keep_from);
+        pos_ -= keep_from;
+        if (open_ && body_len_ != -1) head_at_ = 0;
+    }
     return made;
 }
 
@@ -230,8 +237,11 @@ bool RowWriter::add(const FrameView &f, int32_t peer, const BodyCodec &codec, co
             break;
         case M_PRE_VOTE:     h.hdr = RG_HDR_MAKE(RG_EV_PV_REQ, q.node, 0, 0); ab = {q.term, q.x}; cd = {q.y, 0}; break;
         case M_REQUEST_VOTE: h.hdr = RG_HDR_MAKE(RG_EV_RV_REQ, q.node, 0, 0); ab = {q.term, q.x}; cd = {q.y, 0}; break;
-        case M_INSTALL_SNAPSHOT:                                       // flag = "installed": the host sets it once it has the snapshot
-            h.hdr = RG_HDR_MAKE(RG_EV_IS_REQ, q.node, 1, 0); ab = {q.term, q.x}; cd = {q.y, 0}; break;
+        case M_INSTALL_SNAPSHOT:
+            // flag = what RaftContext.installSnapshot() RETURNED (member/Follower.java:146-148): a frame cannot know that. The row is
+            // written with flag 0 ("not installed"); the host submits it only after its download finished and sets RG_HDR flag bit 8 then
+            // (a row submitted as decoded must not answer success for a snapshot nobody holds).
+            h.hdr = RG_HDR_MAKE(RG_EV_IS_REQ, q.node, 0, 0); ab = {q.term, q.x}; cd = {q.y, 0}; break;
         default: return false;
         }
     } else {                                                           // a response: AsyncService.Invocation by (scope, sequence)

@@ -64,6 +64,7 @@ public:
     bool transparent() const { return transparent_; }
     std::string &passthrough() { return passthrough_; }
     size_t buffered() const { return buf_.size() - pos_; }
+    size_t held() const { return buf_.size(); }          // bytes kept in memory, consumed ones included: bounded by one frame + 64 KiB (test_wire_cpu.py)
 
 private:
     bool need(size_t n) const { return buf_.size() - pos_ >= n; }
@@ -121,6 +122,31 @@ public:
     bool decode_response(const char *body, size_t len, Response &out) const override;
     void encode_request(Method m, const Request &in, std::string &body) const override;
     void encode_response(const Response &in, std::string &body) const override;
+};
+
+// The body as the reference writes it: Kryo 4.0.2 (pom.xml:25-29), `kryo.writeClassAndObject` on a default-configured Kryo
+// (support/serial/Serialization.java:21-26: `new Kryo()` + an instantiator strategy, nothing registered, references on), of
+//   request   Object[]{Long term, NodeID id, Long x, Long y [, RaftLog.Entry[] entries, Long leaderCommit]}   transport/NettyNode.java:54-73
+//   response  RaftResponse{boolean success, long term}                                                          RaftResponse.java:8-24
+// with NodeID{String hostname, int port} (transport/event/NodeID.java:8-17) and entries of class RocksEntry{byte[] data, long index,
+// long term} (command/storage/RocksEntry.java:5-16; data = the stored value, whose first 8 bytes are the term, storage/RocksLog.java:82-89).
+// The byte format is restated in wire.cpp (KryoBodyCodec) from Kryo's published sources, rule by rule with the method each rule comes
+// from. Kryo itself is a JVM library that is absent here: the vectors in tests/golden/kryo_bodies.json are built from the same rules by
+// an independent Python encoder and are UNVERIFIED AGAINST A JVM — INTEGRATION.md shows the one-test check a maintainer with a JDK runs.
+// Peer slots <-> NodeID: the cluster list of the XML config (transport/NettyCluster.java:32-50), given to the constructor.
+class KryoBodyCodec : public BodyCodec {
+public:
+    struct Node { std::string hostname; int32_t port; };
+    explicit KryoBodyCodec(std::vector<Node> nodes) : nodes_(std::move(nodes)) {}
+    using BodyCodec::decode_request;
+    using BodyCodec::decode_response;
+    bool decode_request(Method m, const char *body, size_t len, Request &out) const override;
+    bool decode_response(const char *body, size_t len, Response &out) const override;
+    void encode_request(Method m, const Request &in, std::string &body) const override;
+    void encode_response(const Response &in, std::string &body) const override;
+    // a request's entries carry payload bytes the decision rows never see; index_of_first = prevLogIndex + 1 (what Leader.replicateLog ships)
+private:
+    std::vector<Node> nodes_;
 };
 
 // ---- frames -> rows -------------------------------------------------------------------------------------------------

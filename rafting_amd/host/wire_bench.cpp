@@ -17,7 +17,10 @@ using namespace rafting::wire;
 int main(int argc, char **argv)
 {
     const size_t frames = argc > 1 ? (size_t)atoll(argv[1]) : 2000000;
-    FixedBodyCodec codec;
+    // bodies in the reference's Kryo format by default; `wire_bench <frames> fixed` takes the fixed-layout test codec
+    const FixedBodyCodec fixed;
+    const KryoBodyCodec kryo({{"127.0.0.1", 6001}, {"127.0.0.1", 6002}, {"127.0.0.1", 6003}});
+    const BodyCodec &codec = (argc > 2 && std::string(argv[2]) == "fixed") ? static_cast<const BodyCodec &>(fixed) : kryo;
     std::string stream;
     stream.reserve(frames * 110);
     uint64_t x = 0x9E3779B97F4A7C15ull;

@@ -1,8 +1,11 @@
 // wire_capi.cpp — the C-ABI of include/raftwire.h over wire.hpp
 #include "../../include/raftwire.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <string>
+#include <vector>
 
 #include "wire.hpp"
 
@@ -40,6 +43,7 @@ int rw_splitter_pop(rw_splitter_t *s, uint8_t *type, int32_t *sequence, const ch
 }
 
 int rw_splitter_failed(const rw_splitter_t *s) { return s && s->sp.failed(); }
+size_t rw_splitter_held(const rw_splitter_t *s) { return s ? s->sp.held() : 0; }
 int rw_splitter_transparent(const rw_splitter_t *s) { return s && s->sp.transparent(); }
 size_t rw_splitter_passthrough(rw_splitter_t *s, const uint8_t **data)
 {
@@ -81,6 +85,61 @@ size_t rw_fixed_response(int64_t term, int success, uint8_t *out, size_t cap)
     std::string o;
     FixedBodyCodec().encode_response(Response{term, success != 0}, o);
     return emit(o, out, cap);
+}
+
+// ---- Kryo-format bodies (KryoBodyCodec): nodes = "host:port,host:port,..." in slot order ------------------------------------------
+static std::vector<KryoBodyCodec::Node> parse_nodes(const char *nodes)
+{
+    std::vector<KryoBodyCodec::Node> v;
+    std::string s(nodes ? nodes : "");
+    size_t at = 0;
+    while (at < s.size()) {
+        size_t comma = s.find(',', at);
+        if (comma == std::string::npos) comma = s.size();
+        const std::string one = s.substr(at, comma - at);
+        const size_t colon = one.rfind(':');
+        if (colon != std::string::npos) v.push_back({one.substr(0, colon), atoi(one.c_str() + colon + 1)});
+        at = comma + 1;
+    }
+    return v;
+}
+
+size_t rw_kryo_request(const char *nodes, int method, int64_t term, int32_t node, int64_t x, int64_t y, int64_t leader_commit, const int64_t *entry_terms,
+                       uint32_t n, uint8_t *out, size_t cap)
+{
+    Request q;
+    q.term = term; q.node = node; q.x = x; q.y = y; q.leader_commit = leader_commit;
+    q.entry_terms.assign(entry_terms, entry_terms + n);
+    std::string o;
+    KryoBodyCodec(parse_nodes(nodes)).encode_request((Method)method, q, o);
+    return emit(o, out, cap);
+}
+
+size_t rw_kryo_response(int64_t term, int success, uint8_t *out, size_t cap)
+{
+    std::string o;
+    KryoBodyCodec({}).encode_response(Response{term, success != 0}, o);
+    return emit(o, out, cap);
+}
+
+int rw_kryo_decode_request(const char *nodes, int method, const uint8_t *body, size_t len, int64_t *term, int32_t *node, int64_t *x, int64_t *y,
+                           int64_t *leader_commit, int64_t *entry_terms, uint32_t max_terms, uint32_t *n_terms)
+{
+    Request q;
+    if (!KryoBodyCodec(parse_nodes(nodes)).decode_request((Method)method, reinterpret_cast<const char *>(body), len, q)) return 0;
+    if (q.entry_terms.size() > max_terms) return 0;
+    *term = q.term; *node = q.node; *x = q.x; *y = q.y; *leader_commit = q.leader_commit;
+    *n_terms = (uint32_t)q.entry_terms.size();
+    for (size_t k = 0; k < q.entry_terms.size(); k++) entry_terms[k] = q.entry_terms[k];
+    return 1;
+}
+
+int rw_kryo_decode_response(const uint8_t *body, size_t len, int64_t *term, int *success)
+{
+    Response r;
+    if (!KryoBodyCodec({}).decode_response(reinterpret_cast<const char *>(body), len, r)) return 0;
+    *term = r.term; *success = r.success ? 1 : 0;
+    return 1;
 }
 
 int rw_rows_add_frame(uint8_t type, int32_t sequence, const char *head, size_t head_len, const uint8_t *body, size_t body_len, int32_t peer,

@@ -161,6 +161,35 @@ def test_splitter_matches_the_reference_decoder_on_corrupted_streams(wire, ref):
     assert died > 300 and alive > 300
 
 
+def test_splitter_memory_stays_bounded_on_a_connection_that_never_pauses_between_frames(wire):
+    """reads normally end INSIDE a frame (the next SOH has already been eaten), so compacting the buffer only between frames let
+    a pipelined peer grow it without bound. 300 000 frames in chunks that never align with a frame boundary: every frame comes out, and
+    the bytes held stay below one maximal chunk + frame + the 64 KiB compaction threshold."""
+    wire.rw_splitter_held.restype = sz
+    wire.rw_splitter_held.argtypes = [C.c_void_p]
+    out = C.create_string_buffer(4096)
+    body = bytes(range(41))
+    n = wire.rw_encode_frame(ENQ, 7, b"appendEntries:ctx1", 18, body, len(body), 0, out, 4096)
+    one = out.raw[:n]
+    stream = one * 3000                                     # 3000 frames per pass, 100 passes
+    h = wire.rw_splitter_new()
+    t, s, hp, hl, bp, bl = C.c_uint8(), C.c_int32(), C.c_char_p(), sz(), C.c_void_p(), sz()
+    total, peak, carry = 0, 0, b""
+    chunk = 4093                                            # coprime with the frame length: a chunk never ends on a frame boundary twice in a row
+    for _ in range(100):
+        data = carry + stream
+        cut = (len(data) // chunk) * chunk
+        for at in range(0, cut, chunk):
+            assert wire.rw_splitter_feed(h, data[at:at + chunk], chunk) >= 0
+            while wire.rw_splitter_pop(h, C.byref(t), C.byref(s), C.byref(hp), C.byref(hl), C.byref(bp), C.byref(bl)):
+                total += 1
+            peak = max(peak, wire.rw_splitter_held(h))
+        carry = data[cut:]
+    assert total >= 300000 - 100 and not wire.rw_splitter_failed(h)
+    assert peak < (1 << 17) + 2 * chunk + len(one), peak
+    wire.rw_splitter_free(h)
+
+
 def test_limits_and_quirks_of_the_grammar(wire, ref):
     def both(stream):
         got, exp = product(wire, stream, []), reference(ref, stream, [])

@@ -23,6 +23,22 @@ for step in "$@"; do
     c5) $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c5_65536
         $B --steps 10 --warmup 2 --config 5 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c5_131072
         $B --steps 10 --warmup 2 --config 4 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c4_131072 ;;
+    formats) for i in 1 2 3; do
+          $B --steps 10 --warmup 2 ${AB_ARGS} 2>>$OUT/formats.err | tee -a $OUT/formats.jsonl | line compact
+          $B --steps 10 --warmup 2 --wide-rows ${AB_ARGS} 2>>$OUT/formats.err | tee -a $OUT/formats.jsonl | line wide-rows; done ;;
+    c5w) $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 --wide-rows 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c5_65536_wide
+        $B --steps 10 --warmup 2 --config 4 --wide-rows 2>>$OUT/c5.err | tee -a $OUT/c5.jsonl | line c4_131072_wide ;;
+    c2) $B --steps 10 --warmup 2 --config 2 2>>$OUT/c2.err | tee -a $OUT/c2.jsonl | line c2_4096 ;;
+    probe) for ov in "" "leader_frac=0.0;p_timeout=0.0;p_vote_req=0.0" "leader_frac=1.0;p_higher_term=0.0"; do
+          RG_LIB=$(pwd)/rafting_amd/libraftgpu_probe.so $B --steps 10 --warmup 2 ${ov:+--override "$ov"} 2>>$OUT/probe.err | tee -a $OUT/probe.jsonl | python tools/probe.py; done
+        RG_LIB=$(pwd)/rafting_amd/libraftgpu_probe.so $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/probe.err | tee -a $OUT/probe.jsonl | python tools/probe.py
+        RG_LIB=$(pwd)/rafting_amd/libraftgpu_probe.so $B --steps 10 --warmup 2 --config 4 2>>$OUT/probe.err | tee -a $OUT/probe.jsonl | python tools/probe.py ;;
+    w4) for i in 1 2; do for L in rafting_amd/libraftgpu.so rafting_amd/libraftgpu_w4.so; do
+          RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 2>>$OUT/w4.err | tee -a $OUT/w4.jsonl | line "c3 $L"
+          RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 --config 4 2>>$OUT/w4.err | tee -a $OUT/w4.jsonl | line "c4-131072 $L"; done; done
+        for L in rafting_amd/libraftgpu.so rafting_amd/libraftgpu_w4.so; do
+          RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 --config 5 2>>$OUT/w4.err | tee -a $OUT/w4.jsonl | line "c5-131072 $L"
+          RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/w4.err | tee -a $OUT/w4.jsonl | line "c5-65536 $L"; done ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
     *) echo "unknown step $step" ;;
   esac
