@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rounds", type=int, default=64, help="replay rounds fused into one launch")
     ap.add_argument("--groups-per-gpu", type=int, default=None, help="default: 65536 (config 3) at N=1, 131072 (a config 4/5 shard) at N>1")
-    ap.add_argument("--config", type=int, default=None, choices=(2, 3, 4, 5), help="default: 3 at N=1, 4 at N>1")
+    ap.add_argument("--config", default=None, choices=("2", "2f", "3", "4", "5"), help="default: 3 at N=1, 4 at N>1; 2f = config 2's mirrored follower view")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=6, help="batches of the stream the CPU baseline replays")
     ap.add_argument("--copy-bw", action="store_true", help="(default now) measure a plain HBM copy kernel in the same run")
@@ -91,7 +91,7 @@ def main():
         torch.cuda.synchronize()
 
     # what is measured: N = 1 -> config 3 (the metric's configuration); N > 1 -> shards of config 4 (or 5)
-    number = args.config if args.config is not None else (3 if world == 1 else 4)
+    number = (args.config if args.config == "2f" else int(args.config)) if args.config is not None else (3 if world == 1 else 4)
     shard_default = 131072 if number in (4, 5) else workload.CONFIGS[number].groups
     gpg = args.groups_per_gpu if args.groups_per_gpu is not None else (shard_default if world > 1 or number != 3 else 65536)
     args.config = number

@@ -1009,14 +1009,45 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     const bool fc_newrun = fc & (lt != g_term);
     const bool fc_prepare = fc & !g_prep;
 
-    // ---- election traffic -----------------------------------------------------------------------------
-    // defaults = what the AppendEntries refresh converts to: Follower(request term, lastCandidate)
-    bool conv = false, to_pre = false, to_lead = false, count_grant = false, el_fast = false, el_drop = false, vq = false, vq_success = false,
-         vq_timer = false, el_reqvote = false;
-    int32_t new_role = RG_FOLLOWER, new_vote = g_voted;
-    V new_term = a;
+    // ---- the rows above: apply ---------------------------------------------------------------------------
+    // (of these only the AppendEntries refresh converts: Follower(request term, lastCandidate) — role and vote stay what they are)
+    const bool fast_main = fa | fk | fc | ack_drop;
+    if (fk) pe.store_ack(j, s_epoch, n_next, n_match, flag ? 0 : (int32_t)((uint32_t)s_rej + 1u));
+    if (ae_newrun | fc_newrun | fc_prepare) {                        // rare: one wave-level branch for both
+        if (ae_newrun | fc_newrun) g.push(vadd<V>(g_last, 1), ae_newrun ? pe0 : g_term);
+        if (fc_prepare) {                                            // Leader.prepareReplication after the FIRST new entry: nextIndex = that entry + 1
+            pe.store_prepare(g_epoch, vadd<V>(g_last, 2));
+            g.pending = 0;
+        }
+    }
+    g.prepared = (g_prep & !ae_refresh) | fc_prepare;
+    g.peers_dirty = g.peers_dirty | fk | fc_prepare;
+    g.term = ae_refresh ? a : g_term;
+    g.role_epoch = g_repoch + (ae_refresh ? 1u : 0u);
+    g.td = g_td & !ae_refresh;
+    g.votes = ae_refresh ? 1 : g_votes;
+    g.leader = fa ? (int32_t)slot : g_leader;
+    {
+        const V cur_last = g.last;                                   // (a new run pushed above has already moved it)
+        g.last = ae_append ? ae_last : (fc ? vadd<V>(g_last, (V)n) : cur_last);
+    }
+    g.log_dirty = g.log_dirty | ae_append | fc;
+    g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
+    if (fast_main) {
+        fx.status = ack_drop ? RG_DROPPED_STALE_ROLE : RG_OK;
+        fx.resp_term = a;                                            // only read for AppendEntries (== currentTerm by now)
+        fx.log_from = vadd<V>(g_last, 1);                            // only read with RG_F_LOG_APPEND
+        fx.flags = (fa ? (RG_F_RESET_TIMER | RG_F_REPLIED | (contains ? RG_F_SUCCESS : 0u)) : 0u) |
+                   (ae_refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) |
+                   ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
+                   (fc ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u);
+    }
+
+    // ---- election traffic: decided AND applied behind one wave-uniform branch ---------------------------------
+    // (a lane is in at most one class, and the classes above left the state of every other lane as it was: the snapshot is still valid)
     const bool ack_down = ack_any & lead_ok & (a > g_term);          // Leader -> Follower(result.term, responder)
     const bool election = (allow & (kind - (uint32_t)RG_EV_RV_REQ <= (uint32_t)(RG_EV_TIMEOUT - RG_EV_RV_REQ))) | ack_down;
+    bool el_fast = false;
     if (__builtin_amdgcn_ballot_w64(election) != 0) {               // wave-uniform: steady replication carries no such rows
         const V term1 = vadd<V>(g_term, 1), el_term = g.elected_term;
         const uint32_t el_epoch = g.elected_epoch;
@@ -1040,71 +1071,52 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
         const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
         const bool to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
         const bool to_live = to_kind & !to_stale;
-        to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
+        const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
         const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
-        to_lead = to_live & (role == RG_LEADER);
+        const bool to_lead = to_live & (role == RG_LEADER);
         // RequestVote / PreVote at a Follower that has a log
         const bool is_pvq = kind == RG_EV_PV_REQ;
-        vq = allow & ((kind == RG_EV_RV_REQ) | is_pvq) & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
+        const bool vq = allow & ((kind == RG_EV_RV_REQ) | is_pvq) & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
         const bool utd = (c > lt) | ((c == lt) & (b >= g_last));      // Follower.logUpToDate with a last entry
         const bool pv_judge = vq & is_pvq & (a > g_term) & g_td;      // else failure(currentTerm), no timer touched
         const bool rv_new = vq & !is_pvq & (a > g_term);
         const bool rv_same = vq & !is_pvq & (a == g_term);
-        vq_success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
-        vq_timer = pv_judge | rv_new;
+        const bool vq_success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
 
+        // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`
         const bool conv_self = vr_win | to_cand;                      // ballot = self
-        conv = vr_higher | conv_self | (late_higher & (a >= g_term)) | to_pre | rv_new | ack_down;
-        // (lanes this block converts nothing for keep the defaults: their AppendEntries refresh, if any, needs them)
-        new_role = vr_win ? (is_pv ? RG_CANDIDATE : RG_LEADER) : (to_cand ? RG_CANDIDATE : RG_FOLLOWER);
-        new_term = (to_cand | (vr_win & is_pv)) ? term1 : ((win_rv | to_pre) ? g_term : a);
-        new_vote = conv_self ? (int32_t)self : ((to_pre | !conv) ? g_voted : ((rv_new & !utd) ? RG_NO_NODE : (int32_t)slot));
-        el_reqvote = conv & (new_role == RG_CANDIDATE);
-        count_grant = vr_grant & !vr_win;
-        el_drop = vote_drop | to_stale;
-        el_fast = vr_higher | vr_win | vr_quiet | late_higher | late_noop | el_drop | to_pre | to_cand | to_lead | vq | ack_down;
-        g.elected_epoch = win_rv ? g_repoch : (late_higher ? 0u : el_epoch);      // Candidate.java:75-79 / head.abortRequests()
-        g.elected_term = win_rv ? g_term : el_term;
-    }
-
-    const bool fast = fa | fk | fc | ack_drop | el_fast;
-    if (fk) pe.store_ack(j, s_epoch, n_next, n_match, flag ? 0 : (int32_t)((uint32_t)s_rej + 1u));
-    const bool lead_prepare = fc_prepare | (to_lead & !g_prep);      // Leader.prepareReplication (member/Leader.java:30-50)
-    if (ae_newrun | fc_newrun | lead_prepare) {                      // rare: one wave-level branch for both
-        if (ae_newrun | fc_newrun) g.push(vadd<V>(g_last, 1), ae_newrun ? pe0 : g_term);
-        if (lead_prepare) {                                          // a client append prepares after its FIRST new entry: nextIndex = that entry + 1
-            pe.store_prepare(g_epoch, vadd<V>(has_log ? g_last : g_epoch, fc_prepare ? 2 : 1));
+        const bool conv = vr_higher | conv_self | (late_higher & (a >= g_term)) | to_pre | rv_new | ack_down;
+        const int32_t new_role = vr_win ? (is_pv ? RG_CANDIDATE : RG_LEADER) : (to_cand ? RG_CANDIDATE : RG_FOLLOWER);
+        const V new_term = (to_cand | (vr_win & is_pv)) ? term1 : ((win_rv | to_pre) ? g_term : a);
+        const int32_t new_vote = conv_self ? (int32_t)self : (to_pre ? g_voted : ((rv_new & !utd) ? RG_NO_NODE : (int32_t)slot));
+        const bool lead_prepare = to_lead & !g_prep;                  // a new Leader's first tick: Leader.prepareReplication (member/Leader.java:30-50)
+        if (lead_prepare) {
+            pe.store_prepare(g_epoch, vadd<V>(has_log ? g_last : g_epoch, 1));
             g.pending = 0;
         }
+        el_fast = vr_higher | vr_win | vr_quiet | late_higher | late_noop | vote_drop | to_stale | to_pre | to_cand | to_lead | vq | ack_down;
+        g.elected_epoch = win_rv ? g_repoch : (late_higher ? 0u : el_epoch);      // Candidate.java:75-79 / head.abortRequests()
+        g.elected_term = win_rv ? g_term : el_term;
+        g.term = conv ? new_term : g.term;
+        g.role = conv ? new_role : g.role;
+        g.voted_for = conv ? new_vote : g.voted_for;
+        g.role_epoch = g.role_epoch + (conv ? 1u : 0u);
+        g.td = (g.td & !conv) | to_pre;
+        g.votes = conv ? 1 : (g.votes + ((vr_grant & !vr_win) ? 1 : 0));
+        g.leader = conv ? RG_NO_NODE : g.leader;
+        g.prepared = (g.prepared & !conv) | lead_prepare;
+        g.peers_dirty = g.peers_dirty | lead_prepare;
+        if (el_fast) {
+            fx.status = (vote_drop | to_stale) ? RG_DROPPED_STALE_ROLE : RG_OK;
+            fx.resp_term = rv_new ? a : g_term;                       // only read for the vote requests
+            fx.log_from = 0;
+            fx.flags = (vq ? RG_F_REPLIED : 0u) | (vq_success ? RG_F_SUCCESS : 0u) | ((pv_judge | to_lead) ? RG_F_RESET_TIMER : 0u) |
+                       (conv ? (RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER) : 0u) |
+                       (to_lead ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u) | (to_pre ? (RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT) : 0u) |
+                       ((conv & (new_role == RG_CANDIDATE)) ? (RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT) : 0u);
+        }
     }
-    const bool conv_all = conv | ae_refresh;
-    g.prepared = (g_prep & !conv_all) | lead_prepare;
-    g.peers_dirty = g.peers_dirty | fk | lead_prepare;
-    g.term = conv_all ? new_term : g_term;
-    g.role = conv_all ? new_role : role;
-    g.voted_for = conv_all ? new_vote : g_voted;
-    g.role_epoch = g_repoch + (conv_all ? 1u : 0u);
-    g.td = (g_td & !conv_all) | to_pre;
-    g.votes = conv_all ? 1 : (g_votes + (count_grant ? 1 : 0));
-    g.leader = fa ? (int32_t)slot : (conv_all ? RG_NO_NODE : g_leader);
-    {
-        const V cur_last = g.last;                                   // (a new run pushed above has already moved it)
-        g.last = ae_append ? ae_last : (fc ? vadd<V>(g_last, (V)n) : cur_last);
-    }
-    g.log_dirty = g.log_dirty | ae_append | fc;
-    g.commit = ae_commit ? ae_x : (ack_commit ? commit_to : g_commit);
-    if (fast) {
-        fx.status = (ack_drop | el_drop) ? RG_DROPPED_STALE_ROLE : RG_OK;
-        fx.resp_term = (fa | conv) ? a : g_term;                     // only read for requests: AppendEntries (== currentTerm by now), vote requests
-        fx.log_from = vadd<V>(g_last, 1);                            // only read with RG_F_LOG_APPEND
-        fx.flags = ((fa | vq) ? RG_F_REPLIED : 0u) | (((fa & contains) | vq_success) ? RG_F_SUCCESS : 0u) |
-                   ((fa | vq_timer | to_lead) ? RG_F_RESET_TIMER : 0u) |
-                   (conv_all ? (RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER) : 0u) |
-                   ((ae_append | fc) ? RG_F_LOG_APPEND : 0u) | ((ae_commit | ack_commit) ? RG_F_COMMIT : 0u) |
-                   ((fc | to_lead) ? (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT) : 0u) |
-                   (to_pre ? (RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT) : 0u) | (el_reqvote ? (RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT) : 0u);
-    }
-    return fast;
+    return fast_main | el_fast;
 }
 
 }  // namespace rg

@@ -586,8 +586,9 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 
 // ---- the 32-bit body on compact rows ------------------------------------------------------------------------------------------
 // Same protocol as split_body, with everything that crosses LDS half as wide and one round more of slack:
-//   event   r+2 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store into a FOUR-slot ring, written two rounds ahead, so
-//                 that the deciding wavefront reads event r+1 at the top of round r and its LDS latency hides behind the decision of r
+//   event   r+2 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store into a FOUR-slot ring, written two rounds ahead (the
+//                 I/O wavefront is never the one that is waited for). Reading event r+1 a round early in the deciding wavefront was tried
+//                 and dropped: six more loop-carried registers made the allocator add 53 copies per round (tools/spine.sh: 476 -> 537)
 //   outcome r-1 : {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows (two-slot ring)
 // and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O wavefront's
 // stream is two loads per row, issued six rounds ahead of the decision, four rows in registers (the loop is unrolled by four: no copies).
@@ -725,12 +726,10 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     bool blocked = false;
     lds_barrier();
     if (bailed) return false;
-    U32x2 h = sh_evh[0][lane];                           // event 0; from here on event r+1 is read at the top of round r
-    I32x4 q = sh_evq[0][lane];
     RG_PROBE_BEGIN();
     for (uint32_t r = 0; r < p.rounds; r++) {
-        const U32x2 h_next = sh_evh[(r + 1u) & 3u][lane];
-        const I32x4 q_next = sh_evq[(r + 1u) & 3u][lane];
+        const U32x2 h = sh_evh[r & 3u][lane];
+        const I32x4 q = sh_evq[r & 3u][lane];
         RG_PROBE_MARK(0);
         const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
         const bool skip = blocked & (kind != RG_EV_NONE);
@@ -764,9 +763,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         RG_PROBE_MARK(2);
         lds_barrier();
         RG_PROBE_MARK(3);
-        if (bailed) return false;
-        h = h_next; q = q_next;
+        if (bailed) break;
     }
+    if (bailed) return false;
     RG_PROBE_FLUSH(4);
     if (active) {
         const Group g64 = widen(g);
@@ -779,11 +778,12 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 #define RG_NOTE_FALLBACK() ((void)0)
 #endif
 
-#ifndef RG_STEP32_MIN_WAVES         // experiment knob: waves per SIMD the register allocation must leave room for
-#define RG_STEP32_MIN_WAVES 1
-#endif
-template <int F, bool SPARSE>
-__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(RG_STEP32_MIN_WAVES, 8))) void step32_kernel(const StepParams p)
+// Two register budgets. WAVES = 1: whatever the allocator wants (3 wavefronts per SIMD: enough while a launch has at most one workgroup
+// per pair of SIMDs, 65 536 rows). WAVES = 4: at most 128 VGPRs, so that eight workgroups (18 KB of LDS each) are resident per CU — a
+// launch of 131 072 rows then runs in ONE pass with two deciding wavefronts per SIMD instead of a pass and a third (same-box A/B at config
+// 4's shard: 0.1994 -> 0.1307 ms per launch, profiles/r03d_w4_ab.jsonl; at 65 536 rows the smaller budget costs 2 %).
+template <int F, bool SPARSE, int WAVES>
+__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
     if (narrow_body<F, SPARSE>(p, smem)) return;
@@ -817,8 +817,14 @@ static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s
 {
     const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
     if (blocks == 0) return hipSuccess;
-    if (sparse) hipLaunchKernelGGL((step32_kernel<F, true>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-    else        hipLaunchKernelGGL((step32_kernel<F, false>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    const bool many = blocks > 1024u;                    // more than one workgroup per pair of SIMDs on a 256-CU part
+    if (sparse) {
+        if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        else      hipLaunchKernelGGL((step32_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    } else {
+        if (many) hipLaunchKernelGGL((step32_kernel<F, false, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        else      hipLaunchKernelGGL((step32_kernel<F, false, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+    }
     return hipGetLastError();
 }
 
@@ -837,12 +843,14 @@ static hipError_t launch_f(const StepParams &p, bool sparse, int shape, hipStrea
 hipError_t launch_step(const StepParams &p, int followers, bool sparse, int shape, hipStream_t s)
 {
     switch (followers) {
+#ifndef RG_BUILD_ONLY_F4            // analysis builds (tools/spine.sh): one cluster size, seconds instead of a minute
     case 1: return launch_f<1>(p, sparse, shape, s);
     case 2: return launch_f<2>(p, sparse, shape, s);
     case 3: return launch_f<3>(p, sparse, shape, s);
-    case 4: return launch_f<4>(p, sparse, shape, s);
     case 5: return launch_f<5>(p, sparse, shape, s);
     case 6: return launch_f<6>(p, sparse, shape, s);
+#endif
+    case 4: return launch_f<4>(p, sparse, shape, s);
     default: return hipErrorInvalidValue;
     }
 }

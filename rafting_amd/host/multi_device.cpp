@@ -41,7 +41,7 @@ void MultiDeviceManager::feed(Shard &s)
         lk.unlock();
         std::vector<Outcome> out;
         std::exception_ptr err;
-        try { out = s.mgr->flush(now); } catch (...) { err = std::current_exception(); }
+        try { std::lock_guard<std::mutex> wk(s.work); out = s.mgr->flush(now); } catch (...) { err = std::current_exception(); }
         lk.lock();
         s.out = std::move(out);
         s.error = err;
@@ -52,23 +52,38 @@ void MultiDeviceManager::feed(Shard &s)
 
 RaftContext &MultiDeviceManager::createContext(const std::string &id, int64_t restoreTerm, ID restoreBallot)
 {
-    auto it = where_.find(id);
-    if (it != where_.end()) return *shards_[it->second.first]->mgr->getContext(id);
-    if (created_ >= capacity_) throw std::length_error("context table is full");
-    const uint32_t gid = created_++;
-    const size_t k = gid / per_shard_;                             // gpu = gid / ceil(G / N)
-    where_[id] = {k, gid};
+    size_t k;
+    {
+        std::lock_guard<std::mutex> lk(route_m_);
+        auto it = where_.find(id);
+        if (it == where_.end()) {
+            if (created_ >= capacity_) throw std::length_error("context table is full");
+            const uint32_t gid = created_++;
+            it = where_.emplace(id, std::make_pair((size_t)(gid / per_shard_), gid)).first;    // gpu = gid / ceil(G / N)
+        }
+        k = it->second.first;
+    }
+    // the shard's table is one C-ABI handle: wait for a drain of it that is running (ContextManager::createContext returns the existing
+    // context when another thread won the race for this id)
+    std::lock_guard<std::mutex> wk(shards_[k]->work);
     return shards_[k]->mgr->createContext(id, restoreTerm, restoreBallot);
 }
 
 RaftContext *MultiDeviceManager::getContext(const std::string &id)
 {
-    auto it = where_.find(id);
-    return it == where_.end() ? nullptr : shards_[it->second.first]->mgr->getContext(id);
+    size_t k;
+    {
+        std::lock_guard<std::mutex> lk(route_m_);
+        auto it = where_.find(id);
+        if (it == where_.end()) return nullptr;
+        k = it->second.first;
+    }
+    std::lock_guard<std::mutex> wk(shards_[k]->work);
+    return shards_[k]->mgr->getContext(id);
 }
 
-size_t MultiDeviceManager::shardOf(const std::string &id) const { return where_.at(id).first; }
-uint32_t MultiDeviceManager::globalGid(const std::string &id) const { return where_.at(id).second; }
+size_t MultiDeviceManager::shardOf(const std::string &id) const { std::lock_guard<std::mutex> lk(route_m_); return where_.at(id).first; }
+uint32_t MultiDeviceManager::globalGid(const std::string &id) const { std::lock_guard<std::mutex> lk(route_m_); return where_.at(id).second; }
 
 std::vector<std::vector<Outcome>> MultiDeviceManager::flushAll(int64_t now)
 {

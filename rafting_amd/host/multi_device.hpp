@@ -8,6 +8,11 @@
 //   flushAll(now)   fan-out: every shard with queued rows drains on its own feeder thread — one rg_submit per device, all
 //                   devices at once; fan-in: returns when the last one is done. Outcomes come back per shard, ticket order.
 // A shard is a plain ContextManager: timers, health, replicateLog etc. are reached through shard(k).
+// Threads: the routing table (contextId -> shard, gid) is guarded; createContext / getContext / shardOf / globalGid may be called from any
+// thread while another thread runs flushAll — the reference's map is a ConcurrentHashMap (context/ContextManager.java:41) and its
+// contexts are created while event loops drain. createContext on shard k waits for a drain of shard k that is running (one shard is one
+// C-ABI handle: include/raftgpu.h "not re-entrant per handle"). What stays with the caller, as with ContextManager itself: the rows of ONE
+// shard are queued by one thread at a time and not while that shard drains.
 #pragma once
 #include <condition_variable>
 #include <mutex>
@@ -41,6 +46,7 @@ class MultiDeviceManager {
         std::unique_ptr<ContextManager> mgr;
         std::thread feeder;
         std::mutex m;
+        std::mutex work;                 // held around everything that touches `mgr`'s table: a drain, a createContext
         std::condition_variable cv;
         bool go = false, done = false, quit = false;
         int64_t now = -1;
@@ -50,6 +56,7 @@ class MultiDeviceManager {
     void feed(Shard &s);
     std::vector<std::unique_ptr<Shard>> shards_;
     uint32_t per_shard_, capacity_, created_ = 0;
+    mutable std::mutex route_m_;                                   // guards created_ and where_
     std::map<std::string, std::pair<size_t, uint32_t>> where_;     // id -> (shard, global gid)
 };
 

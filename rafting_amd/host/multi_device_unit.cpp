@@ -3,9 +3,11 @@
 // each drained by its own feeder thread (here: several tables on the one GPU of the test box — the data path is identical, only
 // the device ordinal differs on a multi-GPU node). Every outcome and every mirror must be identical, context by context.
 // usage: multi_device_unit [contexts=96] [shards=3] [rounds=200]      exit code 0 = identical
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <thread>
 
 #include "multi_device.hpp"
 
@@ -85,6 +87,36 @@ int main(int argc, char **argv)
             rows++;
             leaders += a[i]->role() == RG_LEADER;
         }
+    }
+    // createContext / getContext from a second thread WHILE flushAll runs: N2 more contexts appear on a manager whose shards
+    // keep draining; every one of them must exist afterwards, be routed by its creation index, and the drains must not have been disturbed
+    if (!bad) {
+        const uint32_t N2 = N;
+        MultiDeviceManager busy(std::vector<int>(S, 0), N + N2, P, self, true);
+        std::vector<RaftContext *> c;
+        for (uint32_t i = 0; i < N; i++) c.push_back(&busy.createContext("old-" + std::to_string(i)));
+        std::atomic<bool> stop{false};
+        std::atomic<int> made{0}, wrong{0};
+        std::atomic<uint64_t> flushes{0};
+        std::thread creator([&] {
+            for (uint32_t i = 0; i < N2; i++) {
+                while (flushes.load() < i / 4u + 1u) std::this_thread::yield();      // keep the two threads interleaved: a few creations per drain
+                RaftContext &x = busy.createContext("new-" + std::to_string(i));
+                if (busy.getContext("new-" + std::to_string(i)) != &x || busy.globalGid("new-" + std::to_string(i)) != N + i) wrong++;
+                made++;
+            }
+            stop = true;
+        });
+        std::mt19937_64 rng(7);
+        uint64_t drained = 0;
+        while (!stop) {
+            for (uint32_t i = 0; i < N; i++) if (rng() % 3 == 0) c[i]->onTimeout();
+            for (auto &v : busy.flushAll()) drained += v.size();
+            flushes++;
+        }
+        creator.join();
+        for (uint32_t i = 0; i < N2; i++) if (!busy.getContext("new-" + std::to_string(i))) wrong++;
+        if (made != (int)N2 || wrong != 0 || drained == 0) { fprintf(stderr, "concurrent createContext: made %d of %u, %d wrong, %llu rows drained\n", made.load(), N2, wrong.load(), (unsigned long long)drained); bad = 1; }
     }
     printf("multi-device ok=%d contexts=%u shards=%zu rounds=%d rows=%llu leader_rows=%llu\n", !bad, N, S, rounds, (unsigned long long)rows,
            (unsigned long long)leaders);

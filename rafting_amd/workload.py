@@ -68,6 +68,10 @@ CONFIGS = {
     # BASELINE.json configs[1]: 4 096 RaftContexts x 3 peers, batched AppendEntries quorum (all leader view)
     2: ReplayConfig("config2: 4096 groups x 3 peers, leader-view AppendEntries quorum", 4096, 3, 0xC0FFEE01,
                     leader_frac=1.0, p_higher_term=0.0, p_timeout=0.0, p_vote_req=0.0),
+    # the mirrored follower view of configs[1]: every group a follower of a steady leader, AppendEntries requests with
+    # n in {0, 1, 2, 4} entries (25 % each), prevLogIndex = lastIndex, leaderCommit = lastIndex - U{0..3}
+    "2f": ReplayConfig("config2 (follower view): 4096 groups x 3 peers, AppendEntries requests", 4096, 3, 0xC0FFEE01,
+                       leader_frac=0.0, p_higher_term=0.0, p_timeout=0.0, p_vote_req=0.0),
     # configs[2]: 65 536 x 5, mixed leader/follower roles — the configuration the metric is quoted on
     3: ReplayConfig("config3: 65536 groups x 5 peers, mixed leader/follower roles", 65536, 5, 0xC0FFEE02),
     # configs[3]: 1 M x 5 sharded over 8 GPUs, same mix

@@ -127,3 +127,19 @@ def test_multi_device_manager_matches_a_single_table_on_the_emulation(emulation_
                     os.path.join(host, "stable_store.cpp"), "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
     p = subprocess.run([exe, "48", "3", "120"], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "multi-device ok=1" in p.stdout, p.stdout + p.stderr
+
+
+def test_multi_device_manager_is_race_free_under_thread_sanitizer(emulation_library):
+    """createContext / getContext from one thread while another runs flushAll (the last phase of multi_device_unit.cpp) —
+    the same program built with -fsanitize=thread must finish with `ok=1` and without a single data-race report on the routing table."""
+    exe = os.path.join(ROOT, "build", "devemu_multi_device_unit_tsan")
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-I" + host, "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(host, "multi_device_unit.cpp"), os.path.join(host, "multi_device.cpp"), os.path.join(host, "raft_host.cpp"),
+                        os.path.join(host, "stable_store.cpp"), "-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for g++ here: " + r.stderr[-200:])
+    p = subprocess.run([exe, "48", "3", "40"], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "multi-device ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[-3000:]

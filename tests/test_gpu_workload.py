@@ -12,6 +12,17 @@ from tests.helpers import compare_outcomes, compare_states
 
 pytestmark = pytest.mark.gpu
 
+ROWS = {"format": "wide"}
+
+
+@pytest.fixture(autouse=True, params=["wide", "compact"])
+def rows_format(request):
+    """every replay of this module runs on wide rows (rg_batch_t: step_split_kernel / step_kernel by size) and on compact rows
+    (rg_batch32_t packed by rg_batch32_pack: step32_kernel)"""
+    ROWS["format"] = request.param
+    yield request.param
+    ROWS["format"] = "wide"
+
 
 def _replay(cfg, rounds, batches=2, first=0, count=None):
     gen = workload.ReplayGenerator(cfg, first, count)
@@ -24,11 +35,11 @@ def _replay(cfg, rounds, batches=2, first=0, count=None):
     rows = 0
     for i in range(batches):
         b = gen.next_batch(rounds)
-        db = engine.DeviceBatch(gpu, b)
+        db = engine.DeviceBatch(gpu, b) if ROWS["format"] == "wide" else engine.DeviceBatch32(gpu, b)
         gpu.submit_device(db)
         gpu.sync()
         ref = orc.submit(b)
-        compare_outcomes(ref, db.outcome(), "%s batch %d" % (cfg.name, i))
+        compare_outcomes(ref, db.outcome(), "%s batch %d (%s rows)" % (cfg.name, i, ROWS["format"]))
         db.free()
         hist += np.bincount(ref.status, minlength=256)
         rows += b.rounds * b.count
@@ -48,11 +59,12 @@ def test_config3_with_conflicting_append_entries():
     assert np.array_equal(fin.current_term, gen.term) and np.array_equal(fin.last_index, gen.last) and np.array_equal(fin.commit_index, gen.commit)
 
 
-def test_kernel_choice_follows_batch_size(monkeypatch):
+def test_kernel_choice_follows_batch_size(monkeypatch, rows_format):
     """up to one wavefront of groups per SIMD (65 536 rows on MI355X) a batch is decided by the two-wavefront kernel,
     beyond by the single-wavefront one; RG_SPLIT overrides"""
+    if rows_format == "compact":
+        pytest.skip("compact rows always go to rg::step32_kernel")
     monkeypatch.delenv("RG_SPLIT", raising=False)
-    monkeypatch.delenv("RG_LANES", raising=False)
     t = engine.Table(131072, 5, 0, True)
     assert t.step_kernel(64) == "rg::step_split_kernel" and t.step_kernel(65536) == "rg::step_split_kernel"
     assert t.step_kernel(65537) == "rg::step_kernel" and t.step_kernel() == "rg::step_kernel"
@@ -71,7 +83,7 @@ def test_both_step_kernels_at_full_size(monkeypatch, split):
         assert hist[abi.OK] == rows
 
 
-@pytest.mark.parametrize("number,rounds", [(2, 64), (3, 48), (4, 6), (5, 6)])
+@pytest.mark.parametrize("number,rounds", [(2, 64), ("2f", 64), (3, 48), (4, 6), (5, 6)])
 def test_baseline_config_full_size(number, rounds):
     """configs[1..4] of BASELINE.json at their full group counts (4 096 / 65 536 / 1 M / 1 M churn)."""
     cfg = workload.config(number)

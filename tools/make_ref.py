@@ -904,7 +904,7 @@ def read_lines(path):
 
 def sha_of(lines, a=None, b=None):
     text = "\n".join(lines if a is None else lines[a - 1:b])
-    return hashlib.sha256(text.encode("utf-8")).hexdigest()[:32]
+    return hashlib.sha256(text.encode("utf-8")).hexdigest()          # full-length sha256 (round 2 stored the first 32 hex digits)
 
 
 def apply_substitutions(rel, lines):
