@@ -214,13 +214,23 @@ struct Math {
     template <class A, class B> static typename std::common_type<A, B>::type max(A a, B b) { typedef typename std::common_type<A, B>::type C; return (C)a > (C)b ? (C)a : (C)b; }
     template <class A, class B> static typename std::common_type<A, B>::type min(A a, B b) { typedef typename std::common_type<A, B>::type C; return (C)a < (C)b ? (C)a : (C)b; }
     static double log(double x) { return std::log(x); }
-    static jlong round(double x)         // Math.round(double): floor(x + 0.5), NaN -> 0, saturating
+    // Math.round(double) of Java 7+ (the reference targets 1.8, pom.xml:47-48): floor(x + 1/2) in EXACT arithmetic — not the double
+    // addition of Java 6, which rounds 0.49999999999999994 and the odd integers of [2^52, 2^53) up — saturating, NaN -> 0. Restated from
+    // the specification ("the long closest to the argument, ties rounding to positive infinity") on the bits of the double.
+    static jlong round(double x)
     {
         if (x != x) return 0;
-        double f = std::floor(x + 0.5);
-        if (f >= 9.2233720368547758e18) return INT64_MAX;
-        if (f <= -9.2233720368547758e18) return INT64_MIN;
-        return (jlong)f;
+        uint64_t bits; memcpy(&bits, &x, 8);
+        const int64_t biased = (int64_t)((bits >> 52) & 0x7FF);
+        const int64_t shift = (52 - 1 + 1023) - biased;            // 2^-shift = half an ulp of the significand read as an integer
+        if ((shift & ~(int64_t)63) == 0) {                           // 0 <= shift < 64: |x| in [2^-12, 2^52): the fraction can matter
+            int64_t r = (int64_t)((bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull);
+            if ((int64_t)bits < 0) r = -r;
+            return ((r >> shift) + 1) >> 1;                          // floor(x * 2) -> floor((x + 1/2) * 2) -> floor(x + 1/2)
+        }
+        if (x >= 9.2233720368547758e18) return INT64_MAX;            // (long) x of Java: saturating, and exact for |x| >= 2^52; 0 below 2^-12
+        if (x <= -9.2233720368547758e18) return INT64_MIN;
+        return (jlong)x;
     }
 };
 struct Long {

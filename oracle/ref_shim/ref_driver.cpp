@@ -820,4 +820,38 @@ void ref_major_indices_batch(uint32_t n, int f, const int64_t *match, int64_t *o
     for (uint32_t i = 0; i < n; i++) ref_major_indices(match + (size_t)i * f, f, out + 2 * (size_t)i);
 }
 
+// ---- the java.lang / java.util stand-ins of jrt.hpp, bare (tests/test_ref_parity.py holds them to Python's exact integer model) -----------
+// op: 0 a + b   1 a - b   2 a * b   3 a >>> (b)   4 Long.compare   5 Long.hashCode(a)   6 Math.max   7 Math.min   8 -a   9 (long)(int)a + (int)b as int
+void ref_jrt_long_ops(uint32_t n, int op, const int64_t *a, const int64_t *b, int64_t *out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        const jlong x = a[i], y = b[i];
+        switch (op) {
+        case 0: out[i] = x + y; break;
+        case 1: out[i] = x - y; break;
+        case 2: out[i] = x * y; break;
+        case 3: out[i] = jushr(x, (int)y); break;
+        case 4: out[i] = Long::compare(x, y); break;
+        case 5: out[i] = Long::hashCode(x); break;
+        case 6: out[i] = Math::max(x, y); break;
+        case 7: out[i] = Math::min(x, y); break;
+        case 8: out[i] = -x; break;
+        default: out[i] = (jint)((jint)x + (jint)y); break;
+        }
+    }
+}
+void ref_jrt_int_ops(uint32_t n, int op, const int32_t *a, const int32_t *b, int32_t *out)      // 0 compareUnsigned  1 a >>> b  2 a + b
+{
+    for (uint32_t i = 0; i < n; i++)
+        out[i] = op == 0 ? Integer::compareUnsigned(a[i], b[i]) : op == 1 ? jushr((jint)a[i], (int)b[i]) : (jint)(a[i] + b[i]);
+}
+void ref_jrt_math_round(uint32_t n, const double *x, int64_t *out) { for (uint32_t i = 0; i < n; i++) out[i] = Math::round(x[i]); }
+void ref_jrt_arrays_sort(int64_t *v, uint32_t n)
+{
+    JArr<jlong> a = JArr<jlong>::make((jint)n);
+    for (uint32_t i = 0; i < n; i++) a[(jint)i] = v[i];
+    Arrays::sort(a);
+    for (uint32_t i = 0; i < n; i++) v[i] = a[(jint)i];
+}
+
 }  // extern "C"

@@ -173,3 +173,112 @@ def test_send_side_oracle_vs_reference_code():
         assert np.array_equal(ho, hr), "send heads, round %d" % r
         assert np.array_equal(so, sr), "sends, round %d" % r
         compare_states(canonical_state(ref.read_state()), canonical_state(orc.read_state()), "after replicate %d" % r)
+
+
+# ---- the stand-ins the translated reference stands ON (oracle/ref_shim/jrt.hpp) against Python's exact integers --------------------------
+# a mistake in jrt.hpp would be common-mode with the oracle's author. Java's arithmetic is specified exactly (JLS 15.17-15.19:
+# two's-complement wrap-around, >>> on the low 6 / 5 bits of the count; Math.round = floor(x + 1/2) saturating, NaN -> 0; Long.compare,
+# Long.hashCode, Integer.compareUnsigned and Arrays.sort(long[]) as documented), so each stand-in is held to that specification written
+# with Python's unbounded integers — no C arithmetic on the checking side — on 10^6 inputs including every boundary.
+def _jrt():
+    import ctypes as C
+    L = ref_lib.lib()
+    vp, u32 = C.c_void_p, C.c_uint32
+    L.ref_jrt_long_ops.argtypes = [u32, C.c_int, vp, vp, vp]
+    L.ref_jrt_int_ops.argtypes = [u32, C.c_int, vp, vp, vp]
+    L.ref_jrt_math_round.argtypes = [u32, vp, vp]
+    L.ref_jrt_arrays_sort.argtypes = [vp, u32]
+    for f in (L.ref_jrt_long_ops, L.ref_jrt_int_ops, L.ref_jrt_math_round, L.ref_jrt_arrays_sort):
+        f.restype = None
+    return L
+
+
+def _wrap64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def _wrap32(v):
+    v &= (1 << 32) - 1
+    return v - (1 << 32) if v >> 31 else v
+
+
+def _edge_longs(rng, n):
+    edges = [0, 1, -1, 2, -2, (1 << 31) - 1, 1 << 31, -(1 << 31), (1 << 32) - 1, 1 << 32, (1 << 62), (1 << 63) - 1, -(1 << 63), -(1 << 63) + 1,
+             (1 << 63) - 2, 0x5555555555555555, -0x5555555555555556]
+    vals = [rng.choice(edges) if rng.random() < 0.2 else _wrap64(rng.getrandbits(64) >> rng.choice([0, 0, 8, 33, 50])) * rng.choice([1, -1]) for _ in range(n)]
+    return [_wrap64(v) for v in vals]
+
+
+def test_jrt_long_and_int_arithmetic_is_javas():
+    import random
+    L = _jrt()
+    rng = random.Random(9)
+    n = 125000
+    a, b = _edge_longs(rng, n), _edge_longs(rng, n)
+    A, B = np.array(a, dtype=np.int64), np.array(b, dtype=np.int64)
+    out = np.zeros(n, dtype=np.int64)
+    models = {0: lambda x, y: _wrap64(x + y), 1: lambda x, y: _wrap64(x - y), 2: lambda x, y: _wrap64(x * y),
+              3: lambda x, y: _wrap64((x & ((1 << 64) - 1)) >> (y & 63)), 4: lambda x, y: (x > y) - (x < y),
+              5: lambda x, y: _wrap32((x ^ ((x & ((1 << 64) - 1)) >> 32)) & 0xFFFFFFFF), 6: max, 7: min, 8: lambda x, y: _wrap64(-x),
+              9: lambda x, y: _wrap32(_wrap32(x) + _wrap32(y))}
+    for op, f in models.items():
+        L.ref_jrt_long_ops(n, op, A.ctypes.data, B.ctypes.data, out.ctypes.data)
+        want = [f(x, y) for x, y in zip(a, b)]
+        bad = [i for i in range(n) if int(out[i]) != want[i]]
+        assert not bad, (op, a[bad[0]], b[bad[0]], int(out[bad[0]]), want[bad[0]])
+    ia = np.array([_wrap32(v) for v in a], dtype=np.int32)
+    ib = np.array([_wrap32(v) for v in b], dtype=np.int32)
+    io = np.zeros(n, dtype=np.int32)
+    imodels = {0: lambda x, y: ((x & 0xFFFFFFFF) > (y & 0xFFFFFFFF)) - ((x & 0xFFFFFFFF) < (y & 0xFFFFFFFF)),
+               1: lambda x, y: _wrap32((x & 0xFFFFFFFF) >> (y & 31)), 2: lambda x, y: _wrap32(x + y)}
+    for op, f in imodels.items():
+        L.ref_jrt_int_ops(n, op, ia.ctypes.data, ib.ctypes.data, io.ctypes.data)
+        want = [f(int(x), int(y)) for x, y in zip(ia, ib)]
+        bad = [i for i in range(n) if int(io[i]) != want[i]]
+        assert not bad, (op, int(ia[bad[0]]), int(ib[bad[0]]), int(io[bad[0]]), want[bad[0]])
+
+
+def test_jrt_math_round_is_javas():
+    """Math.round(double) of Java 7+ = floor(x + 1/2) computed EXACTLY, NaN -> 0, saturating (java.lang.Math; Java 6 added in double
+    arithmetic and got 0.49999999999999994 and the odd integers of [2^52, 2^53) wrong — so did jrt.hpp until this test existed; the
+    reference's one call site, Leadership.java:105, cannot produce such an argument). Checked with fractions.Fraction."""
+    import random
+    from fractions import Fraction
+    import math
+    import struct
+    rng = random.Random(10)
+    xs = [0.0, -0.0, 0.5, -0.5, 1.5, -1.5, 2.5, 0.49999999999999994, -0.49999999999999994, 4503599627370495.5, 4503599627370496.5, 9007199254740993.0,
+          9.223372036854775e18, 9.223372036854776e18, -9.223372036854776e18, -9.3e18, 1e300, -1e300, float("inf"), float("-inf"), float("nan")]
+    while len(xs) < 250000:
+        k = rng.random()
+        if k < 0.4:
+            xs.append(math.log(math.e + rng.randrange(0, 1 << 31)))                      # the one call site: Leadership.java:105
+        elif k < 0.6:
+            xs.append(rng.randrange(-(1 << 40), 1 << 40) + rng.choice([0.5, -0.5, 0.25, 0.49999999999999994, 0.5000000000000001]))
+        else:
+            xs.append(struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0])    # any bit pattern
+    X = np.array(xs, dtype=np.float64)
+    out = np.zeros(len(xs), dtype=np.int64)
+    _jrt().ref_jrt_math_round(len(xs), X.ctypes.data, out.ctypes.data)
+    lo, hi = -(1 << 63), (1 << 63) - 1
+
+    def model(x):                        # Java 7+: "the long closest to the argument, ties rounding to positive infinity", saturating
+        if x != x:
+            return 0
+        if x in (float("inf"), float("-inf")):
+            return hi if x > 0 else lo
+        return max(lo, min(hi, math.floor(Fraction(x) + Fraction(1, 2))))         # exact rational arithmetic
+    for i, x in enumerate(xs):
+        assert int(out[i]) == model(x), (x, int(out[i]), model(x))
+
+
+def test_jrt_arrays_sort_is_an_ascending_permutation():
+    import random
+    rng = random.Random(11)
+    for _ in range(2000):
+        n = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 50, 500])
+        v = _edge_longs(rng, n)
+        a = np.array(v, dtype=np.int64)
+        _jrt().ref_jrt_arrays_sort(a.ctypes.data, n)
+        assert a.tolist() == sorted(v)
