@@ -88,10 +88,14 @@ struct Out {
     void boxed_long(int64_t v) { varint(ID_LONG + 2); varlong_zz(v); }                                                      // R2 + R5 (no R4 marker)
 };
 
+enum Klass { K_NULL = 0, K_OTHER, K_OBJECT_ARRAY, K_NODE_ID, K_ENTRY_ARRAY, K_ROCKS_ENTRY, K_RESPONSE, K_REGISTERED };
+
+// No allocation on the decode path: class names and the host name are compared where they lie in the body.
 struct In {
     const uint8_t *p, *end;
     bool ok = true;
-    std::vector<std::string> names;
+    Klass names[8];                                          // nameId -> class, in order of first appearance (R2)
+    uint32_t n_names = 0, registered = 0;
     explicit In(const char *s, size_t n) : p(reinterpret_cast<const uint8_t *>(s)), end(p + n) {}
     uint8_t u8() { if (p >= end) { ok = false; return 0; } return *p++; }
     uint32_t varint()
@@ -110,40 +114,62 @@ struct In {
     done:
         return (int64_t)((u >> 1) ^ (~(u & 1) + 1));
     }
-    bool string(std::string &s)                                                                                             // R3 (never null here)
+    // R3 (never null here): the characters of the string as a span of the body. ASCII form: `len` bytes, the last one with bit 7 set
+    // (`ascii` = true); length-prefixed form: `len` bytes of UTF-8
+    bool string_span(const uint8_t *&at, size_t &len, bool &ascii)
     {
-        s.clear();
         if (p >= end) { ok = false; return false; }
         const uint8_t b = *p;
-        if (!(b & 0x80)) {                                   // ASCII run ending at the first byte with bit 7 set
-            while (true) { const uint8_t c = u8(); if (!ok) return false; s.push_back((char)(c & 0x7F)); if (c & 0x80) return true; }
+        if (!(b & 0x80)) {
+            at = p;
+            while (p < end && !(*p & 0x80)) p++;
+            if (p >= end) { ok = false; return false; }
+            p++;
+            len = (size_t)(p - at); ascii = true;
+            return true;
         }
         p++;
         uint32_t v = b & 0x3F;                               // writeUtf8Length
         if (b & 0x40) { int shift = 6; while (true) { const uint8_t c = u8(); if (!ok) return false; v |= (uint32_t)(c & 0x7F) << shift; if (!(c & 0x80)) break; shift += 7; if (shift > 34) { ok = false; return false; } } }
         if (v == 0) { ok = false; return false; }            // null
+        at = p;
         for (uint32_t i = 1; i < v; i++) {                   // v - 1 chars as UTF-8
             const uint8_t c = u8();
             if (!ok) return false;
-            s.push_back((char)c);
-            if (c >= 0xE0) { s.push_back((char)u8()); s.push_back((char)u8()); }
-            else if (c >= 0xC0) s.push_back((char)u8());
+            if (c >= 0xE0) { u8(); u8(); } else if (c >= 0xC0) u8();
         }
+        len = (size_t)(p - at); ascii = false;
         return ok;
     }
-    // R2: 0 = null, 1 = by name (returned through `name`), else registered id + 2
-    uint32_t klass(std::string &name)
+    static bool same(const uint8_t *at, size_t len, bool ascii, const char *want, size_t wlen)
+    {
+        if (len != wlen || len == 0) return false;
+        if (!ascii) return memcmp(at, want, len) == 0;
+        return memcmp(at, want, len - 1) == 0 && (uint8_t)(at[len - 1] & 0x7F) == (uint8_t)want[len - 1];
+    }
+    // R2: which class follows
+    Klass klass()
     {
         const uint32_t c = varint();
-        if (c != 1) return c;
+        if (c == 0) return K_NULL;
+        if (c != 1) { registered = c - 2; return K_REGISTERED; }
         const uint32_t id = varint();
-        if (id < names.size()) { name = names[id]; return 1; }
-        if (id != names.size() || !string(name)) { ok = false; return 1; }
-        names.push_back(name);
-        return 1;
+        if (id < n_names) return names[id];
+        const uint8_t *at; size_t len; bool ascii;
+        if (id != n_names || n_names == 8 || !string_span(at, len, ascii)) { ok = false; return K_OTHER; }
+        Klass k = K_OTHER;
+#define RG_KRYO_NAME(cst, val) if (same(at, len, ascii, cst, sizeof(cst) - 1)) k = val
+        RG_KRYO_NAME("[Ljava.lang.Object;", K_OBJECT_ARRAY);
+        else RG_KRYO_NAME("io.lubricant.consensus.raft.transport.event.NodeID", K_NODE_ID);
+        else RG_KRYO_NAME("[Lio.lubricant.consensus.raft.command.RaftLog$Entry;", K_ENTRY_ARRAY);
+        else RG_KRYO_NAME("io.lubricant.consensus.raft.command.storage.RocksEntry", K_ROCKS_ENTRY);
+        else RG_KRYO_NAME("io.lubricant.consensus.raft.RaftResponse", K_RESPONSE);
+#undef RG_KRYO_NAME
+        names[n_names++] = k;
+        return k;
     }
     bool first_occurrence() { if (varint() != 1) { ok = false; return false; } return ok; }                                  // R4: NOT_NULL, not a back-reference
-    bool boxed_long(int64_t &v) { std::string nm; if (klass(nm) != ID_LONG + 2) { ok = false; return false; } v = varlong_zz(); return ok; }
+    bool boxed_long(int64_t &v) { if (klass() != K_REGISTERED || registered != ID_LONG) { ok = false; return false; } v = varlong_zz(); return ok; }
 };
 
 }  // namespace
@@ -188,26 +214,27 @@ void KryoBodyCodec::encode_response(const Response &in, std::string &body) const
 bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Request &out) const
 {
     In r(body, len);
-    std::string nm, host;
     out.leader_commit = 0;
     out.entry_terms.clear();
     out.node = RG_NO_NODE;
-    if (r.klass(nm) != 1 || nm != N_OBJECT_ARRAY || !r.first_occurrence()) return false;
+    if (r.klass() != K_OBJECT_ARRAY || !r.first_occurrence()) return false;
     const uint32_t n1 = r.varint();
     const bool ae = m == M_APPEND_ENTRIES;
     if (!r.ok || n1 != (ae ? 7u : 5u)) return false;                               // NettyNode.prepareLocalInvocation: params.length != 6 / 4 throws
     if (!r.boxed_long(out.term)) return false;
-    if (r.klass(nm) != 1 || nm != N_NODE_ID || !r.first_occurrence()) return false;
-    if (!r.first_occurrence() || !r.string(host)) return false;
+    if (r.klass() != K_NODE_ID || !r.first_occurrence()) return false;
+    const uint8_t *host; size_t host_len; bool ascii;
+    if (!r.first_occurrence() || !r.string_span(host, host_len, ascii)) return false;
     const int32_t port = r.varint_zz();
-    for (size_t i = 0; i < nodes_.size(); i++) if (nodes_[i].port == port && nodes_[i].hostname == host) out.node = (int32_t)i;
+    for (size_t i = 0; i < nodes_.size(); i++)
+        if (nodes_[i].port == port && In::same(host, host_len, ascii, nodes_[i].hostname.data(), nodes_[i].hostname.size())) out.node = (int32_t)i;
     if (!r.boxed_long(out.x) || !r.boxed_long(out.y)) return false;
     if (ae) {
-        if (r.klass(nm) != 1 || nm != N_ENTRY_ARRAY || !r.first_occurrence()) return false;
+        if (r.klass() != K_ENTRY_ARRAY || !r.first_occurrence()) return false;
         const uint32_t e1 = r.varint();
         if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p)) return false;
         for (uint32_t k = 0; k + 1 < e1; k++) {
-            if (r.klass(nm) != 1 || nm != N_ROCKS_ENTRY || !r.first_occurrence()) return false;
+            if (r.klass() != K_ROCKS_ENTRY || !r.first_occurrence()) return false;
             if (!r.first_occurrence()) return false;                               // data (never null: RocksLog.get builds entries from stored values)
             const uint32_t d1 = r.varint();
             if (!r.ok || d1 == 0 || (size_t)(d1 - 1) > (size_t)(r.end - r.p)) return false;
@@ -224,8 +251,7 @@ bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Reque
 bool KryoBodyCodec::decode_response(const char *body, size_t len, Response &out) const
 {
     In r(body, len);
-    std::string nm;
-    if (r.klass(nm) != 1 || nm != N_RESPONSE || !r.first_occurrence()) return false;
+    if (r.klass() != K_RESPONSE || !r.first_occurrence()) return false;
     out.success = r.u8() != 0;
     out.term = r.varlong_zz();
     return r.ok && r.p == r.end;

@@ -259,6 +259,6 @@ def test_zero_copy_stream_path_decodes_every_frame(tmp_path):
     checks that every frame of a 200 000-frame stream, fed in 64 KiB reads, comes out as a row)."""
     exe = str(tmp_path / "wire_bench")
     host = os.path.join(ROOT, "rafting_amd", "host")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(host, "wire_bench.cpp"), os.path.join(host, "wire.cpp")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(host, "wire_bench.cpp"), os.path.join(host, "wire.cpp"), os.path.join(host, "kryo_body.cpp")], check=True)
     p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "split+rows 200000 rows" in p.stdout, p.stdout + p.stderr
