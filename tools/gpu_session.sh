@@ -44,6 +44,11 @@ for step in "$@"; do
         for L in rafting_amd/libraftgpu_s2.so rafting_amd/libraftgpu.so; do
           RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/ab3.err | tee -a $OUT/ab3.jsonl | line "c5-65536 $L"
           RG_LIB=$(pwd)/$L $B --steps 10 --warmup 2 --override "leader_frac=0.0;p_timeout=0.0;p_vote_req=0.0" 2>>$OUT/ab3.err | tee -a $OUT/ab3.jsonl | line "followers $L"; done ;;
+    el) for i in 1 2; do for L in ${LIBS}; do      # LIBS="libraftgpu.so libraftgpu_x.so ..." (file names under rafting_amd/)
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c3 $L"; done; done
+        for L in ${LIBS}; do
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c5-65536 $L"
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 4 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c4-131072 $L"; done ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
     *) echo "unknown step $step" ;;
   esac

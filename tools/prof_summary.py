@@ -28,7 +28,7 @@ def main(out):
                 acc[name][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
             lines.append("== counters (%s)" % os.path.relpath(f, out))
             for name, ctrs in acc.items():
-                if "step_kernel" not in name and "step_split_kernel" not in name:
+                if not any(k in name for k in ("step_kernel", "step_split_kernel", "step32_kernel")):
                     continue
                 lines.append("  %s" % name[:90])
                 for c, vals in sorted(ctrs.items()):
