@@ -2,7 +2,7 @@
 # rocprofv3 passes for the step kernel (run on the GPU box, from the repo root).
 #   tools/prof.sh <tag> [bench args...]
 # Writes gpurun_out/prof_<tag>/{trace,pmc1,pmc2,pmc3,pmc4}/... ; counter passes use --pmc only
-# (never combined with trace domains other than the kernel trace needed to name dispatches).
+# (never combined with trace domains other than the kernel trace needed to name dispatches). LIGHT=1: kernel trace + the two HBM byte passes only.
 set -u
 TAG=$1; shift
 ROOT=$(pwd)
@@ -11,10 +11,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --no-pcie --steps 4 --warmup 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
+if [ -z "${LIGHT:-}" ]; then
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc1 -o p -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU --output-format csv -d $OUT/pmc2 -o p -- $BENCH > $OUT/pmc2.log 2>&1
+fi
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o p -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o p -- $BENCH > $OUT/pmc4.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc5 -o p -- $BENCH > $OUT/pmc5.log 2>&1
+[ -z "${LIGHT:-}" ] && rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc5 -o p -- $BENCH > $OUT/pmc5.log 2>&1
 cd $ROOT
 python tools/prof_summary.py $OUT
