@@ -286,7 +286,7 @@ def main():
         # passes, gfx950 x2 fetch correction applied; tools/prof.sh writes profiles/traffic.json) — quoted only when the entry
         # describes this very workload, kernel and library build
         traffic = traffic_src = None
-        kernel_name = "%s<%d,false>" % (table.step_kernel() if args.wide_rows else table.step_kernel32(), F)
+        kernel_name = "%s<%d,false>" % (table.step_kernel() if args.wide_rows else "rg::step32_kernel", F)
         try:
             for tr in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]:
                 if (tr["config"], tr["groups_per_gpu"], tr["rounds"], tr["kernel"]) == (args.config, gpg, args.rounds, kernel_name) \

@@ -57,9 +57,8 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      4     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
-                                     3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows
-                                     4: rg_step_kernel32 */
+#define RG_ABI_VERSION      3     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
+                                     3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -346,11 +345,8 @@ int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, 
 int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
  * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel";
- * compact batches (rg_submit32, rg_submit_async_packed): rg_step_kernel32 — "rg::step32x_kernel" (two deciding wavefronts and an I/O
- * wavefront per 64 groups: the groups that lead are decided by one, all others by the other) while the batch has at most one workgroup per
- * pair of SIMDs, "rg::step32_kernel" (one deciding wavefront) beyond. The choice never changes a result. */
+ * compact batches (rg_submit32, rg_submit_async_packed) are always decided by "rg::step32_kernel" */
 const char *rg_step_kernel(rg_table_t *t, uint32_t count);
-const char *rg_step_kernel32(rg_table_t *t, uint32_t count);
 
 /* ---- N1: the leader's send side ---------------------------------------------------------------- */
 /* Leader.replicateLog (member/Leader.java:142-245) for many leader groups at once: WHAT to send to each follower —

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 3
 MIN_CLUSTER, MAX_CLUSTER = 2, 7
 TERM_RUNS = 4
 NO_NODE = -1

@@ -58,7 +58,6 @@ struct rg_table {
     int force_wide = 0;                         // RG_FORCE_WIDE=1: the compact-format kernel skips its 32-bit body (differential tests)
     Staging st_abcd32, st_terms32;
     int lanes = -1;                             // -1: pick per launch; 0: split kernel; 64: single-wavefront kernel (RG_SPLIT env forces one)
-    int dual = -1;                              // compact rows: -1: pick per launch; 0: step32_kernel; 1: step32x_kernel (RG_DUAL env forces one)
     uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
     bool timing = false;
@@ -220,7 +219,6 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     }
     t->lanes = -1;
     if (const char *e = getenv("RG_SPLIT")) t->lanes = atoi(e) != 0 ? 0 : 64;   // force either kernel
-    if (const char *e = getenv("RG_DUAL")) t->dual = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("RG_FAST")) t->fast_paths = atoi(e) != 0;
     if (const char *e = getenv("RG_FORCE_WIDE")) t->force_wide = atoi(e) != 0;
     t->counter_slots = (G + 63) / 64 + 1;       // one slot per workgroup of a dense launch
@@ -264,16 +262,6 @@ static int step_lanes(const rg_table *t, uint32_t count)
     if (t->lanes >= 0) return t->lanes;
     const uint32_t wavefronts = (count + 63u) / 64u;
     return wavefronts <= t->simds ? 0 : 64;
-}
-
-// compact rows: 33 = step32x_kernel (two deciding wavefronts per 64 groups) while a launch has at most one workgroup per pair of SIMDs —
-// the deciding wavefront is then alone on its SIMD and its instruction stream is the launch time; 32 = step32_kernel beyond, where the
-// SIMDs are shared by several workgroups and the shorter total instruction count wins
-static int compact_shape(const rg_table *t, uint32_t count)
-{
-    if (t->dual >= 0) return t->dual ? 33 : 32;
-    const uint32_t workgroups = (count + 63u) / 64u;
-    return workgroups <= t->simds ? 33 : 32;
 }
 
 static bool state_complete(const rg_group_state_t *s)
@@ -433,7 +421,7 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
     // Up to one wavefront of groups per SIMD, a lone deciding wavefront leaves half of its SIMD's issue slots empty:
     // give it an I/O partner (step_split_kernel). With more groups the SIMDs are shared by several deciding
     // wavefronts anyway and the single-wavefront kernel is the faster one.
-    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, p.abcd32 ? compact_shape(t, p.count) : step_lanes(t, p.count), t->stream));
+    HIP_TRY(t, rg::launch_step(p, (int)t->F, sparse, p.abcd32 ? 32 : step_lanes(t, p.count), t->stream));
     if (t->timing) {
         HIP_TRY(t, hipEventRecord(e1, t->stream));
         t->ev_used += 1;
@@ -1030,12 +1018,6 @@ const char *rg_step_kernel(rg_table_t *t, uint32_t count)
 {
     if (!t) return "";
     return step_lanes(t, count) == 0 ? "rg::step_split_kernel" : "rg::step_kernel";
-}
-
-const char *rg_step_kernel32(rg_table_t *t, uint32_t count)
-{
-    if (!t) return "";
-    return compact_shape(t, count) == 33 ? "rg::step32x_kernel" : "rg::step32_kernel";
 }
 
 int rg_sync(rg_table_t *t)

@@ -946,19 +946,11 @@ struct Stepper {
 // NOTE: bool operands are combined with & and | (never && / ||): short-circuit operators are compiled back
 // into exec-mask branches, which is exactly what this tier exists to avoid.
 // hdr: header with HDR_AE_OK / HDR_PEER_OK worked out by the loader; pe0: the term shared by the carried entries (if any)
-// TC: which groups the calling wavefront decides. TC_ALL: every group of its lanes. A workgroup with TWO deciding wavefronts (rg_step.hpp,
-// step32x_kernel) gives the groups that lead to one (TC_LEAD) and all others to the other (TC_FOLLOW); the row classes the other wavefront's
-// groups receive are compiled out here. That is an optimisation only: a row of a compiled-out class is left untouched like any other
-// row that misses a precondition and goes to Stepper::run(), so the result does not depend on who owns a group.
-enum TierClass { TC_ALL = 0, TC_FOLLOW = 1, TC_LEAD = 2 };
-
-template <int F, class V, class PE, int TC = TC_ALL>
+template <int F, class V, class PE>
 __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe, FxT<V> &fx, bool allow, uint32_t hdr, uint32_t aux,
                                       V a, V b, V c, V d, V pe0)
 {
     constexpr bool NARROW = sizeof(V) == 4;
-    constexpr bool FOLLOW_ROWS = TC != TC_LEAD;                      // rows of groups that do not lead: AppendEntries requests, elections
-    constexpr bool LEAD_ROWS = TC != TC_FOLLOW;                      // rows of groups that lead: replication acks, client appends, heartbeat ticks
     const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
     const bool flag = RG_HDR_FLAG(hdr) != 0;
     const uint32_t self = (uint32_t)p.self;
@@ -974,7 +966,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     const V ae_last = contains ? vadd<V>(b, (V)n) : g_last;
     const bool want_commit = contains & (d > g_epoch);
     const V ae_x = vmin<V>(d, ae_last);
-    const bool fa = FOLLOW_ROWS & allow & ((hdr & HDR_AE_OK) != 0) & (role == RG_FOLLOWER) & (a >= g_term) &
+    const bool fa = allow & ((hdr & HDR_AE_OK) != 0) & (role == RG_FOLLOWER) & (a >= g_term) &
                     (refresh | (g_leader == RG_NO_NODE) | (g_leader == (int32_t)slot)) & has_log & (b == g_last) &
                     (b > g_epoch) & !(want_commit & (ae_x < g_commit));
     const bool ae_refresh = fa & refresh;
@@ -984,7 +976,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
 
     // ---- AppendEntries ack at a leader ----------------------------------------------------------
     const bool ack_kind = (kind == RG_EV_AE_ACK) | (kind == RG_EV_IS_ACK);
-    const bool ack_shape = LEAD_ROWS & allow & (kind == RG_EV_AE_ACK) & peer_ok;
+    const bool ack_shape = allow & (kind == RG_EV_AE_ACK) & peer_ok;
     const uint32_t j = ack_shape ? (slot < self ? slot : slot - 1u) : 0u;
     V s_epoch, s_next, s_match;
     int32_t s_rej;
@@ -1003,7 +995,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     const bool major_ok = has_log & (major >= top) & (major <= g_last);     // inside the newest run: present, cached, its term is lt
     const V commit_to = lookup ? (lt == g_term ? major : full) : (V)0;
     const bool do_commit = (commit_to != 0) & (commit_to != g_commit);
-    const bool lead_ok = LEAD_ROWS & (aux == g_repoch) & (role == RG_LEADER) & g_prep;
+    const bool lead_ok = (aux == g_repoch) & (role == RG_LEADER) & g_prep;
     const bool fk = ack_shape & lead_ok & (a <= g_term) &
                     (b == s_epoch) & !s_pend & (c >= s_match) & (flag | (s_match != 0)) & (n_next > b) &
                     (!lookup | major_ok) & !(do_commit & (commit_to < g_commit));
@@ -1012,7 +1004,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     const bool ack_drop = ack_any & (aux != g_repoch);               // AsyncHead aborted: response dropped
 
     // ---- client append at a leader ----------------------------------------------------------------
-    bool fc = LEAD_ROWS & allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
+    bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
     if constexpr (NARROW) fc = fc & ((uint32_t)g_last + n < STATE_LIMIT);     // (n < 2^20: the sum cannot wrap)
     const bool fc_newrun = fc & (lt != g_term);
     const bool fc_prepare = fc & !g_prep;
@@ -1069,7 +1061,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
         {
             const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
             const V T = is_pv ? term1 : g_term;
-            const bool vr_cur = FOLLOW_ROWS & vr_shape & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);     // (currentTerm + 1 wrapped: the general handlers)
+            const bool vr_cur = vr_shape & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);     // (currentTerm + 1 wrapped: the general handlers)
             vr_higher = vr_cur & (a > T);
             vr_grant = vr_cur & (a <= T) & flag;
             vr_win = vr_grant & (g_votes + 1 >= p.majority);
@@ -1086,15 +1078,15 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
         {
             to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
             const bool to_live = to_kind & !to_stale;
-            to_pre = FOLLOW_ROWS & to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
-            to_cand = FOLLOW_ROWS & to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
-            to_lead = LEAD_ROWS & to_live & (role == RG_LEADER);
+            to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
+            to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
+            to_lead = to_live & (role == RG_LEADER);
         }
         // RequestVote / PreVote at a Follower that has a log
         bool vq = false, utd = false, pv_judge = false, rv_new = false, vq_success = false;
         const bool vq_kind = allow & ((kind == RG_EV_RV_REQ) | is_pvq);
         {
-            vq = FOLLOW_ROWS & vq_kind & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
+            vq = vq_kind & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
             utd = (c > lt) | ((c == lt) & (b >= g_last));             // Follower.logUpToDate with a last entry
             pv_judge = vq & is_pvq & (a > g_term) & g_td;             // else failure(currentTerm), no timer touched
             rv_new = vq & !is_pvq & (a > g_term);

@@ -431,9 +431,6 @@ struct SplitLds {
     static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 8,
                             N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16, N_END = N_BAIL + 16;
     static constexpr size_t BYTES = EV32 ? (W_END > N_END ? W_END : N_END) : W_END;
-    // two deciding wavefronts (step32x_kernel): the image of a group that changes hands (seven 16-byte rows per lane) and who owns each lane's group
-    static constexpr int XF_ROWS = 7;
-    static constexpr size_t X_XFER = (BYTES + 15) / 16 * 16, X_OWN = X_XFER + XF_ROWS * BLOCK * 16, X_END = X_OWN + BLOCK * 4;
 };
 
 // The 64-bit body of a two-wavefront workgroup, on wide (EV32 = false) or compact (EV32 = true) rows.
@@ -614,126 +611,102 @@ __device__ __forceinline__ uint32_t decorate_narrow(const StepParams &p, const R
     return (w >= EV_LIMIT) ? (out | KIND_OUT_OF_DOMAIN) : out;
 }
 
-// The I/O wavefront of the 32-bit body (wave 1 of the workgroup).
 template <int F, bool SPARSE>
-__device__ __forceinline__ bool narrow_io(const StepParams &p, unsigned char *smem)
+__device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
     typedef SplitLds<F, true> L;
-    U32x2 (*sh_evh)[BLOCK] = reinterpret_cast<U32x2 (*)[BLOCK]>(smem + L::N_EVH);
-    I32x4 (*sh_evq)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVQ);
-    I32x4 (*sh_o0)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O0);
-    I32x4 (*sh_o1)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O1);
-    // The bail mark: 0, 1 (the state load left the domain) or r + 2 (round r did). Written by a deciding wavefront before a barrier, read by
-    // the others after it — a plain LDS word (a `volatile` generic pointer would become a FLAT load whose vmcnt(0) drains the I/O
-    // wavefront's whole prefetch every round). A deciding wavefront may already be one round further and have written a LATER round's
-    // mark when another wavefront looks: only a mark that is due makes it leave, so all always pass the same number of barriers.
-    uint32_t *sh_bail = reinterpret_cast<uint32_t *>(smem + L::N_BAIL);
-
-    const uint32_t lane = threadIdx.x & (BLOCK - 1);
-    const uint32_t i = blockIdx.x * BLOCK + lane;
-    const bool active = i < p.count;
-    const uint32_t ir = active ? i : p.count - 1u;
-    const uint32_t last_round = p.rounds - 1u;
-
-    auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
-    auto fetch = [&](uint32_t r, Row32 &x) {
-        const size_t row = row_of(r);
-        x.h = nt_load8(reinterpret_cast<const U32x2 *>(p.head) + row);
-        x.q = nt_load16(p.abcd32 + row);
-    };
-    auto publish = [&](uint32_t slot, const Row32 &x) {
-        sh_evh[slot][lane] = U32x2{decorate_narrow(p, x), x.h.y};
-        sh_evq[slot][lane] = x.q;
-    };
-    Tally tally;
-    auto retire = [&](uint32_t r, uint32_t hdr) {
-        const uint32_t slot = r & 1u;
-        const size_t row = (size_t)r * p.count + ir;
-        const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
-        const uint32_t flags_all = (uint32_t)o0.y, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
-        rg_reply_t rep;
-        rep.resp_term = (int64_t)o0.x; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
-        if (active) nt_store16(p.reply + row, rep);
-        const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-        if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)o0.w, (int64_t)o1.x});
-        if (active & ((flags & RG_F_PERSIST) != 0)) {
-            rg_persist_t per;
-            per.term = (int64_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
-            nt_store16(p.persist + row, per);
-        }
-        tally.add(RG_HDR_KIND(hdr), flags, status);
-    };
-    // Rows r+2 .. r+5 are in registers at the top of round r, row k in buf[k & 3]; the loop is unrolled by four so that the indices are
-    // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
-    Row32 buf[4];
-    uint32_t hdr_m1 = 0u, hdr_0, hdr_1;              // headers of rounds r-1, r, r+1 (the tallies need the kind of a retired row)
-    {
-        Row32 e0, e1;
-        fetch(0, e0); fetch(1, e1); fetch(2, buf[2]); fetch(3, buf[3]); fetch(4, buf[0]); fetch(5, buf[1]);
-        publish(0u, e0); publish(1u, e1);
-        hdr_0 = e0.h.x; hdr_1 = e1.h.x;
-    }
-    lds_barrier();                                   // events 0, 1 and the mark of the state load are visible
-    { const uint32_t seen0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(seen0) == 1u) return false; }
-    bool bailed = false;
-    RG_PROBE_BEGIN();
-    for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t r = r0 + (uint32_t)k;
-            if (r >= p.rounds) break;
-            Row32 &x = buf[(k + 2) & 3];
-            publish((r + 2u) & 3u, x);
-            RG_PROBE_MARK(0);
-            if (r > 0) retire(r - 1u, hdr_m1);
-            hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
-            fetch(r + 6u, x);
-            RG_PROBE_MARK(1);
-            lds_barrier();
-            RG_PROBE_MARK(2);
-            const uint32_t seen = *sh_bail;
-            const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
-            if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
-        }
-    }
-    if (bailed) return false;
-    retire(last_round, hdr_m1);
-#ifdef RG_PROBE
-    RG_PROBE_FLUSH(0);
-#else
-    tally.flush(p, lane, active);
-#endif
-    return true;
-}
-
-// A deciding wavefront of the 32-bit body. TC_ALL: the only one (wave 0 of step32_kernel). TC_FOLLOW / TC_LEAD: one of two (waves 0 and 2 of
-// step32x_kernel): both hold a register image per lane, but only the OWNER's is live — the groups that lead belong to the TC_LEAD
-// wavefront, all others to the TC_FOLLOW one — and each runs tier 1 without the row classes of the other's groups, so a round's critical
-// path is the longer of two short instruction streams instead of their sum. A group whose role crosses the line changes hands at the end
-// of that round: the owner writes the image (and whether the group is blocked after a NEED_HOST) to its lane's transfer record and flips
-// the lane's owner mark; the other wavefront finds the mark after the barrier and picks the image up before it looks at the next row.
-// Per-group order — the only order the reference's EventLoop keeps — is untouched: exactly one wavefront decides a group's row in a round.
-template <int F, bool SPARSE, int TC>
-__device__ __forceinline__ bool narrow_decide(const StepParams &p, unsigned char *smem)
-{
-    typedef SplitLds<F, true> L;
-    constexpr bool DUAL = TC != TC_ALL;
-    constexpr uint32_t ME = TC == TC_LEAD ? 1u : 0u;
     I32x4 *sh_rec = reinterpret_cast<I32x4 *>(smem + L::N_REC);
     int32_t *sh_mv = reinterpret_cast<int32_t *>(smem + L::N_MV);
     U32x2 (*sh_evh)[BLOCK] = reinterpret_cast<U32x2 (*)[BLOCK]>(smem + L::N_EVH);
     I32x4 (*sh_evq)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVQ);
     I32x4 (*sh_o0)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O0);
     I32x4 (*sh_o1)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O1);
+    // The bail mark: 0, 1 (the state load left the domain) or r + 2 (round r did). Written by the deciding wavefront before a barrier, read by
+    // the I/O wavefront after it — a plain LDS word (a `volatile` generic pointer would become a FLAT load whose vmcnt(0) drains the I/O
+    // wavefront's whole prefetch every round). The deciding wavefront may already be one round further and have written a LATER round's
+    // mark when the I/O wavefront looks: only a mark that is due makes it leave, so both always pass the same number of barriers.
     uint32_t *sh_bail = reinterpret_cast<uint32_t *>(smem + L::N_BAIL);
-    I32x4 (*sh_xfer)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::X_XFER);     // (DUAL only; the memory exists only in step32x_kernel)
-    uint32_t *sh_own = reinterpret_cast<uint32_t *>(smem + L::X_OWN);
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
+    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
     const uint32_t i = blockIdx.x * BLOCK + lane;
     const bool active = i < p.count;
     const uint32_t ir = active ? i : p.count - 1u;
+    const uint32_t last_round = p.rounds - 1u;
 
+    if (io_wave) {
+        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        auto fetch = [&](uint32_t r, Row32 &x) {
+            const size_t row = row_of(r);
+            x.h = nt_load8(reinterpret_cast<const U32x2 *>(p.head) + row);
+            x.q = nt_load16(p.abcd32 + row);
+        };
+        auto publish = [&](uint32_t slot, const Row32 &x) {
+            sh_evh[slot][lane] = U32x2{decorate_narrow(p, x), x.h.y};
+            sh_evq[slot][lane] = x.q;
+        };
+        Tally tally;
+        auto retire = [&](uint32_t r, uint32_t hdr) {
+            const uint32_t slot = r & 1u;
+            const size_t row = (size_t)r * p.count + ir;
+            const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
+            const uint32_t flags_all = (uint32_t)o0.y, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
+            rg_reply_t rep;
+            rep.resp_term = (int64_t)o0.x; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
+            if (active) nt_store16(p.reply + row, rep);
+            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
+            if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)o0.w, (int64_t)o1.x});
+            if (active & ((flags & RG_F_PERSIST) != 0)) {
+                rg_persist_t per;
+                per.term = (int64_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
+                nt_store16(p.persist + row, per);
+            }
+            tally.add(RG_HDR_KIND(hdr), flags, status);
+        };
+        // Rows r+2 .. r+5 are in registers at the top of round r, row k in buf[k & 3]; the loop is unrolled by four so that the indices are
+        // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
+        Row32 buf[4];
+        uint32_t hdr_m1 = 0u, hdr_0, hdr_1;              // headers of rounds r-1, r, r+1 (the tallies need the kind of a retired row)
+        {
+            Row32 e0, e1;
+            fetch(0, e0); fetch(1, e1); fetch(2, buf[2]); fetch(3, buf[3]); fetch(4, buf[0]); fetch(5, buf[1]);
+            publish(0u, e0); publish(1u, e1);
+            hdr_0 = e0.h.x; hdr_1 = e1.h.x;
+        }
+        lds_barrier();                                   // events 0, 1 and the mark of the state load are visible
+        { const uint32_t seen0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(seen0) == 1u) return false; }
+        bool bailed = false;
+        RG_PROBE_BEGIN();
+        for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t r = r0 + (uint32_t)k;
+                if (r >= p.rounds) break;
+                Row32 &x = buf[(k + 2) & 3];
+                publish((r + 2u) & 3u, x);
+                RG_PROBE_MARK(0);
+                if (r > 0) retire(r - 1u, hdr_m1);
+                hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
+                fetch(r + 6u, x);
+                RG_PROBE_MARK(1);
+                lds_barrier();
+                RG_PROBE_MARK(2);
+                const uint32_t seen = *sh_bail;
+                const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
+                if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
+            }
+        }
+        if (bailed) return false;
+        retire(last_round, hdr_m1);
+#ifdef RG_PROBE
+        RG_PROBE_FLUSH(0);
+#else
+        tally.flush(p, lane, active);
+#endif
+        return true;
+    }
+
+    // ---- the deciding wavefront ----------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     Group32 g;
@@ -745,58 +718,24 @@ __device__ __forceinline__ bool narrow_decide(const StepParams &p, unsigned char
         load_group(p.t, gi, g64);
         in_domain = fits32(g64, EV_LIMIT) & (p.force_wide == 0);
         g = narrow(g64);
-        // (two deciders: both stage the same values into the same LDS words — each needs the verdict, and the table is read through L2)
         in_domain = in_domain & stage_peers<F>(p.t, gi, g.prepared, pe);
     }
-    bool bailed = __builtin_amdgcn_ballot_w64(!in_domain) != 0;        // (two deciders: both reach the same verdict from the same data)
-    bool mine = true;
-    if constexpr (DUAL) mine = (g.role == RG_LEADER) == (TC == TC_LEAD);
-    if (TC != TC_LEAD) {
-        if (lane == 0) *sh_bail = bailed ? 1u : 0u;
-        if constexpr (DUAL) sh_own[lane] = g.role == RG_LEADER ? 1u : 0u;
-    }
+    bool bailed = __builtin_amdgcn_ballot_w64(!in_domain) != 0;
+    if (lane == 0) *sh_bail = bailed ? 1u : 0u;
     const bool FAST = p.fast_paths != 0;
     bool blocked = false;
-    // a group the other deciding wavefront handed over before the last barrier: its image becomes this lane's (own = the lane's owner mark)
-    auto pick_up = [&](uint32_t own) {
-        const bool take = !mine & (own == ME);
-        if (__builtin_amdgcn_ballot_w64(take) != 0) {
-            if (take) {
-                const I32x4 x0 = sh_xfer[0][lane], x1 = sh_xfer[1][lane], x2 = sh_xfer[2][lane], x3 = sh_xfer[3][lane], x4 = sh_xfer[4][lane],
-                            x5 = sh_xfer[5][lane], x6 = sh_xfer[6][lane];
-                g.term = x0.x; g.commit = x0.y; g.epoch_index = x0.z; g.epoch_term = x0.w;
-                g.first = x1.x; g.last = x1.y; g.elected_term = x1.z; g.lt = x1.w;
-                g.s0 = x2.x; g.s1 = x2.y; g.s2 = x2.z; g.s3 = x2.w;
-                g.t0 = x3.x; g.t1 = x3.y; g.t2 = x3.z; g.t3 = x3.w;
-                g.top = x4.x; g.voted_for = x4.y; g.leader = x4.z; g.votes = x4.w;
-                g.role = x5.x; g.rc = x5.y; g.role_epoch = (uint32_t)x5.z; g.elected_epoch = (uint32_t)x5.w;
-                g.pending = (uint32_t)x6.x;
-                const uint32_t fl = (uint32_t)x6.y;
-                g.td = (fl & 1u) != 0; g.prepared = (fl & 2u) != 0; g.log_dirty = (fl & 4u) != 0; g.peers_dirty = (fl & 8u) != 0;
-                blocked = (fl & 16u) != 0;
-                mine = true;
-            }
-        }
-    };
     lds_barrier();
     if (bailed) return false;
     RG_PROBE_BEGIN();
     for (uint32_t r = 0; r < p.rounds; r++) {
         const U32x2 h = sh_evh[r & 3u][lane];
         const I32x4 q = sh_evq[r & 3u][lane];
-        if constexpr (DUAL) {
-            const uint32_t own = sh_own[lane];
-            const uint32_t seen = *sh_bail;
-            const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
-            if ((mark != 0u) & (mark <= r + 1u)) { bailed = true; break; }       // the other deciding wavefront left the domain in round r-1
-            pick_up(own);
-        }
         RG_PROBE_MARK(0);
         const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
-        const bool skip = mine & blocked & (kind != RG_EV_NONE);
+        const bool skip = blocked & (kind != RG_EV_NONE);
         FxT<int32_t> fx{0u, RG_OK, 0, 0};
-        const bool done = tier1<F, int32_t, PeersNarrow<F>, TC>(p, g, pe, fx, FAST & !skip & mine, hdr, aux, q.x, q.y, q.z, q.w, (int32_t)aux);
-        const bool slow = !done & !skip & mine;
+        const bool done = tier1<F, int32_t, PeersNarrow<F>>(p, g, pe, fx, FAST & !skip, hdr, aux, q.x, q.y, q.z, q.w, (int32_t)aux);
+        const bool slow = !done & !skip;
         if (skip) fx = FxT<int32_t>{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
         RG_PROBE_MARK(1);
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
@@ -819,27 +758,8 @@ __device__ __forceinline__ bool narrow_decide(const StepParams &p, unsigned char
         if (status == RG_NEED_HOST) blocked = true;
         const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
         const uint32_t slot = r & 1u;
-        if (mine) {                                                    // (one decider: every lane)
-            sh_o0[slot][lane] = I32x4{(flags & RG_F_REPLIED) ? fx.resp_term : 0, (int32_t)flags_all, (int32_t)g.role_epoch, g.commit};
-            sh_o1[slot][lane] = I32x4{fx.log_from, g.term, g.voted_for, g.role};
-        }
-        if constexpr (DUAL) {
-            const bool leave = mine & ((g.role == RG_LEADER) != (TC == TC_LEAD));
-            if (__builtin_amdgcn_ballot_w64(leave) != 0) {
-                if (leave) {
-                    sh_xfer[0][lane] = I32x4{g.term, g.commit, g.epoch_index, g.epoch_term};
-                    sh_xfer[1][lane] = I32x4{g.first, g.last, g.elected_term, g.lt};
-                    sh_xfer[2][lane] = I32x4{g.s0, g.s1, g.s2, g.s3};
-                    sh_xfer[3][lane] = I32x4{g.t0, g.t1, g.t2, g.t3};
-                    sh_xfer[4][lane] = I32x4{g.top, g.voted_for, g.leader, g.votes};
-                    sh_xfer[5][lane] = I32x4{g.role, g.rc, (int32_t)g.role_epoch, (int32_t)g.elected_epoch};
-                    sh_xfer[6][lane] = I32x4{(int32_t)g.pending, (int32_t)((g.td ? 1u : 0u) | (g.prepared ? 2u : 0u) | (g.log_dirty ? 4u : 0u) |
-                                                                          (g.peers_dirty ? 8u : 0u) | (blocked ? 16u : 0u)), 0, 0};
-                    sh_own[lane] = 1u - ME;
-                    mine = false;
-                }
-            }
-        }
+        sh_o0[slot][lane] = I32x4{(flags & RG_F_REPLIED) ? fx.resp_term : 0, (int32_t)flags_all, (int32_t)g.role_epoch, g.commit};
+        sh_o1[slot][lane] = I32x4{fx.log_from, g.term, g.voted_for, g.role};
         RG_PROBE_MARK(2);
         lds_barrier();
         RG_PROBE_MARK(3);
@@ -847,17 +767,13 @@ __device__ __forceinline__ bool narrow_decide(const StepParams &p, unsigned char
     }
     if (bailed) return false;
     RG_PROBE_FLUSH(4);
-    if constexpr (DUAL) pick_up(sh_own[lane]);                         // a group that changed hands in the last round is stored by its new owner
-    if (active & mine) {
+    if (active) {
         const Group g64 = widen(g);
         store_group(p.t, gi, g64, pe, F);
     }
     return true;
 }
 
-#ifndef RG_SPINE_TC                 // tools/spine.sh -DRG_SPINE_TC=TC_FOLLOW|TC_LEAD: static instruction counts of step32x_kernel's two deciding wavefronts
-#define RG_SPINE_TC TC_ALL
-#endif
 #ifndef RG_NOTE_FALLBACK            // the host emulation (tests/devemu) counts the workgroups that take the 64-bit body; nothing on the GPU
 #define RG_NOTE_FALLBACK() ((void)0)
 #endif
@@ -870,30 +786,9 @@ template <int F, bool SPARSE, int WAVES>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
-    if (io_wave ? narrow_io<F, SPARSE>(p, smem) : narrow_decide<F, SPARSE, RG_SPINE_TC>(p, smem)) return;
+    if (narrow_body<F, SPARSE>(p, smem)) return;
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
     // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic
-    split_body<F, SPARSE, true>(p, smem);
-}
-
-// Launches of at most one workgroup per pair of SIMDs (65 536 rows on MI355X): the deciding wavefront is alone on its SIMD and its serial
-// instruction stream IS the launch time, while the SIMDs have issue slots to spare (two of these workgroups per pair of SIMDs decide twice
-// the rows in 1.33x the time). So the stream is cut in two: wave 0 decides the groups that do not lead, wave 2 those that lead, wave 1 does
-// the I/O for both (narrow_decide). The 64-bit fallback keeps the two-wavefront protocol; wave 2 only keeps its barriers company.
-template <int F, bool SPARSE>
-__global__ __launch_bounds__(3 * BLOCK) __attribute__((amdgpu_waves_per_eu(3, 8))) void step32x_kernel(const StepParams p)
-{
-    __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::X_END];
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x) / (uint32_t)BLOCK;       // wave-uniform
-    const bool ok = wave == 1u ? narrow_io<F, SPARSE>(p, smem)
-                  : wave == 0u ? narrow_decide<F, SPARSE, TC_FOLLOW>(p, smem) : narrow_decide<F, SPARSE, TC_LEAD>(p, smem);
-    if (ok) return;
-    if (threadIdx.x == 0) RG_NOTE_FALLBACK();
-    if (wave == 2u) {                                  // split_body's barriers: one before round 0, one per round
-        for (uint32_t r = 0; r <= p.rounds; r++) lds_barrier();
-        return;
-    }
     split_body<F, SPARSE, true>(p, smem);
 }
 
@@ -918,15 +813,12 @@ static hipError_t launch_split(const StepParams &p, bool sparse, hipStream_t s)
 }
 
 template <int F>
-static hipError_t launch_compact(const StepParams &p, bool sparse, int shape, hipStream_t s)
+static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s)
 {
     const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
     if (blocks == 0) return hipSuccess;
     const bool many = blocks > 1024u;                    // more than one workgroup per pair of SIMDs on a 256-CU part
-    if (shape == 33) {                                   // two deciding wavefronts
-        if (sparse) hipLaunchKernelGGL((step32x_kernel<F, true>), dim3(blocks), dim3(3 * BLOCK), 0, s, p);
-        else        hipLaunchKernelGGL((step32x_kernel<F, false>), dim3(blocks), dim3(3 * BLOCK), 0, s, p);
-    } else if (sparse) {
+    if (sparse) {
         if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
         else      hipLaunchKernelGGL((step32_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
     } else {
@@ -936,14 +828,14 @@ static hipError_t launch_compact(const StepParams &p, bool sparse, int shape, hi
     return hipGetLastError();
 }
 
-// shape: 0 = step_split_kernel, 64 = step_kernel (wide rows); 32 = step32_kernel, 33 = step32x_kernel (compact rows: p.abcd32 set)
+// shape: 0 = step_split_kernel, 64 = step_kernel (wide rows); 32 = step32_kernel (compact rows: p.abcd32 set)
 template <int F>
 static hipError_t launch_f(const StepParams &p, bool sparse, int shape, hipStream_t s)
 {
     switch (shape) {
     case 0:  return launch_split<F>(p, sparse, s);
     case 64: return launch_single<F>(p, sparse, s);
-    case 32: case 33: return launch_compact<F>(p, sparse, shape, s);
+    case 32: return launch_compact<F>(p, sparse, s);
     default: return hipErrorInvalidValue;
     }
 }

@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_step_kernel32", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -98,8 +98,6 @@ def lib():
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_step_kernel.restype = C.c_char_p
         L.rg_step_kernel.argtypes = [vp, u32]
-        L.rg_step_kernel32.restype = C.c_char_p
-        L.rg_step_kernel32.argtypes = [vp, u32]
         L.rg_timers_configure.argtypes = [vp, C.c_int64, C.c_int64, C.c_uint64]
         L.rg_timers_update.argtypes = [vp, u32, u32, vp, vp, vp, i32]
         L.rg_timers_expired.argtypes = [vp, C.c_int64, vp, u32, C.POINTER(u32), i32]
@@ -445,10 +443,6 @@ class Table:
     def step_kernel(self, count=None):
         """Name of the step kernel that decides a batch with `count` rows per round (default: every group)."""
         return lib().rg_step_kernel(self._h, self.groups if count is None else count).decode()
-
-    def step_kernel32(self, count=None):
-        """which kernel decides a compact batch (rg_submit32 / the packed pipeline) of `count` rows per round"""
-        return lib().rg_step_kernel32(self._h, self.groups if count is None else count).decode()
 
     # N4 timers ------------------------------------------------------------------------------------
     def timers_configure(self, election_ms, heartbeat_ms, seed=0):

@@ -75,13 +75,11 @@ def test_packed_pipeline_formats():
 
 
 # ---- compact rows (rg_batch32_t) through step32_kernel: the 32-bit body, and the 64-bit body it falls back to ------------------------
-@pytest.fixture(params=["narrow", "narrow-one-decider", "forced-wide"])
+@pytest.fixture(params=["narrow", "forced-wide"])
 def compact_route(request, monkeypatch):
     """Table.submit packs every batch that fits (no hints, values < 2^31) and sends it through rg_submit32"""
     if request.param == "forced-wide":
         monkeypatch.setenv("RG_FORCE_WIDE", "1")
-    if request.param == "narrow-one-decider":              # step32_kernel; the others: step32x_kernel (two deciding wavefronts), the library's choice at these sizes
-        monkeypatch.setenv("RG_DUAL", "0")
     T.route_through_compact(monkeypatch)
     return request.param
 

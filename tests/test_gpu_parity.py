@@ -27,20 +27,17 @@ def route_through_compact(monkeypatch):
     monkeypatch.setattr(engine.Table, "submit", submit)
 
 
-@pytest.fixture(autouse=True, params=["split", "single", "compact", "compact-one-decider", "compact-forced-wide"])
+@pytest.fixture(autouse=True, params=["split", "single", "compact", "compact-forced-wide"])
 def step_kernel_variant(request, monkeypatch):
     """Every test of this module runs against every step kernel: `split` = decide + I/O wavefront per 64 groups on wide rows (what the
     library picks up to one wavefront of groups per SIMD), `single` = one wavefront does both (picked beyond that), `compact` = the
-    compact-format kernels as the library picks them (at these sizes step32x_kernel: two deciding wavefronts per 64 groups, the 32-bit body
-    wherever the values allow it), `compact-one-decider` = step32_kernel (what launches beyond one workgroup per pair of SIMDs get,
-    RG_DUAL=0), `compact-forced-wide` = made to take the 64-bit body from the start (RG_FORCE_WIDE=1)."""
+    compact-format kernel (32-bit body wherever the values allow it), `compact-forced-wide` = the same kernel made to take its 64-bit
+    body from the start (RG_FORCE_WIDE=1)."""
     monkeypatch.setenv("RG_SPLIT", "0" if request.param == "single" else "1")
     if request.param.startswith("compact"):
         route_through_compact(monkeypatch)
         if request.param == "compact-forced-wide":
             monkeypatch.setenv("RG_FORCE_WIDE", "1")
-        if request.param == "compact-one-decider":
-            monkeypatch.setenv("RG_DUAL", "0")
 
 
 def mk_gpu(groups, cluster, self_slot, pre_vote):

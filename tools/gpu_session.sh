@@ -49,16 +49,6 @@ for step in "$@"; do
         for L in ${LIBS}; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c5-65536 $L"
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 4 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c4-131072 $L"; done ;;
-    dual) for i in 1 2 3; do for D in 0 1; do
-          RG_DUAL=$D $B --steps 10 --warmup 2 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c3 RG_DUAL=$D"; done; done
-        for D in 0 1; do
-          RG_DUAL=$D $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c5-65536 RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 10 --warmup 2 --config 2 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c2 RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 10 --warmup 2 --config 2f 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c2f RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c3 p_conflict=0.005 RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 10 --warmup 2 --config 4 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c4-131072 RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 20 --warmup 3 --rounds 1 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c3 rounds=1 RG_DUAL=$D"
-          RG_DUAL=$D $B --steps 20 --warmup 3 --rounds 16 2>>$OUT/dual.err | tee -a $OUT/dual.jsonl | line "c3 rounds=16 RG_DUAL=$D"; done ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
     *) echo "unknown step $step" ;;
   esac

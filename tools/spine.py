@@ -7,8 +7,7 @@ start = next(i for i, l in enumerate(L) if l.startswith(k + ':'))
 end = next(i for i in range(start, len(L)) if '.end_amdhsa_kernel' in L[i])
 K = L[start:end]
 isinstr = lambda l: l.startswith('\t') and not l.strip().startswith(';') and not l.strip().startswith('.')
-# the narrow decide loop = the depth-1 loop with the most code in front of its s_barrier (it holds the general handlers)
-hdr = max((i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l), key=lambda i: next((j for j in range(i, len(K)) if 's_barrier' in K[j]), i) - i)
+hdr = next(i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l)          # first depth-1 loop = narrow decide loop
 # the tail block: the first block after hdr that contains two ds_write_b128 followed by s_barrier
 labels = {l.split(':')[0]: i for i, l in enumerate(K) if l.startswith('.LBB')}
 bar = next(i for i in range(hdr, len(K)) if 's_barrier' in K[i])
