@@ -49,6 +49,13 @@ for step in "$@"; do
         for L in ${LIBS}; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 5 --groups-per-gpu 65536 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c5-65536 $L"
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 --config 4 2>>$OUT/el.err | tee -a $OUT/el.jsonl | line "c4-131072 $L"; done ;;
+    aux) for R in 1 4 16 64; do $B --steps 20 --warmup 3 --rounds $R 2>>$OUT/aux.err | tee -a $OUT/rounds.jsonl | line rounds=$R; done
+        $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/aux.err | tee -a $OUT/conflict.jsonl | line p_conflict=0.005
+        timeout 300 build/flush_bench 65536 20 5 > $OUT/flush_bench.txt 2>&1; cat $OUT/flush_bench.txt
+        python tools/bench_replicate.py 1048576 50 > $OUT/bench_repl.json 2>>$OUT/aux.err; cut -c1-300 $OUT/bench_repl.json
+        timeout 120 build/wire_bench > $OUT/wire_bench.txt 2>&1; tail -n 6 $OUT/wire_bench.txt
+        timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 2 $OUT/smoke.txt
+        timeout 400 python tools/soak.py ${SOAK_SECONDS:-200} > $OUT/soak.txt 2>&1; tail -n 3 $OUT/soak.txt ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
     *) echo "unknown step $step" ;;
   esac

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Soak differential fuzz on the GPU box: many seeds x cluster shapes, HIP path vs oracle in lockstep with the hint
-protocol, both with and without the fast-path tier. usage: python tools/soak.py [seconds=240]"""
+protocol, with and without the fast-path tier, through every step kernel in turn: wide rows on the two-wavefront kernel / on the
+single-wavefront kernel, compact rows (rg_submit32: step32_kernel's 32-bit body), compact rows forced onto the 64-bit body.
+usage: python tools/soak.py [seconds=240]"""
 import os
 import sys
 import time
@@ -9,8 +11,19 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from rafting_amd import abi  # noqa: E402
+from rafting_amd import abi, engine  # noqa: E402
 from tests import test_gpu_parity as T  # noqa: E402
+
+WIDE_SUBMIT = engine.Table.submit
+
+
+def compact_submit(self, batch, out=None, fill=0):      # what tests/test_gpu_parity.py::route_through_compact installs
+    if batch.hint is None and abi.batch_fits_32(batch):
+        return self.submit32(batch, out, fill)
+    return WIDE_SUBMIT(self, batch, out, fill)
+
+
+ROUTES = ("split", "compact", "single", "compact-forced-wide")
 
 
 def main():
@@ -18,11 +31,17 @@ def main():
     t0 = time.time()
     seed, runs, rows, misses = 1000, 0, 0, 0
     hist = np.zeros(256, dtype=np.int64)
+    per_route = {}
     shapes = [(3, 0), (3, 2), (5, 0), (5, 3), (2, 0), (4, 1), (6, 2), (7, 6)]
     while time.time() - t0 < budget:
         cluster, self_slot = shapes[runs % len(shapes)]
         pre_vote = (runs // len(shapes)) % 2 == 0
         os.environ["RG_FAST"] = "0" if runs % 5 == 4 else "1"
+        route = ROUTES[(runs // 3) % len(ROUTES)]
+        os.environ["RG_SPLIT"] = "0" if route == "single" else "1"
+        os.environ["RG_FORCE_WIDE"] = "1" if route == "compact-forced-wide" else "0"
+        engine.Table.submit = compact_submit if route.startswith("compact") else WIDE_SUBMIT
+        per_route[route] = per_route.get(route, 0) + 1
         # group counts that are not multiples of the wavefront size exercise the shadow lanes of the tail wavefront
         groups, rounds = ((1024, 150), (1000, 150), (257, 400), (65, 600))[runs % 4]
         _, _, _, h, m, _ = T._lockstep(groups, cluster, self_slot, pre_vote, rounds, seed, allow_miss=True)
@@ -32,7 +51,7 @@ def main():
         runs += 1
         seed += 1
     seen = {int(i): int(c) for i, c in enumerate(hist) if c}
-    print("soak ok: %d runs, %d rows, %d hinted rows, %.0f s; statuses %s" % (runs, rows, misses, time.time() - t0, seen))
+    print("soak ok: %d runs (%s), %d rows, %d hinted rows, %.0f s; statuses %s" % (runs, per_route, rows, misses, time.time() - t0, seen))
 
 
 if __name__ == "__main__":
