@@ -62,6 +62,10 @@ template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
 #define RG_PROBE_FLUSH(base) ((void)0)
 #endif
 
+#ifndef RG_NOTE_SLOW                // the host emulation counts the rows and the wave-rounds that leave tier 1 (tools/tier1_coverage.py); nothing on the GPU
+#define RG_NOTE_SLOW(rows, any) ((void)0)
+#endif
+
 constexpr uint32_t KIND_OUT_OF_DOMAIN = 15u;      // LDS copy of a compact row whose fields leave [0, EV_LIMIT): no event kind has this code
 constexpr uint32_t HDR_SAME_IN = 1u << 9;         // compact rows, LDS / register copy: RG_HDR_SAME_TERM of the wire header (wide rows keep the hint bit here)
 
@@ -738,6 +742,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         const bool slow = !done & !skip;
         if (skip) fx = FxT<int32_t>{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
         RG_PROBE_MARK(1);
+        RG_NOTE_SLOW(slow, lane == 0);
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {

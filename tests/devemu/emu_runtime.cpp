@@ -16,6 +16,12 @@ extern "C" int rg_is_host_emulation() { return 1; }
 // test hook: workgroups of step32_kernel that fell back to the 64-bit body since the last read
 static std::atomic<long> g_fallbacks{0};
 extern "C" void rg_emu_note_fallback() { g_fallbacks.fetch_add(1); }
+static std::atomic<long> g_slow_rows{0}, g_slow_wave_rounds{0}, g_lane_rounds{0};
+extern "C" void rg_emu_note_slow(int slow_row, int wave_round) { g_lane_rounds.fetch_add(1); g_slow_rows.fetch_add(slow_row); g_slow_wave_rounds.fetch_add(wave_round); }
+extern "C" void rg_emu_slow_counts(long *lane_rounds, long *slow_rows, long *slow_wave_rounds)
+{
+    *lane_rounds = g_lane_rounds.exchange(0); *slow_rows = g_slow_rows.exchange(0); *slow_wave_rounds = g_slow_wave_rounds.exchange(0);
+}
 extern "C" long rg_emu_fallbacks(int reset) { return reset ? g_fallbacks.exchange(0) : g_fallbacks.load(); }
 
 namespace hipemu {

@@ -57,6 +57,9 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const ch
 }
 extern "C" void rg_emu_note_fallback();                    // step32_kernel: a workgroup left the 32-bit domain (emu_runtime.cpp counts them)
 #define RG_NOTE_FALLBACK() rg_emu_note_fallback()
+extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kernel's deciding wavefront, per lane and round
+#define RG_NOTE_SLOW(slow, first_lane) do { const unsigned long long any_ = ::hipemu::wave_ballot(slow); /* every lane meets */ \
+                                            rg_emu_note_slow((slow) ? 1 : 0, ((first_lane) && any_ != 0) ? 1 : 0); } while (0)
 #define threadIdx (::hipemu::threadIdx_)
 #define blockIdx (::hipemu::blockIdx_)
 #define blockDim (::hipemu::blockDim_)
