@@ -56,6 +56,10 @@ for step in "$@"; do
         timeout 120 build/wire_bench > $OUT/wire_bench.txt 2>&1; tail -n 6 $OUT/wire_bench.txt
         timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 2 $OUT/smoke.txt
         timeout 400 python tools/soak.py ${SOAK_SECONDS:-200} > $OUT/soak.txt 2>&1; tail -n 3 $OUT/soak.txt ;;
+    final) python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default
+        python -c "import json; d=json.load(open('$OUT/bench_default.json')); r=d['roofline']; print('traffic', r['traffic'], 'hbm_frac_measured', r['hbm_frac_measured'], 'frac', r['frac'])"
+        timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 1 $OUT/smoke.txt
+        timeout 500 python tools/soak.py ${SOAK_SECONDS:-300} > $OUT/soak.txt 2>&1; tail -n 1 $OUT/soak.txt ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
     *) echo "unknown step $step" ;;
   esac
