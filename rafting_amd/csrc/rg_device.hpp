@@ -1055,44 +1055,33 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
         const bool is_pv = kind == RG_EV_PV_REPLY;
         const bool is_pvq = kind == RG_EV_PV_REQ;
         // vote replies
-        bool vr_higher = false, vr_grant = false, vr_win = false, win_rv = false, vr_quiet = false, late_higher = false, late_noop = false,
-             vote_drop = false;
         const bool vr_shape = allow & ((kind == RG_EV_RV_REPLY) | is_pv) & peer_ok;
-        {
-            const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
-            const V T = is_pv ? term1 : g_term;
-            const bool vr_cur = vr_shape & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);     // (currentTerm + 1 wrapped: the general handlers)
-            vr_higher = vr_cur & (a > T);
-            vr_grant = vr_cur & (a <= T) & flag;
-            vr_win = vr_grant & (g_votes + 1 >= p.majority);
-            win_rv = vr_win & !is_pv;
-            vr_quiet = vr_cur & (a <= T) & !vr_win;                   // counted, or refused: nothing else changes
-            const bool late = vr_shape & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
-            late_higher = late & (a > el_term);                       // head.abortRequests(); Follower if that is "better"
-            late_noop = late & (a <= el_term) & (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
-            vote_drop = vr_shape & !cur_epoch & !late;
-        }
+        const bool sender_ok = is_pv ? ((role == RG_FOLLOWER) & g_td) : (role == RG_CANDIDATE);
+        const V T = is_pv ? term1 : g_term;
+        const bool vr_cur = vr_shape & cur_epoch & sender_ok & ((term1 > g_term) | !is_pv);     // (currentTerm + 1 wrapped: the general handlers)
+        const bool vr_higher = vr_cur & (a > T);
+        const bool vr_grant = vr_cur & (a <= T) & flag;
+        const bool vr_win = vr_grant & (g_votes + 1 >= p.majority);
+        const bool win_rv = vr_win & !is_pv;
+        const bool vr_quiet = vr_cur & (a <= T) & !vr_win;            // counted, or refused: nothing else changes
+        const bool late = vr_shape & !is_pv & !cur_epoch & (el_epoch != 0u) & (aux == el_epoch);
+        const bool late_higher = late & (a > el_term);                // head.abortRequests(); Follower if that is "better"
+        const bool late_noop = late & (a <= el_term) & (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
+        const bool vote_drop = vr_shape & !cur_epoch & !late;
         // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
-        bool to_stale = false, to_pre = false, to_cand = false, to_lead = false;
         const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
-        {
-            to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
-            const bool to_live = to_kind & !to_stale;
-            to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
-            to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
-            to_lead = to_live & (role == RG_LEADER);
-        }
+        const bool to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
+        const bool to_live = to_kind & !to_stale;
+        const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);
+        const bool to_cand = to_live & (((role == RG_FOLLOWER) & (p.pre_vote == 0)) | (role == RG_CANDIDATE)) & (term1 > g_term);
+        const bool to_lead = to_live & (role == RG_LEADER);
         // RequestVote / PreVote at a Follower that has a log
-        bool vq = false, utd = false, pv_judge = false, rv_new = false, vq_success = false;
-        const bool vq_kind = allow & ((kind == RG_EV_RV_REQ) | is_pvq);
-        {
-            vq = vq_kind & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
-            utd = (c > lt) | ((c == lt) & (b >= g_last));             // Follower.logUpToDate with a last entry
-            pv_judge = vq & is_pvq & (a > g_term) & g_td;             // else failure(currentTerm), no timer touched
-            rv_new = vq & !is_pvq & (a > g_term);
-            const bool rv_same = vq & !is_pvq & (a == g_term);
-            vq_success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
-        }
+        const bool vq = allow & ((kind == RG_EV_RV_REQ) | is_pvq) & (slot < (uint32_t)p.cluster) & (role == RG_FOLLOWER) & has_log;
+        const bool utd = (c > lt) | ((c == lt) & (b >= g_last));      // Follower.logUpToDate with a last entry
+        const bool pv_judge = vq & is_pvq & (a > g_term) & g_td;      // else failure(currentTerm), no timer touched
+        const bool rv_new = vq & !is_pvq & (a > g_term);
+        const bool rv_same = vq & !is_pvq & (a == g_term);
+        const bool vq_success = (pv_judge & utd) | (rv_same & ((int32_t)slot == g_voted)) | (rv_new & utd);
 
         // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`
         const bool conv_self = vr_win | to_cand;                      // ballot = self
