@@ -591,8 +591,10 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 // ---- the 32-bit body on compact rows ------------------------------------------------------------------------------------------
 // Same protocol as split_body, with everything that crosses LDS half as wide and one round more of slack:
 //   event   r+2 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store into a FOUR-slot ring, written two rounds ahead (the
-//                 I/O wavefront is never the one that is waited for). Reading event r+1 a round early in the deciding wavefront was tried
-//                 and dropped: six more loop-carried registers made the allocator add 53 copies per round (tools/spine.sh: 476 -> 537)
+//                 I/O wavefront is never the one that is waited for). With the register budget of launches up to 65 536 rows (PREFETCH) the
+//                 deciding wavefront reads event r+1 while it decides event r, into a second register set — the round loop is written out
+//                 twice so that the two sets swap roles without a copy (as a rotating set the six registers cost 53 copies per round):
+//                 a round no longer opens with an LDS round trip (same-box A/B 0.0961 -> 0.0940 ms at config 3, profiles/r03m_event_prefetch_ab.jsonl)
 //   outcome r-1 : {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows (two-slot ring)
 // and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O wavefront's
 // stream is two loads per row, issued six rounds ahead of the decision, four rows in registers (the loop is unrolled by four: no copies).
@@ -615,7 +617,7 @@ __device__ __forceinline__ uint32_t decorate_narrow(const StepParams &p, const R
     return (w >= EV_LIMIT) ? (out | KIND_OUT_OF_DOMAIN) : out;
 }
 
-template <int F, bool SPARSE>
+template <int F, bool SPARSE, bool PREFETCH>
 __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
     typedef SplitLds<F, true> L;
@@ -731,9 +733,14 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     lds_barrier();
     if (bailed) return false;
     RG_PROBE_BEGIN();
-    for (uint32_t r = 0; r < p.rounds; r++) {
-        const U32x2 h = sh_evh[r & 3u][lane];
-        const I32x4 q = sh_evq[r & 3u][lane];
+    // One round. The event of round r is in registers (h, q) when the round starts: it was read from the ring a round earlier — it has been
+    // there since round r-2 — so the round does not open with an LDS round trip; this round reads event r+1 into (hn, qn). The two register
+    // sets swap roles every round: the loop is written out twice (no copies).
+    auto round = [&](const uint32_t r, const U32x2 &h, const I32x4 &q, U32x2 &hn, I32x4 &qn) {
+        if constexpr (PREFETCH) {
+            hn = sh_evh[(r + 1u) & 3u][lane];
+            qn = sh_evq[(r + 1u) & 3u][lane];
+        }
         RG_PROBE_MARK(0);
         const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
         const bool skip = blocked & (kind != RG_EV_NONE);
@@ -768,7 +775,23 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         RG_PROBE_MARK(2);
         lds_barrier();
         RG_PROBE_MARK(3);
-        if (bailed) break;
+    };
+    if constexpr (PREFETCH) {
+        U32x2 h0 = sh_evh[0][lane], h1{0u, 0u};
+        I32x4 q0 = sh_evq[0][lane], q1{0, 0, 0, 0};
+        for (uint32_t r = 0; r < p.rounds; r += 2u) {
+            round(r, h0, q0, h1, q1);
+            if (bailed | (r + 1u >= p.rounds)) break;
+            round(r + 1u, h1, q1, h0, q0);
+            if (bailed) break;
+        }
+    } else {                                             // the 128-VGPR budget has no room for a second event: read it where it is used
+        for (uint32_t r = 0; r < p.rounds; r++) {
+            U32x2 h = sh_evh[r & 3u][lane], hn;
+            I32x4 q = sh_evq[r & 3u][lane], qn;
+            round(r, h, q, hn, qn);
+            if (bailed) break;
+        }
     }
     if (bailed) return false;
     RG_PROBE_FLUSH(4);
@@ -791,7 +814,7 @@ template <int F, bool SPARSE, int WAVES>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    if (narrow_body<F, SPARSE>(p, smem)) return;
+    if (narrow_body<F, SPARSE, WAVES == 1>(p, smem)) return;
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
     // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic
     split_body<F, SPARSE, true>(p, smem);
