@@ -56,6 +56,8 @@ for step in "$@"; do
         timeout 120 build/wire_bench > $OUT/wire_bench.txt 2>&1; tail -n 6 $OUT/wire_bench.txt
         timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 2 $OUT/smoke.txt
         timeout 400 python tools/soak.py ${SOAK_SECONDS:-200} > $OUT/soak.txt 2>&1; tail -n 3 $OUT/soak.txt ;;
+    sweep) for R in 1 4 16 64; do $B --steps 20 --warmup 3 --rounds $R 2>>$OUT/aux.err | tee -a $OUT/rounds.jsonl | line rounds=$R; done
+        $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/aux.err | tee -a $OUT/conflict.jsonl | line p_conflict=0.005 ;;
     final) python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default
         python -c "import json; d=json.load(open('$OUT/bench_default.json')); r=d['roofline']; print('traffic', r['traffic'], 'hbm_frac_measured', r['hbm_frac_measured'], 'frac', r['frac'])"
         timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 1 $OUT/smoke.txt
