@@ -1,0 +1,64 @@
+"""Static checks of the compiled gfx950 code of the step kernels (no GPU: hipcc cross-compiles; F = 4 only, ~15 s). They pin properties the
+measurements of DESIGN.md section 6 rest on and that a harmless-looking source change can lose without any test failing:
+  * no FLAT memory instruction in a step kernel — a pointer that lost its address space (e.g. through inline assembly) turns every access
+    into flat_load / flat_store, which also count on lgkmcnt, so the LDS hand-over barrier of the two-wavefront kernels would wait for the
+    whole global prefetch every round (seen in session r03k before it reached the GPU);
+  * no scratch (private segment) in the kernel the bench runs on, and register budgets that keep the occupancy the launch shapes assume;
+  * the deciding wavefront's tier-1 spine stays within its instruction budget (tools/spine.py)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+K32 = "_ZN2rg13step32_kernelILi4ELb0ELi%dEEEvNS_10StepParamsE"
+STEP_KERNELS = [K32 % 1, K32 % 4, "_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE", "_ZN2rg11step_kernelILi4ELb0EEEvNS_10StepParamsE"]
+
+
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    out = str(tmp_path_factory.mktemp("isa") / "rg.s")
+    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-DRG_BUILD_ONLY_F4", "-S",
+                    "--cuda-device-only", "-o", out, os.path.join(ROOT, "rafting_amd", "csrc", "rg_kernels.hip")], check=True, capture_output=True, timeout=600)
+    return out
+
+
+def kernel_text(path, name):
+    lines = open(path).read().split("\n")
+    start = next(i for i, ln in enumerate(lines) if ln.startswith(name + ":"))
+    end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+    return lines[start:end]
+
+
+def descriptor(lines, key):
+    return int(next(re.search(r"(\d+)", ln.split(key)[1]).group(1) for ln in lines if key in ln))
+
+
+@pytest.mark.parametrize("kernel", STEP_KERNELS)
+def test_step_kernels_use_no_flat_memory_instructions(assembly, kernel):
+    flat = [ln.strip() for ln in kernel_text(assembly, kernel) if re.match(r"\s+flat_(load|store|atomic)", ln)]
+    assert not flat, "%s: %d FLAT instructions, e.g. %s" % (kernel, len(flat), flat[:3])
+
+
+def test_register_and_scratch_budgets(assembly):
+    bench = kernel_text(assembly, K32 % 1)                # launches up to 65 536 rows: three wavefronts per SIMD, nothing in scratch
+    assert descriptor(bench, ".amdhsa_private_segment_fixed_size") == 0
+    assert descriptor(bench, ".amdhsa_next_free_vgpr") <= 168
+    shard = kernel_text(assembly, K32 % 4)                # beyond: four wavefronts per SIMD (eight workgroups per CU)
+    assert descriptor(shard, ".amdhsa_next_free_vgpr") <= 128
+    assert descriptor(shard, ".amdhsa_private_segment_fixed_size") <= 32     # (spills of the 64-bit fallback's prologue only)
+    for k in (K32 % 1, K32 % 4):
+        assert descriptor(kernel_text(assembly, k), ".amdhsa_group_segment_fixed_size") <= 20 * 1024       # eight workgroups per CU fit 160 KB
+
+
+def test_tier1_spine_stays_within_its_instruction_budget(assembly):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spine.py"), assembly, K32 % 1], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    spine = int(re.search(r"spine (\d+) instructions", p.stdout).group(1))
+    assert spine <= 500, p.stdout          # about 490 with the election block; every instruction is four cycles of every round
