@@ -262,3 +262,19 @@ def test_zero_copy_stream_path_decodes_every_frame(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(host, "wire_bench.cpp"), os.path.join(host, "wire.cpp"), os.path.join(host, "kryo_body.cpp")], check=True)
     p = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "split+rows 200000 rows" in p.stdout, p.stdout + p.stderr
+
+
+def test_decoders_survive_hostile_bytes_under_sanitizers(tmp_path):
+    """tests/native/wire_fuzz.cpp with ASan + UBSan: random bytes, mutated valid bodies and truncations through both body codecs, garbage through
+    the frame splitter — a peer must not be able to crash the host or make it read out of bounds (the Kryo-format reader parses lengths and
+    class names that come off the wire)."""
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    exe = str(tmp_path / "wire_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I" + host,
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "wire_fuzz.cpp"), os.path.join(host, "wire.cpp"),
+                        os.path.join(host, "kryo_body.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("no sanitizer runtime: " + r.stderr[-200:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = subprocess.run([exe, "300000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "fuzz ok" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
