@@ -168,6 +168,14 @@ struct In {
         names[n_names++] = k;
         return k;
     }
+    // fast path: the next bytes are exactly `tpl` (the body is left where it was when they are not)
+    bool expect(const std::string &tpl)
+    {
+        if ((size_t)(end - p) < tpl.size() || memcmp(p, tpl.data(), tpl.size()) != 0) return false;
+        p += tpl.size();
+        return true;
+    }
+    bool expect_long(int64_t &v) { if (p >= end || *p != ID_LONG + 2) return false; p++; v = varlong_zz(); return ok; }
     bool first_occurrence() { if (varint() != 1) { ok = false; return false; } return ok; }                                  // R4: NOT_NULL, not a back-reference
     bool boxed_long(int64_t &v) { if (klass() != K_REGISTERED || registered != ID_LONG) { ok = false; return false; } v = varlong_zz(); return ok; }
 };
@@ -211,7 +219,8 @@ void KryoBodyCodec::encode_response(const Response &in, std::string &body) const
     w.varlong_zz(in.term);
 }
 
-bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Request &out) const
+// The general reader: any body the rules above allow (class records in any order of first appearance, either string form).
+bool KryoBodyCodec::decode_request_general(Method m, const char *body, size_t len, Request &out) const
 {
     In r(body, len);
     out.leader_commit = 0;
@@ -248,13 +257,104 @@ bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Reque
     return r.ok && r.p == r.end && out.node != RG_NO_NODE;
 }
 
-bool KryoBodyCodec::decode_response(const char *body, size_t len, Response &out) const
+static bool decode_response_general(const char *body, size_t len, Response &out)
 {
     In r(body, len);
     if (r.klass() != K_RESPONSE || !r.first_occurrence()) return false;
     out.success = r.u8() != 0;
     out.term = r.varlong_zz();
     return r.ok && r.p == r.end;
+}
+
+// ---- the fast path -----------------------------------------------------------------------------------------------------------------------
+// What the reference's own encoder produces has ONE shape per method: the class records appear in a fixed order (Object[] = name 0, NodeID = 1,
+// Entry[] = 2, RocksEntry = 3; RaftResponse = 0), names in the ASCII form. Those runs of constant bytes are built once with the writer above
+// and compared with memcmp; only the varints between them are parsed. Any deviation — another order, the length-prefixed string form, a
+// back-reference — leaves the fast path without a verdict and the general reader decides from the start of the body: the fast path accepts
+// a subset of what the general reader accepts, with the same result (tests/test_kryo_cpu.py runs both on every vector and on random bodies).
+namespace {
+
+struct Templates {
+    std::string head_ae, head_rq, node, entries, entry_first, entry_next, response;
+    Templates()
+    {
+        { std::string s; Out w(s); w.class_by_name(N_OBJECT_ARRAY); w.varint(1); const size_t a = s.size(); w.varint(7); head_ae = s;
+          s.resize(a); w.varint(5); head_rq = s; }
+        std::string s;
+        Out w(s);
+        w.class_by_name(N_OBJECT_ARRAY);                     // (name ids as they stand after the head)
+        size_t at = s.size();
+        auto cut = [&](std::string &dst) { dst.assign(s, at, std::string::npos); at = s.size(); };
+        w.class_by_name(N_NODE_ID); w.varint(1); w.varint(1); cut(node);                 // class, first occurrence, hostname's NOT_NULL marker
+        w.class_by_name(N_ENTRY_ARRAY); w.varint(1); cut(entries);
+        w.class_by_name(N_ROCKS_ENTRY); w.varint(1); w.varint(1); cut(entry_first);      // class (by name), first occurrence, data's NOT_NULL marker
+        w.class_by_name(N_ROCKS_ENTRY); w.varint(1); w.varint(1); cut(entry_next);       // class (by id), ...
+        std::string r; Out wr(r); wr.class_by_name(N_RESPONSE); wr.varint(1); response = r;
+    }
+};
+const Templates &templates() { static const Templates t; return t; }
+
+// 1 = decoded, 0 = refused, -1 = not the encoder's shape (ask the general reader)
+int decode_request_fast(const std::vector<std::string> &node_bytes, Method m, const char *body, size_t len, Request &out)
+{
+    const Templates &T = templates();
+    const bool ae = m == M_APPEND_ENTRIES;
+    In r(body, len);
+    out.leader_commit = 0;
+    out.entry_terms.clear();
+    out.node = RG_NO_NODE;
+    if (!r.expect(ae ? T.head_ae : T.head_rq) || !r.expect_long(out.term) || !r.expect(T.node)) return -1;
+    for (size_t i = 0; i < node_bytes.size(); i++)
+        if (r.expect(node_bytes[i])) { out.node = (int32_t)i; break; }
+    if (out.node == RG_NO_NODE) return -1;                   // an unknown node, or a name in the other string form: the general reader says which
+    if (!r.expect_long(out.x) || !r.expect_long(out.y)) return -1;
+    if (ae) {
+        if (!r.expect(T.entries)) return -1;
+        const uint32_t e1 = r.varint();
+        if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p)) return -1;
+        for (uint32_t k = 0; k + 1 < e1; k++) {
+            if (!r.expect(k == 0 ? T.entry_first : T.entry_next)) return -1;
+            const uint32_t d1 = r.varint();
+            if (!r.ok || d1 == 0 || (size_t)(d1 - 1) > (size_t)(r.end - r.p)) return -1;
+            r.p += d1 - 1;
+            const int64_t index = r.varlong_zz(), term = r.varlong_zz();
+            if (!r.ok) return -1;
+            if (index != (int64_t)((uint64_t)out.x + 1u + k)) return 0;
+            out.entry_terms.push_back(term);
+        }
+        if (!r.expect_long(out.leader_commit)) return -1;
+    }
+    return (r.ok && r.p == r.end) ? 1 : -1;
+}
+
+}  // namespace
+
+KryoBodyCodec::KryoBodyCodec(std::vector<Node> nodes) : nodes_(std::move(nodes))
+{
+    for (const Node &n : nodes_) {                           // hostname (R3) + port (zig-zag varint) as the encoder writes them
+        std::string s;
+        Out w(s);
+        w.string(n.hostname);
+        w.varint_zz(n.port);
+        node_bytes_.push_back(s);
+    }
+}
+
+bool KryoBodyCodec::decode_request(Method m, const char *body, size_t len, Request &out) const
+{
+    const int fast = decode_request_fast(node_bytes_, m, body, len, out);
+    return fast >= 0 ? fast == 1 : decode_request_general(m, body, len, out);
+}
+
+bool KryoBodyCodec::decode_response(const char *body, size_t len, Response &out) const
+{
+    In r(body, len);
+    if (r.expect(templates().response) && r.p < r.end) {
+        out.success = *r.p++ != 0;
+        out.term = r.varlong_zz();
+        if (r.ok && r.p == r.end) return true;
+    }
+    return decode_response_general(body, len, out);
 }
 
 }  // namespace wire

@@ -137,16 +137,20 @@ public:
 class KryoBodyCodec : public BodyCodec {
 public:
     struct Node { std::string hostname; int32_t port; };
-    explicit KryoBodyCodec(std::vector<Node> nodes) : nodes_(std::move(nodes)) {}
+    explicit KryoBodyCodec(std::vector<Node> nodes);
     using BodyCodec::decode_request;
     using BodyCodec::decode_response;
     bool decode_request(Method m, const char *body, size_t len, Request &out) const override;
     bool decode_response(const char *body, size_t len, Response &out) const override;
     void encode_request(Method m, const Request &in, std::string &body) const override;
     void encode_response(const Response &in, std::string &body) const override;
+    // decode_request = a fast path for the one byte shape the reference's encoder produces, else this: the reader of everything the format allows
+    // (public so that tests can hold the two to the same answers)
+    bool decode_request_general(Method m, const char *body, size_t len, Request &out) const;
     // a request's entries carry payload bytes the decision rows never see; index_of_first = prevLogIndex + 1 (what Leader.replicateLog ships)
 private:
     std::vector<Node> nodes_;
+    std::vector<std::string> node_bytes_;     // hostname + port of each node as the encoder writes them (the decoder's fast path compares bytes)
 };
 
 // ---- frames -> rows -------------------------------------------------------------------------------------------------

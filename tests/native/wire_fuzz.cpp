@@ -30,6 +30,15 @@ int main(int argc, char **argv) {
         // exact-size heap copy so that ASan sees any over-read
         std::vector<char> buf(body.begin(), body.end());
         bool a = c.decode_request(m, buf.data(), buf.size(), scratch);
+        if (&c == &kryo) {                                   // the fast path must answer exactly like the general reader
+            Request ref;
+            const bool g = kryo.decode_request_general(m, buf.data(), buf.size(), ref);
+            if (g != a || (g && (ref.term != scratch.term || ref.node != scratch.node || ref.x != scratch.x || ref.y != scratch.y ||
+                                 ref.leader_commit != scratch.leader_commit || ref.entry_terms != scratch.entry_terms))) {
+                printf("fast path and general reader disagree on input %d\n", iter);
+                return 1;
+            }
+        }
         bool b = c.decode_response(buf.data(), buf.size(), rsp);
         (a || b) ? ok++ : bad++;
     }
