@@ -5,6 +5,9 @@
  *   rw_encode_frame    EventCodec.FrameEncoder.encode      transport/EventCodec.java:169-196
  *   rw_rows_add_frame  NettyCluster.on(PingEvent/PongEvent) + NettyNode.parseContextId / prepareLocalInvocation
  *                                                          transport/NettyCluster.java:59-105, transport/NettyNode.java:93-158
+ *   rw_ingress_*       the same for MANY connections and contexts at once, laid out as the multi-round batch of the step kernel; with the
+ *                      contextId map (context/ContextManager.java:41), the invocation table (transport/rpc/AsyncService.java:18-24,91-104)
+ *                      and the reply frames (transport/NettyCluster.java:75-90)
  * The BODY of a frame is Kryo 4.0.2 (third party, a JVM library that is absent here). rafting_amd/host/kryo_body.cpp restates the part of its
  * byte format these bodies use (KryoBodyCodec; rw_kryo_* below) — UNVERIFIED AGAINST A JVM, see tests/golden/kryo_bodies.json and
  * INTEGRATION.md. FixedBodyCodec (rw_fixed_*, rw_rows_add_frame) is a fixed-layout codec for tests only.
@@ -60,6 +63,56 @@ int rw_rows_add_frame(uint8_t type, int32_t sequence, const char *head, size_t h
                       const char *const *ctx_ids, uint32_t n_ctx, uint32_t pending_role_epoch, int64_t pending_epoch_at_send,
                       int64_t pending_last_index_sent, rg_ev_head_t *head_out, rg_ev_pair_t *ab, rg_ev_pair_t *cd, uint32_t *gid,
                       int64_t *entry_terms, size_t max_rows, size_t max_terms, size_t *rows, size_t *terms);
+
+/* ---- many connections -> ONE multi-round compact batch (rafting_amd/host/ingress.hpp) -----------------------------------------------
+ * What NettyCluster.on(PingEvent / PongEvent) -> context.eventLoop().execute(...) does for one context at a time
+ * (transport/NettyCluster.java:59-105, support/EventLoopGroup.java:32-46,77-80), for all contexts of a table: every decoded RPC becomes the
+ * next row of ITS group — cell [k][gid] of a dense [round][group] rg_batch32_t for the k-th row a batch holds for that group — so the batch
+ * goes to rg_submit32 / rg_submit_async_packed as it stands. Rows of one connection keep their order per group; rows of different
+ * connections interleave in arrival order. Rows beyond `max_rounds` for a group, or behind a row the compact format cannot express, wait on
+ * their connection for the next batch.
+ *   threads   rw_ingress_feed: one thread per connection at a time, any number of connections at once (a row costs one relaxed fetch_add on
+ *             its group's counter). Everything else: the flush thread.
+ *   memory    head / abcd / entry_terms of the two banks are the CALLER's (page-locked memory from rg_host_alloc in a deployment),
+ *             head and abcd [max_rounds * groups], entry_terms [entry_cap] each.
+ * nodes: "host:port,..." in peer-slot order for Kryo-format bodies (rw_kryo_*), NULL for the fixed-layout test codec. */
+typedef struct rw_ingress rw_ingress_t;
+rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conns, const char *nodes,
+                             rg_ev_head_t *head0, rg_ev_quad32_t *abcd0, int32_t *entry_terms0,
+                             rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap);
+void     rw_ingress_free(rw_ingress_t *g);
+/* ContextManager.createContext: contextId -> group id (1 ok, 0 refused: duplicate id / gid, gid out of range, id longer than 128 bytes) */
+int      rw_ingress_add_context(rw_ingress_t *g, const char *id, size_t len, uint32_t gid);
+int      rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot);
+/* what the host remembers when it SENDS request `sequence` of `method` for group `gid` on `conn` (AsyncService.invoke,
+ * transport/rpc/AsyncService.java:91-104): the response row needs it (RG_EV_AE_ACK b, c and aux) */
+int      rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method, uint32_t gid, uint32_t role_epoch, int64_t epoch_at_send,
+                         int64_t last_index_sent);
+/* bytes as they arrive: rows queued by this call, or -1 once the connection broke the frame grammar */
+int      rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n);
+/* a row that does not come off the wire (RG_EV_TIMEOUT, RG_EV_CLIENT_APPEND, RG_EV_LOG_FLUSH, an RG_EV_IS_REQ released with the host's verdict),
+ * queued like a row of connection `conn` — give local sources connection numbers of their own. reply_conn = UINT32_MAX: nobody waits for a
+ * reply, else the RG_F_REPLIED answer is emitted as the response to (reply_conn, reply_sequence). Not for RG_EV_AE_REQ (entries travel in frames). */
+int      rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
+                            uint32_t reply_conn, int32_t reply_sequence);
+/* close the batch being filled: *batch describes it (dense, gid NULL; rounds may be 0), *rows = cells that hold an event, *wide = rows that
+ * had to stay out of the compact format (read them with rw_ingress_wide_row, decide them with one sparse rg_submit AFTER this batch).
+ * Returns the bank (0 / 1) the batch lies in. The batch stays valid until rw_ingress_recycle(bank). */
+int      rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32_t *wide);
+int      rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms,
+                             uint32_t max_terms, uint32_t *reply_conn, int32_t *reply_sequence);
+                             /* ascending gid; returns the row's entry count, -1 if it exceeds max_terms; reply_conn UINT32_MAX = a response row */
+/* who sent the request in cell `cell` (= round * groups + gid) of that bank's batch: 1 and (*conn, *sequence), or 0 for a response row */
+int      rw_ingress_origin(const rw_ingress_t *g, int bank, uint64_t cell, uint32_t *conn, int32_t *sequence);
+/* the PongEvent frames of cells [cell_begin, cell_end) whose reply carries RG_F_REPLIED, for connection `conn`, into out[cap]: returns the
+ * bytes written, or the size needed (nothing written) when that exceeds cap. Persist the batch's RG_F_PERSIST rows BEFORE releasing these
+ * bytes (member/RaftMember.java:25). */
+size_t   rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn,
+                         uint8_t *out, size_t cap);
+/* the batch of that bank is done with: wipe the cells it used (may run beside rw_ingress_feed) */
+int      rw_ingress_recycle(rw_ingress_t *g, int bank);
+uint64_t rw_ingress_refused(const rw_ingress_t *g);      /* frames that were no decision row: unknown context / method, undecodable body, unmatched response */
+uint64_t rw_ingress_held(const rw_ingress_t *g);         /* rows waiting on their connections for the next batch */
 
 #ifdef __cplusplus
 }

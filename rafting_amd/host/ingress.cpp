@@ -1,0 +1,324 @@
+// ingress.cpp — see ingress.hpp.
+#include "ingress.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace rafting {
+namespace wire {
+
+// ---- ContextIndex ---------------------------------------------------------------------------------------------------------
+static uint32_t pow2_at_least(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+ContextIndex::ContextIndex(uint32_t capacity)
+    : mask_(pow2_at_least(capacity < 8 ? 16 : capacity * 2) - 1), slot_(new std::atomic<uint64_t>[mask_ + 1]), key_(new Key[capacity]), capacity_(capacity)
+{
+    for (uint32_t i = 0; i <= mask_; i++) slot_[i].store(0, std::memory_order_relaxed);
+    for (uint32_t g = 0; g < capacity; g++) key_[g].len = 0;
+}
+
+uint64_t ContextIndex::hash(const char *s, size_t n)
+{
+    // 8 bytes at a time, multiply-xorshift (the ids are short ASCII names; what matters is that "ctx123" and "ctx124" part ways)
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+    while (n >= 8) { uint64_t w; memcpy(&w, s, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; s += 8; n -= 8; }
+    uint64_t w = 0;
+    memcpy(&w, s, n);
+    h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+    return h ^ (h >> 29);
+}
+
+bool ContextIndex::insert(const char *id, size_t len, uint32_t gid)
+{
+    if (gid >= capacity_ || len == 0 || len >= KEY_BYTES) return false;
+    std::lock_guard<std::mutex> lk(mu_);
+    if (key_[gid].len != 0) return false;
+    const uint64_t h = hash(id, len);
+    uint32_t at = (uint32_t)h & mask_;
+    for (;; at = (at + 1) & mask_) {
+        const uint64_t v = slot_[at].load(std::memory_order_relaxed);
+        if (v == 0) break;
+        const Key &k = key_[(uint32_t)v - 1];
+        if ((v >> 32) == (h >> 32) && k.len == len && memcmp(k.bytes, id, len) == 0) return false;
+    }
+    memcpy(key_[gid].bytes, id, len);
+    key_[gid].len = (uint8_t)len;
+    slot_[at].store((uint64_t)(gid + 1) | (h >> 32 << 32), std::memory_order_release);     // the key bytes are visible to whoever sees the slot
+    n_++;
+    return true;
+}
+
+bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const
+{
+    const uint64_t h = hash(id, len);
+    for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
+        const uint64_t v = slot_[at].load(std::memory_order_acquire);
+        if (v == 0) return false;
+        if ((v >> 32) != (h >> 32)) continue;
+        const Key &k = key_[(uint32_t)v - 1];
+        if (k.len == len && memcmp(k.bytes, id, len) == 0) { gid = (uint32_t)v - 1; return true; }
+    }
+}
+
+std::string ContextIndex::id_of(uint32_t gid) const { return gid < capacity_ ? std::string(key_[gid].bytes, key_[gid].len) : std::string(); }
+
+// ---- PendingRing ------------------------------------------------------------------------------------------------------------
+PendingRing::PendingRing(uint32_t capacity_pow2) : mask_(pow2_at_least(capacity_pow2) - 1), s_(new Slot[mask_ + 1]) {}
+
+// bit 0 = occupied, bits 1-32 the sequence, 33-35 the method, 36-63 the group id (28 bits: 268 M groups — a table holds far fewer)
+uint64_t PendingRing::key_of(int32_t sequence, Method m, uint32_t gid)
+{
+    return 1ull | ((uint64_t)(uint32_t)sequence << 1) | ((uint64_t)((uint32_t)m & 7u) << 33) | ((uint64_t)(gid & 0x0FFFFFFFu) << 36);
+}
+
+void PendingRing::put(int32_t sequence, Method m, uint32_t gid, const Pending &p)
+{
+    Slot &s = s_[(uint32_t)sequence & mask_];
+    s.key.store(0, std::memory_order_relaxed);                   // (single producer: nobody takes a half-written slot)
+    s.p = p;
+    s.key.store(key_of(sequence, m, gid), std::memory_order_release);
+}
+
+bool PendingRing::take(int32_t sequence, Method m, uint32_t gid, Pending &p)
+{
+    Slot &s = s_[(uint32_t)sequence & mask_];
+    const uint64_t want = key_of(sequence, m, gid);
+    if (s.key.load(std::memory_order_acquire) != want) return false;
+    p = s.p;
+    uint64_t expect = want;                                      // the invocation is REMOVED (AsyncService.remove): a duplicate response finds nothing
+    return s.key.compare_exchange_strong(expect, 0, std::memory_order_acq_rel);
+}
+
+// ---- Ingress ------------------------------------------------------------------------------------------------------------------
+Ingress::Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const BodyCodec &codec, const ContextIndex &index, Buffers bank0, Buffers bank1,
+                 uint32_t pending_capacity)
+    : groups_(groups), rounds_(max_rounds), codec_(codec), index_(index), c_(conns)
+{
+    const Buffers b[2] = {bank0, bank1};
+    for (int i = 0; i < 2; i++) {
+        bank_[i].buf = b[i];
+        bank_[i].depth.reset(new std::atomic<uint32_t>[groups]);
+        for (uint32_t g = 0; g < groups; g++) bank_[i].depth[g].store(0, std::memory_order_relaxed);
+        bank_[i].origin.assign((size_t)groups * max_rounds, Origin{NO_CONN, 0});
+        bank_[i].dirty_rounds = max_rounds;                       // caller memory: content unknown
+        wipe(bank_[i]);
+    }
+    for (Conn &c : c_) c.ring.reset(new PendingRing(pending_capacity));
+}
+
+void Ingress::set_peer(uint32_t conn, int32_t peer_slot) { c_[conn].peer = peer_slot; }
+
+void Ingress::wipe(Bank &bk)
+{
+    const size_t cells = (size_t)bk.dirty_rounds * groups_;
+    memset(bk.buf.head, 0, cells * sizeof(rg_ev_head_t));        // RG_EV_NONE
+    memset(bk.buf.abcd, 0, cells * sizeof(rg_ev_quad32_t));      // (the kernel's 32-bit domain check reads the fields of every cell)
+    for (uint32_t g = 0; g < groups_; g++) bk.depth[g].store(0, std::memory_order_relaxed);
+    bk.terms_used.store(0, std::memory_order_relaxed);
+    bk.dirty_rounds = 0;
+    bk.wide.clear();
+    bk.clean = true;
+}
+
+void Ingress::recycle(const SealedBatch &b) { wipe(bank_[bank_of(b)]); }
+
+void Ingress::hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from)
+{
+    HeldRow h{gid, head, a, b, c4, d, from, {}, ticket_.fetch_add(1, std::memory_order_relaxed)};
+    h.terms.assign(terms, terms + n_terms);
+    c.held.push_back(std::move(h));
+}
+
+// true: the row sits in the bank (or in its wide list); false: the caller keeps it for the next batch
+bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
+                    Origin from)
+{
+    std::atomic<uint32_t> &depth = bk.depth[gid];
+    const bool ae = RG_HDR_KIND(head.hdr) == RG_EV_AE_REQ;
+    bool same = true;
+    for (size_t k = 1; k < n_terms; k++) same &= terms[k] == terms[0];
+    uint64_t all = (uint64_t)a | (uint64_t)b | (uint64_t)c4 | (uint64_t)d;
+    for (size_t k = 0; k < n_terms; k++) all |= (uint64_t)terms[k];
+    if (all >> 31) {                                              // not a compact row: close the group, hand the row over on its own
+        const uint32_t was = depth.fetch_or(CLOSED, std::memory_order_relaxed);
+        if (was >= rounds_) return false;                         // the group was full or closed already: wait for the next batch (it stays closed)
+        HeldRow h{gid, head, a, b, c4, d, from, {}, 0};
+        h.terms.assign(terms, terms + n_terms);
+        std::lock_guard<std::mutex> lk(bk.wide_mu);
+        bk.wide.push_back(std::move(h));
+        return true;
+    }
+    uint64_t toff = 0;
+    if (ae && n_terms > 0 && !same) {                             // entries of several terms: they need room in the batch's term array
+        toff = bk.terms_used.fetch_add(n_terms, std::memory_order_relaxed);
+        if (toff + n_terms > bk.buf.entry_cap || toff + n_terms > 0xFFFFFFFFull) {
+            depth.fetch_or(CLOSED, std::memory_order_relaxed);
+            return false;
+        }
+    }
+    const uint32_t r = depth.fetch_add(1, std::memory_order_relaxed);
+    if (r >= rounds_) return false;                               // the group's rounds are used up, or it is closed: either way it stays so
+    const size_t cell = (size_t)r * groups_ + gid;
+    if (ae && n_terms > 0) {
+        if (same) { head.hdr |= RG_HDR_SAME_TERM; head.aux = (uint32_t)terms[0]; }
+        else {
+            head.aux = (uint32_t)toff;
+            for (size_t k = 0; k < n_terms; k++) bk.buf.entry_terms[toff + k] = (int32_t)terms[k];
+        }
+    }
+    bk.buf.abcd[cell] = rg_ev_quad32_t{(int32_t)a, (int32_t)b, (int32_t)c4, (int32_t)d};
+    bk.buf.head[cell] = head;
+    bk.origin[cell] = from;
+    cn.rows++;
+    cn.max_depth = std::max(cn.max_depth, r + 1);
+    return true;
+}
+
+// One frame -> one row (RowWriter::add's mapping, wire.cpp, with the lookups this class owns)
+void Ingress::on_frame(uint32_t conn, const FrameView &f)
+{
+    Conn &c = c_[conn];
+    Method m;
+    uint32_t gid = 0;
+    if ((f.type != ENQ && f.type != ACK) || !parse_scope(f.head, f.head_len, m, c.ctx) || !index_.find(c.ctx.data(), c.ctx.size(), gid)) {
+        refused_.fetch_add(1, std::memory_order_relaxed);
+        return;
+    }
+    rg_ev_head_t h{0, 0};
+    int64_t a = 0, b = 0, c4 = 0, d = 0;
+    const int64_t *terms = nullptr;
+    size_t n_terms = 0;
+    Origin from{NO_CONN, 0};
+    if (f.type == ENQ) {
+        Request &q = c.q;
+        if (!codec_.decode_request(m, f.body, f.body_len, q) || q.node < 0 || q.node > 15 || q.entry_terms.size() > RG_MAX_AE_ENTRIES) {
+            refused_.fetch_add(1, std::memory_order_relaxed);
+            return;
+        }
+        from = Origin{conn, f.sequence};
+        a = q.term; b = q.x; c4 = q.y;
+        switch (m) {
+        case M_APPEND_ENTRIES:
+            h.hdr = RG_HDR_MAKE(RG_EV_AE_REQ, q.node, 0, q.entry_terms.size());
+            d = q.leader_commit; terms = q.entry_terms.data(); n_terms = q.entry_terms.size();
+            break;
+        case M_PRE_VOTE:         h.hdr = RG_HDR_MAKE(RG_EV_PV_REQ, q.node, 0, 0); break;
+        case M_REQUEST_VOTE:     h.hdr = RG_HDR_MAKE(RG_EV_RV_REQ, q.node, 0, 0); break;
+        case M_INSTALL_SNAPSHOT: h.hdr = RG_HDR_MAKE(RG_EV_IS_REQ, q.node, 0, 0); break;    // flag 0: the host holds the verdict (raftwire.h)
+        default: refused_.fetch_add(1, std::memory_order_relaxed); return;
+        }
+    } else {
+        Response r;
+        Pending p;
+        if (c.peer < 0 || c.peer > 15 || !codec_.decode_response(f.body, f.body_len, r) || !c.ring->take(f.sequence, m, gid, p)) {
+            refused_.fetch_add(1, std::memory_order_relaxed);
+            return;
+        }
+        a = r.term;
+        h.aux = p.role_epoch;
+        switch (m) {
+        case M_APPEND_ENTRIES:   h.hdr = RG_HDR_MAKE(RG_EV_AE_ACK, c.peer, r.success, 0); b = p.epoch_at_send; c4 = p.last_index_sent; break;
+        case M_INSTALL_SNAPSHOT: h.hdr = RG_HDR_MAKE(RG_EV_IS_ACK, c.peer, r.success, 0); b = p.epoch_at_send; break;
+        case M_PRE_VOTE:         h.hdr = RG_HDR_MAKE(RG_EV_PV_REPLY, c.peer, r.success, 0); break;
+        case M_REQUEST_VOTE:     h.hdr = RG_HDR_MAKE(RG_EV_RV_REPLY, c.peer, r.success, 0); break;
+        default: refused_.fetch_add(1, std::memory_order_relaxed); return;
+        }
+    }
+    c.queued++;
+    // a connection that already holds rows back keeps its order: a group with a held row is closed in this bank, so place() refuses
+    if (!place(bank_[fill_], c, gid, h, a, b, c4, d, terms, n_terms, from)) hold(c, gid, h, a, b, c4, d, terms, n_terms, from);
+}
+
+int Ingress::feed(uint32_t conn, const uint8_t *data, size_t n)
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    Conn &c = c_[conn];
+    c.queued = 0;
+    c.sp.feed_views(data, n, [this, conn](const FrameView &f) { on_frame(conn, f); });
+    return c.sp.failed() ? -1 : c.queued;
+}
+
+void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, Origin reply_to)
+{
+    std::shared_lock<std::shared_mutex> lk(mu_);
+    Conn &c = c_[conn];
+    if (gid >= groups_ || RG_HDR_KIND(head.hdr) == RG_EV_AE_REQ) { refused_.fetch_add(1, std::memory_order_relaxed); return; }   // (entries travel in frames)
+    if (!place(bank_[fill_], c, gid, head, a, b, c4, d, nullptr, 0, reply_to)) hold(c, gid, head, a, b, c4, d, nullptr, 0, reply_to);
+}
+
+const SealedBatch &Ingress::seal()
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    const int done = fill_, next = fill_ ^ 1;
+    Bank &bk = bank_[done];
+    SealedBatch &s = sealed_[done];
+    uint32_t rounds = 0;
+    s.rows = 0;
+    for (Conn &c : c_) { rounds = std::max(rounds, c.max_depth); s.rows += c.rows; c.rows = 0; c.max_depth = 0; }
+    s.batch.rounds = rounds;
+    s.batch.count = groups_;
+    s.batch.gid = nullptr;
+    s.batch.head = bk.buf.head;
+    s.batch.abcd = bk.buf.abcd;
+    s.batch.entry_terms = bk.buf.entry_terms;
+    s.batch.entry_count = std::min<uint64_t>(bk.terms_used.load(std::memory_order_relaxed), bk.buf.entry_cap);
+    s.origin = bk.origin.data();
+    s.wide = std::move(bk.wide);
+    std::sort(s.wide.begin(), s.wide.end(), [](const HeldRow &x, const HeldRow &y) { return x.gid < y.gid; });
+    bk.wide.clear();
+    bk.dirty_rounds = rounds;
+    bk.clean = false;
+    // open the other bank, oldest held rows first
+    Bank &nb = bank_[next];
+    if (!nb.clean) wipe(nb);                                      // (a caller that skipped recycle(): correct, but feeders wait for the wipe)
+    nb.clean = false;
+    fill_ = next;
+    std::vector<std::pair<HeldRow, uint32_t>> waiting;            // every held row with its connection, oldest ticket first
+    for (uint32_t i = 0; i < c_.size(); i++) {
+        for (HeldRow &h : c_[i].held) waiting.emplace_back(std::move(h), i);
+        c_[i].held.clear();
+    }
+    std::sort(waiting.begin(), waiting.end(), [](const auto &x, const auto &y) { return x.first.ticket < y.first.ticket; });
+    for (auto &w : waiting) {
+        HeldRow &h = w.first;
+        Conn &c = c_[w.second];
+        if (!place(nb, c, h.gid, h.head, h.a, h.b, h.c, h.d, h.terms.data(), h.terms.size(), h.from)) c.held.push_back(std::move(h));   // keeps its ticket
+    }
+    return s;
+}
+
+uint64_t Ingress::held() const
+{
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    uint64_t n = 0;
+    for (const Conn &c : c_) n += c.held.size();
+    return n;
+}
+
+size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end) const
+{
+    static const Method METHOD_OF_KIND[16] = {M_NONE, M_APPEND_ENTRIES, M_NONE, M_NONE, M_REQUEST_VOTE, M_PRE_VOTE, M_NONE, M_NONE,
+                                               M_NONE, M_NONE, M_NONE, M_INSTALL_SNAPSHOT, M_NONE, M_NONE, M_NONE, M_NONE};
+    static const char *const SCOPE_OF_METHOD[] = {"", "appendEntries:", "preVote:", "requestVote:", "installSnapshot:"};
+    size_t made = 0;
+    Frame f;
+    f.type = ACK;
+    const size_t cells = std::min(cell_end, (size_t)b.batch.rounds * b.batch.count);
+    for (size_t cell = cell_begin; cell < cells; cell++) {
+        const Method m = METHOD_OF_KIND[RG_HDR_KIND(b.batch.head[cell].hdr)];
+        if (m == M_NONE || !(reply[cell].flags & RG_F_REPLIED)) continue;            // an empty cell, a response row, or a handler that died
+        const Origin o = b.origin[cell];
+        if (o.conn == NO_CONN) continue;
+        f.sequence = o.sequence;
+        f.head.assign(SCOPE_OF_METHOD[m]);                                           // "<method>:<contextId>", as the request carried it
+        index_.append_id((uint32_t)(cell % b.batch.count), f.head);
+        f.body.clear();
+        codec_.encode_response(Response{reply[cell].resp_term, (reply[cell].flags & RG_F_SUCCESS) != 0}, f.body);
+        encode_frame(f, false, out[o.conn]);
+        made++;
+    }
+    return made;
+}
+
+}  // namespace wire
+}  // namespace rafting

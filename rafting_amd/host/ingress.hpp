@@ -1,0 +1,172 @@
+// ingress.hpp — N2 + the host half of a8: bytes from many peer connections -> ONE multi-round compact batch the step kernel takes as it is,
+// and the replies of that batch -> response frames on the connections the requests came from. Host C++, any number of decoder threads.
+//
+// What it replaces in the reference (paths relative to src/main/java/io/lubricant/consensus/raft/):
+//   ContextIndex     the contextId -> RaftContext map                                context/ContextManager.java:41
+//   PendingRing      AsyncService's invocations by (scope, sequence), one sequence counter per node
+//                                                                                    transport/rpc/AsyncService.java:18-24,91-104
+//   Ingress::feed    NettyCluster.on(PingEvent / PongEvent) -> context.eventLoop().execute(...): a decoded request / response becomes a task
+//                    of ITS context's loop                                           transport/NettyCluster.java:59-105, NettyNode.java:109-158
+//   rounds           the per-context FIFO of support/EventLoopGroup.java:32-46,77-80: tasks of one context run in the order they were
+//                    queued; tasks of different contexts are unordered. Here: the k-th row a batch holds for a group lies in round k
+//                    (cell [k][gid] of a dense [round][group] batch), rows of one connection keep their order, rows of different
+//                    connections interleave in arrival order — exactly what execute() from several Netty threads gives.
+//   Ingress::emit    reply(...) -> channel.writeAndFlush(new PongEvent(...))           transport/NettyCluster.java:75-90
+//
+// Threading: feed(conn, ...) may run on one thread per connection at a time, any number of connections concurrently — a row claims its
+// cell with ONE relaxed fetch_add on its group's depth counter and writes 24 bytes nobody else touches; there is no lock on that path
+// beyond a shared lock that only seal() takes exclusively. seal() / emit() / the pending rings' put side belong to the flush thread.
+//
+// Rows that cannot sit in the compact format (a value outside [0, 2^31)) or that find their group's rounds used up are kept on their
+// connection and go first into the next batch, in the order they were held back (one ticket counter for all connections: a group's rows
+// stay in arrival order across batches too); a group is closed for the rest of a batch once one of its rows was held back, so a later
+// row never overtakes an earlier one.
+#pragma once
+#include <atomic>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+#include "wire.hpp"
+
+namespace rafting {
+namespace wire {
+
+// contextId -> gid, fixed capacity (the table's group count is fixed at rg_table_create). insert() under a mutex, find() lock-free
+// (a slot is published with a release store after its key bytes are in place).
+class ContextIndex {
+public:
+    explicit ContextIndex(uint32_t capacity);
+    bool insert(const char *id, size_t len, uint32_t gid);      // false: gid beyond the capacity or taken, id empty / longer than MAX_HEAD_SIZE / present
+    bool find(const char *id, size_t len, uint32_t &gid) const;
+    std::string id_of(uint32_t gid) const;                      // "" if that gid was never inserted
+    void append_id(uint32_t gid, std::string &to) const { if (gid < capacity_) to.append(key_[gid].bytes, key_[gid].len); }
+    uint32_t size() const { return n_; }
+
+private:
+    // open addressing; a slot holds gid + 1 (0 = empty) and 32 bits of the key's hash, so a probe touches the key bytes — one fixed-size
+    // record per gid in ONE array, no pointer to chase — only for the slot that matches
+    static constexpr size_t KEY_BYTES = 128;                    // MAX_HEAD_SIZE: a scope "<method>:<contextId>" is at most that long
+    struct Key { uint8_t len; char bytes[KEY_BYTES - 1]; };     // (ids of 128 bytes cannot occur: the method name and the colon take at least 8)
+    static uint64_t hash(const char *s, size_t n);
+    uint32_t mask_;
+    std::unique_ptr<std::atomic<uint64_t>[]> slot_;             // (gid + 1) | tag << 32
+    std::unique_ptr<Key[]> key_;                                // by gid
+    uint32_t capacity_;
+    std::mutex mu_;
+    uint32_t n_ = 0;
+};
+
+// What the host remembered when it sent request `sequence` on a connection. One ring per connection; put() by the sending side,
+// take() by the thread decoding that connection's responses. A slot is matched on (sequence, method, gid): a response whose request
+// was overwritten (more than `capacity` requests in flight) or never sent is refused, as AsyncService.remove returns null.
+class PendingRing {
+public:
+    explicit PendingRing(uint32_t capacity_pow2 = 1u << 16);
+    void put(int32_t sequence, Method m, uint32_t gid, const Pending &p);
+    bool take(int32_t sequence, Method m, uint32_t gid, Pending &p);
+
+private:
+    struct Slot { std::atomic<uint64_t> key{0}; Pending p; };   // key = 1 | sequence << 1 | method << 33 | gid low bits << 36 ... (see .cpp)
+    static uint64_t key_of(int32_t sequence, Method m, uint32_t gid);
+    uint32_t mask_;
+    std::unique_ptr<Slot[]> s_;
+};
+
+struct Origin { uint32_t conn; int32_t sequence; };             // who gets the reply of a cell (conn == NO_CONN: nobody — a response row)
+constexpr uint32_t NO_CONN = 0xFFFFFFFFu;
+
+struct HeldRow {                                                  // a row kept on its connection, in the wide form
+    uint32_t gid; rg_ev_head_t head; int64_t a, b, c, d; Origin from;
+    std::vector<int64_t> terms;
+    uint64_t ticket = 0;                                          // order in which rows were held back, across connections
+};
+
+// One sealed batch: what rg_submit32 / rg_submit_async_packed take (dense, `rounds` rounds of `groups` cells) plus where its replies go.
+struct SealedBatch {
+    rg_batch32_t batch;                 // gid == NULL (dense); pointers into the bank
+    const Origin *origin;               // [rounds * groups]
+    uint64_t rows;                      // cells that hold an event
+    std::vector<HeldRow> wide;          // rows the compact format cannot express, at most one per group, ascending gid: the host decides them
+                                        // with ONE sparse rg_submit AFTER this batch (their groups took no later row into the batch)
+};
+
+class Ingress {
+public:
+    struct Buffers {                    // caller-owned memory of ONE bank, ideally page-locked (rg_host_alloc): the batch is uploaded from it
+        rg_ev_head_t *head; rg_ev_quad32_t *abcd; int32_t *entry_terms; uint64_t entry_cap;
+    };
+    // groups, max_rounds: the shape of a batch. conns: number of peer connections. banks: two sets of caller buffers, filled alternately.
+    Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const BodyCodec &codec, const ContextIndex &index, Buffers bank0, Buffers bank1,
+            uint32_t pending_capacity = 1u << 16);     // requests in flight per connection whose responses can still be matched
+
+    void set_peer(uint32_t conn, int32_t peer_slot);             // the node at the other end (its slot in the cluster list)
+    PendingRing &pending(uint32_t conn) { return *c_[conn].ring; }
+
+    // Bytes as they arrive on `conn`. Returns the number of rows this call queued (placed or held), -1 once the stream broke the grammar.
+    int feed(uint32_t conn, const uint8_t *data, size_t n);
+    // A row that does not come off the wire — RG_EV_TIMEOUT from rg_timers_expired, RG_EV_CLIENT_APPEND, RG_EV_LOG_FLUSH, an installSnapshot
+    // request released with the host's verdict — queued like a row of connection `conn` (give local sources connection numbers of their own:
+    // one caller per connection at a time, as for feed()). reply_to: where an RG_F_REPLIED answer goes ({NO_CONN, 0}: nowhere).
+    void add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c, int64_t d, Origin reply_to);
+    // Close the bank being filled and open the other one (rows held back by the closed bank are placed first). The other bank must have
+    // been recycle()d. The sealed batch stays valid until its recycle().
+    const SealedBatch &seal();
+    // After the batch was decided: one PongEvent frame per cell whose reply carries RG_F_REPLIED, appended to out[conn] in cell order.
+    // N3's rule — no reply before its (term, votedFor) is durable (member/RaftMember.java:25) — is the caller's: StableStore::persist of the
+    // batch's RG_F_PERSIST rows comes before this call. Cells [cell_begin, cell_end) only: several threads may share a batch, each with its
+    // own `out` (responses are matched by sequence number, their order on a connection carries no meaning).
+    size_t emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin = 0, size_t cell_end = (size_t)-1) const;
+    // The batch is done with (decided, effects applied, replies emitted): wipe the cells it used so that its bank can be filled again.
+    // Touches only that bank: runs beside feed() without a lock.
+    void recycle(const SealedBatch &b);
+    int bank_of(const SealedBatch &b) const { return &b == &sealed_[0] ? 0 : 1; }
+
+    uint64_t refused() const { return refused_.load(std::memory_order_relaxed); }     // frames that were no decision row (unknown context, ...)
+    uint64_t held() const;                                                            // rows waiting for the next batch
+
+private:
+    struct Bank {
+        Buffers buf;
+        std::unique_ptr<std::atomic<uint32_t>[]> depth;          // per group: rows claimed; bit 30 (CLOSED): no more rows in this batch
+        std::vector<Origin> origin;                              // meaningful where the cell's head holds an event
+        std::atomic<uint64_t> terms_used{0};
+        uint32_t dirty_rounds = 0;                               // rounds to wipe before the bank is filled again
+        bool clean = false;
+        std::mutex wide_mu;
+        std::vector<HeldRow> wide;
+    };
+    struct Conn {
+        FrameSplitter sp;
+        int32_t peer = RG_NO_NODE;
+        std::unique_ptr<PendingRing> ring;
+        std::vector<HeldRow> held;                               // in arrival order
+        Request q;                                               // decode scratch
+        std::string ctx;
+        int queued = 0;
+        uint64_t rows = 0;                                       // rows this connection placed into the bank being filled, and the deepest
+        uint32_t max_depth = 0;                                  // round it reached (folded by seal(): no shared counter on the row path)
+    };
+    static constexpr uint32_t CLOSED = 1u << 30;
+    bool place(Bank &bk, Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
+               Origin from);
+    void hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from);
+    void on_frame(uint32_t conn, const FrameView &f);
+    void wipe(Bank &bk);
+
+    const uint32_t groups_, rounds_;
+    const BodyCodec &codec_;
+    const ContextIndex &index_;
+    std::vector<Conn> c_;
+    Bank bank_[2];
+    SealedBatch sealed_[2];
+    int fill_ = 0;                                               // bank being filled (changed under the exclusive lock)
+    mutable std::shared_mutex mu_;
+    std::atomic<uint64_t> refused_{0}, ticket_{0};
+};
+
+}  // namespace wire
+}  // namespace rafting

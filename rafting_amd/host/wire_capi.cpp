@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "ingress.hpp"
 #include "wire.hpp"
 
 using namespace rafting::wire;
@@ -161,5 +162,101 @@ int rw_rows_add_frame(uint8_t type, int32_t sequence, const char *head, size_t h
     *terms += w.terms();
     return 1;
 }
+
+// ---- rw_ingress_* ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct rw_ingress {
+    std::unique_ptr<BodyCodec> codec;
+    ContextIndex index;
+    std::unique_ptr<Ingress> in;
+    const SealedBatch *sealed[2] = {nullptr, nullptr};
+    uint32_t conns;
+    rw_ingress(uint32_t groups) : index(groups), conns(0) {}
+};
+
+extern "C" {
+
+rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conns, const char *nodes, rg_ev_head_t *head0, rg_ev_quad32_t *abcd0,
+                             int32_t *entry_terms0, rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap)
+{
+    if (!groups || !max_rounds || !conns || !head0 || !abcd0 || !head1 || !abcd1 || (entry_cap && (!entry_terms0 || !entry_terms1))) return nullptr;
+    rw_ingress *g = new rw_ingress(groups);
+    if (nodes) g->codec.reset(new KryoBodyCodec(parse_nodes(nodes))); else g->codec.reset(new FixedBodyCodec());
+    g->conns = conns;
+    g->in.reset(new Ingress(groups, max_rounds, conns, *g->codec, g->index, Ingress::Buffers{head0, abcd0, entry_terms0, entry_cap},
+                            Ingress::Buffers{head1, abcd1, entry_terms1, entry_cap}));
+    return g;
+}
+void rw_ingress_free(rw_ingress_t *g) { delete g; }
+int rw_ingress_add_context(rw_ingress_t *g, const char *id, size_t len, uint32_t gid) { return g && g->index.insert(id, len, gid); }
+int rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot)
+{
+    if (!g || conn >= g->conns) return 0;
+    g->in->set_peer(conn, peer_slot);
+    return 1;
+}
+int rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method, uint32_t gid, uint32_t role_epoch, int64_t epoch_at_send,
+                    int64_t last_index_sent)
+{
+    if (!g || conn >= g->conns || method < M_APPEND_ENTRIES || method > M_INSTALL_SNAPSHOT) return 0;
+    Pending p;
+    p.role_epoch = role_epoch; p.epoch_at_send = epoch_at_send; p.last_index_sent = last_index_sent;
+    g->in->pending(conn).put(sequence, (Method)method, gid, p);
+    return 1;
+}
+int rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n) { return (!g || conn >= g->conns) ? -1 : g->in->feed(conn, data, n); }
+int rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
+                       uint32_t reply_conn, int32_t reply_sequence)
+{
+    if (!g || conn >= g->conns || (reply_conn != NO_CONN && reply_conn >= g->conns)) return 0;
+    g->in->add_row(conn, gid, rg_ev_head_t{hdr, aux}, a, b, c, d, Origin{reply_conn, reply_sequence});
+    return 1;
+}
+int rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32_t *wide)
+{
+    if (!g) return -1;
+    const SealedBatch &s = g->in->seal();
+    const int bank = g->in->bank_of(s);
+    g->sealed[bank] = &s;
+    *batch = s.batch; *rows = s.rows; *wide = (uint32_t)s.wide.size();
+    return bank;
+}
+int rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms, uint32_t max_terms,
+                        uint32_t *reply_conn, int32_t *reply_sequence)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || i >= g->sealed[bank]->wide.size()) return -1;
+    const HeldRow &h = g->sealed[bank]->wide[i];
+    if (h.terms.size() > max_terms) return -1;
+    *reply_conn = h.from.conn; *reply_sequence = h.from.sequence;
+    *gid = h.gid; *head = h.head; abcd[0] = h.a; abcd[1] = h.b; abcd[2] = h.c; abcd[3] = h.d;
+    for (size_t k = 0; k < h.terms.size(); k++) entry_terms[k] = h.terms[k];
+    return (int)h.terms.size();
+}
+int rw_ingress_origin(const rw_ingress_t *g, int bank, uint64_t cell, uint32_t *conn, int32_t *sequence)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank]) return 0;
+    const SealedBatch &s = *g->sealed[bank];
+    if (cell >= (uint64_t)s.batch.rounds * s.batch.count || RG_HDR_KIND(s.batch.head[cell].hdr) == RG_EV_NONE || s.origin[cell].conn == NO_CONN) return 0;
+    *conn = s.origin[cell].conn; *sequence = s.origin[cell].sequence;
+    return 1;
+}
+size_t rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn, uint8_t *out, size_t cap)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || conn >= g->conns) return 0;
+    std::vector<std::string> o(g->conns);
+    g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end);
+    if (o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
+    return o[conn].size();
+}
+int rw_ingress_recycle(rw_ingress_t *g, int bank)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank]) return 0;
+    g->in->recycle(*g->sealed[bank]);
+    g->sealed[bank] = nullptr;
+    return 1;
+}
+uint64_t rw_ingress_refused(const rw_ingress_t *g) { return g ? g->in->refused() : 0; }
+uint64_t rw_ingress_held(const rw_ingress_t *g) { return g ? g->in->held() : 0; }
 
 }  // extern "C"
