@@ -108,3 +108,17 @@ def test_compact_multi_round_launch_and_domain_exits():
 
 def test_compact_workload_replays():
     T.compact_workload_case(groups=200, rounds=12)
+
+
+def test_ingress_batches_are_decided_like_the_history_row_by_row():
+    """N2 + a8's host half in front of the kernels: a fuzzed history as wire frames and local rows -> rafting_amd/host/ingress -> the sealed
+    multi-round compact batch through rg_submit32 (step32_kernel), its wide leftovers through a sparse rg_submit; tests/ingress_flow.py
+    holds every group's rows, replies and response frames to the oracle's row-by-row decisions."""
+    from tests import ingress_flow
+    G, P = 64, 5
+    st0, batches, outs, final = ingress_flow.history(G, P, 2, True, 24, 91, view=engine.Table(G, P, 2, True))
+    gpu = engine.Table(G, P, 2, True)
+    gpu.load_state(st0)
+    nodes = [("10.1.0.%d" % i, 7000 + i) for i in range(P)]
+    ingress_flow.drive(lambda b32: gpu.submit32(b32), lambda sp: gpu.submit(sp), G, P, batches, outs, 64, nodes)
+    compare_states(final, gpu.read_state(), "after the ingress")

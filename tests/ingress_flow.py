@@ -13,23 +13,30 @@ ACK_METHOD = {abi.EV_AE_ACK: 1, abi.EV_PV_REPLY: 2, abi.EV_RV_REPLY: 3, abi.EV_I
 LOCAL_CONN = 16                       # connections 0..15 = the peer in that slot; 16 = the host's own rows
 
 
-def history(groups, cluster, self_slot, pre_vote, rounds, seed):
-    """(initial state, [one-round batches], [the oracle's outcomes])"""
+def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None):
+    """(initial state, [one-round batches], [the oracle's outcomes], final state). view: a table of the kind under test (engine.Table), decided
+    in lockstep — the fuzzer then draws its rows from THAT table's state image, whose cached term runs are the device's own (no row of the
+    history leaves them: RG_NEED_HOST round trips are the host's business and have their own tests), and its outcomes are held to the oracle's."""
+    from tests.helpers import compare_outcomes
     st0 = fuzz.random_initial_state(groups, cluster, self_slot, seed)
     for g in range(5, groups, 23):                    # a few groups whose terms lie beyond int32: their rows cannot be compact rows
         st0.current_term[g] += 1 << 33
     orc = oracle_lib.OracleTable(groups, cluster, self_slot, pre_vote)
     orc.load_state(st0)
+    if view is not None:
+        view.load_state(st0)
     fz = fuzz.Fuzzer(groups, cluster, self_slot, seed, allow_miss=False)
     batches, outs = [], []
-    for _ in range(rounds):
+    for r in range(rounds):
         b = abi.Batch(1, groups)
-        fz.round(orc.read_state(), b, 0)
+        fz.round((view or orc).read_state(), b, 0)
         hdr = b.head["hdr"]
         cannot_travel = ((hdr & 0xF) == abi.EV_AE_REQ) & ((((hdr >> 4) & 0xF) >= cluster) | ((hdr >> 12) > abi.MAX_AE_ENTRIES))    # no NodeID / refused frame
         cannot_travel |= (hdr & abi.HDR_HINT_BIT) != 0
         b.head[cannot_travel] = (0, 0)
         outs.append(orc.submit(b))
+        if view is not None:
+            compare_outcomes(outs[-1], view.submit(b), "history round %d" % r)
         batches.append(b)
     return st0, batches, outs, orc.read_state()
 
