@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=6, help="batches of the stream the CPU baseline replays")
     ap.add_argument("--copy-bw", action="store_true", help="(default now) measure a plain HBM copy kernel in the same run")
     ap.add_argument("--no-copy-bw", action="store_true", help="skip the plain-copy bandwidth measurement")
+    ap.add_argument("--copy-bytes", type=int, default=1 << 30, help="size of the plain-copy measurement (tests on the host emulation shrink it)")
     ap.add_argument("--pcie-batches", type=int, default=12, help="host-memory legs: batches per leg (the first two size the staging buffers)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
     ap.add_argument("--dist-backend", default="gloo", help="how the three result scalars are added up: gloo (default, host sum — the "
@@ -147,7 +148,7 @@ def main():
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
     elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device=red_dev if world > 1 else None)
 
-    copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(1 << 30, 10)     # the measured-copy yardstick, same run, same device
+    copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
 
     # ---- the same step with caller-owned HOST buffers (PCIe both ways): reported, never `value` -----------------------------
     # Three ways over the link, each from the same table state with the same FRESH batches of the stream (B0, B1 size the staging

@@ -25,7 +25,7 @@ def test_kat_on_the_two_wavefront_kernel(scenario):
 
 @pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (7, 3, True, 16)])
 def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
-    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 40, seed, allow_miss=True)
+    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 24, seed, allow_miss=True)
     c = gpu.counters()
     assert c[0] > 0 and c[1] > 0 and c[2] > 0
 
@@ -92,13 +92,13 @@ def test_kat_on_compact_rows(scenario, compact_route):
 @pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(3, 0, True, 11), (5, 2, True, 12), (5, 4, False, 13), (2, 1, True, 14),
                                                              (7, 3, True, 16)])
 def test_fuzz_lockstep_on_compact_rows(cluster, self_slot, pre_vote, seed, compact_route):
-    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 40, seed, allow_miss=True)
+    _, _, _, hist, misses, gpu = T._lockstep(128, cluster, self_slot, pre_vote, 24, seed, allow_miss=True)
     assert hist[abi.OK] > 0
 
 
 def test_fuzz_general_handlers_only_on_compact_rows(monkeypatch, compact_route):
     monkeypatch.setenv("RG_FAST", "0")
-    _, _, _, hist, _, _ = T._lockstep(128, 5, 0, True, 40, 41, allow_miss=True)
+    _, _, _, hist, _, _ = T._lockstep(128, 5, 0, True, 24, 41, allow_miss=True)
     assert hist[abi.OK] > 0
 
 

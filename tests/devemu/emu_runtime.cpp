@@ -188,7 +188,8 @@ static LanePool &lane_pool() { static LanePool *p = new LanePool; return *p; }  
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const char *kernel)
 {
-    if (!waves_mode() && !lanes_must_meet(kernel)) {
+    // (copy_kernel: a grid-stride copy, 2 048 x 256 lanes that never meet — one OS thread per lane would only make it slow)
+    if ((!waves_mode() && !lanes_must_meet(kernel)) || (kernel && strstr(kernel, "copy_kernel"))) {
         gridDim_ = grid; blockDim_ = block;
         try {
             for (unsigned b = 0; b < grid.x; b++)
