@@ -108,6 +108,21 @@ def test_cpp_host_mirror_runs_a_whole_exchange_on_the_emulation(emulation_librar
     assert p.returncode == 0 and "host flow ok" in p.stdout, p.stdout + p.stderr
 
 
+def test_ingress_pipeline_from_socket_bytes_to_response_bytes_on_the_emulation(emulation_library, tmp_path):
+    """rafting_amd/host/ingress_pipeline.cpp — reader threads feeding the ingress, the flush thread sealing into rg_submit_async_packed
+    (the sealed bank is the upload buffer), the durability journal, emitter threads — with the compact-row step kernel on the wavefront
+    emulation: every follower's log ends where its requests said, every request got one successful response frame, no row needed the host."""
+    exe = os.path.join(ROOT, "build", "devemu_ingress_pipeline")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include")] +
+                   [os.path.join(host, f) for f in ("ingress_pipeline.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "stable_store.cpp")] +
+                   ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
+    for args in (["256", "12", "4", "2", "2", "5"], ["200", "9", "3", "3", "1", "16"]):
+        p = subprocess.run([exe] + args + [str(tmp_path / "journal")], env=dict(os.environ, RG_SPLIT="1", RG_EMU_WAVES="1"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ingress pipeline ok=1" in p.stdout, p.stdout + p.stderr
+
+
 def test_the_product_binding_refuses_the_emulation_library(emulation_library):
     """rafting_amd.engine must not be talked into a CPU path by pointing RG_LIB at the test artefact"""
     env = dict(os.environ, RG_LIB=emulation_library, PYTHONPATH=ROOT)

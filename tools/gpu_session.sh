@@ -56,6 +56,10 @@ for step in "$@"; do
         timeout 120 build/wire_bench > $OUT/wire_bench.txt 2>&1; tail -n 6 $OUT/wire_bench.txt
         timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 2 $OUT/smoke.txt
         timeout 400 python tools/soak.py ${SOAK_SECONDS:-200} > $OUT/soak.txt 2>&1; tail -n 3 $OUT/soak.txt ;;
+    ingress) for K in 1 2 4 8; do     # socket bytes -> ingress -> rg_submit_async_packed -> response bytes, K reader + K emitter threads (the box has many host cores)
+          timeout 300 build/ingress_pipeline 65536 64 16 $K $K 16 - > $OUT/ingress_pipeline_$K.txt 2>&1; tail -n 3 $OUT/ingress_pipeline_$K.txt; done
+        timeout 300 build/ingress_pipeline 65536 64 16 8 8 64 - > $OUT/ingress_pipeline_8_r64.txt 2>&1; tail -n 3 $OUT/ingress_pipeline_8_r64.txt
+        timeout 120 build/ingress_bench 65536 16 16 1,2,4,8,16 > $OUT/ingress_bench.txt 2>&1; tail -n 5 $OUT/ingress_bench.txt ;;
     sweep) for R in 1 4 16 64; do $B --steps 20 --warmup 3 --rounds $R 2>>$OUT/aux.err | tee -a $OUT/rounds.jsonl | line rounds=$R; done
         $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/aux.err | tee -a $OUT/conflict.jsonl | line p_conflict=0.005 ;;
     final) python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default
