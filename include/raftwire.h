@@ -109,6 +109,22 @@ int      rw_ingress_origin(const rw_ingress_t *g, int bank, uint64_t cell, uint3
  * bytes (member/RaftMember.java:25). */
 size_t   rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn,
                          uint8_t *out, size_t cap);
+/* RG_NEED_HOST inside the batch of that bank (a term lookup left the device's cached runs: the row came back unapplied, the later rows of its
+ * group RG_SKIPPED_AFTER_NEED_HOST): decide those rows, in order, BEFORE the next batch is submitted — the missed row again with a hint
+ * read from the host's RaftLog, then the group's later rows one by one — with one sparse single-round submit per step for all broken groups
+ * together. The final replies are written over reply[cell] (rw_ingress_emit then answers the requests); every repaired row's outcome is
+ * handed to `applied` at once, because the hint of the group's next row is read from the log as that row left it.
+ *   logfx   the batch's log-effect rows: dense [rounds * groups] (rg_submit32), or packed != 0: the row-ordered list of rg_submit_async_packed
+ * returns the rows decided here (0: nothing to repair), -1 when a submit failed or a hinted row still missed. */
+typedef struct {
+    void    *user;
+    int64_t (*term_at)(void *user, uint32_t gid, int64_t index);                 /* RaftLog.get(index).term(), -1 = no such entry */
+    int64_t (*conflict)(void *user, uint32_t gid, int64_t first_index, const int64_t *terms, uint32_t n);  /* RaftLog.conflict(entries).index(), 0 = none */
+    int64_t (*epoch_index)(void *user, uint32_t gid);                            /* RaftLog.epoch().index() */
+    int     (*submit)(void *user, const rg_batch_t *in, const rg_outcome_t *out); /* rg_submit(table, in, out, RG_MEM_HOST) */
+    void    (*applied)(void *user, uint32_t gid, uint64_t cell, const rg_reply_t *reply, const rg_logfx_t *logfx, const rg_persist_t *persist);
+} rw_repair_host_t;
+int64_t  rw_ingress_repair(const rw_ingress_t *g, int bank, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host);
 /* the batch of that bank is done with: wipe the cells it used (may run beside rw_ingress_feed) */
 int      rw_ingress_recycle(rw_ingress_t *g, int bank);
 uint64_t rw_ingress_refused(const rw_ingress_t *g);      /* frames that were no decision row: unknown context / method, undecodable body, unmatched response */

@@ -320,5 +320,103 @@ size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<
     return made;
 }
 
+// ---- repair_need_host ----------------------------------------------------------------------------------------------------------------------
+static bool has_logfx_item(uint32_t flags)
+{
+    return (flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0 || RG_F_STATUS(flags) == RG_NEED_HOST;
+}
+
+int64_t repair_need_host(const SealedBatch &b, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host)
+{
+    const uint32_t G = b.batch.count, R = b.batch.rounds;
+    const size_t cells = (size_t)G * R;
+    struct Broken { uint32_t gid, round; bool missed; int64_t need; };            // the group's next undecided row; need = logfx.log_from of its miss
+    std::vector<Broken> broken;
+    {
+        std::vector<uint8_t> seen(G, 0);
+        size_t item = 0;                                                          // position in the packed list
+        for (size_t cell = 0; cell < cells; cell++) {
+            if (RG_HDR_KIND(b.batch.head[cell].hdr) == RG_EV_NONE) continue;
+            const uint32_t fl = reply[cell].flags, g = (uint32_t)(cell % G);
+            const bool marked = has_logfx_item(fl);
+            if (RG_F_STATUS(fl) == RG_NEED_HOST && !seen[g]) {
+                seen[g] = 1;
+                broken.push_back(Broken{g, (uint32_t)(cell / G), true, packed ? logfx[item].log_from : logfx[cell].log_from});
+            }
+            item += marked;
+        }
+    }
+    if (broken.empty()) return 0;
+    std::sort(broken.begin(), broken.end(), [](const Broken &x, const Broken &y) { return x.gid < y.gid; });     // sparse rows ascend
+    int64_t decided = 0;
+    std::vector<uint32_t> gid;
+    std::vector<rg_ev_head_t> head;
+    std::vector<rg_ev_pair_t> ab, cd, hint;
+    std::vector<int64_t> terms;
+    std::vector<rg_reply_t> rep;
+    std::vector<rg_logfx_t> lfx;
+    std::vector<rg_persist_t> per;
+    while (!broken.empty()) {
+        const size_t n = broken.size();
+        gid.resize(n); head.resize(n); ab.resize(n); cd.resize(n); hint.assign(n, rg_ev_pair_t{0, 0});
+        rep.assign(n, rg_reply_t{0, 0, 0}); lfx.assign(n, rg_logfx_t{0, 0}); per.assign(n, rg_persist_t{0, 0, 0});
+        terms.clear();
+        for (size_t i = 0; i < n; i++) {
+            const Broken &k = broken[i];
+            const size_t cell = (size_t)k.round * G + k.gid;
+            rg_ev_head_t h = b.batch.head[cell];
+            const rg_ev_quad32_t q = b.batch.abcd[cell];
+            const uint32_t cnt = RG_HDR_N(h.hdr);
+            const bool ae = RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ;
+            const size_t t0 = terms.size();
+            if (ae && cnt > 0) {                                                  // the wide form of the compact row
+                for (uint32_t e = 0; e < cnt; e++) terms.push_back((h.hdr & RG_HDR_SAME_TERM) ? (int64_t)h.aux : (int64_t)b.batch.entry_terms[h.aux + e]);
+                h.hdr &= ~RG_HDR_SAME_TERM;
+                h.aux = (uint32_t)t0;
+            }
+            if (k.missed) {
+                h.hdr |= RG_HDR_HINT_BIT;
+                if (ae) {
+                    const int64_t prev = q.b, epoch = host.epoch_index(k.gid);
+                    int64_t first = prev + 1;
+                    uint32_t skip = 0;
+                    if (cnt > 0 && first <= epoch) {                              // entries at or below the epoch are purged first (member/Follower.java:209-221)
+                        skip = (uint32_t)std::min<int64_t>(cnt, epoch - first + 1);
+                        first += skip;
+                    }
+                    hint[i] = rg_ev_pair_t{host.term_at(k.gid, prev), cnt > skip ? host.conflict(k.gid, first, terms.data() + t0 + skip, cnt - skip) : 0};
+                } else {
+                    hint[i] = rg_ev_pair_t{k.need, host.term_at(k.gid, k.need)};
+                }
+            }
+            gid[i] = k.gid; head[i] = h; ab[i] = rg_ev_pair_t{q.a, q.b}; cd[i] = rg_ev_pair_t{q.c, q.d};
+        }
+        rg_batch_t in{};
+        in.rounds = 1; in.count = (uint32_t)n; in.gid = gid.data(); in.head = head.data(); in.ab = ab.data(); in.cd = cd.data();
+        in.entry_terms = terms.empty() ? nullptr : terms.data(); in.entry_count = terms.size(); in.hint = hint.data();
+        const rg_outcome_t out{rep.data(), lfx.data(), per.data()};
+        if (host.submit(in, out) != 0) return -1;
+        std::vector<Broken> next;
+        for (size_t i = 0; i < n; i++) {
+            Broken k = broken[i];
+            const size_t cell = (size_t)k.round * G + k.gid;
+            if (RG_F_STATUS(rep[i].flags) == RG_NEED_HOST) {
+                if (k.missed) return -1;                                          // a hinted row must apply
+                k.missed = true; k.need = lfx[i].log_from;
+                next.push_back(k);
+                continue;
+            }
+            reply[cell] = rep[i];
+            host.applied(k.gid, cell, rep[i], lfx[i], per[i]);
+            decided++;
+            uint32_t r = k.round + 1;
+            while (r < R && RG_HDR_KIND(b.batch.head[(size_t)r * G + k.gid].hdr) == RG_EV_NONE) r++;
+            if (r < R) next.push_back(Broken{k.gid, r, false, 0});
+        }
+        broken.swap(next);
+    }
+    return decided;
+}
+
 }  // namespace wire
 }  // namespace rafting

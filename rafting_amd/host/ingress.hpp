@@ -168,5 +168,26 @@ private:
     std::atomic<uint64_t> refused_{0}, ticket_{0};
 };
 
+// ---- RG_NEED_HOST inside a multi-round batch -------------------------------------------------------------------------------------------
+// A row whose term lookup leaves the device's cached runs comes back RG_NEED_HOST, unapplied, and the later rows of its group in the same
+// launch come back RG_SKIPPED_AFTER_NEED_HOST (include/raftgpu.h). Before the next batch may be submitted those rows have to be decided, in
+// order: the missed row again with a hint read from the host's RaftLog (rg_batch_t.hint), then the group's later rows of the batch one by
+// one — each can miss in its turn. repair_need_host does that with one sparse single-round rg_submit per step for ALL broken groups
+// together, writes the final replies over reply[cell] (so that emit() answers the requests) and hands every repaired row's outcome to the
+// host at once: the hint of a group's next row is read from the log as that row left it.
+struct RepairHost {
+    virtual ~RepairHost() {}
+    virtual int64_t term_at(uint32_t gid, int64_t index) = 0;                   // RaftLog.get(index).term(), -1: no such entry (storage/RocksLog.java:122-128)
+    virtual int64_t conflict(uint32_t gid, int64_t first_index, const int64_t *terms, uint32_t n) = 0;   // RaftLog.conflict(entries).index(), 0: none (:199-225)
+    virtual int64_t epoch_index(uint32_t gid) = 0;                              // RaftLog.epoch().index()
+    virtual int submit(const rg_batch_t &in, const rg_outcome_t &out) = 0;      // rg_submit(table, &in, &out, RG_MEM_HOST); 0 = ok
+    // a repaired row was applied: its log effects / (term, votedFor) go to the host-owned plugins NOW, before the group's next row is hinted
+    virtual void applied(uint32_t gid, size_t cell, const rg_reply_t &reply, const rg_logfx_t &logfx, const rg_persist_t &persist) = 0;
+};
+// logfx: the batch's log-effect rows — dense [rounds * groups] (rg_submit32) or, packed = true, the row-ordered list of
+// rg_submit_async_packed. Returns the number of rows decided here (0: the batch had no RG_NEED_HOST), -1 when a submit failed or a hinted
+// row still missed.
+int64_t repair_need_host(const SealedBatch &b, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host);
+
 }  // namespace wire
 }  // namespace rafting

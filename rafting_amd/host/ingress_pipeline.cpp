@@ -9,7 +9,11 @@
 // heartbeat acks from their followers' connections. At the end every Follower's log must end exactly where its requests said, every request
 // must have got one successful response frame, no row may have needed the host.
 // Needs libraftgpu.so and a GPU (tests/test_devemu_cpu.py runs it against the host emulation of the kernels for its logic only).
+// With old_prev_percent > 0 the Followers' logs hold SIX term runs (the device caches the newest four) and that share of the requests are
+// heartbeats whose prevLogIndex lies in the oldest run: those rows come back RG_NEED_HOST, the rows behind them RG_SKIPPED_AFTER_NEED_HOST, and
+// the flush thread repairs them (repair_need_host: hints from the host's log, sparse resubmission) before it emits the batch's responses.
 // usage: ingress_pipeline [groups=65536] [rounds per group=64] [conns=8] [readers=4] [emitters=4] [max rounds per batch=16] [journal path | -]
+//                         [old_prev_percent=0]
 #include <pthread.h>
 #include <sched.h>
 
@@ -35,6 +39,24 @@ static void pin(unsigned t)
     CPU_SET(t % std::thread::hardware_concurrency(), &set);
     pthread_setaffinity_np(pthread_self(), sizeof set, &set);
 }
+// the host's RaftLog for the repair: the Followers' logs are the initial runs plus entries of term `term` behind them
+struct PipelineLog : RepairHost {
+    rg_table_t *table;
+    int64_t term, last0;
+    int runs;
+    uint64_t repaired = 0, submits = 0;
+    int64_t term_at(uint32_t, int64_t index) override
+    {
+        if (index < 1) return -1;
+        if (index > last0) return term;
+        return term - runs + 1 + std::min<int64_t>(runs - 1, (index - 1) / (last0 / runs));
+    }
+    int64_t conflict(uint32_t, int64_t, const int64_t *, uint32_t) override { return 0; }      // every shipped entry extends the log in its own term
+    int64_t epoch_index(uint32_t) override { return 0; }
+    int submit(const rg_batch_t &in, const rg_outcome_t &out) override { submits++; return rg_submit(table, &in, &out, RG_MEM_HOST); }
+    void applied(uint32_t, size_t, const rg_reply_t &, const rg_logfx_t &, const rg_persist_t &) override { repaired++; }
+};
+
 #define RG(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, rg_last_error(table)); return 1; } } while (0)
 
 int main(int argc, char **argv)
@@ -43,6 +65,8 @@ int main(int argc, char **argv)
     const unsigned READERS = argc > 4 ? (unsigned)atoi(argv[4]) : 4, EMITTERS = argc > 5 ? (unsigned)atoi(argv[5]) : 4;
     const uint32_t R = argc > 6 ? (uint32_t)atoi(argv[6]) : 16;
     const char *journal = argc > 7 && strcmp(argv[7], "-") != 0 ? argv[7] : nullptr;
+    const int OLD_PCT = argc > 8 ? atoi(argv[8]) : 0;
+    const int RUNS = OLD_PCT > 0 ? 6 : 1;                       // term runs of a Follower's log: terms TERM - RUNS + 1 .. TERM, LAST0 / RUNS entries each
     const int P = 5, SELF = 0, F = P - 1;
     const int64_t TERM = 7, LAST0 = 1000;
 
@@ -64,15 +88,17 @@ int main(int argc, char **argv)
         conn_of[g] = (uint32_t)((h >> 40) % C);                  // a Follower's leader sits behind this connection; peer slot = 1 + conn % 4
     }
     {
-        std::vector<int64_t> term(G, TERM), elected_term(G, 0), commit(G, LAST0), eidx(G, 0), eterm(G, 0), first(G, 1), last(G, LAST0), run_start(G, 1), run_term(G, TERM);
+        std::vector<int64_t> term(G, TERM), elected_term(G, 0), commit(G, LAST0), eidx(G, 0), eterm(G, 0), first(G, 1), last(G, LAST0);
+        std::vector<int64_t> run_start((size_t)G * RUNS), run_term((size_t)G * RUNS);
         std::vector<int32_t> voted(G), role(G), leader(G), votes(G, 1);
         std::vector<uint8_t> td(G, 0), prepared(G);
-        std::vector<uint32_t> repoch(G, 3), elected_epoch(G, 0), run_count(G, 1), run_offset(G);
+        std::vector<uint32_t> repoch(G, 3), elected_epoch(G, 0), run_count(G, (uint32_t)RUNS), run_offset(G);
         std::vector<int64_t> pe((size_t)G * F, 0), pn((size_t)G * F, LAST0 + 1), pm((size_t)G * F, LAST0);
         std::vector<int32_t> pr((size_t)G * F, 0);
         std::vector<uint8_t> pp((size_t)G * F, 0);
         for (uint32_t g = 0; g < G; g++) {
-            run_offset[g] = g;
+            run_offset[g] = g * (uint32_t)RUNS;
+            for (int k = 0; k < RUNS; k++) { run_start[(size_t)g * RUNS + k] = 1 + k * (LAST0 / RUNS); run_term[(size_t)g * RUNS + k] = TERM - RUNS + 1 + k; }
             role[g] = leads[g] ? RG_LEADER : RG_FOLLOWER;
             voted[g] = leads[g] ? SELF : 1 + (int32_t)(conn_of[g] % 4);
             leader[g] = leads[g] ? RG_NO_NODE : voted[g];
@@ -106,6 +132,10 @@ int main(int argc, char **argv)
                 q.term = TERM; q.node = 1 + (int32_t)(conn % 4); q.x = want_last[g]; q.y = TERM; q.leader_commit = q.x;
                 const uint64_t e = rnd() % 4;
                 q.entry_terms.assign(e == 3 ? 4 : e, TERM);
+                if (OLD_PCT > 0 && (int)(rnd() % 100) < OLD_PCT) {   // a heartbeat probing an entry of the oldest run: consistent, but below the cached runs
+                    q.x = 2; q.y = TERM - RUNS + 1; q.leader_commit = 0;
+                    q.entry_terms.clear();
+                }
                 want_last[g] += (int64_t)q.entry_terms.size();
                 f.type = ENQ;
                 codec.encode_request(M_APPEND_ENTRIES, q, f.body);
@@ -168,6 +198,9 @@ int main(int argc, char **argv)
             reading--;
         });
     uint64_t decided = 0, replied = 0, succeeded = 0, need_host = 0, frames = 0, out_bytes = 0, batches = 0, persisted = 0, wide = 0;
+    PipelineLog hostlog;
+    hostlog.table = table; hostlog.term = TERM; hostlog.last0 = LAST0; hostlog.runs = RUNS;
+    double t_repair = 0;
     double t_submit = 0, t_emit = 0, t_recycle = 0, t_seal = 0, t_scan = 0, t_persist = 0;
     for (;;) {
         const bool readers_done = reading.load() == 0;
@@ -188,6 +221,9 @@ int main(int argc, char **argv)
         if (w < 0) { fprintf(stderr, "rg_submit_wait: %s\n", rg_last_error(table)); return 1; }
         t_submit += now_s() - a;
         a = now_s();
+        if (OLD_PCT > 0 && repair_need_host(b, out[k].reply, out[k].logfx, true, hostlog) < 0) { fprintf(stderr, "repair failed: %s\n", rg_last_error(table)); return 1; }
+        t_repair += now_s() - a;
+        a = now_s();
         const size_t n = (size_t)b.batch.rounds * G;
         std::vector<raftgpu::host::StableStore::Record> dirty;
         size_t pi = 0;
@@ -198,7 +234,10 @@ int main(int argc, char **argv)
             replied += (fl & RG_F_REPLIED) != 0;
             succeeded += (fl & RG_F_SUCCESS) != 0;
             need_host += RG_F_STATUS(fl) == RG_NEED_HOST || RG_F_STATUS(fl) == RG_SKIPPED_AFTER_NEED_HOST;
-            if (fl & RG_F_PERSIST) { const rg_persist_t &p = out[k].persist[pi++]; dirty.push_back({(uint32_t)(i % G), p.term, p.voted_for}); }
+            if (fl & RG_F_PERSIST) {                                   // (a repaired row's persist item reached the host through applied(): none in this workload)
+                if (pi < out[k].counts[1]) { const rg_persist_t &p = out[k].persist[pi]; dirty.push_back({(uint32_t)(i % G), p.term, p.voted_for}); }
+                pi++;
+            }
         }
         t_scan += now_s() - a;
         a = now_s();
@@ -245,14 +284,15 @@ int main(int argc, char **argv)
     uint64_t wrong = 0;
     for (uint32_t g = 0; g < G; g++) wrong += last[g] != want_last[g] || term[g] != TERM || role[g] != (leads[g] ? RG_LEADER : RG_FOLLOWER);
     const bool ok = decided == rows && replied == requests && succeeded == requests && frames == requests && need_host == 0 && wrong == 0 && wide == 0 &&
-                    ing.refused() == 0;
+                    ing.refused() == 0 && (OLD_PCT == 0 || hostlog.repaired > 0);
     printf("ingress pipeline ok=%d: %u groups, %llu rows (%llu requests) in %.1f MB of frames on %u connections, %u readers, %u emitters, <= %u rounds per batch\n",
            (int)ok, G, (unsigned long long)rows, (unsigned long long)requests, bytes / 1e6, C, READERS, EMITTERS, R);
     printf("  socket bytes -> decisions -> response bytes: %.3f s = %.3e rows/s end to end; %llu batches (%.0f rows each), %llu response frames (%.1f MB), "
            "%llu groups wrong, %llu rows needed the host, %llu persisted\n", s, rows / s, (unsigned long long)batches, batches ? (double)decided / batches : 0.0,
            (unsigned long long)frames, out_bytes / 1e6, (unsigned long long)wrong, (unsigned long long)need_host, (unsigned long long)persisted);
-    printf("  flush thread: seal %.3f s, submit + wait %.3f s, reply scan %.3f s, persist %.3f s, emit %.3f s, recycle %.3f s (of %.3f s)\n", t_seal, t_submit, t_scan,
-           t_persist, t_emit, t_recycle, s);
+    printf("  flush thread: seal %.3f s, submit + wait %.3f s, repair %.3f s (%llu rows in %llu sparse submits), reply scan %.3f s, persist %.3f s, emit %.3f s, "
+           "recycle %.3f s (of %.3f s)\n", t_seal, t_submit, t_repair, (unsigned long long)hostlog.repaired, (unsigned long long)hostlog.submits, t_scan, t_persist, t_emit,
+           t_recycle, s);
     rg_table_destroy(table);
     return ok ? 0 : 1;
 }

@@ -249,6 +249,26 @@ size_t rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply,
     if (o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
     return o[conn].size();
 }
+}  // extern "C"
+namespace {
+struct CRepairHost : RepairHost {
+    const rw_repair_host_t &h;
+    explicit CRepairHost(const rw_repair_host_t &host) : h(host) {}
+    int64_t term_at(uint32_t gid, int64_t index) override { return h.term_at(h.user, gid, index); }
+    int64_t conflict(uint32_t gid, int64_t first, const int64_t *terms, uint32_t n) override { return h.conflict(h.user, gid, first, terms, n); }
+    int64_t epoch_index(uint32_t gid) override { return h.epoch_index(h.user, gid); }
+    int submit(const rg_batch_t &in, const rg_outcome_t &out) override { return h.submit(h.user, &in, &out); }
+    void applied(uint32_t gid, size_t cell, const rg_reply_t &r, const rg_logfx_t &l, const rg_persist_t &p) override { h.applied(h.user, gid, cell, &r, &l, &p); }
+};
+}  // namespace
+extern "C" {
+int64_t rw_ingress_repair(const rw_ingress_t *g, int bank, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || !reply || !logfx || !host || !host->term_at || !host->conflict || !host->epoch_index ||
+        !host->submit || !host->applied) return -1;
+    CRepairHost h(*host);
+    return repair_need_host(*g->sealed[bank], reply, logfx, packed != 0, h);
+}
 int rw_ingress_recycle(rw_ingress_t *g, int bank)
 {
     if (!g || bank < 0 || bank > 1 || !g->sealed[bank]) return 0;

@@ -48,6 +48,8 @@ def lib():
         L.rw_ingress_origin.argtypes = [_vp, C.c_int, _u64, C.POINTER(_u32), C.POINTER(_i32)]
         L.rw_ingress_emit.restype = _sz
         L.rw_ingress_emit.argtypes = [_vp, C.c_int, _vp, _u64, _u64, _u32, C.c_char_p, _sz]
+        L.rw_ingress_repair.restype = _i64
+        L.rw_ingress_repair.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(RepairHost)]
         L.rw_ingress_recycle.argtypes = [_vp, C.c_int]
         L.rw_ingress_refused.restype = _u64
         L.rw_ingress_refused.argtypes = [_vp]
@@ -55,6 +57,17 @@ def lib():
         L.rw_ingress_held.argtypes = [_vp]
         _lib = L
     return _lib
+
+
+TERM_AT = C.CFUNCTYPE(_i64, _vp, _u32, _i64)
+CONFLICT = C.CFUNCTYPE(_i64, _vp, _u32, _i64, C.POINTER(_i64), _u32)
+EPOCH_INDEX = C.CFUNCTYPE(_i64, _vp, _u32)
+SUBMIT = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome))
+APPLIED = C.CFUNCTYPE(None, _vp, _u32, _u64, _vp, _vp, _vp)
+
+
+class RepairHost(C.Structure):          # rw_repair_host_t
+    _fields_ = [("user", _vp), ("term_at", TERM_AT), ("conflict", CONFLICT), ("epoch_index", EPOCH_INDEX), ("submit", SUBMIT), ("applied", APPLIED)]
 
 
 def nodes_arg(nodes):
@@ -175,6 +188,20 @@ class Ingress:
         out = C.create_string_buffer(max(need, 1))
         assert lib().rw_ingress_emit(self._h, bank, reply.ctypes.data, cell_begin, cell_end, conn, out, need) == need
         return out.raw[:need]
+
+    def repair(self, bank, reply, logfx, packed, term_at, conflict, epoch_index, submit, applied):
+        """rw_ingress_repair with Python callables: term_at(gid, index), conflict(gid, first_index, [terms]), epoch_index(gid) -> int;
+        submit(CBatch*, COutcome*) -> 0; applied(gid, cell, reply row, logfx row, persist row as numpy records). reply is patched in place."""
+        assert reply.flags["C_CONTIGUOUS"] and reply.dtype == abi.REPLY_DT
+        logfx = np.ascontiguousarray(logfx)
+
+        def _applied(_u, gid, cell, r, l, p):
+            applied(gid, cell, np.frombuffer(C.string_at(r, 16), dtype=abi.REPLY_DT)[0], np.frombuffer(C.string_at(l, 16), dtype=abi.LOGFX_DT)[0],
+                    np.frombuffer(C.string_at(p, 16), dtype=abi.PERSIST_DT)[0])
+
+        host = RepairHost(None, TERM_AT(lambda _u, g, i: term_at(g, i)), CONFLICT(lambda _u, g, f, t, n: conflict(g, f, [t[k] for k in range(n)])),
+                          EPOCH_INDEX(lambda _u, g: epoch_index(g)), SUBMIT(lambda _u, b, o: submit(b, o)), APPLIED(_applied))
+        return lib().rw_ingress_repair(self._h, bank, reply.ctypes.data, logfx.ctypes.data, int(packed), C.byref(host))
 
     def recycle(self, bank):
         assert lib().rw_ingress_recycle(self._h, bank)

@@ -133,3 +133,25 @@ def test_split_kernel_is_refused_not_hung(monkeypatch):
     t = engine.Table(64, 3, 0, True)
     with pytest.raises(engine.EngineError):
         t.submit(abi.Batch(1, 64))
+
+
+def test_ingress_repairs_need_host_inside_multi_round_batches():
+    """A history whose rows DO leave the device's cached term runs, through the ingress: the multi-round batch comes back with RG_NEED_HOST rows
+    and RG_SKIPPED_AFTER_NEED_HOST rows behind them; rw_ingress_repair (hints from the host's log — a lossless shadow oracle here —, one sparse
+    submit per step for all broken groups, the group's later rows one by one) must leave every group with the rows, order, replies, response
+    frames and final state of the history decided row by row. (Lane-serial emulation: the wide step kernel decides the batches.)"""
+    from rafting_amd import wirelib
+    from tests import ingress_flow
+    G, P = 96, 5
+    st0, batches, outs, final = ingress_flow.history(G, P, 2, True, 60, 95, view=engine.Table(G, P, 2, True), allow_miss=True)
+    gpu = engine.Table(G, P, 2, True)
+    gpu.load_state(st0)
+    shadow = oracle_lib.OracleTable(G, P, 2, True)
+    shadow.load_state(st0)
+    nodes = [("10.1.0.%d" % i, 7000 + i) for i in range(P)]
+    sealed, repaired = ingress_flow.drive(lambda b32: gpu.submit(wirelib.unpack32(b32)), lambda sp: ingress_flow.decide_sparse_with_hints(gpu, shadow, sp),
+                                          G, P, batches, outs, 64, nodes, shadow=shadow,
+                                          raw_submit=lambda inp, outp: engine.lib().rg_submit(gpu._h, inp, outp, abi.MEM_HOST))
+    assert repaired > 0, "the history never left the cached term runs: nothing was repaired"
+    compare_states(final, gpu.read_state(), "after the ingress and its repairs")
+    compare_states(final, shadow.read_state(), "the host's log")

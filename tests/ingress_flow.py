@@ -13,10 +13,11 @@ ACK_METHOD = {abi.EV_AE_ACK: 1, abi.EV_PV_REPLY: 2, abi.EV_RV_REPLY: 3, abi.EV_I
 LOCAL_CONN = 16                       # connections 0..15 = the peer in that slot; 16 = the host's own rows
 
 
-def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None):
+def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None, allow_miss=False):
     """(initial state, [one-round batches], [the oracle's outcomes], final state). view: a table of the kind under test (engine.Table), decided
-    in lockstep — the fuzzer then draws its rows from THAT table's state image, whose cached term runs are the device's own (no row of the
-    history leaves them: RG_NEED_HOST round trips are the host's business and have their own tests), and its outcomes are held to the oracle's."""
+    in lockstep — the fuzzer then draws its rows from THAT table's state image, whose cached term runs are the device's own, and its outcomes
+    are held to the oracle's. allow_miss: rows whose lookups leave the cached runs are drawn too (the view answers RG_NEED_HOST, resolved with
+    hints from the oracle's lossless log as tests/test_gpu_parity.py does): the ingress flow then has to repair them (drive(shadow=...))."""
     from tests.helpers import compare_outcomes
     st0 = fuzz.random_initial_state(groups, cluster, self_slot, seed)
     for g in range(5, groups, 23):                    # a few groups whose terms lie beyond int32: their rows cannot be compact rows
@@ -25,7 +26,7 @@ def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None):
     orc.load_state(st0)
     if view is not None:
         view.load_state(st0)
-    fz = fuzz.Fuzzer(groups, cluster, self_slot, seed, allow_miss=False)
+    fz = fuzz.Fuzzer(groups, cluster, self_slot, seed, allow_miss=allow_miss)
     batches, outs = [], []
     for r in range(rounds):
         b = abi.Batch(1, groups)
@@ -34,16 +35,25 @@ def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None):
         cannot_travel = ((hdr & 0xF) == abi.EV_AE_REQ) & ((((hdr >> 4) & 0xF) >= cluster) | ((hdr >> 12) > abi.MAX_AE_ENTRIES))    # no NodeID / refused frame
         cannot_travel |= (hdr & abi.HDR_HINT_BIT) != 0
         b.head[cannot_travel] = (0, 0)
+        if view is not None:
+            cur = view.read_state()
+            og = view.submit(b)
+            if allow_miss:
+                from tests import test_gpu_parity as T
+                T._resolve_need_host(view, orc, b, og, cur)          # (needs the oracle's log as it is BEFORE the round)
         outs.append(orc.submit(b))
         if view is not None:
-            compare_outcomes(outs[-1], view.submit(b), "history round %d" % r)
+            compare_outcomes(outs[-1], og, "history round %d" % r)
         batches.append(b)
     return st0, batches, outs, orc.read_state()
 
 
-def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, max_rounds, nodes):
+def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, max_rounds, nodes, shadow=None, raw_submit=None):
     """Feeds the history, seals until everything was decided. table_decide32(abi.Batch32) and table_decide_sparse(abi.Batch with gid) return
-    objects with .reply (REPLY_DT rows). Returns the number of batches sealed."""
+    objects with .reply (REPLY_DT rows) and .logfx. Returns the number of batches sealed.
+    shadow + raw_submit: the table answers RG_NEED_HOST for rows that leave its cached term runs. shadow is an OracleTable loaded with the initial
+    state — it plays the host's RaftLog (lossless), kept in step with what the table has applied; raw_submit(CBatch*, COutcome*) is rg_submit on
+    the table. Missed rows and the rows skipped behind them are then decided through rw_ingress_repair before the next batch is sealed."""
     ctx = [b"group-%05d" % g for g in range(groups)]
     nodes_b = wirelib.nodes_arg(nodes)
     ing = wirelib.Ingress(groups, max_rounds, LOCAL_CONN + 1, nodes=nodes, entry_cap=1 << 18)
@@ -97,6 +107,7 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
     seen = [0] * groups
     got_answers = {}
     sealed = 0
+    repaired = []
     while True:
         s = ing.seal()
         if s.rows == 0 and not s.wide:
@@ -106,7 +117,34 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
         sealed += 1
         G = groups
         if s.batch.rounds:
-            reply = table_decide32(s.batch).reply
+            out = table_decide32(s.batch)
+            reply = out.reply
+            if shadow is not None:
+                status = (reply["flags"] >> abi.F_STATUS_SHIFT) & 0xFF
+                unapplied = (status == abi.NEED_HOST) | (status == abi.SKIPPED_AFTER_NEED_HOST)
+                wide_form = wirelib.unpack32(s.batch)
+                applied_part = wirelib.unpack32(s.batch)
+                applied_part.head[unapplied] = (0, 0)
+                shadow.submit(applied_part)                       # the host's log follows what the table applied
+                if unapplied.any():
+                    repaired.append(int(np.count_nonzero(unapplied & ((s.batch.head["hdr"] & 0xF) != 0))))
+
+                    def on_applied(gid, cell, rep, lfx, per):
+                        one = abi.Batch(1, 1, gid=np.array([gid], dtype=np.uint32))
+                        hdr, aux = int(wide_form.head["hdr"][cell]), int(wide_form.head["aux"][cell])
+                        n = hdr >> 12
+                        ents = wide_form.entry_terms[aux:aux + n] if (hdr & 0xF) == abi.EV_AE_REQ and n else None
+                        one.put(0, 0, hdr & 0xF, slot=(hdr >> 4) & 0xF, flag=(hdr >> 8) & 1, a=int(wide_form.ab["x"][cell]), b=int(wide_form.ab["y"][cell]),
+                                c=int(wide_form.cd["x"][cell]), d=int(wide_form.cd["y"][cell]), aux=aux, entries=ents, n=n)
+                        shadow.submit(one)
+
+                    def term_at(gid, index):
+                        t = shadow.log_term(gid, index)
+                        return -1 if t is None else t
+
+                    got = ing.repair(s.bank, reply, out.logfx, False, term_at, lambda g, first, terms: shadow.log_conflict(g, first, np.array(terms, dtype=np.int64)),
+                                     lambda g: int(shadow.read_state(g, 1).epoch_index[0]), raw_submit, on_applied)
+                    assert got == repaired[-1], (got, repaired[-1])
             for r in range(s.batch.rounds):
                 kinds = s.batch.head["hdr"][r * G:(r + 1) * G] & 0xF
                 for g in np.flatnonzero(kinds):
@@ -140,4 +178,36 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
     assert seen == [len(e) for e in expected] and sum(seen) == queued
     assert got_answers == answers
     ing.close()
-    return sealed
+    return (sealed, sum(repaired)) if shadow is not None else sealed
+
+
+def decide_sparse_with_hints(table, shadow, sp):
+    """rg_submit of a sparse single-round batch (the wide rows beside an ingress batch) with the host half of the RG_NEED_HOST protocol:
+    hints from the shadow log, resubmission of the missed rows; the shadow then follows. Returns the outcome with the final rows."""
+    out = table.submit(sp)
+    rows = np.flatnonzero(out.status == abi.NEED_HOST)
+    for row in rows:
+        g = int(sp.gid[row])
+        hdr, aux = int(sp.head["hdr"][row]), int(sp.head["aux"][row])
+        kind, n = hdr & 0xF, hdr >> 12
+        ents = sp.entry_terms[aux:aux + n] if kind == abi.EV_AE_REQ and n else None
+        one = abi.Batch(1, 1, gid=np.array([g], dtype=np.uint32), hints=True)
+        r = one.put(0, 0, kind, slot=(hdr >> 4) & 0xF, flag=(hdr >> 8) & 1, a=int(sp.ab["x"][row]), b=int(sp.ab["y"][row]), c=int(sp.cd["x"][row]),
+                    d=int(sp.cd["y"][row]), aux=aux, entries=ents, n=n)
+        if kind == abi.EV_AE_REQ:
+            prev, eidx = int(sp.ab["y"][row]), int(shadow.read_state(g, 1).epoch_index[0])
+            terms, e0 = ([] if ents is None else list(ents)), prev + 1
+            if n and e0 <= eidx:
+                skip = min(n, eidx - e0 + 1)
+                terms, e0 = terms[skip:], e0 + skip
+            pt = shadow.log_term(g, prev)
+            one.set_hint(r, -1 if pt is None else pt, shadow.log_conflict(g, e0, terms) if len(terms) else 0)
+        else:
+            idx = int(out.logfx["log_from"][row])
+            t = shadow.log_term(g, idx)
+            one.set_hint(r, idx, -1 if t is None else t)
+        o2 = table.submit(one)
+        assert o2.status[0] != abi.NEED_HOST
+        out.reply[row], out.logfx[row], out.persist[row] = o2.reply[0], o2.logfx[0], o2.persist[0]
+    shadow.submit(sp)
+    return out
