@@ -77,3 +77,18 @@ def test_argument_validation_needs_no_gpu():
     assert L.rg_table_create(0, 4, 9, 0, 1, C.byref(h)) == -1
     assert L.rg_table_create(0, 4, 3, 3, 1, C.byref(h)) == -1
     assert b"self_slot" in L.rg_last_error(None)
+
+
+def test_wire_library_exports_every_declared_symbol():
+    """include/raftwire.h (the host-side wire decoder and the ingress): every declared entry point is exported by build/libraftwire.so,
+    and the library exports no rw_* symbol the header does not declare."""
+    import subprocess
+    from rafting_amd import wirelib
+    header = open(os.path.join(ROOT, "include", "raftwire.h")).read()
+    declared = set(re.findall(r"\b(rw_[a-z_0-9]+)\s*\(", header)) - {"rw_splitter_t", "rw_ingress_t", "rw_repair_host_t"}
+    L = wirelib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", wirelib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.split() and ln.split()[-1].startswith("rw_")}
+    assert exported == declared, exported ^ declared
