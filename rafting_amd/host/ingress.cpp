@@ -139,7 +139,8 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
     for (size_t k = 1; k < n_terms; k++) same &= terms[k] == terms[0];
     uint64_t all = (uint64_t)a | (uint64_t)b | (uint64_t)c4 | (uint64_t)d;
     for (size_t k = 0; k < n_terms; k++) all |= (uint64_t)terms[k];
-    if (all >> 31) {                                              // not a compact row: close the group, hand the row over on its own
+    if ((all >> 31) || (!same && n_terms > bk.buf.entry_cap)) {  // not a compact row (a value beyond int32, or more terms than a bank's term array
+                                                                  // holds at all): close the group, hand the row over on its own
         const uint32_t was = depth.fetch_or(CLOSED, std::memory_order_relaxed);
         if (was >= rounds_) return false;                         // the group was full or closed already: wait for the next batch (it stays closed)
         HeldRow h{gid, head, a, b, c4, d, from, {}, 0};
@@ -242,7 +243,8 @@ void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a,
 {
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
-    if (gid >= groups_ || RG_HDR_KIND(head.hdr) == RG_EV_AE_REQ) { refused_.fetch_add(1, std::memory_order_relaxed); return; }   // (entries travel in frames)
+    const uint32_t kind = RG_HDR_KIND(head.hdr);                 // (AppendEntries: entries travel in frames; NONE / unknown kinds are no rows)
+    if (gid >= groups_ || kind == RG_EV_AE_REQ || kind == RG_EV_NONE || kind > RG_EV_IS_REQ) { refused_.fetch_add(1, std::memory_order_relaxed); return; }
     if (!place(bank_[fill_], c, gid, head, a, b, c4, d, nullptr, 0, reply_to)) hold(c, gid, head, a, b, c4, d, nullptr, 0, reply_to);
 }
 

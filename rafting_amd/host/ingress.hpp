@@ -90,7 +90,8 @@ struct SealedBatch {
     rg_batch32_t batch;                 // gid == NULL (dense); pointers into the bank
     const Origin *origin;               // [rounds * groups]
     uint64_t rows;                      // cells that hold an event
-    std::vector<HeldRow> wide;          // rows the compact format cannot express, at most one per group, ascending gid: the host decides them
+    std::vector<HeldRow> wide;          // rows the compact format cannot express (a value beyond 2^31, entry terms of several terms that outnumber
+                                        // the bank's term array), at most one per group, ascending gid: the host decides them
                                         // with ONE sparse rg_submit AFTER this batch (their groups took no later row into the batch)
 };
 

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include "ingress.hpp"
 #include "wire.hpp"
 using namespace rafting::wire;
 int main(int argc, char **argv) {
@@ -52,6 +53,78 @@ int main(int argc, char **argv) {
             sp.feed(chunk.data(), chunk.size(), out);
         }
     }
-    printf("fuzz ok: %zu decoded, %zu refused\n", ok, bad);
+    // the ingress on streams of valid frames with damage: flipped bytes, cut tails, frames for unknown contexts, responses nobody waits for, values
+    // beyond int32, more entries than a row may carry, more rows than rounds. Whatever arrives: no out-of-bounds access, every cell that holds an event
+    // belongs to a known group and a known round, rows + held + refused account for every frame that decoded
+    size_t ing_rows = 0, ing_refused = 0;
+    for (int iter = 0; iter < iters / 300; iter++) {
+        const uint32_t G = 1 + rng() % 40, R = 1 + rng() % 5, C = 1 + rng() % 3;
+        ContextIndex index(G);
+        for (uint32_t g = 0; g < G; g++) { const std::string id = "c" + std::to_string(g); index.insert(id.data(), id.size(), g); }
+        const size_t cells = (size_t)G * R;
+        std::vector<rg_ev_head_t> head[2] = {std::vector<rg_ev_head_t>(cells), std::vector<rg_ev_head_t>(cells)};
+        std::vector<rg_ev_quad32_t> abcd[2] = {std::vector<rg_ev_quad32_t>(cells), std::vector<rg_ev_quad32_t>(cells)};
+        const uint64_t cap = rng() % 64;
+        std::vector<int32_t> terms[2] = {std::vector<int32_t>(cap + 1), std::vector<int32_t>(cap + 1)};     // exact sizes: ASan sees an overrun of the term array
+        Ingress ing(G, R, C, kryo, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), cap},
+                    Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), cap}, 64);
+        for (uint32_t c = 0; c < C; c++) if (rng() % 4) ing.set_peer(c, (int32_t)(rng() % 3));
+        for (uint32_t c = 0; c < C; c++) {
+            std::string st;
+            const int frames = (int)(rng() % 200);
+            for (int k = 0; k < frames; k++) {
+                Frame f;
+                f.type = (rng() % 3) ? ENQ : ACK; f.sequence = (int32_t)(rng() % 100);
+                const Method m = (Method)(1 + rng() % 4);
+                f.head = make_scope(m, "c" + std::to_string(rng() % (G + 3)));
+                if (f.type == ENQ) {
+                    Request q; q.term = (rng() % 20) ? (int64_t)(rng() % 1000) : (int64_t)rng(); q.node = rng() % 3; q.x = (int64_t)(rng() % 5000); q.y = (int64_t)(rng() % 1000);
+                    q.leader_commit = q.x;
+                    q.entry_terms.assign((rng() % 50) ? rng() % 6 : 190 + rng() % 30, (int64_t)(rng() % 100));
+                    if (rng() % 3 == 0 && !q.entry_terms.empty()) q.entry_terms.back() += 1;
+                    kryo.encode_request(m, q, f.body);
+                } else {
+                    kryo.encode_response(Response{(int64_t)(rng() % 1000), (bool)(rng() & 1)}, f.body);
+                    if (rng() % 2) ing.pending(c).put(f.sequence, m, (uint32_t)(rng() % G), Pending{(uint32_t)rng(), (int64_t)(rng() % 100), (int64_t)(rng() % 100)});
+                }
+                if (rng() % 40 == 0 && !f.body.empty()) f.body[rng() % f.body.size()] = (char)rng();
+                encode_frame(f, false, st);
+            }
+            if (rng() % 5 == 0 && !st.empty()) st[rng() % st.size()] = (char)rng();          // damage to the framing itself: the connection dies there
+            if (rng() % 7 == 0 && !st.empty()) st.resize(rng() % st.size());
+            for (size_t at = 0; at < st.size();) {
+                const size_t n = std::min<size_t>(1 + rng() % 700, st.size() - at);
+                std::vector<uint8_t> piece(st.begin() + (long)at, st.begin() + (long)(at + n));
+                ing.feed(c, piece.data(), piece.size());
+                at += n;
+                if (rng() % 20 == 0) ing.add_row(c, (uint32_t)(rng() % (G + 2)), rg_ev_head_t{RG_HDR_MAKE(rng() % 12, 0, 0, 0), 0}, (int64_t)(rng() % 100), 0, 0, 0, Origin{NO_CONN, 0});
+            }
+        }
+        for (int round = 0; round < 400; round++) {
+            const SealedBatch &b = ing.seal();
+            if (b.batch.rounds > R || b.batch.count != G || b.batch.entry_count > cap) { printf("ingress: batch out of shape\n"); return 1; }
+            size_t events = 0;
+            std::vector<rg_reply_t> reply((size_t)b.batch.rounds * G, rg_reply_t{7, RG_F_REPLIED, 1});
+            for (size_t cell = 0; cell < (size_t)b.batch.rounds * G; cell++) {
+                const rg_ev_head_t h = b.batch.head[cell];
+                if (RG_HDR_KIND(h.hdr) == RG_EV_NONE) continue;
+                events++;
+                if (RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ && RG_HDR_N(h.hdr) > 0 && !(h.hdr & RG_HDR_SAME_TERM) && (uint64_t)h.aux + RG_HDR_N(h.hdr) > b.batch.entry_count) {
+                    printf("ingress: a row's entry terms lie outside the term array\n"); return 1;
+                }
+                if (RG_HDR_N(h.hdr) > RG_MAX_AE_ENTRIES && RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ) { printf("ingress: oversized row\n"); return 1; }
+            }
+            if (events != b.rows) { printf("ingress: %zu events, %llu counted\n", events, (unsigned long long)b.rows); return 1; }
+            std::vector<std::string> out(C);
+            ing.emit(b, reply.data(), out);
+            ing_rows += events + b.wide.size();
+            const bool last = b.rows == 0 && b.wide.empty();
+            ing.recycle(b);
+            if (last) break;
+        }
+        if (ing.held() != 0) { printf("ingress: rows still held after 400 batches\n"); return 1; }
+        ing_refused += ing.refused();
+    }
+    printf("fuzz ok: %zu decoded, %zu refused; ingress %zu rows, %zu refused\n", ok, bad, ing_rows, ing_refused);
     return 0;
 }

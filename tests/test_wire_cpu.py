@@ -266,13 +266,13 @@ def test_zero_copy_stream_path_decodes_every_frame(tmp_path):
 
 def test_decoders_survive_hostile_bytes_under_sanitizers(tmp_path):
     """tests/native/wire_fuzz.cpp with ASan + UBSan: random bytes, mutated valid bodies and truncations through both body codecs, garbage through
-    the frame splitter — a peer must not be able to crash the host or make it read out of bounds (the Kryo-format reader parses lengths and
-    class names that come off the wire)."""
+    the frame splitter, damaged frame streams through the ingress (cells, term array and held rows stay in bounds and accounted for) — a peer
+    must not be able to crash the host or make it read out of bounds (the Kryo-format reader parses lengths and class names that come off the wire)."""
     host = os.path.join(ROOT, "rafting_amd", "host")
     exe = str(tmp_path / "wire_fuzz")
     r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-I" + host,
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "wire_fuzz.cpp"), os.path.join(host, "wire.cpp"),
-                        os.path.join(host, "kryo_body.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+                        os.path.join(host, "kryo_body.cpp"), os.path.join(host, "ingress.cpp"), "-pthread", "-o", exe], capture_output=True, text=True, timeout=600)
     if r.returncode != 0 and "sanitize" in r.stderr:
         pytest.skip("no sanitizer runtime: " + r.stderr[-200:])
     assert r.returncode == 0, r.stderr[-3000:]
