@@ -90,6 +90,15 @@ int      rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int m
                          int64_t last_index_sent);
 /* bytes as they arrive: rows queued by this call, or -1 once the connection broke the frame grammar */
 int      rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n);
+/* N1's output on the wire: what rg_replicate decided for follower j of `count` leader rows (head[count]; send_j = send + j * count, the rg_send_t
+ * of that follower; gid NULL = rows are groups 0..count-1) as the request frames Leader.replicateLog ships (member/Leader.java:168-245,
+ * transport/NettyNode.java:54-73), written to out[cap] for connection `conn`, each under the connection's next sequence number with its
+ * invocation record filed for the response (what rw_ingress_sent does by hand). term_of(user, gid, index) reads an entry's term from the host's
+ * RaftLog; the command payload is the transport's and is not modelled. RG_SEND_NEED_HOST rows are skipped and counted in *need_host.
+ * Returns the bytes written, or the bytes needed when that exceeds cap — in which case NOTHING happened (no sequence number used, no record filed). */
+size_t   rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head,
+                                 const rg_send_t *send_j, int64_t (*term_of)(void *user, uint32_t gid, int64_t index), void *user,
+                                 uint8_t *out, size_t cap, uint32_t *frames, uint32_t *need_host);
 /* a row that does not come off the wire (RG_EV_TIMEOUT, RG_EV_CLIENT_APPEND, RG_EV_LOG_FLUSH, an RG_EV_IS_REQ released with the host's verdict),
  * queued like a row of connection `conn` — give local sources connection numbers of their own. reply_conn = UINT32_MAX: nobody waits for a
  * reply, else the RG_F_REPLIED answer is emitted as the response to (reply_conn, reply_sequence). Not for RG_EV_AE_REQ (entries travel in frames). */
@@ -97,7 +106,8 @@ int      rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32
                             uint32_t reply_conn, int32_t reply_sequence);
 /* close the batch being filled: *batch describes it (dense, gid NULL; rounds may be 0), *rows = cells that hold an event, *wide = rows that
  * had to stay out of the compact format (read them with rw_ingress_wide_row, decide them with one sparse rg_submit AFTER this batch).
- * Returns the bank (0 / 1) the batch lies in. The batch stays valid until rw_ingress_recycle(bank). */
+ * Returns the bank (0 / 1) the batch lies in, or -1 when the batch sealed before this one has not been recycled yet (one sealed batch is with
+ * the flusher at a time; the feeders fill the other bank meanwhile). The batch stays valid until rw_ingress_recycle(bank). */
 int      rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32_t *wide);
 int      rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms,
                              uint32_t max_terms, uint32_t *reply_conn, int32_t *reply_sequence);

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <stdexcept>
 
 namespace rafting {
 namespace wire {
@@ -239,6 +240,46 @@ int Ingress::feed(uint32_t conn, const uint8_t *data, size_t n)
     return c.sp.failed() ? -1 : c.queued;
 }
 
+size_t Ingress::encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head, const rg_send_t *send_j,
+                             TermOf &log, std::string &out, uint32_t *need_host)
+{
+    Conn &c = c_[conn];
+    size_t made = 0;
+    uint32_t missing = 0;
+    Frame f;
+    f.type = ENQ;
+    Request q;
+    q.node = self_slot;
+    for (uint32_t i = 0; i < count; i++) {
+        const rg_send_t &s = send_j[i];
+        const rg_send_head_t &h = head[i];
+        if (s.kind == RG_SEND_NEED_HOST) { missing++; continue; }
+        if (s.kind != RG_SEND_APPEND && s.kind != RG_SEND_SNAPSHOT) continue;
+        const uint32_t g = gid ? gid[i] : i;
+        const Method m = s.kind == RG_SEND_APPEND ? M_APPEND_ENTRIES : M_INSTALL_SNAPSHOT;
+        q.term = h.term;
+        q.entry_terms.clear();
+        if (m == M_APPEND_ENTRIES) {
+            q.x = s.prev_index; q.y = s.prev_term; q.leader_commit = h.leader_commit;
+            for (uint32_t k = 0; k < s.count; k++) q.entry_terms.push_back(log.term_of(g, s.prev_index + 1 + (int64_t)k));
+        } else {
+            q.x = h.epoch_index; q.y = h.epoch_term; q.leader_commit = 0;
+        }
+        f.sequence = c.next_sequence++;
+        f.head.assign(m == M_APPEND_ENTRIES ? "appendEntries:" : "installSnapshot:");
+        index_.append_id(g, f.head);
+        f.body.clear();
+        codec_.encode_request(m, q, f.body);
+        encode_frame(f, false, out);
+        Pending p;
+        p.role_epoch = h.role_epoch; p.epoch_at_send = h.epoch_index; p.last_index_sent = s.last_index;
+        c.ring->put(f.sequence, m, g, p);
+        made++;
+    }
+    if (need_host) *need_host = missing;
+    return made;
+}
+
 void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, Origin reply_to)
 {
     std::shared_lock<std::shared_mutex> lk(mu_);
@@ -252,6 +293,9 @@ const SealedBatch &Ingress::seal()
 {
     std::unique_lock<std::shared_mutex> lk(mu_);
     const int done = fill_, next = fill_ ^ 1;
+    // two banks: one being filled, one sealed and with the flusher. Sealing again before that one was recycle()d would hand its memory to the
+    // feeders while the flusher still reads it
+    if (!bank_[next].clean) throw std::logic_error("Ingress::seal: the batch sealed before this one has not been recycled");
     Bank &bk = bank_[done];
     SealedBatch &s = sealed_[done];
     uint32_t rounds = 0;
@@ -272,7 +316,6 @@ const SealedBatch &Ingress::seal()
     bk.clean = false;
     // open the other bank, oldest held rows first
     Bank &nb = bank_[next];
-    if (!nb.clean) wipe(nb);                                      // (a caller that skipped recycle(): correct, but feeders wait for the wipe)
     nb.clean = false;
     fill_ = next;
     std::vector<std::pair<HeldRow, uint32_t>> waiting;            // every held row with its connection, oldest ticket first

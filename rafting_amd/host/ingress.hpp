@@ -106,15 +106,29 @@ public:
 
     void set_peer(uint32_t conn, int32_t peer_slot);             // the node at the other end (its slot in the cluster list)
     PendingRing &pending(uint32_t conn) { return *c_[conn].ring; }
+    int32_t &send_sequence(uint32_t conn) { return c_[conn].next_sequence; }   // the sequence number encode_sends gives its next request on `conn`
 
     // Bytes as they arrive on `conn`. Returns the number of rows this call queued (placed or held), -1 once the stream broke the grammar.
     int feed(uint32_t conn, const uint8_t *data, size_t n);
+    // N1's output on the wire: what rg_replicate decided for follower j of `count` leader rows (send_j = the rg_send_t of that follower, one per
+    // row; head = the rows' rg_send_head_t; gid NULL = rows 0..count-1 are groups 0..count-1) as the request frames Leader.replicateLog ships —
+    // appendEntries(term, self, prevLogIndex, prevLogTerm, entries, leaderCommit) / installSnapshot(term, self, epoch.index, epoch.term)
+    // (member/Leader.java:168-245, transport/NettyNode.java:54-73) — appended to `out` for connection `conn`, each under the connection's next
+    // sequence number with its invocation record (role epoch, epoch.index at send, lastIndex) filed for the response
+    // (transport/rpc/AsyncService.java:91-104). term_of(gid, index) reads an entry's term from the host's RaftLog (the command payload is the
+    // transport's and is not modelled: an entry travels as the 8 bytes of its term, as KryoBodyCodec writes it). Rows with RG_SEND_NONE /
+    // RG_SEND_GATED send nothing; RG_SEND_NEED_HOST rows are the caller's to complete first (prev_term from its log) — they are skipped and
+    // counted in *need_host. Returns the frames written. One caller per connection at a time, like feed().
+    struct TermOf { virtual ~TermOf() {} virtual int64_t term_of(uint32_t gid, int64_t index) = 0; };
+    size_t encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head, const rg_send_t *send_j, TermOf &log,
+                        std::string &out, uint32_t *need_host = nullptr);
     // A row that does not come off the wire — RG_EV_TIMEOUT from rg_timers_expired, RG_EV_CLIENT_APPEND, RG_EV_LOG_FLUSH, an installSnapshot
     // request released with the host's verdict — queued like a row of connection `conn` (give local sources connection numbers of their own:
     // one caller per connection at a time, as for feed()). reply_to: where an RG_F_REPLIED answer goes ({NO_CONN, 0}: nowhere).
     void add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c, int64_t d, Origin reply_to);
-    // Close the bank being filled and open the other one (rows held back by the closed bank are placed first). The other bank must have
-    // been recycle()d. The sealed batch stays valid until its recycle().
+    // Close the bank being filled and open the other one (rows held back by the closed bank are placed first). At most ONE sealed batch is
+    // with the flusher at a time: sealing again before the previous batch was recycle()d throws std::logic_error. The sealed batch stays
+    // valid until its recycle().
     const SealedBatch &seal();
     // After the batch was decided: one PongEvent frame per cell whose reply carries RG_F_REPLIED, appended to out[conn] in cell order.
     // N3's rule — no reply before its (term, votedFor) is durable (member/RaftMember.java:25) — is the caller's: StableStore::persist of the
@@ -148,6 +162,7 @@ private:
         Request q;                                               // decode scratch
         std::string ctx;
         int queued = 0;
+        int32_t next_sequence = 0;                               // of the requests this side sends on the connection (AsyncService.sequence)
         uint64_t rows = 0;                                       // rows this connection placed into the bank being filled, and the deepest
         uint32_t max_depth = 0;                                  // round it reached (folded by seal(): no shared counter on the row path)
     };

@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <stdexcept>
 #include <deque>
 #include <string>
 #include <vector>
@@ -206,6 +207,29 @@ int rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method
     return 1;
 }
 int rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n) { return (!g || conn >= g->conns) ? -1 : g->in->feed(conn, data, n); }
+}  // extern "C"
+namespace {
+struct CTermOf : Ingress::TermOf {
+    int64_t (*fn)(void *, uint32_t, int64_t);
+    void *user;
+    int64_t term_of(uint32_t gid, int64_t index) override { return fn(user, gid, index); }
+};
+}  // namespace
+extern "C" {
+size_t rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head,
+                               const rg_send_t *send_j, int64_t (*term_of)(void *user, uint32_t gid, int64_t index), void *user, uint8_t *out, size_t cap,
+                               uint32_t *frames, uint32_t *need_host)
+{
+    if (!g || conn >= g->conns || !head || !send_j || !term_of || !frames || !need_host) return 0;
+    CTermOf log;
+    log.fn = term_of; log.user = user;
+    std::string o;
+    const int32_t seq0 = g->in->send_sequence(conn);
+    *frames = (uint32_t)g->in->encode_sends(conn, self_slot, count, gid, head, send_j, log, o, need_host);
+    if (o.size() > cap) { g->in->send_sequence(conn) = seq0; *frames = 0; return o.size(); }   // (the records filed are filed again, identically, by the retry)
+    memcpy(out, o.data(), o.size());
+    return o.size();
+}
 int rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
                        uint32_t reply_conn, int32_t reply_sequence)
 {
@@ -216,7 +240,9 @@ int rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hd
 int rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32_t *wide)
 {
     if (!g) return -1;
-    const SealedBatch &s = g->in->seal();
+    const SealedBatch *sp;
+    try { sp = &g->in->seal(); } catch (const std::logic_error &) { return -1; }      // the batch sealed before has not been recycled
+    const SealedBatch &s = *sp;
     const int bank = g->in->bank_of(s);
     g->sealed[bank] = &s;
     *batch = s.batch; *rows = s.rows; *wide = (uint32_t)s.wide.size();

@@ -43,6 +43,8 @@ def lib():
         L.rw_ingress_sent.argtypes = [_vp, _u32, _i32, C.c_int, _u32, _u32, _i64, _i64]
         L.rw_ingress_feed.argtypes = [_vp, _u32, C.c_char_p, _sz]
         L.rw_ingress_add_row.argtypes = [_vp, _u32, _u32, _u32, _u32, _i64, _i64, _i64, _i64, _u32, _i32]
+        L.rw_ingress_encode_sends.restype = _sz
+        L.rw_ingress_encode_sends.argtypes = [_vp, _u32, _i32, _u32, _vp, _vp, _vp, TERM_OF, _vp, C.c_char_p, _sz, C.POINTER(_u32), C.POINTER(_u32)]
         L.rw_ingress_seal.argtypes = [_vp, C.POINTER(abi.CBatch32), C.POINTER(_u64), C.POINTER(_u32)]
         L.rw_ingress_wide_row.argtypes = [_vp, C.c_int, _u32, C.POINTER(_u32), _vp, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_i32)]
         L.rw_ingress_origin.argtypes = [_vp, C.c_int, _u64, C.POINTER(_u32), C.POINTER(_i32)]
@@ -60,6 +62,7 @@ def lib():
 
 
 TERM_AT = C.CFUNCTYPE(_i64, _vp, _u32, _i64)
+TERM_OF = TERM_AT
 CONFLICT = C.CFUNCTYPE(_i64, _vp, _u32, _i64, C.POINTER(_i64), _u32)
 EPOCH_INDEX = C.CFUNCTYPE(_i64, _vp, _u32)
 SUBMIT = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome))
@@ -162,10 +165,23 @@ class Ingress:
     def add_row(self, conn, gid, hdr, aux=0, a=0, b=0, c=0, d=0, reply_conn=NO_CONN, reply_sequence=0):
         assert lib().rw_ingress_add_row(self._h, conn, gid, hdr, aux, a, b, c, d, reply_conn, reply_sequence)
 
+    def encode_sends(self, conn, self_slot, head, send_j, term_of, gid=None):
+        """rw_ingress_encode_sends: (bytes for `conn`, frames, rows that still need the host). head: SEND_HEAD_DT[count], send_j: SEND_DT[count]"""
+        head, send_j = np.ascontiguousarray(head), np.ascontiguousarray(send_j)
+        gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint32)
+        cb = TERM_OF(lambda _u, g, i: term_of(g, i))
+        frames, need = _u32(), _u32()
+        args = (self._h, conn, self_slot, len(head), None if gid is None else gid.ctypes.data, head.ctypes.data, send_j.ctypes.data, cb, None)
+        size = lib().rw_ingress_encode_sends(*args, None, 0, C.byref(frames), C.byref(need))
+        out = C.create_string_buffer(max(size, 1))
+        assert lib().rw_ingress_encode_sends(*args, out, size, C.byref(frames), C.byref(need)) == size
+        return out.raw[:size], frames.value, need.value
+
     def seal(self):
         cb, rows, nwide = abi.CBatch32(), _u64(), _u32()
         bank = lib().rw_ingress_seal(self._h, C.byref(cb), C.byref(rows), C.byref(nwide))
-        assert bank in (0, 1)
+        if bank not in (0, 1):
+            raise RuntimeError("rw_ingress_seal: the batch sealed before this one has not been recycled")
         cells = cb.rounds * cb.count
         b32 = abi.Batch32(cb.rounds, cb.count, None, self.head[bank][:cells], self.abcd[bank][:cells], self.terms[bank], cb.entry_count)
         wide = []

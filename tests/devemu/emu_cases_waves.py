@@ -122,3 +122,14 @@ def test_ingress_batches_are_decided_like_the_history_row_by_row():
     nodes = [("10.1.0.%d" % i, 7000 + i) for i in range(P)]
     ingress_flow.drive(lambda b32: gpu.submit32(b32), lambda sp: gpu.submit(sp), G, P, batches, outs, 64, nodes)
     compare_states(final, gpu.read_state(), "after the ingress")
+
+
+def test_replication_loop_over_frames_equals_the_in_memory_loop():
+    """N1 joined to N2 on the kernels: rg_replicate's plans as request frames (Ingress.encode_sends), the followers' ingress batches through
+    step32_kernel, their response frames matched to the leader's invocation records, its ack rows — against the same loop with rows built
+    directly from plans and replies on the oracle."""
+    from tests import ingress_flow
+    mem = ingress_flow.replication_loop(lambda g, p, s, pv: oracle_lib.OracleTable(g, p, s, pv), 40, 8, 7, over_the_wire=False)
+    net = ingress_flow.replication_loop(lambda g, p, s, pv: engine.Table(g, p, s, pv), 40, 8, 7, over_the_wire=True)
+    for node in range(3):
+        compare_states(mem[node], net[node], "node %d" % node)

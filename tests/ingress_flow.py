@@ -211,3 +211,101 @@ def decide_sparse_with_hints(table, shadow, sp):
         out.reply[row], out.logfx[row], out.persist[row] = o2.reply[0], o2.logfx[0], o2.persist[0]
     shadow.submit(sp)
     return out
+
+
+# ---- a closed replication loop over real frames: Leader.replicateLog -> wire -> Follower.appendEntries -> wire -> the leader's ack callback ------
+def replication_loop(make_table, groups, ticks, seed, over_the_wire):
+    """Three nodes (slot 0 leads every group, slots 1 and 2 follow), `ticks` rounds of: client commands at the leader -> rg_replicate -> the
+    AppendEntries the plan calls for -> the followers decide -> their responses -> the leader's ack rows (match / commit advance).
+    over_the_wire = False: rows are built directly from the send plans and the reply rows (the in-memory reference run).
+    over_the_wire = True: the plans become request frames (Ingress.encode_sends, which files the invocation records), every node's inbound
+    bytes go through its Ingress, replies go back as response frames (emit) and are matched to their invocations by (connection, sequence).
+    Returns the three final states and the leader's commit indices. make_table(groups, cluster, self_slot, pre_vote) -> a table with
+    load_state / read_state / submit / replicate (OracleTable or engine.Table)."""
+    import random
+    from tests.helpers import make_state, simple_log
+    P, TERM, LAST0 = 3, 5, 10
+    rng = random.Random(seed)
+    nodes = [("10.2.0.%d" % i, 7100 + i) for i in range(P)]
+    tabs = [make_table(groups, P, s, True) for s in range(P)]
+    tabs[0].load_state(make_state(P, groups, role=abi.LEADER, term=TERM, voted_for=0, repl_prepared=1, role_epoch=4, commit=LAST0, log=simple_log(LAST0, TERM),
+                                  peers=[(0, LAST0 + 1, LAST0, 0, 0)] * 2))
+    for s in (1, 2):
+        tabs[s].load_state(make_state(P, groups, role=abi.FOLLOWER, term=TERM, voted_for=0, leader=0, role_epoch=2, commit=LAST0, log=simple_log(LAST0, TERM)))
+    ctx = [b"kv/%04d" % g for g in range(groups)]
+    ing = None
+    if over_the_wire:
+        # leader: connection j -> follower slot j + 1, connection 2 = its own rows; follower: connection 0 -> the leader, connection 1 = its own rows
+        ing = [wirelib.Ingress(groups, 4, 3, nodes=nodes), wirelib.Ingress(groups, 4, 2, nodes=nodes), wirelib.Ingress(groups, 4, 2, nodes=nodes)]
+        for i in ing:
+            for g in range(groups):
+                assert i.add_context(ctx[g], g)
+        ing[0].set_peer(0, 1)
+        ing[0].set_peer(1, 2)
+        ing[1].set_peer(0, 0)
+        ing[2].set_peer(0, 0)
+
+    def decide_all(node, then=None):
+        """seal node's ingress until it is empty; every batch is decided, handed to then(sealed, outcome) and recycled before the next seal
+        (no wide rows, no misses in this workload)"""
+        while True:
+            s = ing[node].seal()
+            assert not s.wide
+            if s.rows:
+                out = tabs[node].submit(wirelib.unpack32(s.batch)) if not hasattr(tabs[node], "submit32") else tabs[node].submit32(s.batch)
+                assert not np.any(((out.reply["flags"] >> abi.F_STATUS_SHIFT) & 0xFF) == abi.NEED_HOST)
+                if then:
+                    then(s, out)
+            ing[node].recycle(s.bank)
+            if not s.rows:
+                assert ing[node].held() == 0
+                return
+
+    for tick in range(ticks):
+        # 1. client commands
+        cmds = abi.Batch(1, groups)
+        for g in range(groups):
+            if rng.random() < 0.6:
+                cmds.put(0, g, abi.EV_CLIENT_APPEND, n=rng.randint(1, 3))
+        if over_the_wire:
+            for g in np.flatnonzero(cmds.head["hdr"] & 0xF):
+                ing[0].add_row(2, int(g), int(cmds.head["hdr"][g]))
+            decide_all(0)
+        else:
+            tabs[0].submit(cmds)
+        # 2. the send side
+        head, send = tabs[0].replicate(heartbeat=tick % 2)
+        acks = abi.Batch(2, groups)                         # in-memory run: follower j's ack in round j
+        for j in (0, 1):
+            fol = j + 1
+            if over_the_wire:
+                data, frames, need = ing[0].encode_sends(j, 0, head, send[:, j], lambda g, i: TERM)
+                assert need == 0 and frames == int(np.count_nonzero(send["kind"][:, j] == abi.SEND_APPEND))
+                assert ing[fol].feed(0, data) == frames
+                back = bytearray()
+                decide_all(fol, lambda s, out: back.extend(ing[fol].emit(s.bank, out.reply, 0)))
+                assert ing[0].feed(j, bytes(back)) == frames     # every response finds its invocation
+            else:
+                req = abi.Batch(1, groups)
+                for g in range(groups):
+                    sd = send[g, j]
+                    assert int(sd["kind"]) in (abi.SEND_APPEND, abi.SEND_GATED, abi.SEND_NONE)
+                    if int(sd["kind"]) == abi.SEND_APPEND:
+                        req.put(0, g, abi.EV_AE_REQ, slot=0, a=int(head["term"][g]), b=int(sd["prev_index"]), c=int(sd["prev_term"]),
+                                d=int(head["leader_commit"][g]), entries=[TERM] * int(sd["count"]))
+                out = tabs[fol].submit(req)
+                for g in range(groups):
+                    if int(send[g, j]["kind"]) == abi.SEND_APPEND and int(out.reply["flags"][g]) & abi.F_REPLIED:
+                        acks.put(j, g, abi.EV_AE_ACK, slot=fol, flag=int(bool(int(out.reply["flags"][g]) & abi.F_SUCCESS)), a=int(out.reply["resp_term"][g]),
+                                 b=int(head["epoch_index"][g]), c=int(send[g, j]["last_index"]), aux=int(head["role_epoch"][g]))
+        # 3. the acks at the leader
+        if over_the_wire:
+            decide_all(0)
+        else:
+            tabs[0].submit(acks)
+    states = [t.read_state() for t in tabs]
+    if over_the_wire:
+        assert all(i.refused() == 0 for i in ing)
+        for i in ing:
+            i.close()
+    return states

@@ -131,6 +131,10 @@ def test_what_is_not_a_decision_row_is_refused_and_counted():
     assert s.rows == 1 and s.batch.rounds == 1
     assert int(s.batch.head["hdr"][0]) == abi.hdr_make(abi.EV_AE_ACK, 1, 1, 0) and int(s.batch.head["aux"][0]) == 4
     assert tuple(int(v) for v in s.batch.abcd[0]) == (5, 11, 12, 0) and ing.origin(s.bank, 0) is None
+    with pytest.raises(RuntimeError):                                                 # one sealed batch is with the flusher at a time
+        ing.seal()
+    ing.recycle(s.bank)
+    assert ing.seal().rows == 0
     assert ing.feed(0, b"\x07") == -1                                                 # not SOH: the connection is dead
     assert ing.feed(0, wirelib.request_frame(nodes_b, 3, b"a", 1, 1, 1, 1, 1)) == -1
 
@@ -175,3 +179,17 @@ def test_ingress_threads_under_sanitizers(tmp_path, sanitizer):
     p = subprocess.run([exe, "128", "5", "2500", "4"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "ingress race ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
     assert "Sanitizer" not in p.stderr, p.stderr[-3000:]
+
+
+def test_replication_loop_over_frames_equals_the_in_memory_loop():
+    """N1 joined to N2: what rg_replicate plans leaves the leader as request frames with filed invocation records (Ingress.encode_sends),
+    the followers decide them from their ingress batches and answer with response frames (emit), the leader's ingress matches every response
+    to its invocation and turns it into the ack row — 12 ticks, client commands in between. All three nodes must end exactly where the same
+    loop ends when rows are built directly from plans and reply rows, and the leader must have committed what it appended."""
+    from tests.helpers import compare_states
+    mk = lambda g, p, s, pv: oracle_lib.OracleTable(g, p, s, pv)      # noqa: E731
+    mem = ingress_flow.replication_loop(mk, 48, 12, 7, over_the_wire=False)
+    net = ingress_flow.replication_loop(mk, 48, 12, 7, over_the_wire=True)
+    for node in range(3):
+        compare_states(mem[node], net[node], "node %d" % node)
+    assert int(np.min(mem[0].commit_index)) > 10 and np.array_equal(mem[0].last_index, mem[1].last_index)

@@ -44,3 +44,15 @@ def test_ingress_repairs_need_host_inside_multi_round_batches(compact):
     assert repaired > 0, "the history never left the cached term runs: nothing was repaired"
     compare_states(final, gpu.read_state(), "after the ingress and its repairs")
     compare_states(final, shadow.read_state(), "the host's log")
+
+
+def test_replication_loop_over_frames_equals_the_in_memory_loop():
+    """N1 joined to N2 on the GPU: rg_replicate's plans leave the leader as request frames with filed invocation records
+    (Ingress.encode_sends), the followers decide them from their ingress batches (rg_submit32) and answer with response frames, the leader's
+    ingress matches every response to its invocation and decides the ack rows — three tables on one GPU, 12 ticks with client commands —
+    against the same loop on the oracle with rows built directly from plans and reply rows."""
+    from tests import oracle_lib
+    mem = ingress_flow.replication_loop(lambda g, p, s, pv: oracle_lib.OracleTable(g, p, s, pv), 200, 12, 7, over_the_wire=False)
+    net = ingress_flow.replication_loop(lambda g, p, s, pv: engine.Table(g, p, s, pv), 200, 12, 7, over_the_wire=True)
+    for node in range(3):
+        compare_states(mem[node], net[node], "node %d" % node)
