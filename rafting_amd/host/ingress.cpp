@@ -75,8 +75,10 @@ uint64_t PendingRing::key_of(int32_t sequence, Method m, uint32_t gid)
 void PendingRing::put(int32_t sequence, Method m, uint32_t gid, const Pending &p)
 {
     Slot &s = s_[(uint32_t)sequence & mask_];
-    s.key.store(0, std::memory_order_relaxed);                   // (single producer: nobody takes a half-written slot)
-    s.p = p;
+    s.key.store(0, std::memory_order_release);                   // whoever is reading the old record loses its CAS
+    s.w0.store(p.role_epoch, std::memory_order_relaxed);
+    s.w1.store((uint64_t)p.epoch_at_send, std::memory_order_relaxed);
+    s.w2.store((uint64_t)p.last_index_sent, std::memory_order_relaxed);
     s.key.store(key_of(sequence, m, gid), std::memory_order_release);
 }
 
@@ -85,7 +87,9 @@ bool PendingRing::take(int32_t sequence, Method m, uint32_t gid, Pending &p)
     Slot &s = s_[(uint32_t)sequence & mask_];
     const uint64_t want = key_of(sequence, m, gid);
     if (s.key.load(std::memory_order_acquire) != want) return false;
-    p = s.p;
+    p.role_epoch = (uint32_t)s.w0.load(std::memory_order_relaxed);
+    p.epoch_at_send = (int64_t)s.w1.load(std::memory_order_relaxed);
+    p.last_index_sent = (int64_t)s.w2.load(std::memory_order_relaxed);
     uint64_t expect = want;                                      // the invocation is REMOVED (AsyncService.remove): a duplicate response finds nothing
     return s.key.compare_exchange_strong(expect, 0, std::memory_order_acq_rel);
 }
@@ -353,7 +357,7 @@ size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<
         const Method m = METHOD_OF_KIND[RG_HDR_KIND(b.batch.head[cell].hdr)];
         if (m == M_NONE || !(reply[cell].flags & RG_F_REPLIED)) continue;            // an empty cell, a response row, or a handler that died
         const Origin o = b.origin[cell];
-        if (o.conn == NO_CONN) continue;
+        if (o.conn == NO_CONN || o.conn >= out.size()) continue;
         f.sequence = o.sequence;
         f.head.assign(SCOPE_OF_METHOD[m]);                                           // "<method>:<contextId>", as the request carried it
         index_.append_id((uint32_t)(cell % b.batch.count), f.head);

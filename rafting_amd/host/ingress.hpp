@@ -70,7 +70,9 @@ public:
     bool take(int32_t sequence, Method m, uint32_t gid, Pending &p);
 
 private:
-    struct Slot { std::atomic<uint64_t> key{0}; Pending p; };   // key = 1 | sequence << 1 | method << 33 | gid low bits << 36 ... (see .cpp)
+    // key = 1 | sequence << 1 | method << 33 | gid << 36 (see .cpp). The record is three relaxed atomic words between two key stores (put) /
+    // a key load and a key CAS (take): a take that overlaps the put of a later request to the same slot reads garbage and then loses the CAS
+    struct Slot { std::atomic<uint64_t> key{0}, w0{0}, w1{0}, w2{0}; };
     static uint64_t key_of(int32_t sequence, Method m, uint32_t gid);
     uint32_t mask_;
     std::unique_ptr<Slot[]> s_;

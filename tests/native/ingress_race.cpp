@@ -19,6 +19,26 @@ int main(int argc, char **argv)
 {
     const uint32_t G = argc > 1 ? (uint32_t)atoi(argv[1]) : 256, C = argc > 2 ? (uint32_t)atoi(argv[2]) : 6;
     const uint32_t N = argc > 3 ? (uint32_t)atoi(argv[3]) : 20000, R = argc > 4 ? (uint32_t)atoi(argv[4]) : 4;
+    {   // the invocation ring with its two threads: the sender files requests while the reader takes the responses of earlier ones out of the SAME
+        // slots (capacity 16: the sender laps the reader all the time). A take that succeeds must return exactly what was filed for that sequence.
+        PendingRing ring(16);
+        std::atomic<int32_t> filed{-1};
+        std::atomic<bool> bad{false};
+        const int32_t M = 200000;
+        std::thread sender([&] { for (int32_t q = 0; q < M; q++) { ring.put(q, M_APPEND_ENTRIES, (uint32_t)q & 1023u, Pending{(uint32_t)q, (int64_t)q * 3, (int64_t)q * 7}); filed.store(q); } });
+        uint64_t taken = 0;
+        for (int32_t q = 0; q < M; q++) {
+            while (filed.load() < q) std::this_thread::yield();
+            Pending p;
+            if (ring.take(q, M_APPEND_ENTRIES, (uint32_t)q & 1023u, p)) {
+                taken++;
+                if (p.role_epoch != (uint32_t)q || p.epoch_at_send != (int64_t)q * 3 || p.last_index_sent != (int64_t)q * 7) bad = true;
+            }
+            if (ring.take(q, M_APPEND_ENTRIES, (uint32_t)q & 1023u, p)) bad = true;      // removed: a duplicate response finds nothing
+        }
+        sender.join();
+        if (bad || taken == 0) { printf("pending ring: a take returned another request's record (or nothing was ever taken: %llu)\n", (unsigned long long)taken); return 1; }
+    }
     const KryoBodyCodec codec({{"a", 1}, {"b", 2}, {"c", 3}});
     ContextIndex index(G);
     auto id_of = [](uint32_t g) { return "group/" + std::to_string(g); };
