@@ -344,7 +344,7 @@ uint64_t Ingress::held() const
     return n;
 }
 
-size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end) const
+size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end, uint32_t only_conn) const
 {
     static const Method METHOD_OF_KIND[16] = {M_NONE, M_APPEND_ENTRIES, M_NONE, M_NONE, M_REQUEST_VOTE, M_PRE_VOTE, M_NONE, M_NONE,
                                                M_NONE, M_NONE, M_NONE, M_INSTALL_SNAPSHOT, M_NONE, M_NONE, M_NONE, M_NONE};
@@ -357,7 +357,7 @@ size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<
         const Method m = METHOD_OF_KIND[RG_HDR_KIND(b.batch.head[cell].hdr)];
         if (m == M_NONE || !(reply[cell].flags & RG_F_REPLIED)) continue;            // an empty cell, a response row, or a handler that died
         const Origin o = b.origin[cell];
-        if (o.conn == NO_CONN || o.conn >= out.size()) continue;
+        if (o.conn == NO_CONN || o.conn >= out.size() || (only_conn != NO_CONN && o.conn != only_conn)) continue;
         f.sequence = o.sequence;
         f.head.assign(SCOPE_OF_METHOD[m]);                                           // "<method>:<contextId>", as the request carried it
         index_.append_id((uint32_t)(cell % b.batch.count), f.head);

@@ -136,7 +136,8 @@ public:
     // N3's rule — no reply before its (term, votedFor) is durable (member/RaftMember.java:25) — is the caller's: StableStore::persist of the
     // batch's RG_F_PERSIST rows comes before this call. Cells [cell_begin, cell_end) only: several threads may share a batch, each with its
     // own `out` (responses are matched by sequence number, their order on a connection carries no meaning).
-    size_t emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin = 0, size_t cell_end = (size_t)-1) const;
+    size_t emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin = 0, size_t cell_end = (size_t)-1,
+                uint32_t only_conn = NO_CONN) const;       // only_conn: the frames of that connection alone
     // The batch is done with (decided, effects applied, replies emitted): wipe the cells it used so that its bank can be filled again.
     // Touches only that bank: runs beside feed() without a lock.
     void recycle(const SealedBatch &b);

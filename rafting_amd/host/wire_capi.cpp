@@ -271,7 +271,7 @@ size_t rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply,
 {
     if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || conn >= g->conns) return 0;
     std::vector<std::string> o(g->conns);
-    g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end);
+    g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end, conn);
     if (o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
     return o[conn].size();
 }
