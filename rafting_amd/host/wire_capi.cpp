@@ -227,7 +227,7 @@ size_t rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_slot
     const int32_t seq0 = g->in->send_sequence(conn);
     *frames = (uint32_t)g->in->encode_sends(conn, self_slot, count, gid, head, send_j, log, o, need_host);
     if (o.size() > cap) { g->in->send_sequence(conn) = seq0; *frames = 0; return o.size(); }   // (the records filed are filed again, identically, by the retry)
-    memcpy(out, o.data(), o.size());
+    if (!o.empty()) memcpy(out, o.data(), o.size());
     return o.size();
 }
 int rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
@@ -272,7 +272,7 @@ size_t rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply,
     if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || conn >= g->conns) return 0;
     std::vector<std::string> o(g->conns);
     g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end, conn);
-    if (o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
+    if (!o[conn].empty() && o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
     return o[conn].size();
 }
 }  // extern "C"
