@@ -75,11 +75,15 @@ int rw_rows_add_frame(uint8_t type, int32_t sequence, const char *head, size_t h
  *             its group's counter). Everything else: the flush thread.
  *   memory    head / abcd / entry_terms of the two banks are the CALLER's (page-locked memory from rg_host_alloc in a deployment),
  *             head and abcd [max_rounds * groups], entry_terms [entry_cap] each.
+ *   shards    tables behind the ingress (block partition gpu = gid / ceil(groups / shards), one table, stream and feeder per GPU):
+ *             a row is routed by its group id as it is placed; a bank's head / abcd arrays hold the shards one after the other (shard s at cell
+ *             s * ceil(groups / shards) * max_rounds), its term array is split evenly; rw_ingress_seal closes all shards at once and
+ *             rw_ingress_shard describes each one's dense batch — what THAT table's rg_submit32 / rg_submit_async_packed takes. 1 = one table.
  * nodes: "host:port,..." in peer-slot order for Kryo-format bodies (rw_kryo_*), NULL for the fixed-layout test codec. */
 typedef struct rw_ingress rw_ingress_t;
 rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conns, const char *nodes,
                              rg_ev_head_t *head0, rg_ev_quad32_t *abcd0, int32_t *entry_terms0,
-                             rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap);
+                             rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap, uint32_t shards);
 void     rw_ingress_free(rw_ingress_t *g);
 /* ContextManager.createContext: contextId -> group id (1 ok, 0 refused: duplicate id / gid, gid out of range, id longer than 128 bytes) */
 int      rw_ingress_add_context(rw_ingress_t *g, const char *id, size_t len, uint32_t gid);
@@ -104,20 +108,23 @@ size_t   rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_sl
  * reply, else the RG_F_REPLIED answer is emitted as the response to (reply_conn, reply_sequence). Not for RG_EV_AE_REQ (entries travel in frames). */
 int      rw_ingress_add_row(rw_ingress_t *g, uint32_t conn, uint32_t gid, uint32_t hdr, uint32_t aux, int64_t a, int64_t b, int64_t c, int64_t d,
                             uint32_t reply_conn, int32_t reply_sequence);
-/* close the batch being filled: *batch describes it (dense, gid NULL; rounds may be 0), *rows = cells that hold an event, *wide = rows that
+/* close the batch being filled: *batch describes shard 0 (dense, gid NULL; rounds may be 0), *rows = cells that hold an event (all shards), *wide = rows that
  * had to stay out of the compact format (read them with rw_ingress_wide_row, decide them with one sparse rg_submit AFTER this batch).
  * Returns the bank (0 / 1) the batch lies in, or -1 when the batch sealed before this one has not been recycled yet (one sealed batch is with
  * the flusher at a time; the feeders fill the other bank meanwhile). The batch stays valid until rw_ingress_recycle(bank). */
 int      rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32_t *wide);
+/* shard `shard` of that bank's sealed batch: its dense rg_batch32_t (group g of the table = global group *first_gid + g), the cells that hold an
+ * event. 1, or 0 for a bad bank / shard */
+int      rw_ingress_shard(const rw_ingress_t *g, int bank, uint32_t shard, rg_batch32_t *batch, uint64_t *events, uint32_t *first_gid);
 int      rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms,
                              uint32_t max_terms, uint32_t *reply_conn, int32_t *reply_sequence);
                              /* ascending gid; returns the row's entry count, -1 if it exceeds max_terms; reply_conn UINT32_MAX = a response row */
-/* who sent the request in cell `cell` (= round * groups + gid) of that bank's batch: 1 and (*conn, *sequence), or 0 for a response row */
-int      rw_ingress_origin(const rw_ingress_t *g, int bank, uint64_t cell, uint32_t *conn, int32_t *sequence);
-/* the PongEvent frames of cells [cell_begin, cell_end) whose reply carries RG_F_REPLIED, for connection `conn`, into out[cap]: returns the
+/* who sent the request in cell `cell` (= round * count + group of the shard) of that shard's batch: 1 and (*conn, *sequence), or 0 for a response row */
+int      rw_ingress_origin(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, uint32_t *conn, int32_t *sequence);
+/* the PongEvent frames of cells [cell_begin, cell_end) of shard `shard` (reply = that table's reply rows) whose reply carries RG_F_REPLIED, for connection `conn`, into out[cap]: returns the
  * bytes written, or the size needed (nothing written) when that exceeds cap. Persist the batch's RG_F_PERSIST rows BEFORE releasing these
  * bytes (member/RaftMember.java:25). */
-size_t   rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn,
+size_t   rw_ingress_emit(const rw_ingress_t *g, int bank, uint32_t shard, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn,
                          uint8_t *out, size_t cap);
 /* RG_NEED_HOST inside the batch of that bank (a term lookup left the device's cached runs: the row came back unapplied, the later rows of its
  * group RG_SKIPPED_AFTER_NEED_HOST): decide those rows, in order, BEFORE the next batch is submitted — the missed row again with a hint
@@ -134,7 +141,8 @@ typedef struct {
     int     (*submit)(void *user, const rg_batch_t *in, const rg_outcome_t *out); /* rg_submit(table, in, out, RG_MEM_HOST) */
     void    (*applied)(void *user, uint32_t gid, uint64_t cell, const rg_reply_t *reply, const rg_logfx_t *logfx, const rg_persist_t *persist);
 } rw_repair_host_t;
-int64_t  rw_ingress_repair(const rw_ingress_t *g, int bank, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host);
+int64_t  rw_ingress_repair(const rw_ingress_t *g, int bank, uint32_t shard, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host);
+/* (the gids the callbacks see are that TABLE's: 0 .. count-1 of the shard) */
 /* the batch of that bank is done with: wipe the cells it used (may run beside rw_ingress_feed) */
 int      rw_ingress_recycle(rw_ingress_t *g, int bank);
 uint64_t rw_ingress_refused(const rw_ingress_t *g);      /* frames that were no decision row: unknown context / method, undecodable body, unmatched response */

@@ -96,31 +96,47 @@ bool PendingRing::take(int32_t sequence, Method m, uint32_t gid, Pending &p)
 
 // ---- Ingress ------------------------------------------------------------------------------------------------------------------
 Ingress::Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const BodyCodec &codec, const ContextIndex &index, Buffers bank0, Buffers bank1,
-                 uint32_t pending_capacity)
+                 uint32_t pending_capacity, uint32_t shards)
     : groups_(groups), rounds_(max_rounds), codec_(codec), index_(index), c_(conns)
 {
+    if (shards == 0 || shards > groups) shards = 1;
+    per_shard_ = (groups + shards - 1) / shards;                  // shard.block_partition: gpu = gid / ceil(G / N)
+    const uint64_t term_cap = bank0.entry_cap / shards;
+    for (uint32_t s = 0; s * per_shard_ < groups; s++) {
+        const uint32_t first = s * per_shard_;
+        shard_.push_back(Shard{first, std::min(per_shard_, groups - first), (size_t)first * max_rounds, (uint64_t)s * term_cap, term_cap});
+    }
     const Buffers b[2] = {bank0, bank1};
     for (int i = 0; i < 2; i++) {
         bank_[i].buf = b[i];
         bank_[i].depth.reset(new std::atomic<uint32_t>[groups]);
         for (uint32_t g = 0; g < groups; g++) bank_[i].depth[g].store(0, std::memory_order_relaxed);
         bank_[i].origin.assign((size_t)groups * max_rounds, Origin{NO_CONN, 0});
-        bank_[i].dirty_rounds = max_rounds;                       // caller memory: content unknown
+        bank_[i].terms_used.reset(new std::atomic<uint64_t>[shard_.size()]);
+        bank_[i].dirty_rounds.assign(shard_.size(), max_rounds);  // caller memory: content unknown
         wipe(bank_[i]);
+        sealed_[i].shard.resize(shard_.size());
     }
-    for (Conn &c : c_) c.ring.reset(new PendingRing(pending_capacity));
+    for (Conn &c : c_) {
+        c.ring.reset(new PendingRing(pending_capacity));
+        c.rows.assign(shard_.size(), 0);
+        c.max_depth.assign(shard_.size(), 0);
+    }
 }
 
 void Ingress::set_peer(uint32_t conn, int32_t peer_slot) { c_[conn].peer = peer_slot; }
 
 void Ingress::wipe(Bank &bk)
 {
-    const size_t cells = (size_t)bk.dirty_rounds * groups_;
-    memset(bk.buf.head, 0, cells * sizeof(rg_ev_head_t));        // RG_EV_NONE
-    memset(bk.buf.abcd, 0, cells * sizeof(rg_ev_quad32_t));      // (the kernel's 32-bit domain check reads the fields of every cell)
+    for (size_t s = 0; s < shard_.size(); s++) {
+        const Shard &sh = shard_[s];
+        const size_t cells = (size_t)bk.dirty_rounds[s] * sh.count;
+        memset(bk.buf.head + sh.cell_off, 0, cells * sizeof(rg_ev_head_t));        // RG_EV_NONE
+        memset(bk.buf.abcd + sh.cell_off, 0, cells * sizeof(rg_ev_quad32_t));      // (the kernel's 32-bit domain check reads the fields of every cell)
+        bk.terms_used[s].store(0, std::memory_order_relaxed);
+        bk.dirty_rounds[s] = 0;
+    }
     for (uint32_t g = 0; g < groups_; g++) bk.depth[g].store(0, std::memory_order_relaxed);
-    bk.terms_used.store(0, std::memory_order_relaxed);
-    bk.dirty_rounds = 0;
     bk.wide.clear();
     bk.clean = true;
 }
@@ -139,12 +155,14 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
                     Origin from)
 {
     std::atomic<uint32_t> &depth = bk.depth[gid];
+    const uint32_t si = gid / per_shard_;
+    const Shard &sh = shard_[si];
     const bool ae = RG_HDR_KIND(head.hdr) == RG_EV_AE_REQ;
     bool same = true;
     for (size_t k = 1; k < n_terms; k++) same &= terms[k] == terms[0];
     uint64_t all = (uint64_t)a | (uint64_t)b | (uint64_t)c4 | (uint64_t)d;
     for (size_t k = 0; k < n_terms; k++) all |= (uint64_t)terms[k];
-    if ((all >> 31) || (!same && n_terms > bk.buf.entry_cap)) {  // not a compact row (a value beyond int32, or more terms than a bank's term array
+    if ((all >> 31) || (!same && n_terms > sh.term_cap)) {       // not a compact row (a value beyond int32, or more terms than the shard's term array
                                                                   // holds at all): close the group, hand the row over on its own
         const uint32_t was = depth.fetch_or(CLOSED, std::memory_order_relaxed);
         if (was >= rounds_) return false;                         // the group was full or closed already: wait for the next batch (it stays closed)
@@ -156,27 +174,27 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
     }
     uint64_t toff = 0;
     if (ae && n_terms > 0 && !same) {                             // entries of several terms: they need room in the batch's term array
-        toff = bk.terms_used.fetch_add(n_terms, std::memory_order_relaxed);
-        if (toff + n_terms > bk.buf.entry_cap || toff + n_terms > 0xFFFFFFFFull) {
+        toff = bk.terms_used[si].fetch_add(n_terms, std::memory_order_relaxed);
+        if (toff + n_terms > sh.term_cap || toff + n_terms > 0xFFFFFFFFull) {
             depth.fetch_or(CLOSED, std::memory_order_relaxed);
             return false;
         }
     }
     const uint32_t r = depth.fetch_add(1, std::memory_order_relaxed);
     if (r >= rounds_) return false;                               // the group's rounds are used up, or it is closed: either way it stays so
-    const size_t cell = (size_t)r * groups_ + gid;
+    const size_t cell = sh.cell_off + (size_t)r * sh.count + (gid - sh.first);
     if (ae && n_terms > 0) {
         if (same) { head.hdr |= RG_HDR_SAME_TERM; head.aux = (uint32_t)terms[0]; }
         else {
-            head.aux = (uint32_t)toff;
-            for (size_t k = 0; k < n_terms; k++) bk.buf.entry_terms[toff + k] = (int32_t)terms[k];
+            head.aux = (uint32_t)toff;                                // an offset into the SHARD's term array (its batch's entry_terms)
+            for (size_t k = 0; k < n_terms; k++) bk.buf.entry_terms[sh.term_off + toff + k] = (int32_t)terms[k];
         }
     }
     bk.buf.abcd[cell] = rg_ev_quad32_t{(int32_t)a, (int32_t)b, (int32_t)c4, (int32_t)d};
     bk.buf.head[cell] = head;
     bk.origin[cell] = from;
-    cn.rows++;
-    cn.max_depth = std::max(cn.max_depth, r + 1);
+    cn.rows[si]++;
+    cn.max_depth[si] = std::max(cn.max_depth[si], r + 1);
     return true;
 }
 
@@ -302,21 +320,30 @@ const SealedBatch &Ingress::seal()
     if (!bank_[next].clean) throw std::logic_error("Ingress::seal: the batch sealed before this one has not been recycled");
     Bank &bk = bank_[done];
     SealedBatch &s = sealed_[done];
-    uint32_t rounds = 0;
     s.rows = 0;
-    for (Conn &c : c_) { rounds = std::max(rounds, c.max_depth); s.rows += c.rows; c.rows = 0; c.max_depth = 0; }
-    s.batch.rounds = rounds;
-    s.batch.count = groups_;
-    s.batch.gid = nullptr;
-    s.batch.head = bk.buf.head;
-    s.batch.abcd = bk.buf.abcd;
-    s.batch.entry_terms = bk.buf.entry_terms;
-    s.batch.entry_count = std::min<uint64_t>(bk.terms_used.load(std::memory_order_relaxed), bk.buf.entry_cap);
-    s.origin = bk.origin.data();
+    for (size_t k = 0; k < shard_.size(); k++) {
+        const Shard &sh = shard_[k];
+        SealedShard &ss = s.shard[k];
+        uint32_t rounds = 0;
+        ss.events = 0;
+        for (Conn &c : c_) { rounds = std::max(rounds, c.max_depth[k]); ss.events += c.rows[k]; c.rows[k] = 0; c.max_depth[k] = 0; }
+        ss.batch.rounds = rounds;
+        ss.batch.count = sh.count;
+        ss.batch.gid = nullptr;
+        ss.batch.head = bk.buf.head + sh.cell_off;
+        ss.batch.abcd = bk.buf.abcd + sh.cell_off;
+        ss.batch.entry_terms = bk.buf.entry_terms ? bk.buf.entry_terms + sh.term_off : nullptr;
+        ss.batch.entry_count = std::min<uint64_t>(bk.terms_used[k].load(std::memory_order_relaxed), sh.term_cap);
+        ss.origin = bk.origin.data() + sh.cell_off;
+        ss.first_gid = sh.first;
+        s.rows += ss.events;
+        bk.dirty_rounds[k] = rounds;
+    }
+    s.batch = s.shard[0].batch;
+    s.origin = s.shard[0].origin;
     s.wide = std::move(bk.wide);
     std::sort(s.wide.begin(), s.wide.end(), [](const HeldRow &x, const HeldRow &y) { return x.gid < y.gid; });
     bk.wide.clear();
-    bk.dirty_rounds = rounds;
     bk.clean = false;
     // open the other bank, oldest held rows first
     Bank &nb = bank_[next];
@@ -344,7 +371,8 @@ uint64_t Ingress::held() const
     return n;
 }
 
-size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end, uint32_t only_conn) const
+size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end, uint32_t only_conn,
+                     uint32_t shard) const
 {
     static const Method METHOD_OF_KIND[16] = {M_NONE, M_APPEND_ENTRIES, M_NONE, M_NONE, M_REQUEST_VOTE, M_PRE_VOTE, M_NONE, M_NONE,
                                                M_NONE, M_NONE, M_NONE, M_INSTALL_SNAPSHOT, M_NONE, M_NONE, M_NONE, M_NONE};
@@ -352,15 +380,16 @@ size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<
     size_t made = 0;
     Frame f;
     f.type = ACK;
-    const size_t cells = std::min(cell_end, (size_t)b.batch.rounds * b.batch.count);
+    const SealedShard &sb = b.shard[shard];
+    const size_t cells = std::min(cell_end, (size_t)sb.batch.rounds * sb.batch.count);
     for (size_t cell = cell_begin; cell < cells; cell++) {
-        const Method m = METHOD_OF_KIND[RG_HDR_KIND(b.batch.head[cell].hdr)];
+        const Method m = METHOD_OF_KIND[RG_HDR_KIND(sb.batch.head[cell].hdr)];
         if (m == M_NONE || !(reply[cell].flags & RG_F_REPLIED)) continue;            // an empty cell, a response row, or a handler that died
-        const Origin o = b.origin[cell];
+        const Origin o = sb.origin[cell];
         if (o.conn == NO_CONN || o.conn >= out.size() || (only_conn != NO_CONN && o.conn != only_conn)) continue;
         f.sequence = o.sequence;
         f.head.assign(SCOPE_OF_METHOD[m]);                                           // "<method>:<contextId>", as the request carried it
-        index_.append_id((uint32_t)(cell % b.batch.count), f.head);
+        index_.append_id(sb.first_gid + (uint32_t)(cell % sb.batch.count), f.head);
         f.body.clear();
         codec_.encode_response(Response{reply[cell].resp_term, (reply[cell].flags & RG_F_SUCCESS) != 0}, f.body);
         encode_frame(f, false, out[o.conn]);
@@ -375,8 +404,9 @@ static bool has_logfx_item(uint32_t flags)
     return (flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0 || RG_F_STATUS(flags) == RG_NEED_HOST;
 }
 
-int64_t repair_need_host(const SealedBatch &b, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host)
+int64_t repair_need_host(const SealedBatch &whole, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host, uint32_t shard)
 {
+    const SealedShard &b = whole.shard[shard];
     const uint32_t G = b.batch.count, R = b.batch.rounds;
     const size_t cells = (size_t)G * R;
     struct Broken { uint32_t gid, round; bool missed; int64_t need; };            // the group's next undecided row; need = logfx.log_from of its miss

@@ -87,14 +87,23 @@ struct HeldRow {                                                  // a row kept 
     uint64_t ticket = 0;                                          // order in which rows were held back, across connections
 };
 
-// One sealed batch: what rg_submit32 / rg_submit_async_packed take (dense, `rounds` rounds of `groups` cells) plus where its replies go.
+// One sealed batch: what rg_submit32 / rg_submit_async_packed take (dense, `rounds` rounds of `count` cells) plus where its replies go.
+// An ingress in front of SEVERAL tables (block partition gpu = gid / ceil(G / N), one table and one feeder per GPU) seals one such
+// batch per shard: rows are routed by their group id as they are placed, every shard's cells are a [round][group of the shard] array of their own.
+struct SealedShard {
+    rg_batch32_t batch;                 // gid == NULL (dense over the shard's groups); pointers into the bank
+    const Origin *origin;               // [rounds * count]
+    uint32_t first_gid;                 // group id of the shard's cell 0 (a table's group g is first_gid + g)
+    uint64_t events;                    // cells that hold an event
+};
 struct SealedBatch {
-    rg_batch32_t batch;                 // gid == NULL (dense); pointers into the bank
-    const Origin *origin;               // [rounds * groups]
-    uint64_t rows;                      // cells that hold an event
+    rg_batch32_t batch;                 // shard 0 — the whole batch of an unsharded ingress
+    const Origin *origin;
+    uint64_t rows;                      // cells that hold an event, all shards together
+    std::vector<SealedShard> shard;     // [shards]; shard[0].batch is `batch`
     std::vector<HeldRow> wide;          // rows the compact format cannot express (a value beyond 2^31, entry terms of several terms that outnumber
-                                        // the bank's term array), at most one per group, ascending gid: the host decides them
-                                        // with ONE sparse rg_submit AFTER this batch (their groups took no later row into the batch)
+                                        // the shard's term array), at most one per group, ascending (global) gid: the host decides them
+                                        // with ONE sparse rg_submit per table AFTER this batch (their groups took no later row into the batch)
 };
 
 class Ingress {
@@ -103,8 +112,12 @@ public:
         rg_ev_head_t *head; rg_ev_quad32_t *abcd; int32_t *entry_terms; uint64_t entry_cap;
     };
     // groups, max_rounds: the shape of a batch. conns: number of peer connections. banks: two sets of caller buffers, filled alternately.
+    // shards: tables behind this ingress (block partition: shard s holds groups [s * per, min(groups, (s + 1) * per)), per = ceil(groups / shards));
+    // a bank's head / abcd arrays hold the shards one after the other (shard s at cell s * per * max_rounds), its term array is split evenly.
     Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const BodyCodec &codec, const ContextIndex &index, Buffers bank0, Buffers bank1,
-            uint32_t pending_capacity = 1u << 16);     // requests in flight per connection whose responses can still be matched
+            uint32_t pending_capacity = 1u << 16,      // requests in flight per connection whose responses can still be matched
+            uint32_t shards = 1);
+    uint32_t shards() const { return (uint32_t)shard_.size(); }
 
     void set_peer(uint32_t conn, int32_t peer_slot);             // the node at the other end (its slot in the cluster list)
     PendingRing &pending(uint32_t conn) { return *c_[conn].ring; }
@@ -136,8 +149,9 @@ public:
     // N3's rule — no reply before its (term, votedFor) is durable (member/RaftMember.java:25) — is the caller's: StableStore::persist of the
     // batch's RG_F_PERSIST rows comes before this call. Cells [cell_begin, cell_end) only: several threads may share a batch, each with its
     // own `out` (responses are matched by sequence number, their order on a connection carries no meaning).
+    // shard: which of the batch's shards `reply` belongs to (its rows [rounds * count] as that table returned them).
     size_t emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin = 0, size_t cell_end = (size_t)-1,
-                uint32_t only_conn = NO_CONN) const;       // only_conn: the frames of that connection alone
+                uint32_t only_conn = NO_CONN, uint32_t shard = 0) const;       // only_conn: the frames of that connection alone
     // The batch is done with (decided, effects applied, replies emitted): wipe the cells it used so that its bank can be filled again.
     // Touches only that bank: runs beside feed() without a lock.
     void recycle(const SealedBatch &b);
@@ -151,8 +165,8 @@ private:
         Buffers buf;
         std::unique_ptr<std::atomic<uint32_t>[]> depth;          // per group: rows claimed; bit 30 (CLOSED): no more rows in this batch
         std::vector<Origin> origin;                              // meaningful where the cell's head holds an event
-        std::atomic<uint64_t> terms_used{0};
-        uint32_t dirty_rounds = 0;                               // rounds to wipe before the bank is filled again
+        std::unique_ptr<std::atomic<uint64_t>[]> terms_used;     // per shard
+        std::vector<uint32_t> dirty_rounds;                      // per shard: rounds to wipe before the bank is filled again
         bool clean = false;
         std::mutex wide_mu;
         std::vector<HeldRow> wide;
@@ -166,9 +180,10 @@ private:
         std::string ctx;
         int queued = 0;
         int32_t next_sequence = 0;                               // of the requests this side sends on the connection (AsyncService.sequence)
-        uint64_t rows = 0;                                       // rows this connection placed into the bank being filled, and the deepest
-        uint32_t max_depth = 0;                                  // round it reached (folded by seal(): no shared counter on the row path)
+        std::vector<uint64_t> rows;                              // per shard: rows this connection placed into the bank being filled, and the
+        std::vector<uint32_t> max_depth;                         // deepest round it reached (folded by seal(): no shared counter on the row path)
     };
+    struct Shard { uint32_t first, count; size_t cell_off; uint64_t term_off, term_cap; };
     static constexpr uint32_t CLOSED = 1u << 30;
     bool place(Bank &bk, Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
                Origin from);
@@ -177,6 +192,8 @@ private:
     void wipe(Bank &bk);
 
     const uint32_t groups_, rounds_;
+    uint32_t per_shard_ = 0;
+    std::vector<Shard> shard_;
     const BodyCodec &codec_;
     const ContextIndex &index_;
     std::vector<Conn> c_;
@@ -206,7 +223,8 @@ struct RepairHost {
 // logfx: the batch's log-effect rows — dense [rounds * groups] (rg_submit32) or, packed = true, the row-ordered list of
 // rg_submit_async_packed. Returns the number of rows decided here (0: the batch had no RG_NEED_HOST), -1 when a submit failed or a hinted
 // row still missed.
-int64_t repair_need_host(const SealedBatch &b, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host);
+// shard: the shard of `b` that reply / logfx belong to; the gids handed to `host` are the TABLE's (0 .. count-1 of that shard).
+int64_t repair_need_host(const SealedBatch &b, rg_reply_t *reply, const rg_logfx_t *logfx, bool packed, RepairHost &host, uint32_t shard = 0);
 
 }  // namespace wire
 }  // namespace rafting

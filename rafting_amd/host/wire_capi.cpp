@@ -179,14 +179,14 @@ struct rw_ingress {
 extern "C" {
 
 rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conns, const char *nodes, rg_ev_head_t *head0, rg_ev_quad32_t *abcd0,
-                             int32_t *entry_terms0, rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap)
+                             int32_t *entry_terms0, rg_ev_head_t *head1, rg_ev_quad32_t *abcd1, int32_t *entry_terms1, uint64_t entry_cap, uint32_t shards)
 {
-    if (!groups || !max_rounds || !conns || !head0 || !abcd0 || !head1 || !abcd1 || (entry_cap && (!entry_terms0 || !entry_terms1))) return nullptr;
+    if (!groups || !max_rounds || !conns || !shards || shards > groups || !head0 || !abcd0 || !head1 || !abcd1 || (entry_cap && (!entry_terms0 || !entry_terms1))) return nullptr;
     rw_ingress *g = new rw_ingress(groups);
     if (nodes) g->codec.reset(new KryoBodyCodec(parse_nodes(nodes))); else g->codec.reset(new FixedBodyCodec());
     g->conns = conns;
     g->in.reset(new Ingress(groups, max_rounds, conns, *g->codec, g->index, Ingress::Buffers{head0, abcd0, entry_terms0, entry_cap},
-                            Ingress::Buffers{head1, abcd1, entry_terms1, entry_cap}));
+                            Ingress::Buffers{head1, abcd1, entry_terms1, entry_cap}, 1u << 16, shards));
     return g;
 }
 void rw_ingress_free(rw_ingress_t *g) { delete g; }
@@ -248,6 +248,13 @@ int rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32
     *batch = s.batch; *rows = s.rows; *wide = (uint32_t)s.wide.size();
     return bank;
 }
+int rw_ingress_shard(const rw_ingress_t *g, int bank, uint32_t shard, rg_batch32_t *batch, uint64_t *events, uint32_t *first_gid)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || shard >= g->sealed[bank]->shard.size()) return 0;
+    const SealedShard &s = g->sealed[bank]->shard[shard];
+    *batch = s.batch; *events = s.events; *first_gid = s.first_gid;
+    return 1;
+}
 int rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms, uint32_t max_terms,
                         uint32_t *reply_conn, int32_t *reply_sequence)
 {
@@ -259,19 +266,20 @@ int rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *g
     for (size_t k = 0; k < h.terms.size(); k++) entry_terms[k] = h.terms[k];
     return (int)h.terms.size();
 }
-int rw_ingress_origin(const rw_ingress_t *g, int bank, uint64_t cell, uint32_t *conn, int32_t *sequence)
+int rw_ingress_origin(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, uint32_t *conn, int32_t *sequence)
 {
-    if (!g || bank < 0 || bank > 1 || !g->sealed[bank]) return 0;
-    const SealedBatch &s = *g->sealed[bank];
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || shard >= g->sealed[bank]->shard.size()) return 0;
+    const SealedShard &s = g->sealed[bank]->shard[shard];
     if (cell >= (uint64_t)s.batch.rounds * s.batch.count || RG_HDR_KIND(s.batch.head[cell].hdr) == RG_EV_NONE || s.origin[cell].conn == NO_CONN) return 0;
     *conn = s.origin[cell].conn; *sequence = s.origin[cell].sequence;
     return 1;
 }
-size_t rw_ingress_emit(const rw_ingress_t *g, int bank, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn, uint8_t *out, size_t cap)
+size_t rw_ingress_emit(const rw_ingress_t *g, int bank, uint32_t shard, const rg_reply_t *reply, uint64_t cell_begin, uint64_t cell_end, uint32_t conn, uint8_t *out,
+                       size_t cap)
 {
-    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || conn >= g->conns) return 0;
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || conn >= g->conns || shard >= g->sealed[bank]->shard.size()) return 0;
     std::vector<std::string> o(g->conns);
-    g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end, conn);
+    g->in->emit(*g->sealed[bank], reply, o, (size_t)cell_begin, (size_t)cell_end, conn, shard);
     if (!o[conn].empty() && o[conn].size() <= cap) memcpy(out, o[conn].data(), o[conn].size());
     return o[conn].size();
 }
@@ -288,12 +296,12 @@ struct CRepairHost : RepairHost {
 };
 }  // namespace
 extern "C" {
-int64_t rw_ingress_repair(const rw_ingress_t *g, int bank, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host)
+int64_t rw_ingress_repair(const rw_ingress_t *g, int bank, uint32_t shard, rg_reply_t *reply, const rg_logfx_t *logfx, int packed, const rw_repair_host_t *host)
 {
-    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || !reply || !logfx || !host || !host->term_at || !host->conflict || !host->epoch_index ||
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || shard >= g->sealed[bank]->shard.size() || !reply || !logfx || !host || !host->term_at || !host->conflict || !host->epoch_index ||
         !host->submit || !host->applied) return -1;
     CRepairHost h(*host);
-    return repair_need_host(*g->sealed[bank], reply, logfx, packed != 0, h);
+    return repair_need_host(*g->sealed[bank], reply, logfx, packed != 0, h, shard);
 }
 int rw_ingress_recycle(rw_ingress_t *g, int bank)
 {

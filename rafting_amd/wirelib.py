@@ -36,7 +36,7 @@ def lib():
         L.rw_splitter_feed.argtypes = [_vp, C.c_char_p, _sz]
         L.rw_splitter_pop.argtypes = [_vp, C.POINTER(C.c_uint8), C.POINTER(_i32), C.POINTER(C.c_char_p), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)]
         L.rw_ingress_new.restype = _vp
-        L.rw_ingress_new.argtypes = [_u32, _u32, _u32, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, _u64]
+        L.rw_ingress_new.argtypes = [_u32, _u32, _u32, C.c_char_p, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _u32]
         L.rw_ingress_free.argtypes = [_vp]
         L.rw_ingress_add_context.argtypes = [_vp, C.c_char_p, _sz, _u32]
         L.rw_ingress_set_peer.argtypes = [_vp, _u32, _i32]
@@ -47,11 +47,12 @@ def lib():
         L.rw_ingress_encode_sends.argtypes = [_vp, _u32, _i32, _u32, _vp, _vp, _vp, TERM_OF, _vp, C.c_char_p, _sz, C.POINTER(_u32), C.POINTER(_u32)]
         L.rw_ingress_seal.argtypes = [_vp, C.POINTER(abi.CBatch32), C.POINTER(_u64), C.POINTER(_u32)]
         L.rw_ingress_wide_row.argtypes = [_vp, C.c_int, _u32, C.POINTER(_u32), _vp, _vp, _vp, _u32, C.POINTER(_u32), C.POINTER(_i32)]
-        L.rw_ingress_origin.argtypes = [_vp, C.c_int, _u64, C.POINTER(_u32), C.POINTER(_i32)]
+        L.rw_ingress_origin.argtypes = [_vp, C.c_int, _u32, _u64, C.POINTER(_u32), C.POINTER(_i32)]
+        L.rw_ingress_shard.argtypes = [_vp, C.c_int, _u32, C.POINTER(abi.CBatch32), C.POINTER(_u64), C.POINTER(_u32)]
         L.rw_ingress_emit.restype = _sz
-        L.rw_ingress_emit.argtypes = [_vp, C.c_int, _vp, _u64, _u64, _u32, C.c_char_p, _sz]
+        L.rw_ingress_emit.argtypes = [_vp, C.c_int, _u32, _vp, _u64, _u64, _u32, C.c_char_p, _sz]
         L.rw_ingress_repair.restype = _i64
-        L.rw_ingress_repair.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int, C.POINTER(RepairHost)]
+        L.rw_ingress_repair.argtypes = [_vp, C.c_int, _u32, _vp, _vp, C.c_int, C.POINTER(RepairHost)]
         L.rw_ingress_recycle.argtypes = [_vp, C.c_int]
         L.rw_ingress_refused.restype = _u64
         L.rw_ingress_refused.argtypes = [_vp]
@@ -121,24 +122,26 @@ def decode_response(body):
 
 
 class Sealed:
-    """One sealed batch: an abi.Batch32 over the bank's memory, its bank, the number of event rows and the rows kept out of the compact format."""
+    """One sealed batch: an abi.Batch32 over the bank's memory (shard 0), its bank, the number of event rows (all shards), the rows kept out of
+    the compact format, and per shard (batch32, events, first_gid)."""
 
-    def __init__(self, bank, batch32, rows, wide):
-        self.bank, self.batch, self.rows, self.wide = bank, batch32, rows, wide
+    def __init__(self, bank, batch32, rows, wide, shards):
+        self.bank, self.batch, self.rows, self.wide, self.shards = bank, batch32, rows, wide, shards
 
 
 class Ingress:
     """rw_ingress_* with numpy-owned banks (a deployment hands over page-locked memory from rg_host_alloc instead)."""
 
-    def __init__(self, groups, max_rounds, conns, nodes=None, entry_cap=1 << 16):
-        self.groups, self.max_rounds, self.conns = groups, max_rounds, conns
+    def __init__(self, groups, max_rounds, conns, nodes=None, entry_cap=1 << 16, shards=1):
+        self.groups, self.max_rounds, self.conns, self.nshards = groups, max_rounds, conns, shards
         cells = groups * max_rounds
         self.head = [np.empty(cells, dtype=abi.HEAD_DT) for _ in range(2)]
         self.abcd = [np.empty(cells, dtype=abi.QUAD32_DT) for _ in range(2)]
         self.terms = [np.empty(max(entry_cap, 1), dtype=np.int32) for _ in range(2)]
+        self._entry_cap = entry_cap
         self._h = lib().rw_ingress_new(groups, max_rounds, conns, None if nodes is None else nodes_arg(nodes),
                                        self.head[0].ctypes.data, self.abcd[0].ctypes.data, self.terms[0].ctypes.data,
-                                       self.head[1].ctypes.data, self.abcd[1].ctypes.data, self.terms[1].ctypes.data, entry_cap)
+                                       self.head[1].ctypes.data, self.abcd[1].ctypes.data, self.terms[1].ctypes.data, entry_cap, shards)
         if not self._h:
             raise ValueError("rw_ingress_new refused its arguments")
 
@@ -182,8 +185,20 @@ class Ingress:
         bank = lib().rw_ingress_seal(self._h, C.byref(cb), C.byref(rows), C.byref(nwide))
         if bank not in (0, 1):
             raise RuntimeError("rw_ingress_seal: the batch sealed before this one has not been recycled")
-        cells = cb.rounds * cb.count
-        b32 = abi.Batch32(cb.rounds, cb.count, None, self.head[bank][:cells], self.abcd[bank][:cells], self.terms[bank], cb.entry_count)
+        shards = []
+        per = (self.groups + self.nshards - 1) // self.nshards
+        term_cap = len(self.terms[bank]) // self.nshards if self.nshards > 1 else len(self.terms[bank])
+        k = 0
+        while True:
+            sb, ev, first = abi.CBatch32(), _u64(), _u32()
+            if not lib().rw_ingress_shard(self._h, bank, k, C.byref(sb), C.byref(ev), C.byref(first)):
+                break
+            off, cells = first.value * self.max_rounds, sb.rounds * sb.count
+            toff = k * (self._entry_cap // self.nshards)
+            shards.append((abi.Batch32(sb.rounds, sb.count, None, self.head[bank][off:off + cells], self.abcd[bank][off:off + cells],
+                                       self.terms[bank][toff:], sb.entry_count), ev.value, first.value))
+            k += 1
+        b32 = shards[0][0]
         wide = []
         for i in range(nwide.value):
             gid, head, q, terms = _u32(), np.zeros(1, dtype=abi.HEAD_DT), np.zeros(4, dtype=np.int64), np.zeros(abi.MAX_AE_ENTRIES, dtype=np.int64)
@@ -192,20 +207,20 @@ class Ingress:
             assert n >= 0
             wide.append((gid.value, int(head["hdr"][0]), int(head["aux"][0]), [int(v) for v in q], [int(v) for v in terms[:n]],
                          None if rc.value == NO_CONN else (rc.value, rs.value)))
-        return Sealed(bank, b32, rows.value, wide)
+        return Sealed(bank, b32, rows.value, wide, shards)
 
-    def origin(self, bank, cell):
+    def origin(self, bank, cell, shard=0):
         c, s = _u32(), _i32()
-        return (c.value, s.value) if lib().rw_ingress_origin(self._h, bank, cell, C.byref(c), C.byref(s)) else None
+        return (c.value, s.value) if lib().rw_ingress_origin(self._h, bank, shard, cell, C.byref(c), C.byref(s)) else None
 
-    def emit(self, bank, reply, conn, cell_begin=0, cell_end=(1 << 62)):
+    def emit(self, bank, reply, conn, cell_begin=0, cell_end=(1 << 62), shard=0):
         reply = np.ascontiguousarray(reply)
-        need = lib().rw_ingress_emit(self._h, bank, reply.ctypes.data, cell_begin, cell_end, conn, None, 0)
+        need = lib().rw_ingress_emit(self._h, bank, shard, reply.ctypes.data, cell_begin, cell_end, conn, None, 0)
         out = C.create_string_buffer(max(need, 1))
-        assert lib().rw_ingress_emit(self._h, bank, reply.ctypes.data, cell_begin, cell_end, conn, out, need) == need
+        assert lib().rw_ingress_emit(self._h, bank, shard, reply.ctypes.data, cell_begin, cell_end, conn, out, need) == need
         return out.raw[:need]
 
-    def repair(self, bank, reply, logfx, packed, term_at, conflict, epoch_index, submit, applied):
+    def repair(self, bank, reply, logfx, packed, term_at, conflict, epoch_index, submit, applied, shard=0):
         """rw_ingress_repair with Python callables: term_at(gid, index), conflict(gid, first_index, [terms]), epoch_index(gid) -> int;
         submit(CBatch*, COutcome*) -> 0; applied(gid, cell, reply row, logfx row, persist row as numpy records). reply is patched in place."""
         assert reply.flags["C_CONTIGUOUS"] and reply.dtype == abi.REPLY_DT
@@ -217,7 +232,7 @@ class Ingress:
 
         host = RepairHost(None, TERM_AT(lambda _u, g, i: term_at(g, i)), CONFLICT(lambda _u, g, f, t, n: conflict(g, f, [t[k] for k in range(n)])),
                           EPOCH_INDEX(lambda _u, g: epoch_index(g)), SUBMIT(lambda _u, b, o: submit(b, o)), APPLIED(_applied))
-        return lib().rw_ingress_repair(self._h, bank, reply.ctypes.data, logfx.ctypes.data, int(packed), C.byref(host))
+        return lib().rw_ingress_repair(self._h, bank, shard, reply.ctypes.data, logfx.ctypes.data, int(packed), C.byref(host))
 
     def recycle(self, bank):
         assert lib().rw_ingress_recycle(self._h, bank)

@@ -48,15 +48,20 @@ def history(groups, cluster, self_slot, pre_vote, rounds, seed, view=None, allow
     return st0, batches, outs, orc.read_state()
 
 
-def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, max_rounds, nodes, shadow=None, raw_submit=None):
+def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, max_rounds, nodes, shadow=None, raw_submit=None, shards=1):
     """Feeds the history, seals until everything was decided. table_decide32(abi.Batch32) and table_decide_sparse(abi.Batch with gid) return
     objects with .reply (REPLY_DT rows) and .logfx. Returns the number of batches sealed.
     shadow + raw_submit: the table answers RG_NEED_HOST for rows that leave its cached term runs. shadow is an OracleTable loaded with the initial
     state — it plays the host's RaftLog (lossless), kept in step with what the table has applied; raw_submit(CBatch*, COutcome*) is rg_submit on
-    the table. Missed rows and the rows skipped behind them are then decided through rw_ingress_repair before the next batch is sealed."""
+    the table. Missed rows and the rows skipped behind them are then decided through rw_ingress_repair before the next batch is sealed.
+    shards > 1: the ingress stands in front of that many tables (block partition); table_decide32 / table_decide_sparse are then LISTS, one per
+    shard, each deciding its own table's groups 0 .. count-1 (the flow maps them back to global group ids)."""
     ctx = [b"group-%05d" % g for g in range(groups)]
     nodes_b = wirelib.nodes_arg(nodes)
-    ing = wirelib.Ingress(groups, max_rounds, LOCAL_CONN + 1, nodes=nodes, entry_cap=1 << 18)
+    ing = wirelib.Ingress(groups, max_rounds, LOCAL_CONN + 1, nodes=nodes, entry_cap=1 << 18, shards=shards)
+    if shards == 1:
+        table_decide32, table_decide_sparse = [table_decide32], [table_decide_sparse]
+    assert shadow is None or shards == 1
     for g in range(groups):
         assert ing.add_context(ctx[g], g)
     for s in range(16):
@@ -115,19 +120,23 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
             ing.recycle(s.bank)
             break
         sealed += 1
-        G = groups
-        if s.batch.rounds:
-            out = table_decide32(s.batch)
+        assert len(s.shards) == shards and sum(ev for _, ev, _ in s.shards) == s.rows
+        for k, (b32, events, first) in enumerate(s.shards):
+            if not b32.rounds:
+                assert events == 0
+                continue
+            G = b32.count
+            out = table_decide32[k](b32)
             reply = out.reply
             if shadow is not None:
                 status = (reply["flags"] >> abi.F_STATUS_SHIFT) & 0xFF
                 unapplied = (status == abi.NEED_HOST) | (status == abi.SKIPPED_AFTER_NEED_HOST)
-                wide_form = wirelib.unpack32(s.batch)
-                applied_part = wirelib.unpack32(s.batch)
+                wide_form = wirelib.unpack32(b32)
+                applied_part = wirelib.unpack32(b32)
                 applied_part.head[unapplied] = (0, 0)
                 shadow.submit(applied_part)                       # the host's log follows what the table applied
                 if unapplied.any():
-                    repaired.append(int(np.count_nonzero(unapplied & ((s.batch.head["hdr"] & 0xF) != 0))))
+                    repaired.append(int(np.count_nonzero(unapplied & ((b32.head["hdr"] & 0xF) != 0))))
 
                     def on_applied(gid, cell, rep, lfx, per):
                         one = abi.Batch(1, 1, gid=np.array([gid], dtype=np.uint32))
@@ -142,32 +151,43 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
                         t = shadow.log_term(gid, index)
                         return -1 if t is None else t
 
-                    got = ing.repair(s.bank, reply, out.logfx, False, term_at, lambda g, first, terms: shadow.log_conflict(g, first, np.array(terms, dtype=np.int64)),
+                    got = ing.repair(s.bank, reply, out.logfx, False, term_at, lambda g, first_, terms: shadow.log_conflict(g, first_, np.array(terms, dtype=np.int64)),
                                      lambda g: int(shadow.read_state(g, 1).epoch_index[0]), raw_submit, on_applied)
                     assert got == repaired[-1], (got, repaired[-1])
-            for r in range(s.batch.rounds):
-                kinds = s.batch.head["hdr"][r * G:(r + 1) * G] & 0xF
-                for g in np.flatnonzero(kinds):
+            n_events = 0
+            for r in range(b32.rounds):
+                kinds = b32.head["hdr"][r * G:(r + 1) * G] & 0xF
+                for lg in np.flatnonzero(kinds):
+                    g = first + int(lg)
                     kind, rep, key = expected[g][seen[g]]
-                    assert kind == kinds[g], (g, seen[g], kind, kinds[g])
-                    got = reply[r * G + g]
+                    assert kind == kinds[lg], (g, seen[g], kind, kinds[lg])
+                    got = reply[r * G + lg]
                     assert (int(got["flags"]), int(got["role_epoch"])) == (int(rep["flags"]), int(rep["role_epoch"])), (g, seen[g], kind)
                     if int(rep["flags"]) & abi.F_REPLIED:
                         assert int(got["resp_term"]) == int(rep["resp_term"])
-                    assert ing.origin(s.bank, r * G + g) == key
+                    assert ing.origin(s.bank, r * G + lg, shard=k) == key
                     seen[g] += 1
+                    n_events += 1
+            assert n_events == events
             for conn in range(LOCAL_CONN + 1):
-                for ftype, sq, head, body in wirelib.split_frames(ing.emit(s.bank, reply, conn)):
+                for ftype, sq, head, body in wirelib.split_frames(ing.emit(s.bank, reply, conn, shard=k)):
                     assert ftype == wirelib.ACK and (conn, sq) not in got_answers
                     got_answers[(conn, sq)] = wirelib.decode_response(body)
-                    kind, rep, key = next(e for e in expected[int(head.split(b"-")[1])] if e[2] == (conn, sq))
-                    assert head == wirelib.METHOD_NAME[REQ_METHOD[kind]] + b":" + ctx[int(head.split(b"-")[1])]
-        if s.wide:                                     # rows the compact format cannot hold: one sparse round after the batch
-            sp = abi.Batch(1, len(s.wide), gid=np.array([w[0] for w in s.wide], dtype=np.uint32))
-            for i, (g, hdr, aux, q, terms, origin) in enumerate(s.wide):
+                    g = int(head.split(b"-")[1])
+                    assert first <= g < first + G
+                    kind, rep, key = next(e for e in expected[g] if e[2] == (conn, sq))
+                    assert head == wirelib.METHOD_NAME[REQ_METHOD[kind]] + b":" + ctx[g]
+        per = -(-groups // shards)
+        for k in range(shards):                        # rows the compact format cannot hold: one sparse round per table after the batch
+            mine = [w for w in s.wide if w[0] // per == k]
+            if not mine:
+                continue
+            first = k * per
+            sp = abi.Batch(1, len(mine), gid=np.array([w[0] - first for w in mine], dtype=np.uint32))
+            for i, (g, hdr, aux, q, terms, origin) in enumerate(mine):
                 sp.put(0, i, hdr & 0xF, slot=(hdr >> 4) & 0xF, flag=(hdr >> 8) & 1, a=q[0], b=q[1], c=q[2], d=q[3], aux=aux, entries=terms or None, n=hdr >> 12)
-            reply = table_decide_sparse(sp).reply
-            for i, (g, hdr, aux, q, terms, origin) in enumerate(s.wide):
+            reply = table_decide_sparse[k](sp).reply
+            for i, (g, hdr, aux, q, terms, origin) in enumerate(mine):
                 kind, rep, key = expected[g][seen[g]]
                 assert kind == hdr & 0xF and origin == key
                 assert (int(reply[i]["flags"]), int(reply[i]["role_epoch"])) == (int(rep["flags"]), int(rep["role_epoch"])), (g, seen[g], kind, "wide")
@@ -309,3 +329,26 @@ def replication_loop(make_table, groups, ticks, seed, over_the_wire):
         for i in ing:
             i.close()
     return states
+
+
+def slice_state(st, first, count):
+    """the GroupState image of groups [first, first + count) of `st` (every term run kept): what a shard's table is loaded with"""
+    F = st.followers
+    total = int(np.sum(st.run_count[first:first + count]))
+    packed = int(np.max(st.run_count[first:first + count], initial=0)) > abi.TERM_RUNS      # else the default layout: TERM_RUNS slots per group
+    out = abi.GroupState(count, st.cluster, runs_total=max(total, 1)) if packed else abi.GroupState(count, st.cluster)
+    for name, _, shape in abi._STATE_FIELDS:
+        if shape == 1 and name != "run_offset":
+            getattr(out, name)[:] = getattr(st, name)[first:first + count]
+        elif shape == "peers":
+            getattr(out, name)[:] = getattr(st, name)[first * F:(first + count) * F]
+    at = 0
+    for i in range(count):
+        n, off = int(st.run_count[first + i]), int(st.run_offset[first + i])
+        if not packed:
+            at = i * abi.TERM_RUNS
+        out.run_offset[i] = at
+        out.run_start[at:at + n] = st.run_start[off:off + n]
+        out.run_term[at:at + n] = st.run_term[off:off + n]
+        at += n
+    return out

@@ -2,7 +2,7 @@
 // C feeder threads (one connection each, random piece sizes), a sender thread that registers pending requests while their responses are
 // already arriving on other connections, a thread that adds contexts to the index while lookups run, and the flush thread sealing,
 // emitting and recycling without waiting for anybody. Checks: every row comes out exactly once, rows of one (connection, group) in order.
-// usage: ingress_race [groups=256] [conns=6] [rows per conn=20000] [max rounds=4]      prints "ingress race ok=1"
+// usage: ingress_race [groups=256] [conns=6] [rows per conn=20000] [max rounds=4] [shards=1]      prints "ingress race ok=1"
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +18,7 @@ using namespace rafting::wire;
 int main(int argc, char **argv)
 {
     const uint32_t G = argc > 1 ? (uint32_t)atoi(argv[1]) : 256, C = argc > 2 ? (uint32_t)atoi(argv[2]) : 6;
-    const uint32_t N = argc > 3 ? (uint32_t)atoi(argv[3]) : 20000, R = argc > 4 ? (uint32_t)atoi(argv[4]) : 4;
+    const uint32_t N = argc > 3 ? (uint32_t)atoi(argv[3]) : 20000, R = argc > 4 ? (uint32_t)atoi(argv[4]) : 4, SHARDS = argc > 5 ? (uint32_t)atoi(argv[5]) : 1;
     {   // the invocation ring with its two threads: the sender files requests while the reader takes the responses of earlier ones out of the SAME
         // slots (capacity 16: the sender laps the reader all the time). A take that succeeds must return exactly what was filed for that sequence.
         PendingRing ring(16);
@@ -48,7 +48,7 @@ int main(int argc, char **argv)
     std::vector<rg_ev_quad32_t> abcd[2] = {std::vector<rg_ev_quad32_t>(cells), std::vector<rg_ev_quad32_t>(cells)};
     std::vector<int32_t> terms[2] = {std::vector<int32_t>(4096), std::vector<int32_t>(4096)};
     Ingress ing(G, R, C + 1, codec, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), terms[0].size()},
-                Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()});
+                Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()}, 1u << 16, SHARDS);
     for (uint32_t c = 0; c < C; c++) ing.set_peer(c, (int32_t)(c % 3));
 
     // streams: requests only for groups of the first half (always known); the tag of a row = its sequence number on its connection
@@ -97,18 +97,19 @@ int main(int argc, char **argv)
     std::vector<rg_reply_t> reply(cells, rg_reply_t{5, RG_F_REPLIED, 1});
     uint64_t total = 0, frames = 0, batches = 0;
     auto take = [&](const SealedBatch &b) {
-        for (uint32_t r = 0; r < b.batch.rounds; r++)
-            for (uint32_t g = 0; g < G; g++) {
-                const size_t cell = (size_t)r * G + g;
-                if (RG_HDR_KIND(b.batch.head[cell].hdr) == RG_EV_NONE) continue;
-                const Origin o = b.origin[cell];
-                if (b.batch.abcd[cell].b != o.sequence) abort();
-                got[o.conn][g].push_back(o.sequence);
-                total++;
-            }
+        for (const SealedShard &sh : b.shard)
+            for (uint32_t r = 0; r < sh.batch.rounds; r++)
+                for (uint32_t g = 0; g < sh.batch.count; g++) {
+                    const size_t cell = (size_t)r * sh.batch.count + g;
+                    if (RG_HDR_KIND(sh.batch.head[cell].hdr) == RG_EV_NONE) continue;
+                    const Origin o = sh.origin[cell];
+                    if (sh.batch.abcd[cell].b != o.sequence) abort();
+                    got[o.conn][sh.first_gid + g].push_back(o.sequence);
+                    total++;
+                }
         for (const HeldRow &h : b.wide) { got[h.from.conn][h.gid].push_back(h.from.sequence); total++; }
         std::vector<std::string> out(C + 1);
-        frames += ing.emit(b, reply.data(), out);
+        for (uint32_t k = 0; k < b.shard.size(); k++) frames += ing.emit(b, reply.data(), out, 0, (size_t)-1, NO_CONN, k);
         ing.recycle(b);
         batches++;
     };

@@ -176,9 +176,10 @@ def test_ingress_threads_under_sanitizers(tmp_path, sanitizer):
                         os.path.join(host, "kryo_body.cpp"), "-pthread", "-o", exe], capture_output=True, text=True)
     if r.returncode != 0:
         pytest.skip("no %s sanitizer runtime for g++ here: %s" % (sanitizer, r.stderr[-200:]))
-    p = subprocess.run([exe, "128", "5", "2500", "4"], capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "ingress race ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
-    assert "Sanitizer" not in p.stderr, p.stderr[-3000:]
+    for shards in ("1", "3"):
+        p = subprocess.run([exe, "128", "5", "1500", "4", shards], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ingress race ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
+        assert "Sanitizer" not in p.stderr, p.stderr[-3000:]
 
 
 def test_replication_loop_over_frames_equals_the_in_memory_loop():
@@ -193,3 +194,26 @@ def test_replication_loop_over_frames_equals_the_in_memory_loop():
     for node in range(3):
         compare_states(mem[node], net[node], "node %d" % node)
     assert int(np.min(mem[0].commit_index)) > 10 and np.array_equal(mem[0].last_index, mem[1].last_index)
+
+
+@pytest.mark.parametrize("groups,shards,max_rounds", [(96, 3, 64), (100, 3, 4), (64, 8, 2), (50, 7, 64)])
+def test_one_ingress_in_front_of_several_tables(groups, shards, max_rounds):
+    """SURVEY 8(e) at the ingress: one set of connections, N tables (block partition gpu = gid / ceil(G / N), a last shard that may be smaller).
+    Rows are routed by group id as they are placed; every shard's sealed batch is decided by ITS table (groups 0 .. count-1) — the same rows,
+    order, replies, response frames and final state as the history decided row by row on one table holding all groups."""
+    from tests.helpers import compare_states
+    P, self_slot = 5, 1
+    st0, batches, outs, final = ingress_flow.history(groups, P, self_slot, True, 30, 300 + shards)
+    per = -(-groups // shards)
+    n = -(-groups // per)                                        # shards that hold groups (50 groups over 7: per = 8, 7 shards of 8,8,8,8,8,8,2)
+    tables = []
+    for k in range(n):
+        first, count = k * per, min(per, groups - k * per)
+        t = oracle_lib.OracleTable(count, P, self_slot, True)
+        t.load_state(ingress_flow.slice_state(st0, first, count))
+        tables.append(t)
+    d32 = [(lambda b32, t=t: t.submit(wirelib.unpack32(b32))) for t in tables]
+    dsp = [(lambda sp, t=t: t.submit(sp)) for t in tables]
+    ingress_flow.drive(d32, dsp, groups, P, batches, outs, max_rounds, NODES[:P], shards=n if n == shards else shards)
+    for k, t in enumerate(tables):
+        compare_states(ingress_flow.slice_state(final, k * per, t.groups), t.read_state(), "shard %d" % k)

@@ -56,3 +56,23 @@ def test_replication_loop_over_frames_equals_the_in_memory_loop():
     net = ingress_flow.replication_loop(lambda g, p, s, pv: engine.Table(g, p, s, pv), 200, 12, 7, over_the_wire=True)
     for node in range(3):
         compare_states(mem[node], net[node], "node %d" % node)
+
+
+def test_one_ingress_in_front_of_several_tables():
+    """SURVEY 8(e) at the ingress: one set of connections, three tables (block partition gpu = gid / ceil(G / N); here three tables on the one
+    GPU of the test box, a smaller last shard). Rows are routed by group id as they are placed; every shard's sealed batch goes to ITS table
+    through rg_submit32 — rows, order, replies, response frames and final state as the history decided row by row on one table of all groups."""
+    groups, shards, P, self_slot = 200, 3, 5, 1
+    st0, batches, outs, final = ingress_flow.history(groups, P, self_slot, True, 30, 303, view=engine.Table(groups, P, self_slot, True))
+    per = -(-groups // shards)
+    tables = []
+    for k in range(shards):
+        first, count = k * per, min(per, groups - k * per)
+        t = engine.Table(count, P, self_slot, True)
+        t.load_state(ingress_flow.slice_state(st0, first, count))
+        tables.append(t)
+    nodes = [("10.1.0.%d" % i, 7000 + i) for i in range(P)]
+    ingress_flow.drive([(lambda b32, t=t: t.submit32(b32)) for t in tables], [(lambda sp, t=t: t.submit(sp)) for t in tables], groups, P, batches, outs, 8,
+                       nodes, shards=shards)
+    for k, t in enumerate(tables):
+        compare_states(ingress_flow.slice_state(final, k * per, t.groups), t.read_state(), "shard %d" % k)
