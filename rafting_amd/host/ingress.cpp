@@ -49,9 +49,20 @@ bool ContextIndex::insert(const char *id, size_t len, uint32_t gid)
     return true;
 }
 
-bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const
+bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const { return find(hash(id, len), id, len, gid); }
+
+uint32_t ContextIndex::peek(uint64_t h) const
 {
-    const uint64_t h = hash(id, len);
+    for (uint32_t at = (uint32_t)h & mask_, probes = 0; probes < 4; at = (at + 1) & mask_, probes++) {
+        const uint64_t v = slot_[at].load(std::memory_order_acquire);
+        if (v == 0) break;
+        if ((v >> 32) == (h >> 32)) return (uint32_t)v - 1;
+    }
+    return capacity_;
+}
+
+bool ContextIndex::find(uint64_t h, const char *id, size_t len, uint32_t &gid) const
+{
     for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
         const uint64_t v = slot_[at].load(std::memory_order_acquire);
         if (v == 0) return false;
@@ -198,13 +209,46 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
     return true;
 }
 
-// One frame -> one row (RowWriter::add's mapping, wire.cpp, with the lookups this class owns)
-void Ingress::on_frame(uint32_t conn, const FrameView &f)
+// feed() in three passes over up to eight frames of a read: (1) stage — scope, hash, prefetch of the index slot (and of the invocation slot
+// of a response); (2) drain, first half — slot -> candidate group, prefetch of its key record and of its round counter; (3) drain, second
+// half — key compare, body decode, cell claim. The cache misses of one frame overlap the work on its neighbours.
+void Ingress::stage(uint32_t conn, const FrameView &f)
 {
     Conn &c = c_[conn];
-    Method m;
+    Conn::Staged &s = c.staged[c.n_staged++];
+    s.f = f;
+    s.ok = (f.type == ENQ || f.type == ACK) && parse_scope(f.head, f.head_len, s.m, s.id, s.id_len);
+    if (s.ok) {
+        s.hash = ContextIndex::hash_of(s.id, s.id_len);
+        index_.prefetch(s.hash);
+        if (f.type == ACK) c.ring->prefetch(f.sequence);
+    }
+    if (c.n_staged == sizeof(c.staged) / sizeof(c.staged[0])) drain(conn);
+}
+
+void Ingress::drain(uint32_t conn)
+{
+    Conn &c = c_[conn];
+    Bank &bk = bank_[fill_];
+    for (uint32_t i = 0; i < c.n_staged; i++) {
+        const Conn::Staged &s = c.staged[i];
+        if (!s.ok) continue;
+        const uint32_t guess = index_.peek(s.hash);
+        index_.prefetch_key(guess);
+        if (guess < groups_) __builtin_prefetch(&bk.depth[guess]);
+    }
+    for (uint32_t i = 0; i < c.n_staged; i++) on_frame(conn, c.staged[i]);
+    c.n_staged = 0;
+}
+
+// One frame -> one row (RowWriter::add's mapping, wire.cpp, with the lookups this class owns)
+void Ingress::on_frame(uint32_t conn, const Conn::Staged &st)
+{
+    Conn &c = c_[conn];
+    const FrameView &f = st.f;
+    const Method m = st.m;
     uint32_t gid = 0;
-    if ((f.type != ENQ && f.type != ACK) || !parse_scope(f.head, f.head_len, m, c.ctx) || !index_.find(c.ctx.data(), c.ctx.size(), gid)) {
+    if (!st.ok || !index_.find(st.hash, st.id, st.id_len, gid)) {
         refused_.fetch_add(1, std::memory_order_relaxed);
         return;
     }
@@ -258,7 +302,7 @@ int Ingress::feed(uint32_t conn, const uint8_t *data, size_t n)
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
     c.queued = 0;
-    c.sp.feed_views(data, n, [this, conn](const FrameView &f) { on_frame(conn, f); });
+    c.sp.feed_views(data, n, [this, conn](const FrameView &f) { stage(conn, f); }, [this, conn] { drain(conn); });
     return c.sp.failed() ? -1 : c.queued;
 }
 

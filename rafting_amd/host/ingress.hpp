@@ -42,6 +42,13 @@ public:
     explicit ContextIndex(uint32_t capacity);
     bool insert(const char *id, size_t len, uint32_t gid);      // false: gid beyond the capacity or taken, id empty / longer than MAX_HEAD_SIZE / present
     bool find(const char *id, size_t len, uint32_t &gid) const;
+    // the same in steps, for a caller that looks several ids up at once and wants the cache misses of one to overlap the work on another:
+    // hash_of, then prefetch(hash) some frames ahead, then find(hash, id, len, gid)
+    static uint64_t hash_of(const char *id, size_t len) { return hash(id, len); }
+    void prefetch(uint64_t h) const { __builtin_prefetch(&slot_[(uint32_t)h & mask_]); }
+    bool find(uint64_t h, const char *id, size_t len, uint32_t &gid) const;
+    void prefetch_key(uint32_t gid) const { if (gid < capacity_) __builtin_prefetch(&key_[gid]); }
+    uint32_t peek(uint64_t h) const;                            // the gid of the first slot whose tag matches (capacity = none): a guess for prefetch_key
     std::string id_of(uint32_t gid) const;                      // "" if that gid was never inserted
     void append_id(uint32_t gid, std::string &to) const { if (gid < capacity_) to.append(key_[gid].bytes, key_[gid].len); }
     uint32_t size() const { return n_; }
@@ -68,6 +75,7 @@ public:
     explicit PendingRing(uint32_t capacity_pow2 = 1u << 16);
     void put(int32_t sequence, Method m, uint32_t gid, const Pending &p);
     bool take(int32_t sequence, Method m, uint32_t gid, Pending &p);
+    void prefetch(int32_t sequence) const { __builtin_prefetch(&s_[(uint32_t)sequence & mask_]); }
 
 private:
     // key = 1 | sequence << 1 | method << 33 | gid << 36 (see .cpp). The record is three relaxed atomic words between two key stores (put) /
@@ -178,6 +186,9 @@ private:
         std::vector<HeldRow> held;                               // in arrival order
         Request q;                                               // decode scratch
         std::string ctx;
+        struct Staged { FrameView f; Method m; const char *id; size_t id_len; uint64_t hash; bool ok; };
+        Staged staged[8];                                        // frames of the current read whose lookups are in flight (feed() works on
+        uint32_t n_staged = 0;                                   // eight at a time so that the cache misses of one overlap the decode of another)
         int queued = 0;
         int32_t next_sequence = 0;                               // of the requests this side sends on the connection (AsyncService.sequence)
         std::vector<uint64_t> rows;                              // per shard: rows this connection placed into the bank being filled, and the
@@ -188,7 +199,9 @@ private:
     bool place(Bank &bk, Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
                Origin from);
     void hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from);
-    void on_frame(uint32_t conn, const FrameView &f);
+    void stage(uint32_t conn, const FrameView &f);
+    void drain(uint32_t conn);
+    void on_frame(uint32_t conn, const Conn::Staged &s);
     void wipe(Bank &bk);
 
     const uint32_t groups_, rounds_;

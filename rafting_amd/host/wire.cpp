@@ -36,7 +36,7 @@ size_t FrameSplitter::feed(const uint8_t *data, size_t n, std::vector<Frame> &ou
     });
 }
 
-size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink)
+size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink, const std::function<void()> &drained)
 {
     if (failed_) return 0;
     if (transparent_) { passthrough_.append(reinterpret_cast<const char *>(data), n); return 0; }
@@ -46,12 +46,13 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
         if (!open_) {
             const uint8_t b = (uint8_t)buf_[pos_++];
             if (b == EOT) {              // end of the framed protocol: the rest of the stream is not ours (:296-298)
+                if (drained) drained();  // (queued views point into buf_, which goes now)
                 transparent_ = true;
                 passthrough_.append(buf_, pos_, std::string::npos);
                 buf_.clear(); pos_ = 0;
                 return made;
             }
-            if (b != SOH) { fail("frame does not start with SOH"); return made; }
+            if (b != SOH) { if (drained) drained(); fail("frame does not start with SOH"); return made; }
             cur_.type = NUL; cur_.sequence = 0;
             head_len_ = body_len_ = -1;
             has_seq_ = false;
@@ -71,10 +72,10 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
         }
         if (head_len_ == -1) {
             if (!need(5)) break;
-            if ((uint8_t)buf_[pos_] != STX) { fail("STX expected"); return made; }
+            if ((uint8_t)buf_[pos_] != STX) { if (drained) drained(); fail("STX expected"); return made; }
             const int32_t len = be32(pos_ + 1);
             pos_ += 5;
-            if (len < 0 || len > MAX_HEAD_SIZE) { fail("illegal head length"); return made; }
+            if (len < 0 || len > MAX_HEAD_SIZE) { if (drained) drained(); fail("illegal head length"); return made; }
             head_len_ = len;
         }
         if (body_len_ == -1) {
@@ -82,7 +83,7 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
             head_at_ = pos_;                                                  // the head stays in buf_ (compaction rebases this offset)
             const int32_t len = be32(pos_ + (size_t)head_len_);
             pos_ += (size_t)head_len_ + 4;
-            if (len < 0 || len > MAX_BODY_SIZE) { fail("illegal body length"); return made; }
+            if (len < 0 || len > MAX_BODY_SIZE) { if (drained) drained(); fail("illegal body length"); return made; }
             body_len_ = len;
         } else {
             if (!need((size_t)body_len_ + 1)) break;
@@ -91,12 +92,13 @@ size_t FrameSplitter::feed_views(const uint8_t *data, size_t n, const std::funct
             v.head = buf_.data() + head_at_; v.head_len = (size_t)head_len_;
             v.body = buf_.data() + pos_; v.body_len = (size_t)body_len_;
             pos_ += (size_t)body_len_;
-            if ((uint8_t)buf_[pos_++] != ETX) { fail("ETX expected"); return made; }
+            if ((uint8_t)buf_[pos_++] != ETX) { if (drained) drained(); fail("ETX expected"); return made; }
             sink(v);
             made++;
             open_ = false;
         }
     }
+    if (drained) drained();
     // Drop what has been consumed. A read normally ENDS inside a frame (the loop has already eaten the next SOH), so waiting for a
     // moment between frames would let a busy connection grow buf_ without bound: while a frame is open everything before
     // the bytes it still needs goes — its head once that has been located (head_at_ is rebased), else the parse position.
@@ -140,6 +142,18 @@ bool parse_scope(const char *head, size_t len, Method &method, std::string &cont
         if (len >= n && memcmp(head, METHOD_NAME[m], n) == 0) {          // scope.startsWith(name): the separator itself is not checked
             method = (Method)m;
             if (len > n) context_id.assign(head + n + 1, len - n - 1); else context_id.clear();
+            return true;
+        }
+    }
+    return false;
+}
+bool parse_scope(const char *head, size_t len, Method &method, const char *&context_id, size_t &id_len)
+{
+    for (int m = M_APPEND_ENTRIES; m <= M_INSTALL_SNAPSHOT; m++) {
+        const size_t n = strlen(METHOD_NAME[m]);
+        if (len >= n && memcmp(head, METHOD_NAME[m], n) == 0) {
+            method = (Method)m;
+            if (len > n) { context_id = head + n + 1; id_len = len - n - 1; } else { context_id = head + len; id_len = 0; }
             return true;
         }
     }

@@ -58,7 +58,9 @@ public:
     size_t feed(const uint8_t *data, size_t n, std::vector<Frame> &out);
     // the same state machine handing every complete frame to `sink` as a view into the internal buffer (nothing is copied or allocated
     // per frame); feed() above is this plus a copy
-    size_t feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink);
+    // `drained` (optional) is called once after the last frame of this call and BEFORE the buffer is compacted: a sink that queues views
+    // (they stay valid until then) finishes its work there
+    size_t feed_views(const uint8_t *data, size_t n, const std::function<void(const FrameView &)> &sink, const std::function<void()> &drained = nullptr);
     bool failed() const { return failed_; }
     const std::string &error() const { return error_; }
     bool transparent() const { return transparent_; }
@@ -87,6 +89,7 @@ void encode_frame(const Frame &f, bool ending, std::string &out);
 enum Method { M_NONE = 0, M_APPEND_ENTRIES, M_PRE_VOTE, M_REQUEST_VOTE, M_INSTALL_SNAPSHOT };
 bool parse_scope(const std::string &head, Method &method, std::string &context_id);
 bool parse_scope(const char *head, size_t len, Method &method, std::string &context_id);
+bool parse_scope(const char *head, size_t len, Method &method, const char *&context_id, size_t &id_len);    // the id as a span of `head`
 std::string make_scope(Method method, const std::string &context_id);
 
 // ---- bodies ---------------------------------------------------------------------------------------------------------
