@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
 
 namespace rafting {
 namespace wire {
@@ -297,8 +298,17 @@ void Ingress::on_frame(uint32_t conn, const Conn::Staged &st)
     if (!place(bank_[fill_], c, gid, h, a, b, c4, d, terms, n_terms, from)) hold(c, gid, h, a, b, c4, d, terms, n_terms, from);
 }
 
+namespace {
+struct StandBack {                                                // feeders do not start a new read while the flusher wants the exclusive lock
+    std::atomic<bool> &f;
+    explicit StandBack(std::atomic<bool> &x) : f(x) { f.store(true, std::memory_order_release); }
+    ~StandBack() { f.store(false, std::memory_order_release); }
+};
+}  // namespace
+
 int Ingress::feed(uint32_t conn, const uint8_t *data, size_t n)
 {
+    while (sealing_.load(std::memory_order_acquire)) std::this_thread::yield();
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
     c.queued = 0;
@@ -348,6 +358,7 @@ size_t Ingress::encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, c
 
 void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, Origin reply_to)
 {
+    while (sealing_.load(std::memory_order_acquire)) std::this_thread::yield();
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
     const uint32_t kind = RG_HDR_KIND(head.hdr);                 // (AppendEntries: entries travel in frames; NONE / unknown kinds are no rows)
@@ -357,6 +368,7 @@ void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a,
 
 const SealedBatch &Ingress::seal()
 {
+    StandBack standing_back(sealing_);
     std::unique_lock<std::shared_mutex> lk(mu_);
     const int done = fill_, next = fill_ ^ 1;
     // two banks: one being filled, one sealed and with the flusher. Sealing again before that one was recycle()d would hand its memory to the
@@ -409,6 +421,7 @@ const SealedBatch &Ingress::seal()
 
 uint64_t Ingress::held() const
 {
+    StandBack standing_back(sealing_);
     std::unique_lock<std::shared_mutex> lk(mu_);
     uint64_t n = 0;
     for (const Conn &c : c_) n += c.held.size();

@@ -165,6 +165,9 @@ public:
     void recycle(const SealedBatch &b);
     int bank_of(const SealedBatch &b) const { return &b == &sealed_[0] ? 0 : 1; }
 
+    // rows of `conn` waiting for the next batch (the reader thread of that connection asks: a reader whose rows pile up because the flusher is
+    // behind stops reading its socket until the next seal — TCP pushes back on the peer — instead of letting the list grow)
+    size_t held_on(uint32_t conn) const { return c_[conn].held.size(); }
     uint64_t refused() const { return refused_.load(std::memory_order_relaxed); }     // frames that were no decision row (unknown context, ...)
     uint64_t held() const;                                                            // rows waiting for the next batch
 
@@ -214,6 +217,8 @@ private:
     SealedBatch sealed_[2];
     int fill_ = 0;                                               // bank being filled (changed under the exclusive lock)
     mutable std::shared_mutex mu_;
+    mutable std::atomic<bool> sealing_{false};                           // seal() is waiting for / holds the exclusive lock: feeders stand back (the rwlock
+                                                                 // alone prefers readers, a stream of overlapping feed() calls would starve the flusher)
     std::atomic<uint64_t> refused_{0}, ticket_{0};
 };
 
