@@ -213,8 +213,9 @@ void KryoBodyCodec::encode_request(Method m, const Request &in, std::string &bod
 
 void KryoBodyCodec::encode_response(const Response &in, std::string &body) const
 {
+    static const std::string head = [] { std::string s; Out w(s); w.class_by_name(N_RESPONSE); w.varint(1); return s; }();   // the same bytes every time
+    body.append(head);
     Out w(body);
-    w.class_by_name(N_RESPONSE); w.varint(1);
     w.u8(in.success ? 1 : 0);                                                      // success before term (R8)
     w.varlong_zz(in.term);
 }

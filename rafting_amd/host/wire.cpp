@@ -120,13 +120,19 @@ static void put64(std::string &o, int64_t v) { put32(o, (int32_t)((uint64_t)v >>
 
 void encode_frame(const Frame &f, bool ending, std::string &out)
 {
-    out.push_back((char)SOH);
-    out.push_back((char)f.type);
-    if (f.type == ENQ || f.type == ACK) put32(out, f.sequence);
-    out.push_back((char)STX);
-    put32(out, (int32_t)f.head.size());
+    char h[11];                                                       // SOH | TYPE | {SEQ} | STX | HEADLEN
+    size_t n = 0;
+    auto be32 = [&](int32_t v) { const uint32_t u = (uint32_t)v; h[n++] = (char)(u >> 24); h[n++] = (char)(u >> 16); h[n++] = (char)(u >> 8); h[n++] = (char)u; };
+    h[n++] = (char)SOH;
+    h[n++] = (char)f.type;
+    if (f.type == ENQ || f.type == ACK) be32(f.sequence);
+    h[n++] = (char)STX;
+    be32((int32_t)f.head.size());
+    out.append(h, n);
     out += f.head;
-    put32(out, (int32_t)f.body.size());
+    n = 0;
+    be32((int32_t)f.body.size());
+    out.append(h, n);
     out += f.body;
     out.push_back((char)ETX);
     if (ending) out.push_back((char)EOT);
