@@ -92,6 +92,9 @@ int      rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot);
  * transport/rpc/AsyncService.java:91-104): the response row needs it (RG_EV_AE_ACK b, c and aux) */
 int      rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method, uint32_t gid, uint32_t role_epoch, int64_t epoch_at_send,
                          int64_t last_index_sent);
+/* the TCP connection behind `conn` was replaced (closed by the peer, or by this side after rw_ingress_feed returned -1): the frame state machine
+ * starts over, invocations still filed for it are dropped (their responses cannot arrive any more), rows already queued stay queued */
+int      rw_ingress_reset_conn(rw_ingress_t *g, uint32_t conn);
 /* bytes as they arrive: rows queued by this call, or -1 once the connection broke the frame grammar */
 int      rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n);
 /* N1's output on the wire: what rg_replicate decided for follower j of `count` leader rows (head[count]; send_j = send + j * count, the rg_send_t

@@ -106,6 +106,8 @@ bool PendingRing::take(int32_t sequence, Method m, uint32_t gid, Pending &p)
     return s.key.compare_exchange_strong(expect, 0, std::memory_order_acq_rel);
 }
 
+void PendingRing::clear() { for (uint32_t i = 0; i <= mask_; i++) s_[i].key.store(0, std::memory_order_release); }
+
 // ---- Ingress ------------------------------------------------------------------------------------------------------------------
 Ingress::Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const BodyCodec &codec, const ContextIndex &index, Buffers bank0, Buffers bank1,
                  uint32_t pending_capacity, uint32_t shards)
@@ -137,6 +139,14 @@ Ingress::Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const Bod
 }
 
 void Ingress::set_peer(uint32_t conn, int32_t peer_slot) { c_[conn].peer = peer_slot; }
+
+void Ingress::reset_connection(uint32_t conn)
+{
+    Conn &c = c_[conn];
+    c.sp = FrameSplitter();
+    c.n_staged = 0;
+    c.ring->clear();
+}
 
 void Ingress::wipe(Bank &bk)
 {

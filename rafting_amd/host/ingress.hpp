@@ -76,6 +76,7 @@ public:
     void put(int32_t sequence, Method m, uint32_t gid, const Pending &p);
     bool take(int32_t sequence, Method m, uint32_t gid, Pending &p);
     void prefetch(int32_t sequence) const { __builtin_prefetch(&s_[(uint32_t)sequence & mask_]); }
+    void clear();                                               // drop every filed invocation
 
 private:
     // key = 1 | sequence << 1 | method << 33 | gid << 36 (see .cpp). The record is three relaxed atomic words between two key stores (put) /
@@ -131,6 +132,11 @@ public:
     PendingRing &pending(uint32_t conn) { return *c_[conn].ring; }
     int32_t &send_sequence(uint32_t conn) { return c_[conn].next_sequence; }   // the sequence number encode_sends gives its next request on `conn`
 
+    // The TCP connection behind `conn` was closed (by the peer, or by this side after feed() returned -1) and a new one takes its place: the
+    // frame state machine starts over, the invocations still filed are dropped — their responses can no longer arrive; the reference fails
+    // them with the channel (transport/rpc/AsyncService.java: the node's pending invocations time out) — rows already queued stay queued.
+    // Called by the thread that reads that connection (or with no reader on it).
+    void reset_connection(uint32_t conn);
     // Bytes as they arrive on `conn`. Returns the number of rows this call queued (placed or held), -1 once the stream broke the grammar.
     int feed(uint32_t conn, const uint8_t *data, size_t n);
     // N1's output on the wire: what rg_replicate decided for follower j of `count` leader rows (send_j = the rg_send_t of that follower, one per

@@ -206,6 +206,12 @@ int rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method
     g->in->pending(conn).put(sequence, (Method)method, gid, p);
     return 1;
 }
+int rw_ingress_reset_conn(rw_ingress_t *g, uint32_t conn)
+{
+    if (!g || conn >= g->conns) return 0;
+    g->in->reset_connection(conn);
+    return 1;
+}
 int rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, size_t n) { return (!g || conn >= g->conns) ? -1 : g->in->feed(conn, data, n); }
 }  // extern "C"
 namespace {

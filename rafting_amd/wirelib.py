@@ -42,6 +42,7 @@ def lib():
         L.rw_ingress_set_peer.argtypes = [_vp, _u32, _i32]
         L.rw_ingress_sent.argtypes = [_vp, _u32, _i32, C.c_int, _u32, _u32, _i64, _i64]
         L.rw_ingress_feed.argtypes = [_vp, _u32, C.c_char_p, _sz]
+        L.rw_ingress_reset_conn.argtypes = [_vp, _u32]
         L.rw_ingress_add_row.argtypes = [_vp, _u32, _u32, _u32, _u32, _i64, _i64, _i64, _i64, _u32, _i32]
         L.rw_ingress_encode_sends.restype = _sz
         L.rw_ingress_encode_sends.argtypes = [_vp, _u32, _i32, _u32, _vp, _vp, _vp, TERM_OF, _vp, C.c_char_p, _sz, C.POINTER(_u32), C.POINTER(_u32)]
@@ -161,6 +162,9 @@ class Ingress:
 
     def sent(self, conn, sequence, method, gid, role_epoch, epoch_at_send=0, last_index_sent=0):
         assert lib().rw_ingress_sent(self._h, conn, sequence, method, gid, role_epoch, epoch_at_send, last_index_sent)
+
+    def reset_conn(self, conn):
+        assert lib().rw_ingress_reset_conn(self._h, conn)
 
     def feed(self, conn, data):
         return lib().rw_ingress_feed(self._h, conn, data, len(data))

@@ -137,6 +137,13 @@ def test_what_is_not_a_decision_row_is_refused_and_counted():
     assert ing.seal().rows == 0
     assert ing.feed(0, b"\x07") == -1                                                 # not SOH: the connection is dead
     assert ing.feed(0, wirelib.request_frame(nodes_b, 3, b"a", 1, 1, 1, 1, 1)) == -1
+    # a new TCP connection in its place: frames are read again; what was filed for the old one is gone
+    ing.sent(0, 20, wirelib.M_APPEND_ENTRIES, 0, role_epoch=4)
+    ing.reset_conn(0)
+    half = wirelib.request_frame(nodes_b, 3, b"a", 7, 1, 1, 1, 1)
+    assert ing.feed(0, half[:10]) == 0 and ing.feed(0, half[10:]) == 1
+    before = ing.refused()
+    assert ing.feed(0, wirelib.response_frame(1, b"a", 20, 5, True)) == 0 and ing.refused() == before + 1
 
 
 def test_entries_of_several_terms_use_the_term_array_and_same_term_rows_do_not():
