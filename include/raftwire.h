@@ -87,6 +87,9 @@ rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conn
 void     rw_ingress_free(rw_ingress_t *g);
 /* ContextManager.createContext: contextId -> group id (1 ok, 0 refused: duplicate id / gid, gid out of range, id longer than 128 bytes) */
 int      rw_ingress_add_context(rw_ingress_t *g, const char *id, size_t len, uint32_t gid);
+/* ContextManager.exitContext / destroyContext (context/ContextManager.java:126-171): the id stops resolving at once; rows already queued for the
+ * group stay queued. The group id may be given to another context after the next rw_ingress_seal (which reclaims it). 1, or 0: no such context */
+int      rw_ingress_remove_context(rw_ingress_t *g, const char *id, size_t len);
 int      rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot);
 /* what the host remembers when it SENDS request `sequence` of `method` for group `gid` on `conn` (AsyncService.invoke,
  * transport/rpc/AsyncService.java:91-104): the response row needs it (RG_EV_AE_ACK b, c and aux) */

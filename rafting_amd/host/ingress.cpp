@@ -34,20 +34,47 @@ bool ContextIndex::insert(const char *id, size_t len, uint32_t gid)
 {
     if (gid >= capacity_ || len == 0 || len >= KEY_BYTES) return false;
     std::lock_guard<std::mutex> lk(mu_);
-    if (key_[gid].len != 0) return false;
+    if (key_[gid].len != 0) return false;                        // taken (or erased and not reclaimed yet)
     const uint64_t h = hash(id, len);
-    uint32_t at = (uint32_t)h & mask_;
+    uint32_t at = (uint32_t)h & mask_, free_at = mask_ + 1;
     for (;; at = (at + 1) & mask_) {
         const uint64_t v = slot_[at].load(std::memory_order_relaxed);
         if (v == 0) break;
+        if ((uint32_t)v == TOMB) { if (free_at > mask_) free_at = at; continue; }
         const Key &k = key_[(uint32_t)v - 1];
         if ((v >> 32) == (h >> 32) && k.len == len && memcmp(k.bytes, id, len) == 0) return false;
     }
+    if (free_at <= mask_) at = free_at;
     memcpy(key_[gid].bytes, id, len);
     key_[gid].len = (uint8_t)len;
     slot_[at].store((uint64_t)(gid + 1) | (h >> 32 << 32), std::memory_order_release);     // the key bytes are visible to whoever sees the slot
     n_++;
     return true;
+}
+
+uint32_t ContextIndex::erase(const char *id, size_t len)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    const uint64_t h = hash(id, len);
+    for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
+        const uint64_t v = slot_[at].load(std::memory_order_relaxed);
+        if (v == 0) return capacity_;
+        if ((uint32_t)v == TOMB || (v >> 32) != (h >> 32)) continue;
+        const uint32_t gid = (uint32_t)v - 1;
+        const Key &k = key_[gid];
+        if (k.len != len || memcmp(k.bytes, id, len) != 0) continue;
+        slot_[at].store((uint64_t)TOMB, std::memory_order_release);
+        retired_.push_back(gid);                                 // the key record stays as it is until reclaim(): a lookup may be comparing it
+        n_--;
+        return gid;
+    }
+}
+
+void ContextIndex::reclaim()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    for (uint32_t gid : retired_) key_[gid].len = 0;
+    retired_.clear();
 }
 
 bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const { return find(hash(id, len), id, len, gid); }
@@ -57,7 +84,7 @@ uint32_t ContextIndex::peek(uint64_t h) const
     for (uint32_t at = (uint32_t)h & mask_, probes = 0; probes < 4; at = (at + 1) & mask_, probes++) {
         const uint64_t v = slot_[at].load(std::memory_order_acquire);
         if (v == 0) break;
-        if ((v >> 32) == (h >> 32)) return (uint32_t)v - 1;
+        if ((uint32_t)v != TOMB && (v >> 32) == (h >> 32)) return (uint32_t)v - 1;
     }
     return capacity_;
 }
@@ -67,7 +94,7 @@ bool ContextIndex::find(uint64_t h, const char *id, size_t len, uint32_t &gid) c
     for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
         const uint64_t v = slot_[at].load(std::memory_order_acquire);
         if (v == 0) return false;
-        if ((v >> 32) != (h >> 32)) continue;
+        if ((uint32_t)v == TOMB || (v >> 32) != (h >> 32)) continue;
         const Key &k = key_[(uint32_t)v - 1];
         if (k.len == len && memcmp(k.bytes, id, len) == 0) { gid = (uint32_t)v - 1; return true; }
     }

@@ -42,6 +42,11 @@ public:
     explicit ContextIndex(uint32_t capacity);
     bool insert(const char *id, size_t len, uint32_t gid);      // false: gid beyond the capacity or taken, id empty / longer than MAX_HEAD_SIZE / present
     bool find(const char *id, size_t len, uint32_t &gid) const;
+    // ContextManager.exitContext / destroyContext (context/ContextManager.java:126-171): the id stops resolving at once (its slot becomes a
+    // tombstone), the group id can be given to another context after reclaim() — which the owner calls when no lookup that began before the
+    // erase can still be running: Ingress::seal() has returned since (it excludes every feed()). Returns the gid the id had, or capacity.
+    uint32_t erase(const char *id, size_t len);
+    void reclaim();
     // the same in steps, for a caller that looks several ids up at once and wants the cache misses of one to overlap the work on another:
     // hash_of, then prefetch(hash) some frames ahead, then find(hash, id, len, gid)
     static uint64_t hash_of(const char *id, size_t len) { return hash(id, len); }
@@ -65,6 +70,8 @@ private:
     uint32_t capacity_;
     std::mutex mu_;
     uint32_t n_ = 0;
+    std::vector<uint32_t> retired_;                             // erased, not yet reclaimed: their key records still belong to lookups in flight
+    static constexpr uint32_t TOMB = 0xFFFFFFFFu;               // low half of a slot whose context was erased: probing goes on
 };
 
 // What the host remembered when it sent request `sequence` on a connection. One ring per connection; put() by the sending side,

@@ -172,8 +172,8 @@ struct rw_ingress {
     ContextIndex index;
     std::unique_ptr<Ingress> in;
     const SealedBatch *sealed[2] = {nullptr, nullptr};
-    uint32_t conns;
-    rw_ingress(uint32_t groups) : index(groups), conns(0) {}
+    uint32_t conns, groups;
+    rw_ingress(uint32_t groups_) : index(groups_), conns(0), groups(groups_) {}
 };
 
 extern "C" {
@@ -191,6 +191,7 @@ rw_ingress_t *rw_ingress_new(uint32_t groups, uint32_t max_rounds, uint32_t conn
 }
 void rw_ingress_free(rw_ingress_t *g) { delete g; }
 int rw_ingress_add_context(rw_ingress_t *g, const char *id, size_t len, uint32_t gid) { return g && g->index.insert(id, len, gid); }
+int rw_ingress_remove_context(rw_ingress_t *g, const char *id, size_t len) { return g && g->index.erase(id, len) < g->groups; }
 int rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot)
 {
     if (!g || conn >= g->conns) return 0;
@@ -249,6 +250,7 @@ int rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32
     const SealedBatch *sp;
     try { sp = &g->in->seal(); } catch (const std::logic_error &) { return -1; }      // the batch sealed before has not been recycled
     const SealedBatch &s = *sp;
+    g->index.reclaim();                                              // (no lookup that began before an earlier remove_context is still running)
     const int bank = g->in->bank_of(s);
     g->sealed[bank] = &s;
     *batch = s.batch; *rows = s.rows; *wide = (uint32_t)s.wide.size();

@@ -40,6 +40,7 @@ def lib():
         L.rw_ingress_free.argtypes = [_vp]
         L.rw_ingress_add_context.argtypes = [_vp, C.c_char_p, _sz, _u32]
         L.rw_ingress_set_peer.argtypes = [_vp, _u32, _i32]
+        L.rw_ingress_remove_context.argtypes = [_vp, C.c_char_p, _sz]
         L.rw_ingress_sent.argtypes = [_vp, _u32, _i32, C.c_int, _u32, _u32, _i64, _i64]
         L.rw_ingress_feed.argtypes = [_vp, _u32, C.c_char_p, _sz]
         L.rw_ingress_reset_conn.argtypes = [_vp, _u32]
@@ -156,6 +157,9 @@ class Ingress:
 
     def add_context(self, ctx, gid):
         return bool(lib().rw_ingress_add_context(self._h, ctx, len(ctx), gid))
+
+    def remove_context(self, ctx):
+        return bool(lib().rw_ingress_remove_context(self._h, ctx, len(ctx)))
 
     def set_peer(self, conn, slot):
         assert lib().rw_ingress_set_peer(self._h, conn, slot)

@@ -137,6 +137,21 @@ def test_what_is_not_a_decision_row_is_refused_and_counted():
     assert ing.seal().rows == 0
     assert ing.feed(0, b"\x07") == -1                                                 # not SOH: the connection is dead
     assert ing.feed(0, wirelib.request_frame(nodes_b, 3, b"a", 1, 1, 1, 1, 1)) == -1
+    # exitContext / destroyContext: the id stops resolving at once, its group id is free for another context after the next seal
+    ing2 = wirelib.Ingress(4, 2, 1, nodes=NODES[:3])
+    for g, c in enumerate((b"p", b"q", b"r")):
+        assert ing2.add_context(c, g)
+    assert ing2.feed(0, wirelib.request_frame(nodes_b, 3, b"q", 1, 1, 1, 1, 1)) == 1
+    assert ing2.remove_context(b"q") and not ing2.remove_context(b"q") and not ing2.remove_context(b"nobody")
+    assert ing2.feed(0, wirelib.request_frame(nodes_b, 3, b"q", 2, 1, 1, 1, 1)) == 0 and ing2.refused() == 1
+    assert ing2.feed(0, wirelib.request_frame(nodes_b, 3, b"r", 3, 1, 1, 1, 1)) == 1       # probing walks over the tombstone
+    assert not ing2.add_context(b"s", 1)                                                   # not before the seal
+    s2 = ing2.seal()
+    assert s2.rows == 2 and ing2.add_context(b"s", 1) and ing2.add_context(b"q", 3)
+    ing2.recycle(s2.bank)
+    assert ing2.feed(0, wirelib.request_frame(nodes_b, 3, b"s", 4, 1, 1, 1, 1) + wirelib.request_frame(nodes_b, 3, b"q", 5, 1, 1, 1, 1)) == 2
+    s3 = ing2.seal()
+    assert [int(h) & 0xF for h in s3.batch.head["hdr"][:4]] == [0, abi.EV_RV_REQ, 0, abi.EV_RV_REQ]
     # a new TCP connection in its place: frames are read again; what was filed for the old one is gone
     ing.sent(0, 20, wirelib.M_APPEND_ENTRIES, 0, role_epoch=4)
     ing.reset_conn(0)
