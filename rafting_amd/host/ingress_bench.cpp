@@ -6,6 +6,7 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -136,6 +137,68 @@ int main(int argc, char **argv)
         printf("threads %d: frames -> batch %.3f s = %.2f M rows/s (%.2f GB/s of frames; seal %.1f ms) | replies -> %zu frames %.3f s = %.2f M/s (%.0f MB) | "
                "recycle %.1f ms\n", K, t1 - t0, rows / (t1 - t0) / 1e6, bytes / (t1 - t0) / 1e9, (t2 - t1) * 1e3, frames, t3 - t2, frames / (t3 - t2) / 1e6,
                ob / 1e6, (t4 - t3) * 1e3);
+    }
+    // (3) both directions at once, as a deployment runs them: K reader threads keep feeding while ONE flusher seals batches of at most RB
+    // rounds, "decides" them (every request answered: the table is not what this measures), emits the responses itself and recycles — the
+    // readers fill the other bank meanwhile. End-to-end rows/s of the host side alone.
+    const uint32_t RB = R >= 4 ? R / 4 : 1;
+    for (int K : ks) {
+        if ((unsigned)K + 1 > std::thread::hardware_concurrency()) continue;               // the flusher wants a core of its own
+        Ingress ing(G, RB, C, codec, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), terms[0].size()},
+                    Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()}, 1u << 22);
+        for (uint32_t c = 0; c < C; c++) ing.set_peer(c, 1 + (int32_t)(c % 4));
+        for (const Put &p : puts) ing.pending(p.conn).put(p.seq, M_APPEND_ENTRIES, p.gid, p.p);
+        std::atomic<int> reading{K};
+        const double t0 = now_s();
+        std::vector<std::thread> th;
+        for (int t = 0; t < K; t++)
+            th.emplace_back([&, t] {
+                pin(t);
+                std::vector<size_t> at(C, 0);
+                for (bool more = true; more;) {
+                    more = false;
+                    for (uint32_t c = (uint32_t)t; c < C; c += (uint32_t)K) {
+                        if (at[c] >= stream[c].size()) continue;
+                        const size_t n = std::min(CH, stream[c].size() - at[c]);
+                        ing.feed(c, reinterpret_cast<const uint8_t *>(stream[c].data()) + at[c], n);
+                        at[c] += n;
+                        more = true;
+                        while (ing.held_on(c) > 100000) std::this_thread::yield();         // the flusher is behind: stop reading this socket for a moment
+                    }
+                }
+                reading--;
+            });
+        pin(K);
+        uint64_t done_rows = 0, frames = 0, batches = 0;
+        std::vector<std::string> out(C);
+        for (;;) {
+            const bool finished = reading.load() == 0;
+            const SealedBatch &b = ing.seal();
+            if (b.rows == 0) {
+                ing.recycle(b);
+                if (finished && ing.held() == 0) break;
+                std::this_thread::yield();
+                continue;
+            }
+            const size_t n = (size_t)b.batch.rounds * G;
+            const unsigned helpers = b.rows > 100000 ? (unsigned)std::max(1, K / 2) : 0;      // a big batch: emitter threads share its cells with the flusher
+            std::vector<size_t> made(helpers, 0);
+            std::vector<std::thread> eth;
+            for (unsigned e = 0; e < helpers; e++)
+                eth.emplace_back([&, e] { std::vector<std::string> o(C); made[e] = ing.emit(b, reply.data(), o, n * (e + 1) / (helpers + 1), n * (e + 2) / (helpers + 1)); });
+            for (std::string &o : out) o.clear();
+            frames += ing.emit(b, reply.data(), out, 0, n / (helpers + 1));
+            for (std::thread &t : eth) t.join();
+            for (size_t m : made) frames += m;
+            done_rows += b.rows;
+            batches++;
+            ing.recycle(b);
+        }
+        for (std::thread &t : th) t.join();
+        const double s = now_s() - t0;
+        if (done_rows != rows || ing.refused()) { fprintf(stderr, "steady K=%d: %llu of %llu rows\n", K, (unsigned long long)done_rows, (unsigned long long)rows); return 1; }
+        printf("readers %d + 1 flusher (+ readers / 2 emitter threads on batches beyond 100 000 rows; <= %u rounds per batch): %llu rows in and %llu response frames out in %.3f s = %.2f M rows/s end to end, %llu batches\n", K, RB,
+               (unsigned long long)done_rows, (unsigned long long)frames, s, rows / s / 1e6, (unsigned long long)batches);
     }
     return 0;
 }
