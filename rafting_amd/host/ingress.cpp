@@ -442,16 +442,28 @@ const SealedBatch &Ingress::seal()
     Bank &nb = bank_[next];
     nb.clean = false;
     fill_ = next;
-    std::vector<std::pair<HeldRow, uint32_t>> waiting;            // every held row with its connection, oldest ticket first
+    // what the readers held back since the last seal joins its group's queue, oldest ticket first ...
+    std::vector<Waiting> fresh;
     for (uint32_t i = 0; i < c_.size(); i++) {
-        for (HeldRow &h : c_[i].held) waiting.emplace_back(std::move(h), i);
+        for (HeldRow &h : c_[i].held) fresh.push_back(Waiting{std::move(h), i});
+        c_[i].backlogged.fetch_add(c_[i].held.size(), std::memory_order_relaxed);
         c_[i].held.clear();
     }
-    std::sort(waiting.begin(), waiting.end(), [](const auto &x, const auto &y) { return x.first.ticket < y.first.ticket; });
-    for (auto &w : waiting) {
-        HeldRow &h = w.first;
-        Conn &c = c_[w.second];
-        if (!place(nb, c, h.gid, h.head, h.a, h.b, h.c, h.d, h.terms.data(), h.terms.size(), h.from)) c.held.push_back(std::move(h));   // keeps its ticket
+    std::sort(fresh.begin(), fresh.end(), [](const Waiting &x, const Waiting &y) { return x.row.ticket < y.row.ticket; });
+    for (Waiting &w : fresh) backlog_[w.row.gid].push_back(std::move(w));
+    // ... and every queue hands over as many of its oldest rows as the new bank takes; a group that keeps a backlog is closed for this batch,
+    // so whatever arrives for it now queues behind
+    for (auto it = backlog_.begin(); it != backlog_.end();) {
+        std::deque<Waiting> &q = it->second;
+        while (!q.empty()) {
+            Waiting &w = q.front();
+            HeldRow &h = w.row;
+            if (!place(nb, c_[w.conn], h.gid, h.head, h.a, h.b, h.c, h.d, h.terms.data(), h.terms.size(), h.from)) break;
+            c_[w.conn].backlogged.fetch_sub(1, std::memory_order_relaxed);
+            q.pop_front();
+        }
+        if (q.empty()) it = backlog_.erase(it);
+        else { nb.depth[it->first].fetch_or(CLOSED, std::memory_order_relaxed); ++it; }
     }
     return s;
 }
@@ -462,6 +474,7 @@ uint64_t Ingress::held() const
     std::unique_lock<std::shared_mutex> lk(mu_);
     uint64_t n = 0;
     for (const Conn &c : c_) n += c.held.size();
+    for (const auto &q : backlog_) n += q.second.size();
     return n;
 }
 

@@ -24,10 +24,12 @@
 #pragma once
 #include <atomic>
 #include <cstdint>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "wire.hpp"
@@ -180,7 +182,7 @@ public:
 
     // rows of `conn` waiting for the next batch (the reader thread of that connection asks: a reader whose rows pile up because the flusher is
     // behind stops reading its socket until the next seal — TCP pushes back on the peer — instead of letting the list grow)
-    size_t held_on(uint32_t conn) const { return c_[conn].held.size(); }
+    size_t held_on(uint32_t conn) const { return c_[conn].held.size() + c_[conn].backlogged.load(std::memory_order_relaxed); }
     uint64_t refused() const { return refused_.load(std::memory_order_relaxed); }     // frames that were no decision row (unknown context, ...)
     uint64_t held() const;                                                            // rows waiting for the next batch
 
@@ -199,7 +201,8 @@ private:
         FrameSplitter sp;
         int32_t peer = RG_NO_NODE;
         std::unique_ptr<PendingRing> ring;
-        std::vector<HeldRow> held;                               // in arrival order
+        std::vector<HeldRow> held;                               // held back since the last seal, in arrival order
+        std::atomic<size_t> backlogged{0};                       // its rows in backlog_ (seal() moves them there)
         Request q;                                               // decode scratch
         std::string ctx;
         struct Staged { FrameView f; Method m; const char *id; size_t id_len; uint64_t hash; bool ok; };
@@ -226,6 +229,10 @@ private:
     const BodyCodec &codec_;
     const ContextIndex &index_;
     std::vector<Conn> c_;
+    // rows held back over more than one batch, one FIFO per group (ticket order): seal() places at most max_rounds of a group per batch, so what a
+    // seal costs follows the rows it can place, not the size of the backlog (a peer that floods one group must not make every seal walk its flood)
+    struct Waiting { HeldRow row; uint32_t conn; };
+    std::unordered_map<uint32_t, std::deque<Waiting>> backlog_;
     Bank bank_[2];
     SealedBatch sealed_[2];
     int fill_ = 0;                                               // bank being filled (changed under the exclusive lock)
