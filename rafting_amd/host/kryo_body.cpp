@@ -242,7 +242,8 @@ bool KryoBodyCodec::decode_request_general(Method m, const char *body, size_t le
     if (ae) {
         if (r.klass() != K_ENTRY_ARRAY || !r.first_occurrence()) return false;
         const uint32_t e1 = r.varint();
-        if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p)) return false;
+        if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p) || e1 - 1 > RG_MAX_ENTRIES) return false;   // (more than a row's header can count:
+                                                                  // refused before a peer's 64 MiB body turns into tens of megabytes of scratch)
         for (uint32_t k = 0; k + 1 < e1; k++) {
             if (r.klass() != K_ROCKS_ENTRY || !r.first_occurrence()) return false;
             if (!r.first_occurrence()) return false;                               // data (never null: RocksLog.get builds entries from stored values)
@@ -313,6 +314,7 @@ int decode_request_fast(const std::vector<std::string> &node_bytes, Method m, co
         if (!r.expect(T.entries)) return -1;
         const uint32_t e1 = r.varint();
         if (!r.ok || e1 == 0 || (size_t)(e1 - 1) > (size_t)(r.end - r.p)) return -1;
+        if (e1 - 1 > RG_MAX_ENTRIES) return 0;
         for (uint32_t k = 0; k + 1 < e1; k++) {
             if (!r.expect(k == 0 ? T.entry_first : T.entry_next)) return -1;
             const uint32_t d1 = r.varint();
