@@ -95,6 +95,12 @@ int      rw_ingress_set_peer(rw_ingress_t *g, uint32_t conn, int32_t peer_slot);
  * transport/rpc/AsyncService.java:91-104): the response row needs it (RG_EV_AE_ACK b, c and aux) */
 int      rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method, uint32_t gid, uint32_t role_epoch, int64_t epoch_at_send,
                          int64_t last_index_sent);
+/* The command payload never reaches the table, but the host has to write it to its RaftLog once the row answers RG_F_LOG_APPEND
+ * (command/storage/RocksLog.java:169-225). rw_ingress_retain_bodies(g, 1) — before the first byte is fed — keeps the body of every
+ * AppendEntries request that carries entries next to its cell (freed by rw_ingress_recycle); rw_ingress_body hands it back: 1 and the
+ * Kryo-format Object[] body as it came off the wire (the entries' payload is in it), or 0 when nothing is kept for that cell. */
+int      rw_ingress_retain_bodies(rw_ingress_t *g, int on);
+int      rw_ingress_body(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, const uint8_t **body, size_t *len);
 /* the TCP connection behind `conn` was replaced (closed by the peer, or by this side after rw_ingress_feed returned -1): the frame state machine
  * starts over, invocations still filed for it are dropped (their responses cannot arrive any more), rows already queued stay queued */
 int      rw_ingress_reset_conn(rw_ingress_t *g, uint32_t conn);

@@ -153,6 +153,7 @@ Ingress::Ingress(uint32_t groups, uint32_t max_rounds, uint32_t conns, const Bod
         bank_[i].depth.reset(new std::atomic<uint32_t>[groups]);
         for (uint32_t g = 0; g < groups; g++) bank_[i].depth[g].store(0, std::memory_order_relaxed);
         bank_[i].origin.assign((size_t)groups * max_rounds, Origin{NO_CONN, 0});
+        bank_[i].body.assign((size_t)groups * max_rounds, Bank::BodyRef{NO_CONN, 0, 0});
         bank_[i].terms_used.reset(new std::atomic<uint64_t>[shard_.size()]);
         bank_[i].dirty_rounds.assign(shard_.size(), max_rounds);  // caller memory: content unknown
         wipe(bank_[i]);
@@ -186,22 +187,25 @@ void Ingress::wipe(Bank &bk)
         bk.dirty_rounds[s] = 0;
     }
     for (uint32_t g = 0; g < groups_; g++) bk.depth[g].store(0, std::memory_order_relaxed);
+    if (retain_) for (Conn &c : c_) c.bodies[&bk - bank_].clear();
     bk.wide.clear();
     bk.clean = true;
 }
 
 void Ingress::recycle(const SealedBatch &b) { wipe(bank_[bank_of(b)]); }
 
-void Ingress::hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from)
+void Ingress::hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from,
+                   const char *body, size_t body_len)
 {
-    HeldRow h{gid, head, a, b, c4, d, from, {}, ticket_.fetch_add(1, std::memory_order_relaxed)};
+    HeldRow h{gid, head, a, b, c4, d, from, {}, ticket_.fetch_add(1, std::memory_order_relaxed), {}};
     h.terms.assign(terms, terms + n_terms);
+    if (body_len) h.body.assign(body, body_len);
     c.held.push_back(std::move(h));
 }
 
 // true: the row sits in the bank (or in its wide list); false: the caller keeps it for the next batch
 bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
-                    Origin from)
+                    Origin from, const char *body, size_t body_len)
 {
     std::atomic<uint32_t> &depth = bk.depth[gid];
     const uint32_t si = gid / per_shard_;
@@ -215,8 +219,9 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
                                                                   // holds at all): close the group, hand the row over on its own
         const uint32_t was = depth.fetch_or(CLOSED, std::memory_order_relaxed);
         if (was >= rounds_) return false;                         // the group was full or closed already: wait for the next batch (it stays closed)
-        HeldRow h{gid, head, a, b, c4, d, from, {}, 0};
+        HeldRow h{gid, head, a, b, c4, d, from, {}, 0, {}};
         h.terms.assign(terms, terms + n_terms);
+        if (body_len) h.body.assign(body, body_len);
         std::lock_guard<std::mutex> lk(bk.wide_mu);
         bk.wide.push_back(std::move(h));
         return true;
@@ -242,6 +247,13 @@ bool Ingress::place(Bank &bk, Conn &cn, uint32_t gid, rg_ev_head_t head, int64_t
     bk.buf.abcd[cell] = rg_ev_quad32_t{(int32_t)a, (int32_t)b, (int32_t)c4, (int32_t)d};
     bk.buf.head[cell] = head;
     bk.origin[cell] = from;
+    if (retain_) {
+        if (body_len) {
+            std::string &arena = cn.bodies[&bk - bank_];
+            bk.body[cell] = Bank::BodyRef{(uint32_t)(&cn - c_.data()), (uint32_t)arena.size(), (uint32_t)body_len};
+            arena.append(body, body_len);
+        } else bk.body[cell] = Bank::BodyRef{NO_CONN, 0, 0};
+    }
     cn.rows[si]++;
     cn.max_depth[si] = std::max(cn.max_depth[si], r + 1);
     return true;
@@ -332,7 +344,22 @@ void Ingress::on_frame(uint32_t conn, const Conn::Staged &st)
     }
     c.queued++;
     // a connection that already holds rows back keeps its order: a group with a held row is closed in this bank, so place() refuses
-    if (!place(bank_[fill_], c, gid, h, a, b, c4, d, terms, n_terms, from)) hold(c, gid, h, a, b, c4, d, terms, n_terms, from);
+    const bool keep = retain_ && n_terms > 0;                    // (an AppendEntries request that carries entries: the host will want their payload)
+    if (!place(bank_[fill_], c, gid, h, a, b, c4, d, terms, n_terms, from, keep ? f.body : nullptr, keep ? f.body_len : 0))
+        hold(c, gid, h, a, b, c4, d, terms, n_terms, from, keep ? f.body : nullptr, keep ? f.body_len : 0);
+}
+
+const char *Ingress::body(const SealedBatch &b, uint32_t shard, size_t cell, size_t &len) const
+{
+    const int k = bank_of(b);
+    len = 0;
+    if (!retain_ || shard >= shard_.size() || cell >= (size_t)b.shard[shard].batch.rounds * shard_[shard].count) return nullptr;
+    const size_t at = shard_[shard].cell_off + cell;
+    if (RG_HDR_KIND(bank_[k].buf.head[at].hdr) != RG_EV_AE_REQ) return nullptr;      // (only those cells' references were written for this batch)
+    const Bank::BodyRef r = bank_[k].body[at];
+    if (r.conn == NO_CONN || r.len == 0 || (size_t)r.off + r.len > c_[r.conn].bodies[k].size()) return nullptr;
+    len = r.len;
+    return c_[r.conn].bodies[k].data() + r.off;
 }
 
 namespace {
@@ -458,7 +485,7 @@ const SealedBatch &Ingress::seal()
         while (!q.empty()) {
             Waiting &w = q.front();
             HeldRow &h = w.row;
-            if (!place(nb, c_[w.conn], h.gid, h.head, h.a, h.b, h.c, h.d, h.terms.data(), h.terms.size(), h.from)) break;
+            if (!place(nb, c_[w.conn], h.gid, h.head, h.a, h.b, h.c, h.d, h.terms.data(), h.terms.size(), h.from, h.body.data(), h.body.size())) break;
             c_[w.conn].backlogged.fetch_sub(1, std::memory_order_relaxed);
             q.pop_front();
         }

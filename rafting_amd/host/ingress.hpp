@@ -103,6 +103,7 @@ struct HeldRow {                                                  // a row kept 
     uint32_t gid; rg_ev_head_t head; int64_t a, b, c, d; Origin from;
     std::vector<int64_t> terms;
     uint64_t ticket = 0;                                          // order in which rows were held back, across connections
+    std::string body;                                             // the request's body, when the ingress retains them (retain_bodies)
 };
 
 // One sealed batch: what rg_submit32 / rg_submit_async_packed take (dense, `rounds` rounds of `count` cells) plus where its replies go.
@@ -136,6 +137,11 @@ public:
             uint32_t pending_capacity = 1u << 16,      // requests in flight per connection whose responses can still be matched
             uint32_t shards = 1);
     uint32_t shards() const { return (uint32_t)shard_.size(); }
+    // The command payload never reaches the table, but the host has to write it to its RaftLog once the row answers RG_F_LOG_APPEND
+    // (storage/RocksLog.java:169-225): with retain_bodies(true) — before the first feed() — the body of every AppendEntries request that
+    // carries entries is kept next to its cell (one arena per connection and bank, freed by recycle()) and body() hands it back.
+    void retain_bodies(bool on) { retain_ = on; }
+    const char *body(const SealedBatch &b, uint32_t shard, size_t cell, size_t &len) const;     // nullptr: nothing kept for that cell
 
     void set_peer(uint32_t conn, int32_t peer_slot);             // the node at the other end (its slot in the cluster list)
     PendingRing &pending(uint32_t conn) { return *c_[conn].ring; }
@@ -191,6 +197,8 @@ private:
         Buffers buf;
         std::unique_ptr<std::atomic<uint32_t>[]> depth;          // per group: rows claimed; bit 30 (CLOSED): no more rows in this batch
         std::vector<Origin> origin;                              // meaningful where the cell's head holds an event
+        struct BodyRef { uint32_t conn, off, len; };
+        std::vector<BodyRef> body;                               // (retain_bodies) where the cell's request body lies: c_[conn].bodies[this bank]
         std::unique_ptr<std::atomic<uint64_t>[]> terms_used;     // per shard
         std::vector<uint32_t> dirty_rounds;                      // per shard: rounds to wipe before the bank is filled again
         bool clean = false;
@@ -203,6 +211,7 @@ private:
         std::unique_ptr<PendingRing> ring;
         std::vector<HeldRow> held;                               // held back since the last seal, in arrival order
         std::atomic<size_t> backlogged{0};                       // its rows in backlog_ (seal() moves them there)
+        std::string bodies[2];                                   // (retain_bodies) request bodies of its rows, per bank
         Request q;                                               // decode scratch
         std::string ctx;
         struct Staged { FrameView f; Method m; const char *id; size_t id_len; uint64_t hash; bool ok; };
@@ -216,14 +225,16 @@ private:
     struct Shard { uint32_t first, count; size_t cell_off; uint64_t term_off, term_cap; };
     static constexpr uint32_t CLOSED = 1u << 30;
     bool place(Bank &bk, Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms,
-               Origin from);
-    void hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from);
+               Origin from, const char *body = nullptr, size_t body_len = 0);
+    void hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, const int64_t *terms, size_t n_terms, Origin from,
+              const char *body = nullptr, size_t body_len = 0);
     void stage(uint32_t conn, const FrameView &f);
     void drain(uint32_t conn);
     void on_frame(uint32_t conn, const Conn::Staged &s);
     void wipe(Bank &bk);
 
     const uint32_t groups_, rounds_;
+    bool retain_ = false;
     uint32_t per_shard_ = 0;
     std::vector<Shard> shard_;
     const BodyCodec &codec_;

@@ -207,6 +207,19 @@ int rw_ingress_sent(rw_ingress_t *g, uint32_t conn, int32_t sequence, int method
     g->in->pending(conn).put(sequence, (Method)method, gid, p);
     return 1;
 }
+int rw_ingress_retain_bodies(rw_ingress_t *g, int on)
+{
+    if (!g) return 0;
+    g->in->retain_bodies(on != 0);
+    return 1;
+}
+int rw_ingress_body(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, const uint8_t **body, size_t *len)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || !body || !len) return 0;
+    const char *p = g->in->body(*g->sealed[bank], shard, (size_t)cell, *len);
+    *body = reinterpret_cast<const uint8_t *>(p);
+    return p != nullptr;
+}
 int rw_ingress_reset_conn(rw_ingress_t *g, uint32_t conn)
 {
     if (!g || conn >= g->conns) return 0;

@@ -44,6 +44,9 @@ def lib():
         L.rw_ingress_sent.argtypes = [_vp, _u32, _i32, C.c_int, _u32, _u32, _i64, _i64]
         L.rw_ingress_feed.argtypes = [_vp, _u32, C.c_char_p, _sz]
         L.rw_ingress_reset_conn.argtypes = [_vp, _u32]
+        L.rw_ingress_retain_bodies.argtypes = [_vp, C.c_int]
+        L.rw_ingress_body.argtypes = [_vp, C.c_int, _u32, _u64, C.POINTER(_vp), C.POINTER(_sz)]
+        L.rw_kryo_decode_request.argtypes = [C.c_char_p, C.c_int, C.c_char_p, _sz, C.POINTER(_i64), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), _vp, _u32, C.POINTER(_u32)]
         L.rw_ingress_add_row.argtypes = [_vp, _u32, _u32, _u32, _u32, _i64, _i64, _i64, _i64, _u32, _i32]
         L.rw_ingress_encode_sends.restype = _sz
         L.rw_ingress_encode_sends.argtypes = [_vp, _u32, _i32, _u32, _vp, _vp, _vp, TERM_OF, _vp, C.c_char_p, _sz, C.POINTER(_u32), C.POINTER(_u32)]
@@ -117,6 +120,15 @@ def split_frames(data):
         L.rw_splitter_free(s)
 
 
+def decode_request(nodes, method, body):
+    """(term, node, x, y, leader_commit, [entry terms]) of a Kryo-format request body, or None"""
+    t, nd, x, y, lc, nt = _i64(), _i32(), _i64(), _i64(), _i64(), _u32()
+    terms = np.zeros(abi.MAX_AE_ENTRIES + 8, dtype=np.int64)
+    if not lib().rw_kryo_decode_request(nodes, method, body, len(body), C.byref(t), C.byref(nd), C.byref(x), C.byref(y), C.byref(lc), terms.ctypes.data, len(terms), C.byref(nt)):
+        return None
+    return t.value, nd.value, x.value, y.value, lc.value, [int(v) for v in terms[:nt.value]]
+
+
 def decode_response(body):
     t, s = _i64(), C.c_int()
     assert lib().rw_kryo_decode_response(body, len(body), C.byref(t), C.byref(s)) == 1
@@ -166,6 +178,13 @@ class Ingress:
 
     def sent(self, conn, sequence, method, gid, role_epoch, epoch_at_send=0, last_index_sent=0):
         assert lib().rw_ingress_sent(self._h, conn, sequence, method, gid, role_epoch, epoch_at_send, last_index_sent)
+
+    def retain_bodies(self, on=True):
+        assert lib().rw_ingress_retain_bodies(self._h, int(on))
+
+    def body(self, bank, cell, shard=0):
+        p, n = _vp(), _sz()
+        return C.string_at(p.value, n.value) if lib().rw_ingress_body(self._h, bank, shard, cell, C.byref(p), C.byref(n)) else None
 
     def reset_conn(self, conn):
         assert lib().rw_ingress_reset_conn(self._h, conn)

@@ -59,6 +59,7 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
     ctx = [b"group-%05d" % g for g in range(groups)]
     nodes_b = wirelib.nodes_arg(nodes)
     ing = wirelib.Ingress(groups, max_rounds, LOCAL_CONN + 1, nodes=nodes, entry_cap=1 << 18, shards=shards)
+    ing.retain_bodies()
     if shards == 1:
         table_decide32, table_decide_sparse = [table_decide32], [table_decide_sparse]
     assert shadow is None or shards == 1
@@ -166,6 +167,14 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
                     if int(rep["flags"]) & abi.F_REPLIED:
                         assert int(got["resp_term"]) == int(rep["resp_term"])
                     assert ing.origin(s.bank, r * G + lg, shard=k) == key
+                    kept = ing.body(s.bank, r * G + lg, shard=k)             # the request body, for the host's RaftLog: exactly the row's request
+                    hdr_c = int(b32.head["hdr"][r * G + lg])
+                    if kind == abi.EV_AE_REQ and (hdr_c >> 12) > 0:
+                        q = wirelib.decode_request(nodes_b, 1, kept)
+                        cell_q = b32.abcd[r * G + lg]
+                        assert q is not None and (q[0], q[2], q[3], q[4]) == tuple(int(v) for v in cell_q) and len(q[5]) == hdr_c >> 12
+                    else:
+                        assert kept is None
                     seen[g] += 1
                     n_events += 1
             assert n_events == events

@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
         std::vector<int32_t> terms[2] = {std::vector<int32_t>(cap + 1), std::vector<int32_t>(cap + 1)};     // exact sizes: ASan sees an overrun of the term array
         Ingress ing(G, R, C, kryo, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), cap},
                     Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), cap}, 64);
+        ing.retain_bodies(rng() % 2 == 0);
         for (uint32_t c = 0; c < C; c++) if (rng() % 4) ing.set_peer(c, (int32_t)(rng() % 3));
         for (uint32_t c = 0; c < C; c++) {
             std::string st;
@@ -113,6 +114,9 @@ int main(int argc, char **argv) {
                     printf("ingress: a row's entry terms lie outside the term array\n"); return 1;
                 }
                 if (RG_HDR_N(h.hdr) > RG_MAX_AE_ENTRIES && RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ) { printf("ingress: oversized row\n"); return 1; }
+                size_t blen = 0;
+                const char *kept = ing.body(b, 0, cell, blen);
+                if (kept) { volatile char first = kept[0], last = kept[blen - 1]; (void)first; (void)last; }      // (ASan: the whole span is readable)
             }
             if (events != b.rows) { printf("ingress: %zu events, %llu counted\n", events, (unsigned long long)b.rows); return 1; }
             std::vector<std::string> out(C);
