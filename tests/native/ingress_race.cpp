@@ -49,6 +49,7 @@ int main(int argc, char **argv)
     std::vector<int32_t> terms[2] = {std::vector<int32_t>(4096), std::vector<int32_t>(4096)};
     Ingress ing(G, R, C + 1, codec, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), terms[0].size()},
                 Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()}, 1u << 16, SHARDS);
+    ing.retain_bodies(true);
     for (uint32_t c = 0; c < C; c++) ing.set_peer(c, (int32_t)(c % 3));
 
     // streams: requests only for groups of the first half (always known); the tag of a row = its sequence number on its connection
@@ -61,10 +62,12 @@ int main(int argc, char **argv)
             const uint32_t g = (uint32_t)(rnd() % (rnd() % 3 ? G / 2 : 4));
             Frame f;
             f.type = ENQ; f.sequence = (int32_t)k;
-            f.head = make_scope(M_REQUEST_VOTE, id_of(g));
+            const Method m = (rnd() & 1) ? M_APPEND_ENTRIES : M_REQUEST_VOTE;                        // (half of them AppendEntries with one entry: their bodies are retained)
+            f.head = make_scope(m, id_of(g));
             Request q;
             q.term = (rnd() % 200 == 0) ? (int64_t)1 << 40 : 5; q.node = 1; q.x = k; q.y = 2;       // a few rows outside the compact format
-            codec.encode_request(M_REQUEST_VOTE, q, f.body);
+            if (m == M_APPEND_ENTRIES) q.entry_terms.assign(1, 5);
+            codec.encode_request(m, q, f.body);
             encode_frame(f, false, stream[c]);
             sent[c][g].push_back((int32_t)k);
         }
@@ -104,6 +107,9 @@ int main(int argc, char **argv)
                     if (RG_HDR_KIND(sh.batch.head[cell].hdr) == RG_EV_NONE) continue;
                     const Origin o = sh.origin[cell];
                     if (sh.batch.abcd[cell].b != o.sequence) abort();
+                    size_t blen = 0;
+                    const char *kept = ing.body(b, (uint32_t)(&sh - b.shard.data()), cell, blen);
+                    if ((RG_HDR_KIND(sh.batch.head[cell].hdr) == RG_EV_AE_REQ) != (kept != nullptr && blen > 40)) abort();     // an AppendEntries row has its body, no other row has one
                     got[o.conn][sh.first_gid + g].push_back(o.sequence);
                     total++;
                 }
