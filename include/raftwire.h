@@ -53,6 +53,9 @@ size_t rw_kryo_response(int64_t term, int success, uint8_t *out, size_t cap);
 int    rw_kryo_decode_request(const char *nodes, int method, const uint8_t *body, size_t len, int64_t *term, int32_t *node, int64_t *x, int64_t *y,
                               int64_t *leader_commit, int64_t *entry_terms, uint32_t max_terms, uint32_t *n_terms);
 int    rw_kryo_decode_response(const uint8_t *body, size_t len, int64_t *term, int *success);
+/* the follower's write path: entry k of an appendEntries body as (index, term, stored value = RocksEntry.data, what RaftLog.append puts under the
+ * index): 1 and *data / *n pointing into `body`, 0 when the body is no appendEntries body of this cluster or has no entry k */
+int    rw_kryo_entry(const char *nodes, const uint8_t *body, size_t len, uint32_t k, int64_t *index, int64_t *term, const uint8_t **data, size_t *n);
 
 /* one frame -> one row appended at index *rows of the caller's structure of arrays (head/ab/cd/gid/entry_terms as rg_batch_t wants them).
  * context ids are resolved through ctx_ids[n_ctx] (gid = position); a response needs what the host kept about its request.

@@ -221,7 +221,10 @@ void KryoBodyCodec::encode_response(const Response &in, std::string &body) const
 }
 
 // The general reader: any body the rules above allow (class records in any order of first appearance, either string form).
-bool KryoBodyCodec::decode_request_general(Method m, const char *body, size_t len, Request &out) const
+bool KryoBodyCodec::decode_request_general(Method m, const char *body, size_t len, Request &out) const { return read_request(m, body, len, out, nullptr); }
+
+// (visit: called with every entry's stored value — RocksEntry.data, the bytes RaftLog.append writes — where it lies in the body)
+bool KryoBodyCodec::read_request(Method m, const char *body, size_t len, Request &out, const EntryVisitor *visit) const
 {
     In r(body, len);
     out.leader_commit = 0;
@@ -249,10 +252,12 @@ bool KryoBodyCodec::decode_request_general(Method m, const char *body, size_t le
             if (!r.first_occurrence()) return false;                               // data (never null: RocksLog.get builds entries from stored values)
             const uint32_t d1 = r.varint();
             if (!r.ok || d1 == 0 || (size_t)(d1 - 1) > (size_t)(r.end - r.p)) return false;
+            const uint8_t *data = r.p;
             r.p += d1 - 1;                                                         // the payload never reaches a decision row
             const int64_t index = r.varlong_zz(), term = r.varlong_zz();
             if (!r.ok || index != (int64_t)((uint64_t)out.x + 1u + k)) return false;   // the C-ABI's rows carry implicit indices
             out.entry_terms.push_back(term);
+            if (visit) (*visit)(index, term, reinterpret_cast<const char *>(data), d1 - 1);
         }
         if (!r.boxed_long(out.leader_commit)) return false;
     }
@@ -331,6 +336,12 @@ int decode_request_fast(const std::vector<std::string> &node_bytes, Method m, co
 }
 
 }  // namespace
+
+bool KryoBodyCodec::entries(const char *body, size_t len, const EntryVisitor &visit) const
+{
+    Request scratch;
+    return read_request(M_APPEND_ENTRIES, body, len, scratch, &visit);
+}
 
 KryoBodyCodec::KryoBodyCodec(std::vector<Node> nodes) : nodes_(std::move(nodes))
 {

@@ -150,8 +150,14 @@ public:
     // decode_request = a fast path for the one byte shape the reference's encoder produces, else this: the reader of everything the format allows
     // (public so that tests can hold the two to the same answers)
     bool decode_request_general(Method m, const char *body, size_t len, Request &out) const;
+    // The follower's write path: every entry of an appendEntries body as (index, term, stored value) — RocksEntry.data is the value RaftLog.append
+    // puts under the index (command/storage/RocksLog.java:169-198; its first 8 bytes are the term, :82-89). The spans point into `body`.
+    // false: not an appendEntries body of this cluster (entries visited before the defect was found have been reported).
+    typedef std::function<void(int64_t index, int64_t term, const char *data, size_t n)> EntryVisitor;
+    bool entries(const char *body, size_t len, const EntryVisitor &visit) const;
     // a request's entries carry payload bytes the decision rows never see; index_of_first = prevLogIndex + 1 (what Leader.replicateLog ships)
 private:
+    bool read_request(Method m, const char *body, size_t len, Request &out, const EntryVisitor *visit) const;
     std::vector<Node> nodes_;
     std::vector<std::string> node_bytes_;     // hostname + port of each node as the encoder writes them (the decoder's fast path compares bytes)
 };

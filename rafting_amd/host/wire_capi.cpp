@@ -136,6 +136,15 @@ int rw_kryo_decode_request(const char *nodes, int method, const uint8_t *body, s
     return 1;
 }
 
+int rw_kryo_entry(const char *nodes, const uint8_t *body, size_t len, uint32_t k, int64_t *index, int64_t *term, const uint8_t **data, size_t *n)
+{
+    uint32_t at = 0;
+    bool found = false;
+    const bool ok = KryoBodyCodec(parse_nodes(nodes)).entries(reinterpret_cast<const char *>(body), len, [&](int64_t i, int64_t t, const char *d, size_t dn) {
+        if (at++ == k) { *index = i; *term = t; *data = reinterpret_cast<const uint8_t *>(d); *n = dn; found = true; }
+    });
+    return ok && found;
+}
 int rw_kryo_decode_response(const uint8_t *body, size_t len, int64_t *term, int *success)
 {
     Response r;

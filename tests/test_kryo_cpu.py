@@ -96,3 +96,21 @@ def test_the_two_restatements_agree_on_random_bodies_and_truncations_are_refused
 def test_a_body_from_an_unknown_node_is_not_a_row(wire):
     body = kryo_ref.request([("10.0.0.9", 7000)], False, 5, 0, 1, 1)
     assert decode(wire, 3, body) is None
+
+
+def test_entries_of_a_request_body_with_their_stored_values(wire):
+    """the follower's write path: rw_kryo_entry walks an appendEntries body and hands out (index, term, stored value) of entry k — the value is
+    RocksEntry.data, whose first 8 bytes are the term (storage/RocksLog.java:82-89); past the last entry, on another method's body or on a cut
+    body it answers 0"""
+    wire.rw_kryo_entry.argtypes = [C.c_char_p, C.c_char_p, sz, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(sz)]
+    terms = [4, 4, 5, 9]
+    body = kryo_ref.request(NODES, True, 9, 1, 100, 4, 97, terms)
+    for k, t in enumerate(terms):
+        i, tt, d, n = C.c_int64(), C.c_int64(), C.c_void_p(), sz()
+        assert wire.rw_kryo_entry(NODES_ARG, body, len(body), k, C.byref(i), C.byref(tt), C.byref(d), C.byref(n)) == 1
+        assert (i.value, tt.value, n.value) == (101 + k, t, 8) and C.string_at(d.value, 8) == t.to_bytes(8, "big")
+    i, tt, d, n = C.c_int64(), C.c_int64(), C.c_void_p(), sz()
+    assert wire.rw_kryo_entry(NODES_ARG, body, len(body), 4, C.byref(i), C.byref(tt), C.byref(d), C.byref(n)) == 0
+    assert wire.rw_kryo_entry(NODES_ARG, body[:-3], len(body) - 3, 0, C.byref(i), C.byref(tt), C.byref(d), C.byref(n)) == 0
+    vote = kryo_ref.request(NODES, False, 5, 0, 1, 1)
+    assert wire.rw_kryo_entry(NODES_ARG, vote, len(vote), 0, C.byref(i), C.byref(tt), C.byref(d), C.byref(n)) == 0
