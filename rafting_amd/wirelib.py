@@ -21,8 +21,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rafting_amd", "host"), os.path.join("..", "..", "build", "libraftwire.so")], check=True)
+        # (a no-op when the library is newer than its sources; a stale library would disagree with include/raftwire.h and this binding)
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "rafting_amd", "host"), os.path.join("..", "..", "build", "libraftwire.so")], check=True)
         L = C.CDLL(LIB_PATH)
         L.rw_encode_frame.restype = _sz
         L.rw_encode_frame.argtypes = [C.c_uint8, _i32, C.c_char_p, _sz, C.c_char_p, _sz, C.c_int, C.c_char_p, _sz]
