@@ -114,7 +114,8 @@ int      rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, si
  * transport/NettyNode.java:54-73), written to out[cap] for connection `conn`, each under the connection's next sequence number with its
  * invocation record filed for the response (what rw_ingress_sent does by hand). term_of(user, gid, index) reads an entry's term from the host's
  * RaftLog; the command payload is the transport's and is not modelled. RG_SEND_NEED_HOST rows are skipped and counted in *need_host.
- * Returns the bytes written, or the bytes needed when that exceeds cap — in which case NOTHING happened (no sequence number used, no record filed). */
+ * Returns the bytes written, or the bytes needed when that exceeds cap — in which case no sequence number was used (the invocation records that
+ * were filed are filed again, identically, by the retry with a larger buffer). */
 size_t   rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head,
                                  const rg_send_t *send_j, int64_t (*term_of)(void *user, uint32_t gid, int64_t index), void *user,
                                  uint8_t *out, size_t cap, uint32_t *frames, uint32_t *need_host);
@@ -161,7 +162,10 @@ int64_t  rw_ingress_repair(const rw_ingress_t *g, int bank, uint32_t shard, rg_r
 /* the batch of that bank is done with: wipe the cells it used (may run beside rw_ingress_feed) */
 int      rw_ingress_recycle(rw_ingress_t *g, int bank);
 uint64_t rw_ingress_refused(const rw_ingress_t *g);      /* frames that were no decision row: unknown context / method, undecodable body, unmatched response */
-uint64_t rw_ingress_held(const rw_ingress_t *g);         /* rows waiting on their connections for the next batch */
+uint64_t rw_ingress_held(const rw_ingress_t *g);         /* rows waiting for the next batch (flush thread) */
+/* rows of `conn` waiting for the next batch — asked by the thread that reads that connection: while the flusher is behind it stops reading the
+ * socket (TCP pushes back on the peer) instead of letting the backlog grow */
+uint64_t rw_ingress_held_on(const rw_ingress_t *g, uint32_t conn);
 
 #ifdef __cplusplus
 }

@@ -342,5 +342,6 @@ int rw_ingress_recycle(rw_ingress_t *g, int bank)
 }
 uint64_t rw_ingress_refused(const rw_ingress_t *g) { return g ? g->in->refused() : 0; }
 uint64_t rw_ingress_held(const rw_ingress_t *g) { return g ? g->in->held() : 0; }
+uint64_t rw_ingress_held_on(const rw_ingress_t *g, uint32_t conn) { return (g && conn < g->conns) ? g->in->held_on(conn) : 0; }
 
 }  // extern "C"

@@ -63,6 +63,8 @@ def lib():
         L.rw_ingress_refused.argtypes = [_vp]
         L.rw_ingress_held.restype = _u64
         L.rw_ingress_held.argtypes = [_vp]
+        L.rw_ingress_held_on.restype = _u64
+        L.rw_ingress_held_on.argtypes = [_vp, _u32]
         _lib = L
     return _lib
 
@@ -269,6 +271,9 @@ class Ingress:
 
     def held(self):
         return lib().rw_ingress_held(self._h)
+
+    def held_on(self, conn):
+        return lib().rw_ingress_held_on(self._h, conn)
 
 
 def unpack32(b32):

@@ -168,7 +168,7 @@ def test_entries_of_several_terms_use_the_term_array_and_same_term_rows_do_not()
         assert ing.add_context(c, g)
     f = lambda ctx, seq, terms: wirelib.request_frame(nodes_b, 1, ctx, seq, 9, 2, 100, 7, 99, terms)   # noqa: E731
     assert ing.feed(0, f(b"a", 1, [7, 7, 7]) + f(b"a", 2, [7, 8]) + f(b"b", 3, [8, 9, 9]) + f(b"b", 4, [9, 9, 9, 10]) + f(b"b", 5, [4])) == 5
-    assert ing.held() == 2
+    assert ing.held() == 2 and ing.held_on(0) == 2
     s = ing.seal()
     assert s.rows == 3 and s.batch.rounds == 2 and ing.held() == 0                      # the four-term row found the array full: it waits, and so does b's next row
     w = wirelib.unpack32(s.batch)
