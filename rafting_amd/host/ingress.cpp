@@ -70,11 +70,18 @@ uint32_t ContextIndex::erase(const char *id, size_t len)
     }
 }
 
-void ContextIndex::reclaim()
+size_t ContextIndex::retired()
 {
     std::lock_guard<std::mutex> lk(mu_);
-    for (uint32_t gid : retired_) key_[gid].len = 0;
-    retired_.clear();
+    return retired_.size();
+}
+
+void ContextIndex::reclaim(size_t n)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    n = std::min(n, retired_.size());
+    for (size_t i = 0; i < n; i++) key_[retired_[i]].len = 0;
+    retired_.erase(retired_.begin(), retired_.begin() + (long)n);
 }
 
 bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const { return find(hash(id, len), id, len, gid); }

@@ -46,9 +46,11 @@ public:
     bool find(const char *id, size_t len, uint32_t &gid) const;
     // ContextManager.exitContext / destroyContext (context/ContextManager.java:126-171): the id stops resolving at once (its slot becomes a
     // tombstone), the group id can be given to another context after reclaim() — which the owner calls when no lookup that began before the
-    // erase can still be running: Ingress::seal() has returned since (it excludes every feed()). Returns the gid the id had, or capacity.
+    // erase can still be running: an Ingress::seal() that STARTED after the erase has returned (it excludes every feed()). Returns the gid the
+    // id had, or capacity.
     uint32_t erase(const char *id, size_t len);
-    void reclaim();
+    size_t retired();                                            // erased ids not reclaimed yet: take this BEFORE the seal ...
+    void reclaim(size_t n = (size_t)-1);                         // ... and free that many (the oldest) after it: later erasures wait for the next seal
     // the same in steps, for a caller that looks several ids up at once and wants the cache misses of one to overlap the work on another:
     // hash_of, then prefetch(hash) some frames ahead, then find(hash, id, len, gid)
     static uint64_t hash_of(const char *id, size_t len) { return hash(id, len); }

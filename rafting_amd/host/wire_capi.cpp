@@ -270,9 +270,10 @@ int rw_ingress_seal(rw_ingress_t *g, rg_batch32_t *batch, uint64_t *rows, uint32
 {
     if (!g) return -1;
     const SealedBatch *sp;
+    const size_t erased_before = g->index.retired();
     try { sp = &g->in->seal(); } catch (const std::logic_error &) { return -1; }      // the batch sealed before has not been recycled
     const SealedBatch &s = *sp;
-    g->index.reclaim();                                              // (no lookup that began before an earlier remove_context is still running)
+    g->index.reclaim(erased_before);                                 // (no lookup that began before those removals is still running)
     const int bank = g->in->bank_of(s);
     g->sealed[bank] = &s;
     *batch = s.batch; *rows = s.rows; *wide = (uint32_t)s.wide.size();
