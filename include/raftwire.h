@@ -135,6 +135,9 @@ int      rw_ingress_shard(const rw_ingress_t *g, int bank, uint32_t shard, rg_ba
 int      rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *gid, rg_ev_head_t *head, int64_t abcd[4], int64_t *entry_terms,
                              uint32_t max_terms, uint32_t *reply_conn, int32_t *reply_sequence);
                              /* ascending gid; returns the row's entry count, -1 if it exceeds max_terms; reply_conn UINT32_MAX = a response row */
+/* the response frame of wide row i (decided by the host's sparse submit: `reply` = its reply row): the bytes written to out[cap] — 0 when the row
+ * was a response row, its handler died (no RG_F_REPLIED) or the frame does not fit — and the connection they belong to in *conn */
+size_t   rw_ingress_emit_wide(const rw_ingress_t *g, int bank, uint32_t i, const rg_reply_t *reply, uint32_t *conn, uint8_t *out, size_t cap);
 /* who sent the request in cell `cell` (= round * count + group of the shard) of that shard's batch: 1 and (*conn, *sequence), or 0 for a response row */
 int      rw_ingress_origin(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, uint32_t *conn, int32_t *sequence);
 /* the PongEvent frames of cells [cell_begin, cell_end) of shard `shard` (reply = that table's reply rows) whose reply carries RG_F_REPLIED, for connection `conn`, into out[cap]: returns the

@@ -539,6 +539,27 @@ size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<
     return made;
 }
 
+uint32_t Ingress::emit_wide(const HeldRow &row, const rg_reply_t &reply, std::string &out) const
+{
+    const char *scope = nullptr;
+    switch (RG_HDR_KIND(row.head.hdr)) {
+    case RG_EV_AE_REQ: scope = "appendEntries:"; break;
+    case RG_EV_PV_REQ: scope = "preVote:"; break;
+    case RG_EV_RV_REQ: scope = "requestVote:"; break;
+    case RG_EV_IS_REQ: scope = "installSnapshot:"; break;
+    default: return NO_CONN;
+    }
+    if (!(reply.flags & RG_F_REPLIED) || row.from.conn == NO_CONN) return NO_CONN;
+    Frame f;
+    f.type = ACK;
+    f.sequence = row.from.sequence;
+    f.head.assign(scope);
+    index_.append_id(row.gid, f.head);
+    codec_.encode_response(Response{reply.resp_term, (reply.flags & RG_F_SUCCESS) != 0}, f.body);
+    encode_frame(f, false, out);
+    return row.from.conn;
+}
+
 // ---- repair_need_host ----------------------------------------------------------------------------------------------------------------------
 static bool has_logfx_item(uint32_t flags)
 {

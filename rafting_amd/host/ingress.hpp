@@ -183,6 +183,9 @@ public:
     // shard: which of the batch's shards `reply` belongs to (its rows [rounds * count] as that table returned them).
     size_t emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin = 0, size_t cell_end = (size_t)-1,
                 uint32_t only_conn = NO_CONN, uint32_t shard = 0) const;       // only_conn: the frames of that connection alone
+    // The response frame of ONE row decided outside the batch — a wide row (b.wide[i], decided by the host's sparse submit): appended to `out`
+    // when its reply carries RG_F_REPLIED and a requester waits for it; returns the connection it belongs to, NO_CONN when nothing was written.
+    uint32_t emit_wide(const HeldRow &row, const rg_reply_t &reply, std::string &out) const;
     // The batch is done with (decided, effects applied, replies emitted): wipe the cells it used so that its bank can be filled again.
     // Touches only that bank: runs beside feed() without a lock.
     void recycle(const SealedBatch &b);

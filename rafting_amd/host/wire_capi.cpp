@@ -297,6 +297,15 @@ int rw_ingress_wide_row(const rw_ingress_t *g, int bank, uint32_t i, uint32_t *g
     for (size_t k = 0; k < h.terms.size(); k++) entry_terms[k] = h.terms[k];
     return (int)h.terms.size();
 }
+size_t rw_ingress_emit_wide(const rw_ingress_t *g, int bank, uint32_t i, const rg_reply_t *reply, uint32_t *conn, uint8_t *out, size_t cap)
+{
+    if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || i >= g->sealed[bank]->wide.size() || !reply || !conn) return 0;
+    std::string o;
+    *conn = g->in->emit_wide(g->sealed[bank]->wide[i], *reply, o);
+    if (*conn == NO_CONN || o.size() > cap) return 0;
+    memcpy(out, o.data(), o.size());
+    return o.size();
+}
 int rw_ingress_origin(const rw_ingress_t *g, int bank, uint32_t shard, uint64_t cell, uint32_t *conn, int32_t *sequence)
 {
     if (!g || bank < 0 || bank > 1 || !g->sealed[bank] || shard >= g->sealed[bank]->shard.size()) return 0;

@@ -58,6 +58,8 @@ def lib():
         L.rw_ingress_emit.argtypes = [_vp, C.c_int, _u32, _vp, _u64, _u64, _u32, C.c_char_p, _sz]
         L.rw_ingress_repair.restype = _i64
         L.rw_ingress_repair.argtypes = [_vp, C.c_int, _u32, _vp, _vp, C.c_int, C.POINTER(RepairHost)]
+        L.rw_ingress_emit_wide.restype = _sz
+        L.rw_ingress_emit_wide.argtypes = [_vp, C.c_int, _u32, _vp, C.POINTER(_u32), C.c_char_p, _sz]
         L.rw_ingress_recycle.argtypes = [_vp, C.c_int]
         L.rw_ingress_refused.restype = _u64
         L.rw_ingress_refused.argtypes = [_vp]
@@ -262,6 +264,13 @@ class Ingress:
         host = RepairHost(None, TERM_AT(lambda _u, g, i: term_at(g, i)), CONFLICT(lambda _u, g, f, t, n: conflict(g, f, [t[k] for k in range(n)])),
                           EPOCH_INDEX(lambda _u, g: epoch_index(g)), SUBMIT(lambda _u, b, o: submit(b, o)), APPLIED(_applied))
         return lib().rw_ingress_repair(self._h, bank, shard, reply.ctypes.data, logfx.ctypes.data, int(packed), C.byref(host))
+
+    def emit_wide(self, bank, i, reply_row):
+        """(conn, frame bytes) of wide row i's response, or None"""
+        row = np.ascontiguousarray(np.array([reply_row], dtype=abi.REPLY_DT))
+        conn, out = _u32(), C.create_string_buffer(512)
+        n = lib().rw_ingress_emit_wide(self._h, bank, i, row.ctypes.data, C.byref(conn), out, len(out))
+        return (conn.value, out.raw[:n]) if n else None
 
     def recycle(self, bank):
         assert lib().rw_ingress_recycle(self._h, bank)

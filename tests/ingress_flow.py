@@ -200,8 +200,13 @@ def drive(table_decide32, table_decide_sparse, groups, cluster, batches, outs, m
                 kind, rep, key = expected[g][seen[g]]
                 assert kind == hdr & 0xF and origin == key
                 assert (int(reply[i]["flags"]), int(reply[i]["role_epoch"])) == (int(rep["flags"]), int(rep["role_epoch"])), (g, seen[g], kind, "wide")
+                frame = ing.emit_wide(s.bank, s.wide.index(mine[i]), reply[i])
                 if key is not None and int(rep["flags"]) & abi.F_REPLIED:
-                    got_answers[key] = (int(reply[i]["resp_term"]), bool(int(reply[i]["flags"]) & abi.F_SUCCESS))
+                    (ftype, sq, head, body), = wirelib.split_frames(frame[1])
+                    assert frame[0] == key[0] and (ftype, sq) == (wirelib.ACK, key[1]) and head == wirelib.METHOD_NAME[REQ_METHOD[kind]] + b":" + ctx[g]
+                    got_answers[key] = wirelib.decode_response(body)
+                else:
+                    assert frame is None
                 seen[g] += 1
         ing.recycle(s.bank)
     assert seen == [len(e) for e in expected] and sum(seen) == queued
