@@ -190,6 +190,10 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body, const ch
 {
     // (copy_kernel: a grid-stride copy, 2 048 x 256 lanes that never meet — one OS thread per lane would only make it slow)
     if ((!waves_mode() && !lanes_must_meet(kernel)) || (kernel && strstr(kernel, "copy_kernel"))) {
+        // `__shared__` is `static` here (hip/hip_runtime.h): ONE copy for the process, so grids launched from several host threads — the feeder
+        // threads of MultiDeviceManager — must not overlap any more than two workgroups of one grid do (found as a one-in-ten flake of the
+        // ThreadSanitizer case: a leader's matchIndex row in "LDS" overwritten by another table's launch, a commit flag more or less)
+        std::lock_guard<std::mutex> one_grid(lane_pool().busy);
         gridDim_ = grid; blockDim_ = block;
         try {
             for (unsigned b = 0; b < grid.x; b++)
