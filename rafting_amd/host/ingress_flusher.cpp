@@ -1,0 +1,167 @@
+// ingress_flusher.cpp — see ingress_flusher.hpp.
+#include "ingress_flusher.hpp"
+
+#include <algorithm>
+
+using raftgpu::host::Entry;
+using raftgpu::host::RaftLog;
+using raftgpu::host::StableStore;
+
+namespace rafting {
+namespace wire {
+
+IngressFlusher::IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<RaftLog &(uint32_t)> log_of,
+                               std::vector<int64_t> term_of_group, StableStore *store, bool wide_kernel)
+    : table_(table), ing_(ing), codec_(codec), log_of_(std::move(log_of)), term_(std::move(term_of_group)), store_(store), wide_kernel_(wide_kernel)
+{
+    ing_.retain_bodies(true);
+}
+
+// One applied row -> the host-owned plugins, in the handler's order.
+void IngressFlusher::apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, const char *body, size_t body_len, const rg_reply_t &rep,
+                           const rg_logfx_t &lfx, const rg_persist_t &per, std::vector<StableStore::Record> &dirty)
+{
+    const uint32_t f = rep.flags, kind = RG_HDR_KIND(head.hdr);
+    RaftLog &log = log_of_(gid);
+    if (kind == RG_EV_AE_REQ) {
+        if (f & RG_F_LOG_TRUNC) { log.truncate(lfx.log_from); st_.truncated++; }
+        if (f & RG_F_LOG_APPEND) {
+            std::vector<Entry> sub;                                // the entries of ITS request at or above log_from (storage/RocksLog.java:169-196)
+            if (body) codec_.entries(body, body_len, [&](int64_t index, int64_t term, const char *, size_t) { if (index >= lfx.log_from) sub.push_back(Entry{index, term}); });
+            log.append(sub);
+            st_.appended += sub.size();
+        }
+    } else if (kind == RG_EV_CLIENT_APPEND && (f & RG_F_LOG_APPEND)) {
+        for (uint32_t k = 0; k < RG_HDR_N(head.hdr); k++) log.newEntry(term_[gid]);
+        st_.appended += RG_HDR_N(head.hdr);
+    } else if (kind == RG_EV_LOG_FLUSH && RG_F_STATUS(f) == RG_OK) {
+        log.flush(a, b);
+    }
+    if (f & RG_F_PERSIST) {                                        // durable BEFORE the response leaves: collected, written once per batch
+        term_[gid] = per.term;
+        dirty.push_back(StableStore::Record{gid, per.term, per.voted_for});
+    }
+    if (f & RG_F_COMMIT) { log.markCommitted(lfx.commit_index); st_.committed++; }
+}
+
+struct IngressFlusher::Host : RepairHost {
+    IngressFlusher &fl;
+    const SealedBatch &b;
+    std::vector<StableStore::Record> &dirty;
+    Host(IngressFlusher &f, const SealedBatch &batch, std::vector<StableStore::Record> &d) : fl(f), b(batch), dirty(d) {}
+    int64_t term_at(uint32_t gid, int64_t index) override { auto e = fl.log_of_(gid).get(index); return e ? e->term : -1; }
+    int64_t conflict(uint32_t gid, int64_t first, const int64_t *terms, uint32_t n) override
+    {
+        std::vector<Entry> es;
+        for (uint32_t k = 0; k < n; k++) es.push_back(Entry{first + (int64_t)k, terms[k]});
+        auto c = fl.log_of_(gid).conflict(es);
+        return c ? c->index : 0;
+    }
+    int64_t epoch_index(uint32_t gid) override { return fl.log_of_(gid).epoch().index; }
+    int submit(const rg_batch_t &in, const rg_outcome_t &out) override { return rg_submit(fl.table_, &in, &out, RG_MEM_HOST); }
+    void applied(uint32_t gid, size_t cell, const rg_reply_t &rep, const rg_logfx_t &lfx, const rg_persist_t &per) override
+    {
+        size_t n = 0;
+        const char *body = fl.ing_.body(b, 0, cell, n);
+        const rg_ev_quad32_t q = b.batch.abcd[cell];
+        fl.apply(gid, b.batch.head[cell], q.a, q.b, body, n, rep, lfx, per, dirty);
+        fl.st_.repaired++;
+    }
+};
+
+int64_t IngressFlusher::flush(std::vector<std::string> &out)
+{
+    const SealedBatch &b = ing_.seal();
+    if (b.rows == 0 && b.wide.empty()) { ing_.recycle(b); return 0; }
+    const uint32_t G = b.batch.count, R = b.batch.rounds;
+    const size_t cells = (size_t)G * R;
+    std::vector<StableStore::Record> dirty;
+    int64_t decided = 0;
+    if (cells) {
+        rep_.assign(cells, rg_reply_t{0, 0, 0}); lfx_.assign(cells, rg_logfx_t{0, 0}); per_.assign(cells, rg_persist_t{0, 0, 0});
+        const rg_outcome_t o{rep_.data(), lfx_.data(), per_.data()};
+        int rc;
+        if (!wide_kernel_) rc = rg_submit32(table_, &b.batch, &o, RG_MEM_HOST);
+        else {                                                     // the same rows as an rg_batch_t (the inverse of rg_batch32_pack)
+            std::vector<rg_ev_head_t> head(b.batch.head, b.batch.head + cells);
+            std::vector<rg_ev_pair_t> ab(cells), cd(cells);
+            std::vector<int64_t> terms;
+            for (size_t i = 0; i < cells; i++) {
+                const rg_ev_quad32_t q = b.batch.abcd[i];
+                ab[i] = rg_ev_pair_t{q.a, q.b}; cd[i] = rg_ev_pair_t{q.c, q.d};
+                const uint32_t n = RG_HDR_N(head[i].hdr);
+                if (RG_HDR_KIND(head[i].hdr) == RG_EV_AE_REQ && n > 0) {
+                    const uint32_t at = (uint32_t)terms.size();
+                    for (uint32_t k = 0; k < n; k++) terms.push_back((head[i].hdr & RG_HDR_SAME_TERM) ? (int64_t)head[i].aux : (int64_t)b.batch.entry_terms[head[i].aux + k]);
+                    head[i].hdr &= ~RG_HDR_SAME_TERM;
+                    head[i].aux = at;
+                }
+            }
+            rg_batch_t in{};
+            in.rounds = R; in.count = G; in.head = head.data(); in.ab = ab.data(); in.cd = cd.data();
+            in.entry_terms = terms.empty() ? nullptr : terms.data(); in.entry_count = terms.size();
+            rc = rg_submit(table_, &in, &o, RG_MEM_HOST);
+        }
+        if (rc != 0) { err_ = rg_last_error(table_); return -1; }
+        // the rows the launch applied, in (round, group) order = every group's own order
+        for (size_t cell = 0; cell < cells; cell++) {
+            if (RG_HDR_KIND(b.batch.head[cell].hdr) == RG_EV_NONE) continue;
+            decided++;
+            const uint32_t s = RG_F_STATUS(rep_[cell].flags);
+            if (s == RG_NEED_HOST || s == RG_SKIPPED_AFTER_NEED_HOST) continue;
+            size_t n = 0;
+            const char *body = ing_.body(b, 0, cell, n);
+            const rg_ev_quad32_t q = b.batch.abcd[cell];
+            apply((uint32_t)(cell % G), b.batch.head[cell], q.a, q.b, body, n, rep_[cell], lfx_[cell], per_[cell], dirty);
+        }
+        Host host(*this, b, dirty);
+        if (repair_need_host(b, rep_.data(), lfx_.data(), false, host) < 0) { err_ = std::string("repair: ") + rg_last_error(table_); return -1; }
+    }
+    // rows beside the batch (a value beyond 2^31 ...): one sparse row each, the same hint protocol
+    std::vector<std::pair<size_t, rg_reply_t>> wide_replies;
+    for (size_t i = 0; i < b.wide.size(); i++) {
+        const HeldRow &w = b.wide[i];
+        rg_ev_head_t h = w.head;
+        h.hdr &= ~(RG_HDR_SAME_TERM | RG_HDR_HINT_BIT);
+        h.aux = RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ ? 0u : h.aux;
+        rg_ev_pair_t ab{w.a, w.b}, cd{w.c, w.d}, hint{0, 0};
+        rg_reply_t rep{0, 0, 0}; rg_logfx_t lfx{0, 0}; rg_persist_t per{0, 0, 0};
+        for (int attempt = 0; attempt < 2; attempt++) {
+            rg_batch_t in{};
+            in.rounds = 1; in.count = 1; in.gid = &w.gid; in.head = &h; in.ab = &ab; in.cd = &cd;
+            in.entry_terms = w.terms.empty() ? nullptr : w.terms.data(); in.entry_count = w.terms.size(); in.hint = &hint;
+            const rg_outcome_t o{&rep, &lfx, &per};
+            if (rg_submit(table_, &in, &o, RG_MEM_HOST) != 0) { err_ = rg_last_error(table_); return -1; }
+            if (RG_F_STATUS(rep.flags) != RG_NEED_HOST) break;
+            RaftLog &log = log_of_(w.gid);
+            h.hdr |= RG_HDR_HINT_BIT;
+            if (RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ) {
+                auto pt = log.get(w.b);
+                std::vector<Entry> rest;
+                for (size_t k = 0; k < w.terms.size(); k++) if (w.b + 1 + (int64_t)k > log.epoch().index) rest.push_back(Entry{w.b + 1 + (int64_t)k, w.terms[k]});
+                auto cf = rest.empty() ? std::nullopt : log.conflict(rest);
+                hint = rg_ev_pair_t{pt ? pt->term : -1, cf ? cf->index : 0};
+            } else {
+                auto t = log.get(lfx.log_from);
+                hint = rg_ev_pair_t{lfx.log_from, t ? t->term : -1};
+            }
+        }
+        apply(w.gid, w.head, w.a, w.b, w.body.empty() ? nullptr : w.body.data(), w.body.size(), rep, lfx, per, dirty);
+        wide_replies.emplace_back(i, rep);
+        decided++;
+        st_.wide++;
+    }
+    if (store_ && !dirty.empty()) { store_->persist(dirty); st_.persisted += dirty.size(); }      // N3: before any reply of this batch leaves
+    if (cells) st_.frames += ing_.emit(b, rep_.data(), out);
+    for (auto &wr : wide_replies) {
+        const HeldRow &w = b.wide[wr.first];
+        if (w.from.conn < out.size()) st_.frames += ing_.emit_wide(w, wr.second, out[w.from.conn]) != NO_CONN;
+    }
+    ing_.recycle(b);
+    st_.batches++;
+    st_.rows += (uint64_t)decided;
+    return decided;
+}
+
+}  // namespace wire
+}  // namespace rafting

@@ -1,0 +1,55 @@
+// ingress_flusher.hpp — the flush thread's loop around an Ingress as ONE call: what INTEGRATION.md §1 / §3 describe, with the host-owned
+// plugins attached. seal -> decide on the table -> apply the log effects of the rows the launch applied -> repair RG_NEED_HOST rows from the
+// host's RaftLog (their effects applied one by one: the next hint reads the log as the last row left it) -> the rows the compact format
+// could not hold (one sparse submit each, same protocol) -> ONE durable write of every (term, votedFor) the batch changed -> only then the
+// response frames -> recycle. The order inside a row is the reference handler's (truncate -> append -> persist -> commit -> reply:
+// member/Follower.java:35-88, member/RaftMember.java:25, context/RaftContext.java:244-255).
+//
+//   RaftLog      raft_host.hpp's interface (command/RaftLog.java:72-132): one per group, owned by the caller
+//   StableStore  N3: optional
+// The request bodies are retained by the ingress (Ingress::retain_bodies), the entries a row appends are read from its own request.
+#pragma once
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "ingress.hpp"
+#include "raft_host.hpp"
+
+namespace rafting {
+namespace wire {
+
+class IngressFlusher {
+public:
+    struct Stats { uint64_t batches = 0, rows = 0, repaired = 0, wide = 0, frames = 0, persisted = 0, appended = 0, truncated = 0, committed = 0; };
+    // log_of(gid) -> the group's RaftLog; term_of_group[gid] = its currentTerm (kept current from the rows' persist records: a client append
+    // creates entries of that term, member/Leader.java:128-140). wide_kernel: decide the batch through rg_submit on an unpacked copy instead
+    // of rg_submit32 (tests on the lane-serial emulation of the kernels, which cannot run the compact-row kernel).
+    IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<raftgpu::host::RaftLog &(uint32_t)> log_of,
+                   std::vector<int64_t> term_of_group, raftgpu::host::StableStore *store = nullptr, bool wide_kernel = false);
+    // One batch. out[conn] receives the response frames. Returns the rows decided (0: nothing was waiting), -1 on a table error (message in error()).
+    int64_t flush(std::vector<std::string> &out);
+    const Stats &stats() const { return st_; }
+    const std::string &error() const { return err_; }
+    int64_t term(uint32_t gid) const { return term_[gid]; }
+
+private:
+    struct Host;
+    void apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, const char *body, size_t body_len, const rg_reply_t &rep, const rg_logfx_t &lfx,
+               const rg_persist_t &per, std::vector<raftgpu::host::StableStore::Record> &dirty);
+    rg_table_t *table_;
+    Ingress &ing_;
+    const KryoBodyCodec &codec_;
+    std::function<raftgpu::host::RaftLog &(uint32_t)> log_of_;
+    std::vector<int64_t> term_;
+    raftgpu::host::StableStore *store_;
+    bool wide_kernel_;
+    Stats st_;
+    std::string err_;
+    std::vector<rg_reply_t> rep_;
+    std::vector<rg_logfx_t> lfx_;
+    std::vector<rg_persist_t> per_;
+};
+
+}  // namespace wire
+}  // namespace rafting

@@ -123,6 +123,21 @@ def test_ingress_pipeline_from_socket_bytes_to_response_bytes_on_the_emulation(e
         assert p.returncode == 0 and "ingress pipeline ok=1" in p.stdout, p.stdout + p.stderr
 
 
+def test_ingress_flusher_repairs_from_real_logs_and_applies_effects_on_the_emulation(emulation_library, tmp_path):
+    """rafting_amd/host/ingress_flusher.cpp — seal, decide, apply log effects, repair RG_NEED_HOST from MemoryLogs (six term runs each, the device
+    caches four: every group misses in its second row and the two rows behind it are skipped), a row beyond int32 beside the batch, the durability
+    journal before the replies, response frames (tests/devemu/ingress_flusher_flow.cpp): every MemoryLog, the table, the journal and the responses
+    agree with what the requests said."""
+    exe = os.path.join(ROOT, "build", "devemu_ingress_flusher_flow")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(EMU, "ingress_flusher_flow.cpp")] +
+                   [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
+                   ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
+    p = subprocess.run([exe, "70", str(tmp_path / "journal")], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "ingress flusher ok=1" in p.stdout, p.stdout + p.stderr
+
+
 def test_the_product_binding_refuses_the_emulation_library(emulation_library):
     """rafting_amd.engine must not be talked into a CPU path by pointing RG_LIB at the test artefact"""
     env = dict(os.environ, RG_LIB=emulation_library, PYTHONPATH=ROOT)
