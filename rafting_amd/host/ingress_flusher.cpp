@@ -42,6 +42,7 @@ void IngressFlusher::apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b
         dirty.push_back(StableStore::Record{gid, per.term, per.voted_for});
     }
     if (f & RG_F_COMMIT) { log.markCommitted(lfx.commit_index); st_.committed++; }
+    if (on_row) on_row(gid, head, rep);
 }
 
 struct IngressFlusher::Host : RepairHost {

@@ -27,6 +27,11 @@ public:
     // of rg_submit32 (tests on the lane-serial emulation of the kernels, which cannot run the compact-row kernel).
     IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<raftgpu::host::RaftLog &(uint32_t)> log_of,
                    std::vector<int64_t> term_of_group, raftgpu::host::StableStore *store = nullptr, bool wide_kernel = false);
+    // Called for every decided row after its effects were applied, in the order the rows were decided: the host's reaction to what the handler
+    // did — RG_F_RESET_TIMER / RG_F_TIMER_MUTED (re-arm the election timer), RG_F_ROLE_CHANGED (abort the old role's invocations), RG_F_EMIT
+    // (broadcast PreVote / RequestVote, start replicating: rg_replicate + Ingress::encode_sends), reply.role_epoch (the tag of RPCs sent from
+    // now on) — INTEGRATION.md §3 step 5.
+    std::function<void(uint32_t gid, const rg_ev_head_t &head, const rg_reply_t &reply)> on_row;
     // One batch. out[conn] receives the response frames. Returns the rows decided (0: nothing was waiting), -1 on a table error (message in error()).
     int64_t flush(std::vector<std::string> &out);
     const Stats &stats() const { return st_; }

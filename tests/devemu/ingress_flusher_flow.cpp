@@ -74,6 +74,8 @@ int main(int argc, char **argv)
     StableStore store(journal);
     IngressFlusher flusher(table, ing, codec, [&](uint32_t g) -> raftgpu::host::RaftLog & { return *logs[g]; }, std::vector<int64_t>(G, TERM), &store, true);
 
+    uint64_t seen_rows = 0, timer_resets = 0;
+    flusher.on_row = [&](uint32_t, const rg_ev_head_t &, const rg_reply_t &r) { seen_rows++; timer_resets += (r.flags & RG_F_RESET_TIMER) != 0; };
     // the leader's stream: per group  append 2 at the tail | heartbeat probing index 15 (term 3: below the cached runs) | append 1 | heartbeat that commits
     std::string stream;
     int32_t seq = 0;
@@ -141,7 +143,8 @@ int main(int argc, char **argv)
     int64_t jt = 0; int32_t jv = 0;
     const bool durable = store.restore(SPECIAL, &jt, &jv) && jt == ((int64_t)1 << 33) + TERM && jv == 0;
     const bool ok = wrong == 0 && answers == requests && successes == requests && s.repaired == (uint64_t)(G - 1) * 3 && s.wide == 1 && s.persisted == 1 && durable &&
-                    s.appended == (uint64_t)(G - 1) * 3 + 1 && s.truncated == 0 && ing.refused() == 0 && ing.held() == 0;
+                    s.appended == (uint64_t)(G - 1) * 3 + 1 && s.truncated == 0 && ing.refused() == 0 && ing.held() == 0 && seen_rows == requests &&
+                    timer_resets == requests;      // (every AppendEntries a Follower accepts re-arms its election timer)
     printf("ingress flusher ok=%d: %llu rows in %llu batches, %llu repaired, %llu beside the batch, %llu entries appended, %llu commits, %llu persisted, "
            "%llu of %llu requests answered (%llu success), %llu wrong\n", (int)ok, (unsigned long long)s.rows, (unsigned long long)s.batches, (unsigned long long)s.repaired,
            (unsigned long long)s.wide, (unsigned long long)s.appended, (unsigned long long)s.committed, (unsigned long long)s.persisted, (unsigned long long)answers,
