@@ -138,6 +138,22 @@ def test_ingress_flusher_repairs_from_real_logs_and_applies_effects_on_the_emula
     assert p.returncode == 0 and "ingress flusher ok=1" in p.stdout, p.stdout + p.stderr
 
 
+def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emulation_library):
+    """BASELINE configs[0] on the wire path only (tests/devemu/ingress_cluster_flow.cpp): three nodes — table + Ingress + IngressFlusher + MemoryLogs
+    each — start from nothing, time out, PreVote, RequestVote, elect a leader per group, take client commands, replicate (rg_replicate ->
+    encode_sends), commit; a leader is cut off and comes back (re-election, step-down). Every decision by the device code on the emulation, every
+    message a frame of the reference's protocol. Election safety and the stability / agreement of committed entries are checked at every tick."""
+    exe = os.path.join(ROOT, "build", "devemu_ingress_cluster_flow")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(EMU, "ingress_cluster_flow.cpp")] +
+                   [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
+                   ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
+    for args in (["6", "500"], ["40", "300"]):
+        p = subprocess.run([exe] + args, env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "ingress cluster ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
+
+
 def test_the_product_binding_refuses_the_emulation_library(emulation_library):
     """rafting_amd.engine must not be talked into a CPU path by pointing RG_LIB at the test artefact"""
     env = dict(os.environ, RG_LIB=emulation_library, PYTHONPATH=ROOT)

@@ -76,3 +76,22 @@ def test_one_ingress_in_front_of_several_tables():
                        nodes, shards=shards)
     for k, t in enumerate(tables):
         compare_states(ingress_flow.slice_state(final, k * per, t.groups), t.read_state(), "shard %d" % k)
+
+
+def test_three_nodes_that_exchange_nothing_but_wire_bytes(tmp_path):
+    """BASELINE configs[0] on the wire path only (tests/devemu/ingress_cluster_flow.cpp, built against libraftgpu.so): three nodes — table +
+    Ingress + IngressFlusher + MemoryLogs each, three tables on the one GPU — start from nothing, time out, PreVote, RequestVote, elect a leader
+    per group, take client commands, replicate (rg_replicate -> encode_sends), commit; a leader is cut off and comes back. Every batch is decided
+    by rg_submit32 (step32_kernel), every message is a frame of the reference's protocol; election safety and the stability / agreement of
+    committed entries are checked at every tick."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host, lib_dir = os.path.join(root, "rafting_amd", "host"), os.path.join(root, "rafting_amd")
+    exe = str(tmp_path / "ingress_cluster_flow")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + host, "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "devemu", "ingress_cluster_flow.cpp")] +
+                   [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
+                   ["-L" + lib_dir, "-lraftgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-pthread", "-o", exe], check=True)
+    for args in (["6", "500", "compact"], ["200", "400", "compact"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "ingress cluster ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
