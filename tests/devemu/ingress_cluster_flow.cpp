@@ -5,7 +5,7 @@
 // A leader is cut off half-way (its bytes are dropped both ways) and comes back: the others elect a new leader, the old one steps down.
 // Checked at every tick: election safety (one leader per group and term), committed entries never change and agree across the nodes; at the
 // end: every group committed commands on all three nodes, the logs are identical up to the smallest commit index.
-// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
+// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact | wide] [journal path prefix]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
 // TEST INFRASTRUCTURE (tests/test_devemu_cpu.py, tests/test_ingress_gpu.py). prints "ingress cluster ok=1"
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +32,7 @@ struct Node {
     std::vector<rg_ev_quad32_t> abcd[2];
     std::vector<int32_t> terms[2];
     std::unique_ptr<Ingress> ing;
+    std::unique_ptr<raftgpu::host::StableStore> store;       // N3: the node's journal of (term, votedFor)
     std::unique_ptr<IngressFlusher> flusher;
     std::vector<std::unique_ptr<MemoryLog>> logs;
     std::vector<int64_t> deadline;
@@ -64,9 +65,12 @@ int main(int argc, char **argv)
                                  Ingress::Buffers{nd.head[1].data(), nd.abcd[1].data(), nd.terms[1].data(), 1024}));
         for (int p = 0; p < P; p++) if (p != n) nd.ing->set_peer((uint32_t)p, p);
         for (uint32_t g = 0; g < G; g++) nd.logs.emplace_back(new MemoryLog);
+        const std::string journal = std::string(argc > 4 ? argv[4] : "/tmp/ingress_cluster_flow") + ".node" + std::to_string(n) + ".journal";
+        remove(journal.c_str());
+        nd.store.reset(new raftgpu::host::StableStore(journal));
         Node *self = &nd;
         nd.flusher.reset(new IngressFlusher(nd.table, *nd.ing, codec, [self](uint32_t g) -> raftgpu::host::RaftLog & { return *self->logs[g]; },
-                                            std::vector<int64_t>(G, 0), nullptr, !compact));
+                                            std::vector<int64_t>(G, 0), nd.store.get(), !compact));
         nd.deadline.assign(G, 0); nd.role.assign(G, RG_FOLLOWER); nd.role_epoch.assign(G, 1);
         nd.want_prevote.assign(G, 0); nd.want_reqvote.assign(G, 0); nd.want_replicate.assign(G, 0);
         for (uint32_t g = 0; g < G; g++) nd.deadline[g] = ELECTION_MS + (int64_t)(rng() % ELECTION_MS);       // RaftConfig: election timeout in [E, 2E)
@@ -191,13 +195,40 @@ int main(int argc, char **argv)
     uint64_t min_commit = UINT64_MAX, refused = 0;
     for (uint32_t g = 0; g < G; g++)
         for (int n = 0; n < P; n++) min_commit = std::min<uint64_t>(min_commit, (uint64_t)nodes[n].logs[g]->lastCommitted());
+    // N3: what every node's journal holds is what its table holds (the journal was written before any reply that depended on it left)
+    uint64_t journal_wrong = 0, persisted = 0;
+    for (int n = 0; n < P; n++) {
+        std::vector<int64_t> term(G), elected_term(G), commit(G), eidx(G), eterm(G), first(G), last(G), run_start((size_t)G * RG_TERM_RUNS), run_term((size_t)G * RG_TERM_RUNS);
+        std::vector<int32_t> voted(G), role(G), leader(G), votes(G), pr((size_t)G * (P - 1));
+        std::vector<uint8_t> td(G), prepared(G), pp((size_t)G * (P - 1));
+        std::vector<uint32_t> repoch(G), elected_epoch(G), run_count(G), run_offset(G);
+        std::vector<int64_t> pe((size_t)G * (P - 1)), pn((size_t)G * (P - 1)), pm((size_t)G * (P - 1));
+        rg_group_state_t st{};
+        st.current_term = term.data(); st.voted_for = voted.data(); st.role = role.data(); st.current_leader = leader.data();
+        st.timeout_detected = td.data(); st.repl_prepared = prepared.data(); st.role_epoch = repoch.data(); st.votes = votes.data();
+        st.elected_epoch = elected_epoch.data(); st.elected_term = elected_term.data(); st.commit_index = commit.data();
+        st.epoch_index = eidx.data(); st.epoch_term = eterm.data(); st.first_index = first.data(); st.last_index = last.data();
+        st.run_count = run_count.data(); st.run_offset = run_offset.data(); st.run_start = run_start.data(); st.run_term = run_term.data();
+        st.peer_last_epoch = pe.data(); st.peer_next_index = pn.data(); st.peer_match_index = pm.data(); st.peer_rejection = pr.data();
+        st.peer_pending = pp.data();
+        if (rg_read_state(nodes[n].table, 0, G, &st) != 0) { fprintf(stderr, "rg_read_state: %s\n", rg_last_error(nodes[n].table)); return 1; }
+        for (uint32_t g = 0; g < G; g++) {
+            int64_t jt = 0; int32_t jv = 0;
+            const bool have = nodes[n].store->restore(g, &jt, &jv);
+            if (!(have ? (jt == term[g] && jv == voted[g]) : (term[g] == 0 && voted[g] == RG_NO_NODE)) || last[g] != (nodes[n].logs[g]->last() ? nodes[n].logs[g]->last()->index : 0)) {
+                journal_wrong++;
+                fprintf(stderr, "node %d group %u: journal (%d: %lld, %d) vs table (%lld, %d)\n", n, g, (int)have, (long long)jt, jv, (long long)term[g], voted[g]);
+            }
+        }
+        persisted += nodes[n].flusher->stats().persisted;
+    }
     uint64_t rows = 0, frames = 0, repaired = 0;
     for (int n = 0; n < P; n++) { rows += nodes[n].flusher->stats().rows; frames += nodes[n].flusher->stats().frames; repaired += nodes[n].flusher->stats().repaired; refused += nodes[n].ing->refused(); }
-    const bool ok = violations == 0 && min_commit >= 10 && elections >= G + 1 && step_downs >= 1;
+    const bool ok = violations == 0 && min_commit >= 10 && elections >= G + 1 && step_downs >= 1 && journal_wrong == 0 && persisted > 0;
     printf("ingress cluster ok=%d: %u groups x 3 nodes, %d ticks, %llu rows decided, %llu response frames, %llu elections won, %llu step-downs, %llu client commands, "
-           "smallest commit index %llu, %llu rows repaired, %llu frames refused (responses whose request was fenced or forgotten), %d violations\n", (int)ok, G, TICKS,
+           "smallest commit index %llu, %llu (term, votedFor) records journalled, %llu rows repaired, %llu frames refused (responses whose request was fenced or forgotten), %d violations\n", (int)ok, G, TICKS,
            (unsigned long long)rows, (unsigned long long)frames, (unsigned long long)elections, (unsigned long long)step_downs, (unsigned long long)commands,
-           (unsigned long long)min_commit, (unsigned long long)repaired, (unsigned long long)refused, violations);
+           (unsigned long long)min_commit, (unsigned long long)persisted, (unsigned long long)repaired, (unsigned long long)refused, violations);
     for (int n = 0; n < P; n++) rg_table_destroy(nodes[n].table);
     return ok ? 0 : 1;
 }

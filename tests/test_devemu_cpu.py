@@ -138,7 +138,7 @@ def test_ingress_flusher_repairs_from_real_logs_and_applies_effects_on_the_emula
     assert p.returncode == 0 and "ingress flusher ok=1" in p.stdout, p.stdout + p.stderr
 
 
-def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emulation_library):
+def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emulation_library, tmp_path):
     """BASELINE configs[0] on the wire path only (tests/devemu/ingress_cluster_flow.cpp): three nodes — table + Ingress + IngressFlusher + MemoryLogs
     each — start from nothing, time out, PreVote, RequestVote, elect a leader per group, take client commands, replicate (rg_replicate ->
     encode_sends), commit; a leader is cut off and comes back (re-election, step-down). Every decision by the device code on the emulation, every
@@ -150,7 +150,7 @@ def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emula
                    [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
                    ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
     for args in (["6", "500"], ["40", "300"]):
-        p = subprocess.run([exe] + args, env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=900)
+        p = subprocess.run([exe] + args + ["wide", str(tmp_path / "cluster")], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ingress cluster ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
 
 

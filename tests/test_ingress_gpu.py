@@ -93,5 +93,5 @@ def test_three_nodes_that_exchange_nothing_but_wire_bytes(tmp_path):
                    [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
                    ["-L" + lib_dir, "-lraftgpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-pthread", "-o", exe], check=True)
     for args in (["6", "500", "compact"], ["200", "400", "compact"]):
-        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900)
+        p = subprocess.run([exe] + args + [str(tmp_path / "cluster")], capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ingress cluster ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
