@@ -113,7 +113,8 @@ int      rw_ingress_feed(rw_ingress_t *g, uint32_t conn, const uint8_t *data, si
  * of that follower; gid NULL = rows are groups 0..count-1) as the request frames Leader.replicateLog ships (member/Leader.java:168-245,
  * transport/NettyNode.java:54-73), written to out[cap] for connection `conn`, each under the connection's next sequence number with its
  * invocation record filed for the response (what rw_ingress_sent does by hand). term_of(user, gid, index) reads an entry's term from the host's
- * RaftLog; the command payload is the transport's and is not modelled. RG_SEND_NEED_HOST rows are skipped and counted in *need_host.
+ * RaftLog; the command payload is the transport's and is not modelled. An RG_SEND_NEED_HOST row (prevLogIndex below the device's cached term
+ * runs) is completed here — prevLogTerm = term_of(gid, prev_index) — and counted in *need_host.
  * Returns the bytes written, or the bytes needed when that exceeds cap — in which case no sequence number was used (the invocation records that
  * were filed are filed again, identically, by the retry with a larger buffer). */
 size_t   rw_ingress_encode_sends(rw_ingress_t *g, uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head,

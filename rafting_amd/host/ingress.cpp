@@ -400,14 +400,18 @@ size_t Ingress::encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, c
     for (uint32_t i = 0; i < count; i++) {
         const rg_send_t &s = send_j[i];
         const rg_send_head_t &h = head[i];
-        if (s.kind == RG_SEND_NEED_HOST) { missing++; continue; }
-        if (s.kind != RG_SEND_APPEND && s.kind != RG_SEND_SNAPSHOT) continue;
+        if (s.kind != RG_SEND_APPEND && s.kind != RG_SEND_SNAPSHOT && s.kind != RG_SEND_NEED_HOST) continue;
         const uint32_t g = gid ? gid[i] : i;
-        const Method m = s.kind == RG_SEND_APPEND ? M_APPEND_ENTRIES : M_INSTALL_SNAPSHOT;
+        const Method m = s.kind == RG_SEND_SNAPSHOT ? M_INSTALL_SNAPSHOT : M_APPEND_ENTRIES;
+        int64_t prev_term = s.prev_term;
+        if (s.kind == RG_SEND_NEED_HOST) {                        // prevLogIndex lies below the device's cached term runs: its term comes from
+            prev_term = log.term_of(g, s.prev_index);            // the log this side owns (what ContextManager::replicateLog does for the mirror)
+            missing++;
+        }
         q.term = h.term;
         q.entry_terms.clear();
         if (m == M_APPEND_ENTRIES) {
-            q.x = s.prev_index; q.y = s.prev_term; q.leader_commit = h.leader_commit;
+            q.x = s.prev_index; q.y = prev_term; q.leader_commit = h.leader_commit;
             for (uint32_t k = 0; k < s.count; k++) q.entry_terms.push_back(log.term_of(g, s.prev_index + 1 + (int64_t)k));
         } else {
             q.x = h.epoch_index; q.y = h.epoch_term; q.leader_commit = 0;

@@ -163,8 +163,8 @@ public:
     // sequence number with its invocation record (role epoch, epoch.index at send, lastIndex) filed for the response
     // (transport/rpc/AsyncService.java:91-104). term_of(gid, index) reads an entry's term from the host's RaftLog (the command payload is the
     // transport's and is not modelled: an entry travels as the 8 bytes of its term, as KryoBodyCodec writes it). Rows with RG_SEND_NONE /
-    // RG_SEND_GATED send nothing; RG_SEND_NEED_HOST rows are the caller's to complete first (prev_term from its log) — they are skipped and
-    // counted in *need_host. Returns the frames written. One caller per connection at a time, like feed().
+    // RG_SEND_GATED send nothing; an RG_SEND_NEED_HOST row (prevLogIndex below the device's cached term runs) is completed here — its
+    // prevLogTerm is term_of(gid, prev_index) — and counted in *need_host. Returns the frames written. One caller per connection at a time.
     struct TermOf { virtual ~TermOf() {} virtual int64_t term_of(uint32_t gid, int64_t index) = 0; };
     size_t encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, const uint32_t *gid, const rg_send_head_t *head, const rg_send_t *send_j, TermOf &log,
                         std::string &out, uint32_t *need_host = nullptr);

@@ -5,7 +5,7 @@
 // A leader is cut off half-way (its bytes are dropped both ways) and comes back: the others elect a new leader, the old one steps down.
 // Checked at every tick: election safety (one leader per group and term), committed entries never change and agree across the nodes; at the
 // end: every group committed commands on all three nodes, the logs are identical up to the smallest commit index.
-// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact | wide] [journal path prefix]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
+// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact | wide] [journal path prefix] [partition every N ticks]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
 // TEST INFRASTRUCTURE (tests/test_devemu_cpu.py, tests/test_ingress_gpu.py). prints "ingress cluster ok=1"
 #include <cstdio>
 #include <cstdlib>
@@ -46,7 +46,8 @@ int main(int argc, char **argv)
 {
     const uint32_t G = argc > 1 ? (uint32_t)atoi(argv[1]) : 6;
     const int TICKS = argc > 2 ? atoi(argv[2]) : 500;
-    const bool compact = argc > 3 && std::string(argv[3]) == "compact";      // decide the batches with rg_submit32 (the GPU, or the wavefront emulation)
+    const bool compact = argc > 3 && std::string(argv[3]) == "compact";
+    const int EVERY = argc > 5 ? atoi(argv[5]) : 0;                          // > 0: a partition every so many ticks instead of the single one      // decide the batches with rg_submit32 (the GPU, or the wavefront emulation)
     const KryoBodyCodec codec({{"10.4.0.1", 7401}, {"10.4.0.2", 7402}, {"10.4.0.3", 7403}});
     std::mt19937_64 rng(20240922);
     std::vector<std::string> ids(G);
@@ -78,15 +79,21 @@ int main(int argc, char **argv)
     std::map<std::pair<uint32_t, int64_t>, int> leader_of;        // (group, term) -> node: election safety
     std::vector<std::vector<int64_t>> committed(G);               // per group: the terms of the committed entries, as first seen
     int violations = 0;
-    uint64_t commands = 0, elections = 0, step_downs = 0;
+    uint64_t commands = 0, elections = 0, step_downs = 0, sends_from_log = 0;
     int cut = -1;                                                  // the node whose bytes are dropped (both ways)
     int64_t now = 0;
 
     for (int tick = 0; tick < TICKS; tick++, now += TICK_MS) {
-        if (tick == TICKS / 2) {                                   // cut off whoever leads group 0 right now, for 60 ticks
-            for (int n = 0; n < P; n++) if (nodes[n].role[0] == RG_LEADER) cut = n;
+        if (EVERY == 0) {
+            if (tick == TICKS / 2) {                               // cut off whoever leads group 0 right now, for 60 ticks
+                for (int n = 0; n < P; n++) if (nodes[n].role[0] == RG_LEADER) cut = n;
+            }
+            if (tick == TICKS / 2 + 60) cut = -1;
+        } else {                                                   // again and again: terms pile up, the logs grow more term runs than the device caches,
+            if (tick >= 100 && (tick - 100) % EVERY == 0)          // a node that was away is probed at entries below the cached runs
+                for (int n = 0; n < P; n++) if (nodes[n].role[0] == RG_LEADER) cut = n;
+            if (tick >= 160 && (tick - 160) % EVERY == 0) cut = -1;
         }
-        if (tick == TICKS / 2 + 60) cut = -1;
         std::string inbox[P][P];                                   // [to][from]: what was written during the previous tick
         for (int n = 0; n < P; n++)
             for (int p = 0; p < P; p++) { if (n != cut && p != cut) inbox[p][n] = nodes[n].outbox[p]; nodes[n].outbox[p].clear(); }
@@ -174,7 +181,9 @@ int main(int argc, char **argv)
                 log.nd = &nd;
                 for (int j = 0; j < P - 1; j++) {
                     const int peer = j < n ? j : j + 1;
-                    nd.ing->encode_sends((uint32_t)peer, n, cnt, rep_gid.data(), sh.data(), sd.data() + (size_t)j * cnt, log, nd.outbox[peer]);
+                    uint32_t from_log = 0;
+                    nd.ing->encode_sends((uint32_t)peer, n, cnt, rep_gid.data(), sh.data(), sd.data() + (size_t)j * cnt, log, nd.outbox[peer], &from_log);
+                    sends_from_log += from_log;
                 }
             }
         }
@@ -226,9 +235,9 @@ int main(int argc, char **argv)
     for (int n = 0; n < P; n++) { rows += nodes[n].flusher->stats().rows; frames += nodes[n].flusher->stats().frames; repaired += nodes[n].flusher->stats().repaired; refused += nodes[n].ing->refused(); }
     const bool ok = violations == 0 && min_commit >= 10 && elections >= G + 1 && step_downs >= 1 && journal_wrong == 0 && persisted > 0;
     printf("ingress cluster ok=%d: %u groups x 3 nodes, %d ticks, %llu rows decided, %llu response frames, %llu elections won, %llu step-downs, %llu client commands, "
-           "smallest commit index %llu, %llu (term, votedFor) records journalled, %llu rows repaired, %llu frames refused (responses whose request was fenced or forgotten), %d violations\n", (int)ok, G, TICKS,
+           "smallest commit index %llu, %llu (term, votedFor) records journalled, %llu requests whose prevLogTerm came from the host's log, %llu rows repaired, %llu frames refused (responses whose request was fenced or forgotten), %d violations\n", (int)ok, G, TICKS,
            (unsigned long long)rows, (unsigned long long)frames, (unsigned long long)elections, (unsigned long long)step_downs, (unsigned long long)commands,
-           (unsigned long long)min_commit, (unsigned long long)persisted, (unsigned long long)repaired, (unsigned long long)refused, violations);
+           (unsigned long long)min_commit, (unsigned long long)persisted, (unsigned long long)sends_from_log, (unsigned long long)repaired, (unsigned long long)refused, violations);
     for (int n = 0; n < P; n++) rg_table_destroy(nodes[n].table);
     return ok ? 0 : 1;
 }

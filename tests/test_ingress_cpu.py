@@ -256,3 +256,34 @@ def test_a_flooded_group_does_not_make_every_seal_walk_its_backlog(tmp_path):
     for args in (["512", "7", "60000", "3", "1"], ["300", "6", "40000", "2", "4"]):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         assert p.returncode == 0 and "ingress race ok=1" in p.stdout, p.stdout + p.stderr[-2000:]
+
+
+def test_a_send_whose_previous_entry_lies_below_the_cached_runs_is_completed_from_the_hosts_log():
+    """rg_replicate answers RG_SEND_NEED_HOST when prevLogIndex lies below the term runs the table caches (the newest four of six here):
+    Ingress.encode_sends reads prevLogTerm from the host's RaftLog (term_of) and ships the request all the same."""
+    from tests.helpers import make_state
+    P, runs = 3, [(1 + 10 * k, 2 + k) for k in range(6)]                    # indices 1..60, terms 2..7
+    st = abi.GroupState(1, P, runs_total=len(runs))
+    st.role[0], st.current_term[0], st.voted_for[0], st.repl_prepared[0], st.role_epoch[0] = abi.LEADER, 7, 0, 1, 4
+    st.commit_index[0], st.first_index[0], st.last_index[0], st.run_count[0], st.run_offset[0] = 60, 1, 60, len(runs), 0
+    for k, (s, t) in enumerate(runs):
+        st.run_start[k], st.run_term[k] = s, t
+    st.peer_next_index[:] = [16, 61]                                        # follower 0 is far behind: prev = 15 (term 3, a forgotten run)
+    st.peer_match_index[:] = [0, 60]
+    leader = oracle_lib.OracleTable(1, P, 0, True)
+    leader.load_state(st)
+    head, send = leader.replicate(heartbeat=0)
+    assert int(send[0, 0]["kind"]) == abi.SEND_APPEND and (int(send[0, 0]["prev_index"]), int(send[0, 0]["prev_term"])) == (15, 3)   # the oracle's log is lossless
+    missed = send[:, 0].copy()                                              # ... the table's answer for the same state: the term is the host's to supply
+    missed["kind"], missed["prev_term"] = abi.SEND_NEED_HOST, 0
+    ing = wirelib.Ingress(1, 2, 2, nodes=NODES[:P])
+    assert ing.add_context(b"g", 0)
+    term_of = lambda g, i: next(t for s, t in reversed(runs) if s <= i)      # noqa: E731
+    data, frames, from_log = ing.encode_sends(0, 0, head, missed, term_of)
+    assert (frames, from_log) == (1, 1)
+    (ftype, seq, scope, body), = wirelib.split_frames(data)
+    q = wirelib.decode_request(wirelib.nodes_arg(NODES[:P]), 1, body)
+    n = int(send[0, 0]["count"])
+    assert scope == b"appendEntries:g" and (q[0], q[1], q[2], q[3]) == (7, 0, 15, 3) and q[5] == [term_of(0, 16 + k) for k in range(n)] and n > 0
+    whole, frames0, from_log0 = ing.encode_sends(0, 0, head, send[:, 0], term_of)      # the complete row gives the same request (under the next sequence number)
+    assert (frames0, from_log0) == (1, 0) and wirelib.split_frames(whole)[0][3] == body and wirelib.split_frames(whole)[0][1] == seq + 1
