@@ -85,7 +85,10 @@ def compact_route(request, monkeypatch):
 
 
 @pytest.mark.parametrize("scenario", kat_scenarios.SCENARIOS, ids=lambda f: f.__name__)
-def test_kat_on_compact_rows(scenario, compact_route):
+def test_kat_on_compact_rows(scenario, monkeypatch):
+    # (the 32-bit body; the 64-bit body of the same kernel answers the fuzz cases below on this emulation and every scenario on the GPU:
+    # tests/test_gpu_parity.py runs all of them on both routes)
+    T.route_through_compact(monkeypatch)
     scenario(T.mk_gpu)
 
 

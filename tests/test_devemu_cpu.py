@@ -149,7 +149,7 @@ def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emula
     subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(EMU, "ingress_cluster_flow.cpp")] +
                    [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
                    ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
-    for args in (["6", "500"], ["40", "300"]):
+    for args in (["6", "500"], ["24", "260"]):
         p = subprocess.run([exe] + args + ["wide", str(tmp_path / "cluster")], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "ingress cluster ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
 
