@@ -60,6 +60,7 @@ for step in "$@"; do
           timeout 300 build/ingress_pipeline 65536 64 16 $K $K 16 - > $OUT/ingress_pipeline_$K.txt 2>&1; tail -n 3 $OUT/ingress_pipeline_$K.txt; done
         timeout 300 build/ingress_pipeline 65536 64 16 8 8 64 - > $OUT/ingress_pipeline_8_r64.txt 2>&1; tail -n 3 $OUT/ingress_pipeline_8_r64.txt
         timeout 300 build/ingress_pipeline 65536 64 16 8 8 16 - 5 > $OUT/ingress_pipeline_8_miss5.txt 2>&1; tail -n 3 $OUT/ingress_pipeline_8_miss5.txt   # 5 % of the requests leave the cached term runs: RG_NEED_HOST repair
+        ( time timeout 300 build/ingress_cluster_flow 4096 400 compact gpurun_out/icf ) > $OUT/ingress_cluster_4096.txt 2>&1; tail -n 4 $OUT/ingress_cluster_4096.txt   # three nodes, wire bytes only, every batch through rg_submit32
         timeout 120 build/ingress_bench 65536 16 16 1,2,4,8,16 > $OUT/ingress_bench.txt 2>&1; tail -n 5 $OUT/ingress_bench.txt ;;
     sweep) for R in 1 4 16 64; do $B --steps 20 --warmup 3 --rounds $R 2>>$OUT/aux.err | tee -a $OUT/rounds.jsonl | line rounds=$R; done
         $B --steps 10 --warmup 2 --override "p_conflict=0.005" 2>>$OUT/aux.err | tee -a $OUT/conflict.jsonl | line p_conflict=0.005 ;;
