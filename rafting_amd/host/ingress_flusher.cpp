@@ -15,7 +15,7 @@ IngressFlusher::IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCo
                                std::vector<int64_t> term_of_group, StableStore *store, bool wide_kernel)
     : table_(table), ing_(ing), codec_(codec), log_of_(std::move(log_of)), term_(std::move(term_of_group)), store_(store), wide_kernel_(wide_kernel)
 {
-    if (ing_.shards() != 1) throw std::invalid_argument("IngressFlusher serves ONE table: give every shard of a sharded ingress a flusher loop of its own");
+    if (ing_.shards() != 1) throw std::invalid_argument("IngressFlusher serves ONE table: a sharded ingress is sealed once and its shards are decided by their tables side by side (SealedBatch::shard)");
     ing_.retain_bodies(true);
 }
 
