@@ -5,7 +5,7 @@
 // A leader is cut off half-way (its bytes are dropped both ways) and comes back: the others elect a new leader, the old one steps down.
 // Checked at every tick: election safety (one leader per group and term), committed entries never change and agree across the nodes; at the
 // end: every group committed commands on all three nodes, the logs are identical up to the smallest commit index.
-// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact | wide] [journal path prefix] [partition every N ticks]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
+// usage: ingress_cluster_flow [groups=6] [ticks=500] [compact | wide] [journal path prefix] [partition every N ticks | 0] [seed]     (compact: rg_submit32 — the GPU, or the wavefront mode of the emulation)
 // TEST INFRASTRUCTURE (tests/test_devemu_cpu.py, tests/test_ingress_gpu.py). prints "ingress cluster ok=1"
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +49,7 @@ int main(int argc, char **argv)
     const bool compact = argc > 3 && std::string(argv[3]) == "compact";
     const int EVERY = argc > 5 ? atoi(argv[5]) : 0;                          // > 0: a partition every so many ticks instead of the single one      // decide the batches with rg_submit32 (the GPU, or the wavefront emulation)
     const KryoBodyCodec codec({{"10.4.0.1", 7401}, {"10.4.0.2", 7402}, {"10.4.0.3", 7403}});
-    std::mt19937_64 rng(20240922);
+    std::mt19937_64 rng(argc > 6 ? (uint64_t)atoll(argv[6]) : 20240922ull);
     std::vector<std::string> ids(G);
     for (uint32_t g = 0; g < G; g++) ids[g] = "file/" + std::to_string(g);
     Node nodes[P];
