@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — raft-group decisions/sec of the HIP decision path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                 (N > 1 without a launcher: bench.py starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One STEP = one launch of the step kernel over one batch of the synthetic RPC replay: `--rounds`
@@ -62,14 +62,52 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: one process per GPU, as torch.distributed.run would start them (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1) — groups are independent (context/ContextManager.java:41-47,
+    112-120; one event loop per context, support/EventLoopGroup.java:77-80), so a rank is a whole engine of its own and the only thing the
+    ranks share is the barrier and the scalars of the result line. Rank 0's line is the job's line; any rank failing fails the run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    entry = os.environ.get("RG_BENCH_ENTRY") or os.path.abspath(__file__)      # (RG_BENCH_ENTRY: the emulation test's wrapper script)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RG_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        deadline = None
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            failed = [p for p in procs if p.poll() not in (None, 0)]
+            if failed and deadline is None:
+                deadline = time.time() + 20.0           # a rank died: its peers hang in the rendezvous / the barrier — give them a moment, then end them
+            if deadline is not None and time.time() > deadline:
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+            rc = rc or (p.returncode or 0)
+    sys.exit(0 if rc == 0 else 1)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
 
     import torch                                   # before libraftgpu: both then share one HIP runtime
@@ -77,6 +115,9 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
     dev = local_rank if args.device is None else args.device
+    if dev >= torch.cuda.device_count() > 0:
+        sys.exit("bench.py --gpus %d: rank %d wants HIP device %d but this node shows %d (one rank per GPU; --device D puts every rank on D: tests only)"
+                 % (args.gpus, rank, dev, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
@@ -146,7 +187,10 @@ def main():
 
     decisions = sum(s[0] for s in stats[args.warmup:])
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
+    elapsed_rank = elapsed
     elapsed, (decisions_all, alg_all) = shard.aggregate(elapsed, [decisions, alg_bytes], device=red_dev if world > 1 else None)
+    per_gpu = shard.gather_rows([decisions / elapsed_rank, elapsed_rank / args.steps * 1e3, kernel_ms / max(launches, 1), float(dev)],
+                                device=red_dev if world > 1 else None)
 
     copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
 
@@ -303,6 +347,9 @@ def main():
             "value": decisions_all / elapsed,
             "unit": "decisions/s",
             "n_gpus": world,
+            "n_gpus_seen": torch.cuda.device_count(),
+            "launcher": "bench.py itself (one process per GPU)" if os.environ.get("RG_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "none"),
+            "per_gpu": [{"rank": r, "device": int(row[3]), "value": row[0], "ms_per_step": row[1], "avg_kernel_ms": row[2]} for r, row in enumerate(per_gpu)],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

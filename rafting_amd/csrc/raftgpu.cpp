@@ -1137,6 +1137,11 @@ int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int rese
     HIP_TRY(t, hipMemcpyAsync(host.data(), t->counters, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, t->stream));
     if (reset) HIP_TRY(t, hipMemsetAsync(t->counters, 0, n * sizeof(unsigned long long), t->stream));
     HIP_TRY(t, hipStreamSynchronize(t->stream));
+#ifdef RG_PROBE_HWID            // experiment build: the raw slots (wavefront placement and times) go to a file, tools/placement.py reads it
+    if (const char *path = getenv("RG_DUMP_COUNTERS")) {
+        if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), sizeof(unsigned long long), n, f); fclose(f); }
+    }
+#endif
     for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] = 0;
     for (size_t s = 0; s < t->counter_slots; s++)
         for (int i = 0; i < RG_NUM_COUNTERS; i++) counters[i] += host[s * RG_NUM_COUNTERS + i];

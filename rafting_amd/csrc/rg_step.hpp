@@ -62,6 +62,19 @@ template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
 #define RG_PROBE_FLUSH(base) ((void)0)
 #endif
 
+// -DRG_PROBE_HWID (experiment build, tools/placement.py): where the dispatcher put the two wavefronts of every workgroup and when each started
+// and ended (HW_REG_HW_ID, HW_REG_XCC_ID, s_memrealtime), written raw into the workgroup's counter slot INSTEAD of the decision counters:
+// words 0/1 = hw id | xcc id << 32 of the deciding / the I/O wavefront, 2/3 = start / end of the deciding one, 4/5 = of the I/O one.
+#ifdef RG_PROBE_HWID
+#define RG_HWID_BEGIN(w) do { if ((threadIdx.x & 63u) == 0u) { unsigned long long *s_ = p.counters + (size_t)blockIdx.x * RG_NUM_COUNTERS; \
+    s_[w] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    s_[2 + 2 * (w)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define RG_HWID_END(w) do { if ((threadIdx.x & 63u) == 0u) p.counters[(size_t)blockIdx.x * RG_NUM_COUNTERS + 3 + 2 * (w)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RG_HWID_BEGIN(w) ((void)0)
+#define RG_HWID_END(w) ((void)0)
+#endif
+
 #ifndef RG_NOTE_SLOW                // the host emulation counts the rows and the wave-rounds that leave tier 1 (tools/tier1_coverage.py); nothing on the GPU
 #define RG_NOTE_SLOW(rows, any) ((void)0)
 #endif
@@ -641,6 +654,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     const uint32_t last_round = p.rounds - 1u;
 
     if (io_wave) {
+        RG_HWID_BEGIN(1);
         auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
         auto fetch = [&](uint32_t r, Row32 &x) {
             const size_t row = row_of(r);
@@ -704,8 +718,10 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         }
         if (bailed) return false;
         retire(last_round, hdr_m1);
-#ifdef RG_PROBE
+#if defined(RG_PROBE)
         RG_PROBE_FLUSH(0);
+#elif defined(RG_PROBE_HWID)
+        RG_HWID_END(1);
 #else
         tally.flush(p, lane, active);
 #endif
@@ -714,6 +730,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 
     // ---- the deciding wavefront ----------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(3);
+    RG_HWID_BEGIN(0);
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     Group32 g;
     PeersNarrow<F> pe;
@@ -795,6 +812,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     }
     if (bailed) return false;
     RG_PROBE_FLUSH(4);
+    RG_HWID_END(0);
     if (active) {
         const Group g64 = widen(g);
         store_group(p.t, gi, g64, pe, F);

@@ -13,10 +13,11 @@ namespace wire {
 static uint32_t pow2_at_least(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
 ContextIndex::ContextIndex(uint32_t capacity)
-    : mask_(pow2_at_least(capacity < 8 ? 16 : capacity * 2) - 1), slot_(new std::atomic<uint64_t>[mask_ + 1]), key_(new Key[capacity]), capacity_(capacity)
+    : mask_(pow2_at_least(capacity < 8 ? 16 : capacity * 2) - 1), owner_(new Slot[mask_ + 1]), key_(new Key[capacity]), capacity_(capacity)
 {
-    for (uint32_t i = 0; i <= mask_; i++) slot_[i].store(0, std::memory_order_relaxed);
+    for (uint32_t i = 0; i <= mask_; i++) owner_[i].store(0, std::memory_order_relaxed);
     for (uint32_t g = 0; g < capacity; g++) key_[g].len = 0;
+    slot_.store(owner_.get(), std::memory_order_release);
 }
 
 uint64_t ContextIndex::hash(const char *s, size_t n)
@@ -30,24 +31,28 @@ uint64_t ContextIndex::hash(const char *s, size_t n)
     return h ^ (h >> 29);
 }
 
+// Every probe loop below is bounded by the table size: the live entries never fill more than half of the slots, but tombstones of erased
+// contexts can take the rest (an unbounded probe then spins for ever on a miss). reclaim() keeps them from getting there.
 bool ContextIndex::insert(const char *id, size_t len, uint32_t gid)
 {
     if (gid >= capacity_ || len == 0 || len >= KEY_BYTES) return false;
     std::lock_guard<std::mutex> lk(mu_);
     if (key_[gid].len != 0) return false;                        // taken (or erased and not reclaimed yet)
+    Slot *slot = owner_.get();
     const uint64_t h = hash(id, len);
-    uint32_t at = (uint32_t)h & mask_, free_at = mask_ + 1;
-    for (;; at = (at + 1) & mask_) {
-        const uint64_t v = slot_[at].load(std::memory_order_relaxed);
+    uint32_t at = (uint32_t)h & mask_, free_at = mask_ + 1, probes = 0;
+    for (; probes <= mask_; at = (at + 1) & mask_, probes++) {
+        const uint64_t v = slot[at].load(std::memory_order_relaxed);
         if (v == 0) break;
         if ((uint32_t)v == TOMB) { if (free_at > mask_) free_at = at; continue; }
         const Key &k = key_[(uint32_t)v - 1];
         if ((v >> 32) == (h >> 32) && k.len == len && memcmp(k.bytes, id, len) == 0) return false;
     }
-    if (free_at <= mask_) at = free_at;
+    if (free_at <= mask_) { at = free_at; tombs_--; }
+    else if (probes > mask_) return false;                       // (cannot happen while live <= capacity <= half of the slots: no empty slot and no tombstone)
     memcpy(key_[gid].bytes, id, len);
     key_[gid].len = (uint8_t)len;
-    slot_[at].store((uint64_t)(gid + 1) | (h >> 32 << 32), std::memory_order_release);     // the key bytes are visible to whoever sees the slot
+    slot[at].store((uint64_t)(gid + 1) | (h >> 32 << 32), std::memory_order_release);      // the key bytes are visible to whoever sees the slot
     n_++;
     return true;
 }
@@ -55,19 +60,34 @@ bool ContextIndex::insert(const char *id, size_t len, uint32_t gid)
 uint32_t ContextIndex::erase(const char *id, size_t len)
 {
     std::lock_guard<std::mutex> lk(mu_);
+    Slot *slot = owner_.get();
     const uint64_t h = hash(id, len);
-    for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
-        const uint64_t v = slot_[at].load(std::memory_order_relaxed);
+    uint32_t at = (uint32_t)h & mask_;
+    for (uint32_t probes = 0; probes <= mask_; at = (at + 1) & mask_, probes++) {
+        const uint64_t v = slot[at].load(std::memory_order_relaxed);
         if (v == 0) return capacity_;
         if ((uint32_t)v == TOMB || (v >> 32) != (h >> 32)) continue;
         const uint32_t gid = (uint32_t)v - 1;
         const Key &k = key_[gid];
         if (k.len != len || memcmp(k.bytes, id, len) != 0) continue;
-        slot_[at].store((uint64_t)TOMB, std::memory_order_release);
+        // A slot whose successor is empty ends its run of occupied slots: no key can lie beyond it, so it may become EMPTY at once — and so
+        // may the tombstones right before it, one after the other (a concurrent lookup that meets the new empty slot stops where nothing it
+        // could be looking for lies behind). Only a slot in the MIDDLE of a run has to stay a tombstone.
+        if (slot[(at + 1) & mask_].load(std::memory_order_relaxed) == 0) {
+            slot[at].store(0, std::memory_order_release);
+            for (uint32_t b = (at - 1) & mask_; slot[b].load(std::memory_order_relaxed) == (uint64_t)TOMB; b = (b - 1) & mask_) {
+                slot[b].store(0, std::memory_order_release);
+                tombs_--;
+            }
+        } else {
+            slot[at].store((uint64_t)TOMB, std::memory_order_release);
+            tombs_++;
+        }
         retired_.push_back(gid);                                 // the key record stays as it is until reclaim(): a lookup may be comparing it
         n_--;
         return gid;
     }
+    return capacity_;
 }
 
 size_t ContextIndex::retired()
@@ -76,20 +96,46 @@ size_t ContextIndex::retired()
     return retired_.size();
 }
 
+// Under mu_. A fresh slot array with the live entries only, published with one pointer store. Lookups that loaded the old pointer go on in
+// the old array — for them the rebuild did not happen yet, which is what a lookup racing an insert / erase may see anyway — so the old array
+// must outlive them: it is kept until the NEXT reclaim(), i.e. (by reclaim()'s contract) until a seal that started after this one returned
+// has excluded every feed().
+void ContextIndex::rebuild()
+{
+    std::unique_ptr<Slot[]> fresh(new Slot[mask_ + 1]);
+    for (uint32_t i = 0; i <= mask_; i++) fresh[i].store(0, std::memory_order_relaxed);
+    for (uint32_t i = 0; i <= mask_; i++) {
+        const uint64_t v = owner_[i].load(std::memory_order_relaxed);
+        if (v == 0 || (uint32_t)v == TOMB) continue;
+        const Key &k = key_[(uint32_t)v - 1];
+        uint32_t at = (uint32_t)hash(k.bytes, k.len) & mask_;
+        while (fresh[at].load(std::memory_order_relaxed) != 0) at = (at + 1) & mask_;       // (live <= half of the slots: ends)
+        fresh[at].store(v, std::memory_order_relaxed);
+    }
+    previous_ = std::move(owner_);
+    owner_ = std::move(fresh);
+    slot_.store(owner_.get(), std::memory_order_release);
+    tombs_ = 0;
+    rebuilds_++;
+}
+
 void ContextIndex::reclaim(size_t n)
 {
     std::lock_guard<std::mutex> lk(mu_);
+    previous_.reset();                                           // the array the rebuild BEFORE the last seal replaced: nobody can be in it any more
     n = std::min(n, retired_.size());
     for (size_t i = 0; i < n; i++) key_[retired_[i]].len = 0;
     retired_.erase(retired_.begin(), retired_.begin() + (long)n);
+    if ((uint64_t)n_ + tombs_ > (uint64_t)(mask_ + 1) * 7 / 10) rebuild();     // live + tombstones beyond 70 % of the slots: probes are getting long
 }
 
 bool ContextIndex::find(const char *id, size_t len, uint32_t &gid) const { return find(hash(id, len), id, len, gid); }
 
 uint32_t ContextIndex::peek(uint64_t h) const
 {
+    const Slot *slot = slot_.load(std::memory_order_acquire);
     for (uint32_t at = (uint32_t)h & mask_, probes = 0; probes < 4; at = (at + 1) & mask_, probes++) {
-        const uint64_t v = slot_[at].load(std::memory_order_acquire);
+        const uint64_t v = slot[at].load(std::memory_order_acquire);
         if (v == 0) break;
         if ((uint32_t)v != TOMB && (v >> 32) == (h >> 32)) return (uint32_t)v - 1;
     }
@@ -98,13 +144,16 @@ uint32_t ContextIndex::peek(uint64_t h) const
 
 bool ContextIndex::find(uint64_t h, const char *id, size_t len, uint32_t &gid) const
 {
-    for (uint32_t at = (uint32_t)h & mask_;; at = (at + 1) & mask_) {
-        const uint64_t v = slot_[at].load(std::memory_order_acquire);
+    const Slot *slot = slot_.load(std::memory_order_acquire);
+    uint32_t at = (uint32_t)h & mask_;
+    for (uint32_t probes = 0; probes <= mask_; at = (at + 1) & mask_, probes++) {
+        const uint64_t v = slot[at].load(std::memory_order_acquire);
         if (v == 0) return false;
         if ((uint32_t)v == TOMB || (v >> 32) != (h >> 32)) continue;
         const Key &k = key_[(uint32_t)v - 1];
         if (k.len == len && memcmp(k.bytes, id, len) == 0) { gid = (uint32_t)v - 1; return true; }
     }
+    return false;
 }
 
 std::string ContextIndex::id_of(uint32_t gid) const { return gid < capacity_ ? std::string(key_[gid].bytes, key_[gid].len) : std::string(); }
@@ -121,7 +170,9 @@ uint64_t PendingRing::key_of(int32_t sequence, Method m, uint32_t gid)
 void PendingRing::put(int32_t sequence, Method m, uint32_t gid, const Pending &p)
 {
     Slot &s = s_[(uint32_t)sequence & mask_];
-    s.key.store(0, std::memory_order_release);                   // whoever is reading the old record loses its CAS
+    s.key.store(0, std::memory_order_relaxed);                   // whoever is reading the old record loses its CAS ...
+    std::atomic_thread_fence(std::memory_order_release);         // ... and the cleared key is visible before any word of the new record is (a release
+                                                                 // STORE orders what precedes it, not the stores that follow: ADVICE r3)
     s.w0.store(p.role_epoch, std::memory_order_relaxed);
     s.w1.store((uint64_t)p.epoch_at_send, std::memory_order_relaxed);
     s.w2.store((uint64_t)p.last_index_sent, std::memory_order_relaxed);
@@ -136,6 +187,7 @@ bool PendingRing::take(int32_t sequence, Method m, uint32_t gid, Pending &p)
     p.role_epoch = (uint32_t)s.w0.load(std::memory_order_relaxed);
     p.epoch_at_send = (int64_t)s.w1.load(std::memory_order_relaxed);
     p.last_index_sent = (int64_t)s.w2.load(std::memory_order_relaxed);
+    std::atomic_thread_fence(std::memory_order_acquire);         // the words were read before the CAS looks at the key again
     uint64_t expect = want;                                      // the invocation is REMOVED (AsyncService.remove): a duplicate response finds nothing
     return s.key.compare_exchange_strong(expect, 0, std::memory_order_acq_rel);
 }
@@ -416,7 +468,7 @@ size_t Ingress::encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, c
         } else {
             q.x = h.epoch_index; q.y = h.epoch_term; q.leader_commit = 0;
         }
-        f.sequence = c.next_sequence++;
+        f.sequence = c.next_sequence; c.next_sequence = (int32_t)((uint32_t)c.next_sequence + 1u);      // wraps like the reference's AtomicInteger
         f.head.assign(m == M_APPEND_ENTRIES ? "appendEntries:" : "installSnapshot:");
         index_.append_id(g, f.head);
         f.body.clear();

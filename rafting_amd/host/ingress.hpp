@@ -54,13 +54,15 @@ public:
     // the same in steps, for a caller that looks several ids up at once and wants the cache misses of one to overlap the work on another:
     // hash_of, then prefetch(hash) some frames ahead, then find(hash, id, len, gid)
     static uint64_t hash_of(const char *id, size_t len) { return hash(id, len); }
-    void prefetch(uint64_t h) const { __builtin_prefetch(&slot_[(uint32_t)h & mask_]); }
+    void prefetch(uint64_t h) const { __builtin_prefetch(&slot_.load(std::memory_order_acquire)[(uint32_t)h & mask_]); }
     bool find(uint64_t h, const char *id, size_t len, uint32_t &gid) const;
     void prefetch_key(uint32_t gid) const { if (gid < capacity_) __builtin_prefetch(&key_[gid]); }
     uint32_t peek(uint64_t h) const;                            // the gid of the first slot whose tag matches (capacity = none): a guess for prefetch_key
     std::string id_of(uint32_t gid) const;                      // "" if that gid was never inserted
     void append_id(uint32_t gid, std::string &to) const { if (gid < capacity_) to.append(key_[gid].bytes, key_[gid].len); }
     uint32_t size() const { return n_; }
+    uint32_t tombstones() const { return tombs_; }              // (tests) slots of erased contexts that probing still has to step over
+    uint32_t rebuilds() const { return rebuilds_; }
 
 private:
     // open addressing; a slot holds gid + 1 (0 = empty) and 32 bits of the key's hash, so a probe touches the key bytes — one fixed-size
@@ -69,11 +71,16 @@ private:
     struct Key { uint8_t len; char bytes[KEY_BYTES - 1]; };     // (ids of 128 bytes cannot occur: the method name and the colon take at least 8)
     static uint64_t hash(const char *s, size_t n);
     uint32_t mask_;
-    std::unique_ptr<std::atomic<uint64_t>[]> slot_;             // (gid + 1) | tag << 32
+    // The slot array is replaced as a whole when tombstones have piled up (rebuild(), from reclaim()): readers load the pointer once per
+    // lookup; the array they may still be walking is freed one reclaim() later (see erase() for why that is late enough).
+    typedef std::atomic<uint64_t> Slot;
+    std::atomic<Slot *> slot_;                                  // (gid + 1) | tag << 32
+    std::unique_ptr<Slot[]> owner_, previous_;
     std::unique_ptr<Key[]> key_;                                // by gid
     uint32_t capacity_;
     std::mutex mu_;
-    uint32_t n_ = 0;
+    uint32_t n_ = 0, tombs_ = 0, rebuilds_ = 0;
+    void rebuild();                                             // under mu_
     std::vector<uint32_t> retired_;                             // erased, not yet reclaimed: their key records still belong to lookups in flight
     static constexpr uint32_t TOMB = 0xFFFFFFFFu;               // low half of a slot whose context was erased: probing goes on
 };

@@ -44,7 +44,9 @@ void IngressFlusher::apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b
         dirty.push_back(StableStore::Record{gid, per.term, per.voted_for});
     }
     if (f & RG_F_COMMIT) { log.markCommitted(lfx.commit_index); st_.committed++; }
-    if (on_row) on_row(gid, head, rep);
+    // the host's reaction (timers, emits, role changes) runs AFTER the batch's durable write: a new term or self-vote that on_row broadcasts
+    // must be on disk first (member/RaftMember.java:25)
+    if (on_row) reactions_.push_back(Reaction{gid, head, rep});
 }
 
 struct IngressFlusher::Host : RepairHost {
@@ -76,6 +78,10 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
 {
     const SealedBatch &b = ing_.seal();
     if (b.rows == 0 && b.wide.empty()) { ing_.recycle(b); return 0; }
+    reactions_.clear();
+    // every way out recycles the sealed batch: the next flush() seals again (an error leaves the table and the logs where the failed call left
+    // them — the caller stops, as with any table error — but does not turn the NEXT call into a logic_error out of seal())
+    struct Recycle { Ingress &ing; const SealedBatch &b; bool armed = true; ~Recycle() { if (armed) ing.recycle(b); } } recycle{ing_, b};
     const uint32_t G = b.batch.count, R = b.batch.rounds;
     const size_t cells = (size_t)G * R;
     std::vector<StableStore::Record> dirty;
@@ -136,6 +142,7 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
             const rg_outcome_t o{&rep, &lfx, &per};
             if (rg_submit(table_, &in, &o, RG_MEM_HOST) != 0) { err_ = rg_last_error(table_); return -1; }
             if (RG_F_STATUS(rep.flags) != RG_NEED_HOST) break;
+            if (attempt == 1) { err_ = "a row beside the batch still answers RG_NEED_HOST after its hint"; return -1; }     // as repair_need_host does
             RaftLog &log = log_of_(w.gid);
             h.hdr |= RG_HDR_HINT_BIT;
             if (RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ) {
@@ -155,11 +162,13 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
         st_.wide++;
     }
     if (store_ && !dirty.empty()) { store_->persist(dirty); st_.persisted += dirty.size(); }      // N3: before any reply of this batch leaves
+    for (const Reaction &r : reactions_) on_row(r.gid, r.head, r.reply);                           // ... and before anything on_row sends
     if (cells) st_.frames += ing_.emit(b, rep_.data(), out);
     for (auto &wr : wide_replies) {
         const HeldRow &w = b.wide[wr.first];
         if (w.from.conn < out.size()) st_.frames += ing_.emit_wide(w, wr.second, out[w.from.conn]) != NO_CONN;
     }
+    recycle.armed = false;
     ing_.recycle(b);
     st_.batches++;
     st_.rows += (uint64_t)decided;

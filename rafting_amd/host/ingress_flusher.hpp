@@ -27,7 +27,8 @@ public:
     // of rg_submit32 (tests on the lane-serial emulation of the kernels, which cannot run the compact-row kernel).
     IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<raftgpu::host::RaftLog &(uint32_t)> log_of,
                    std::vector<int64_t> term_of_group, raftgpu::host::StableStore *store = nullptr, bool wide_kernel = false);
-    // Called for every decided row after its effects were applied, in the order the rows were decided: the host's reaction to what the handler
+    // Called for every decided row, in the order the rows were decided, AFTER the batch's effects were applied and its (term, votedFor)
+    // records are durable (so what it sends never runs ahead of the disk, member/RaftMember.java:25): the host's reaction to what the handler
     // did — RG_F_RESET_TIMER / RG_F_TIMER_MUTED (re-arm the election timer), RG_F_ROLE_CHANGED (abort the old role's invocations), RG_F_EMIT
     // (broadcast PreVote / RequestVote, start replicating: rg_replicate + Ingress::encode_sends), reply.role_epoch (the tag of RPCs sent from
     // now on) — INTEGRATION.md §3 step 5.
@@ -40,6 +41,8 @@ public:
 
 private:
     struct Host;
+    struct Reaction { uint32_t gid; rg_ev_head_t head; rg_reply_t reply; };
+    std::vector<Reaction> reactions_;                            // on_row calls of the batch in flight, made after its durable write
     void apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, const char *body, size_t body_len, const rg_reply_t &rep, const rg_logfx_t &lfx,
                const rg_persist_t &per, std::vector<raftgpu::host::StableStore::Record> &dirty);
     rg_table_t *table_;

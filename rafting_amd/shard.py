@@ -29,3 +29,15 @@ def aggregate(elapsed_s, sums, device=None):
     s = torch.tensor(list(sums), dtype=torch.float64, device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), [float(x) for x in s.tolist()]
+
+
+def gather_rows(row, device=None):
+    """Every rank's `row` (a few floats) on every rank, in rank order: the per-GPU figures next to the whole-job sum."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [[float(x) for x in row]]
+    mine = torch.tensor(list(row), dtype=torch.float64, device=device)
+    rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    return [[float(x) for x in r.tolist()] for r in rows]

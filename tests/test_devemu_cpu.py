@@ -83,6 +83,30 @@ def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):
     assert d["cpu_baseline"] is None and d["pcie_inclusive_value"] is None          # rank-0-at-N=1 legs only
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_does(emulation_library):
+    """`python bench.py --gpus 2` with NO torch.distributed.run around it (the first hardware SCALE run must not die on the launcher):
+    bench.py spawns one process per GPU itself, the ranks rendezvous on 127.0.0.1, rank 0 prints the one line — with every rank's own figures
+    in `per_gpu` and the whole-job sum in `value`."""
+    import json
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1",
+               RG_BENCH_ENTRY=os.path.join(EMU, "bench_dry.py"))
+    for k in ("RG_FAST", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["config_number"] == 4 and d["config"]["groups_total"] == 512 and "itself" in d["launcher"]
+    assert [g["rank"] for g in d["per_gpu"]] == [0, 1] and all(g["value"] > 0 for g in d["per_gpu"])
+    # the whole-job value is the sum of the ranks' decisions over the slowest rank's time: between the slower rank's doubled and the sum of both
+    assert 2 * min(g["value"] for g in d["per_gpu"]) * 0.7 <= d["value"] <= sum(g["value"] for g in d["per_gpu"]) * 1.001
+    # a rank that cannot start takes the run down with a non-zero exit instead of a hang
+    bad = subprocess.run([sys.executable, os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0", "--config", "9"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0
+
+
 def test_kernels_that_need_lanes_to_meet_on_emulated_wavefronts(emulation_library):
     """RG_EMU_WAVES=1: every lane of a workgroup is an OS thread, shuffles / ballots meet per 64-lane wavefront, barriers per
     workgroup — the two-wavefront step kernel with its LDS rings, the decision counters, the ballot-compacted timer list."""

@@ -183,3 +183,23 @@ def test_bench_n_gt_1_defaults_to_config4_shards():
     c = d["config"]
     assert (c["config_number"], c["seed"], c["groups_per_gpu"], c["groups_total"]) == (4, "0xc0ffee03", 131072, 262144)
     assert c["workload"].startswith("config4: 1048576 groups") and "no RCCL" in c["parallelism"]
+
+
+def test_bench_plain_command_with_two_gpus_needs_no_launcher():
+    """`python bench.py --gpus 2` exactly as the driver types it for N = 1 — no torch.distributed.run: bench.py starts its own ranks (here both
+    on the one GPU of the test box), rank 0 prints the line with both ranks' figures."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rounds", "8", "--groups-per-gpu", "8192",
+                        "--device", "0"], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["config_number"] == 4 and d["config"]["groups_total"] == 16384 and "itself" in d["launcher"]
+    assert len(d["per_gpu"]) == 2 and all(g["value"] > 0 and g["device"] == 0 for g in d["per_gpu"])
+    assert d["value"] <= sum(g["value"] for g in d["per_gpu"]) * 1.001

@@ -204,6 +204,31 @@ def test_ingress_threads_under_sanitizers(tmp_path, sanitizer):
         assert "Sanitizer" not in p.stderr, p.stderr[-3000:]
 
 
+@pytest.mark.parametrize("sanitizer", ["", "thread"])
+def test_context_index_survives_churn(tmp_path, sanitizer):
+    """tombstones of erased contexts used to pile up until a miss lookup span for ever (ContextIndex(64) after 1 000 - 2 000
+    insert / erase / reclaim cycles with distinct ids). tests/native/context_index_churn.cpp runs 20 000 such cycles on 64 groups and 200 000 on
+    1 024 while two threads look ids up (hits and misses) behind the seal barrier the owner's contract names: every probe ends, live ids
+    resolve, erased ones do not, tombstones stay bounded (the slot array is rebuilt beside the readers)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "rafting_amd", "host")
+    exe = str(tmp_path / "context_index_churn")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + (["-fsanitize=" + sanitizer, "-fno-sanitize-recover=all"] if sanitizer else []) +
+                       ["-I" + host, "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "native", "context_index_churn.cpp"),
+                        os.path.join(host, "ingress.cpp"), os.path.join(host, "wire.cpp"), os.path.join(host, "kryo_body.cpp"), "-pthread", "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and sanitizer:
+        pytest.skip("no %s sanitizer runtime for g++ here: %s" % (sanitizer, r.stderr[-200:]))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for args in (["64", "20000"], ["1024", "20000" if sanitizer else "200000"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "context index churn ok=1" in p.stdout, p.stdout + p.stderr[-3000:]
+        assert "Sanitizer" not in p.stderr, p.stderr[-3000:]
+        assert int(p.stdout.split("rebuilds")[1]) > 0, p.stdout
+
+
 def test_replication_loop_over_frames_equals_the_in_memory_loop():
     """N1 joined to N2: what rg_replicate plans leaves the leader as request frames with filed invocation records (Ingress.encode_sends),
     the followers decide them from their ingress batches and answer with response frames (emit), the leader's ingress matches every response

@@ -69,6 +69,12 @@ for step in "$@"; do
         timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -n 1 $OUT/smoke.txt
         timeout 500 python tools/soak.py ${SOAK_SECONDS:-300} > $OUT/soak.txt 2>&1; tail -n 1 $OUT/soak.txt ;;
     bench) python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | line default ;;
+    hwid) for C in "--config 3" "--config 4" "--config 2" "--config 5 --groups-per-gpu 65536"; do     # where the dispatcher puts the deciding / I/O wavefronts (tools/placement.py)
+          T=$(echo $C | tr -d ' -'); RG_DUMP_COUNTERS=$OUT/hwid_$T.bin RG_LIB=$(pwd)/rafting_amd/libraftgpu_hwid.so $B --steps 10 --warmup 2 $C 2>>$OUT/hwid.err | tee -a $OUT/hwid.jsonl | line "hwid $C"
+          python tools/placement.py $OUT/hwid_$T.bin | tee -a $OUT/placement.txt; done ;;
+    base) for C in "--config 3" "--config 4" "--config 2" "--config 5 --groups-per-gpu 65536" "--config 5"; do
+          $B --steps 20 --warmup 3 $C 2>>$OUT/base.err | tee -a $OUT/base.jsonl | line "base $C"; done ;;
+    issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done
