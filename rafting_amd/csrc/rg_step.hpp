@@ -24,6 +24,7 @@
 //                                 outcome rows are simply written again, so the results are the 64-bit ones, bit for bit.
 #pragma once
 #include "rg_device.hpp"
+#include "rg_tier1n.hpp"
 
 namespace rg {
 
@@ -48,6 +49,26 @@ template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
     static_assert(sizeof(T) == 16, "16-byte row");
     u32x4 v; __builtin_memcpy(&v, &x, 16);
     __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p));
+}
+
+// Global-memory pointers made from integers (the I/O wavefront of the 32-bit body keeps its five column bases as scalars of their own, see
+// there): the address space must be spelled out, or every access through them becomes a FLAT instruction — which also counts on lgkmcnt and
+// would make the LDS hand-over barrier wait for the global prefetch (tests/test_kernel_static_cpu.py holds the kernels to "no FLAT").
+#ifndef RG_GLOBAL_AS                // (the host emulation of tests/devemu defines these away)
+#define RG_GLOBAL_AS __attribute__((address_space(1)))
+#define RG_OWN_SGPRS(v) asm volatile("; %0 in scalar registers of its own" : "+s"(v))
+#endif
+template <class T> __device__ __forceinline__ T nt_load_at(uint64_t base, uint32_t byte_offset)
+{
+    typedef uint32_t vec_t __attribute__((vector_size(sizeof(T))));
+    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const RG_GLOBAL_AS vec_t *>(reinterpret_cast<const RG_GLOBAL_AS char *>(base) + byte_offset));
+    T r; __builtin_memcpy(&r, &v, sizeof(T)); return r;
+}
+template <class T> __device__ __forceinline__ void nt_store_at(uint64_t base, uint32_t byte_offset, const T &x)
+{
+    typedef uint32_t vec_t __attribute__((vector_size(sizeof(T))));
+    vec_t v; __builtin_memcpy(&v, &x, sizeof(T));
+    __builtin_nontemporal_store(v, reinterpret_cast<RG_GLOBAL_AS vec_t *>(reinterpret_cast<RG_GLOBAL_AS char *>(base) + byte_offset));
 }
 
 // -DRG_PROBE (experiment build, tools/probe.py): s_memtime deltas per section of a round, summed per wavefront and reported through the
@@ -442,11 +463,13 @@ struct SplitLds {
     static constexpr int EVF = EV32 ? (int)EV_D + 1 : (int)EV_FIELDS;
     static constexpr size_t W_EPOCH = 0, W_NEXT = W_EPOCH + F * BLOCK * 8, W_MATCH = W_NEXT + F * BLOCK * 8, W_REJ = W_MATCH + F * BLOCK * 8,
                             W_EV = W_REJ + F * BLOCK * 4, W_OUT = W_EV + 2 * EVF * BLOCK * 8, W_END = W_OUT + 2 * OUT_FIELDS * BLOCK * 8;
-    // 32-bit body: follower records, their matchIndex row, a four-slot event ring (written two rounds ahead), a two-slot outcome ring
+    // 32-bit body: follower records, their matchIndex row, a four-slot event ring (written two rounds ahead), a two-slot outcome ring, the I/O
+    // wavefront's tables: class word by (kind, slot), flags by predicate word (19 KB in all: eight workgroups per CU still fit)
     static constexpr int MV = (F + 3) / 4;
     static constexpr int NEV = 4;
-    static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 8,
-                            N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16, N_END = N_BAIL + 16;
+    static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 16,
+                            N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16,
+                            N_LUTC = N_BAIL + 16, N_LUTM = N_LUTC + 256 * 4, N_LUTE = N_LUTM + 128 * 4, N_END = N_LUTE + 128 * 2;      // the I/O wavefront's tables (below)
     static constexpr size_t BYTES = EV32 ? (W_END > N_END ? W_END : N_END) : W_END;
 };
 
@@ -617,17 +640,52 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 // outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
 struct Row32 { U32x2 h; I32x4 q; };
 
-// decorate<true> for the 32-bit body, on the row as loaded: the same header bits, plus KIND_OUT_OF_DOMAIN when a field leaves [0, EV_LIMIT)
-__device__ __forceinline__ uint32_t decorate_narrow(const StepParams &p, const Row32 &x)
+// What the I/O wavefront makes of a compact row for the deciding wavefront of the 32-bit body: {class word, aux, n, header'}. The class word
+// (rg_tier1n.hpp: CW_*) holds every fact about the row that does not depend on the group's state, one bit each, plus the follower index of an
+// ack's responder. Most of it depends on (kind, slot) only — cluster size and own slot are launch constants — and comes from a 256-entry
+// table in LDS that the I/O wavefront fills before the first round (class_entry); what depends on the row's other fields is cleared per row
+// (class_word). header' is the header as loaded, with KIND_OUT_OF_DOMAIN when a field leaves [0, EV_LIMIT) — `aux` too where it is a role
+// epoch (acks, vote replies, timeouts) or the entries' term: such a row has no class and sends the workgroup to the 64-bit body.
+constexpr int CW_AUXC = 18;         // table only: aux of this kind is a role epoch (it must be in the domain)
+__device__ __forceinline__ uint32_t class_entry(const StepParams &p, uint32_t idx)
 {
-    const uint32_t hdr = x.h.x, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+    const uint32_t kind = idx & 15u, slot = idx >> 4;
     const uint32_t P = (uint32_t)p.cluster, self = (uint32_t)p.self;
-    const bool same = (hdr & RG_HDR_SAME_TERM) != 0, ae = kind == RG_EV_AE_REQ;
-    const bool ae_ok = ae & (slot < P) & (x.q.z != 0) & (n <= RG_MAX_AE_ENTRIES) & ((n == 0) | same);
     const bool peer_ok = (slot < P) & (slot != self);
-    const uint32_t w = (uint32_t)x.q.x | (uint32_t)x.q.y | (uint32_t)x.q.z | (uint32_t)x.q.w | ((ae & same) ? x.h.y : 0u);
-    const uint32_t out = (hdr & ~(7u << 9)) | (same ? HDR_SAME_IN : 0u) | (ae_ok ? HDR_AE_OK : 0u) | (peer_ok ? HDR_PEER_OK : 0u);
-    return (w >= EV_LIMIT) ? (out | KIND_OUT_OF_DOMAIN) : out;
+    const bool ack = (kind == RG_EV_AE_ACK) & peer_ok, vreq = (kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ),
+               vrep = (kind == RG_EV_RV_REPLY) | (kind == RG_EV_PV_REPLY);
+    const uint32_t j = ack ? (slot < self ? slot : slot - 1u) : 0u;
+    const uint32_t cls = (ack ? 1u << CW_ACK : 0u) | (((kind == RG_EV_AE_REQ) & (slot < P)) ? 1u << CW_AE : 0u) | ((kind == RG_EV_CLIENT_APPEND) ? 1u << CW_CLIENT : 0u) |
+                         (((ack | (kind == RG_EV_IS_ACK)) & peer_ok) ? 1u << CW_ACKANY : 0u) |
+                         ((kind - (uint32_t)RG_EV_RV_REQ <= (uint32_t)(RG_EV_TIMEOUT - RG_EV_RV_REQ)) ? 1u << CW_ELK : 0u) |
+                         ((vrep & peer_ok) ? 1u << CW_VR : 0u) | ((kind == RG_EV_PV_REPLY) ? 1u << CW_PV : 0u) | ((kind == RG_EV_TIMEOUT) ? 1u << CW_TO : 0u) |
+                         ((vreq & (slot < P)) ? 1u << CW_VQ : 0u) | ((kind == RG_EV_PV_REQ) ? 1u << CW_PVQ : 0u) | ((kind == RG_EV_NONE) ? 1u << CW_NONE : 0u) |
+                         ((((0x1CCu >> kind) & 1u) != 0) ? 1u << CW_AUXC : 0u);              // kinds 2, 3, 6, 7, 8
+    return cls | (j << 10) | (slot << 5) | (31u - j);
+}
+// Per row, in sign words (rg_tier1n.hpp): AE stays only with prevLogTerm != 0 and no entries, or at most RG_MAX_AE_ENTRIES of one term;
+// CLIENT only with n >= 1; nothing stays when a field is out of the domain.
+__device__ __forceinline__ I32x4 class_word(const uint32_t *lutc, const Row32 &x)
+{
+    const uint32_t hdr = x.h.x, aux = x.h.y;
+    const uint32_t e = lutc[hdr & 0xFFu];
+    const int32_t n = (int32_t)(hdr >> 12);
+    const sw same = (int32_t)(hdr << (31 - 10));                                           // RG_HDR_SAME_TERM
+    const int32_t n_lim = (same >> 31) & (int32_t)RG_MAX_AE_ENTRIES;
+    const sw ae_bad = ~s_pos(x.q.z) | s_lt(n_lim, n), cli_bad = s_lt(n, 1);
+    const uint32_t auxm = (uint32_t)(((int32_t)(e << (31 - CW_AUXC)) | ((int32_t)(e << (31 - CW_AE)) & same)) >> 31);    // aux counts: a role epoch, or the entries' term
+    const uint32_t w = (uint32_t)x.q.x | (uint32_t)x.q.y | (uint32_t)x.q.z | (uint32_t)x.q.w | (aux & auxm);
+    const uint32_t ood = (uint32_t)((int32_t)(w | (w << 1)) >> 31);                         // a field >= 2^30
+    const uint32_t off = (((uint32_t)ae_bad & 0x80000000u) >> (31 - CW_AE)) | (((uint32_t)cli_bad & 0x80000000u) >> (31 - CW_CLIENT)) | (1u << CW_AUXC) |
+                         (ood & 0xFFF80000u);
+    const uint32_t cw = (e & ~off) | ((hdr & 0x100u) << (CW_FLAG - 8));
+    return I32x4{(int32_t)cw, (int32_t)aux, n, (int32_t)(hdr | (ood & KIND_OUT_OF_DOMAIN))};
+}
+// the flags | status << 16 of a predicate word, from two 128-entry tables (main block: bits 6..0, election block: bits 13..7)
+__device__ __forceinline__ uint32_t expand_by_table(const uint32_t *lutm, const uint16_t *lute, uint32_t w)
+{
+    const uint32_t fast = lutm[w & 127u] | (uint32_t)lute[(w >> 7) & 127u];
+    return ((int32_t)w < 0) ? (w & 0x00FFFFFFu) : fast;
 }
 
 template <int F, bool SPARSE, bool PREFETCH>
@@ -636,7 +694,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     typedef SplitLds<F, true> L;
     I32x4 *sh_rec = reinterpret_cast<I32x4 *>(smem + L::N_REC);
     int32_t *sh_mv = reinterpret_cast<int32_t *>(smem + L::N_MV);
-    U32x2 (*sh_evh)[BLOCK] = reinterpret_cast<U32x2 (*)[BLOCK]>(smem + L::N_EVH);
+    I32x4 (*sh_evh)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVH);
     I32x4 (*sh_evq)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVQ);
     I32x4 (*sh_o0)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O0);
     I32x4 (*sh_o1)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_O1);
@@ -645,6 +703,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     // wavefront's whole prefetch every round). The deciding wavefront may already be one round further and have written a LATER round's
     // mark when the I/O wavefront looks: only a mark that is due makes it leave, so both always pass the same number of barriers.
     uint32_t *sh_bail = reinterpret_cast<uint32_t *>(smem + L::N_BAIL);
+    uint32_t *sh_lutc = reinterpret_cast<uint32_t *>(smem + L::N_LUTC), *sh_lutm = reinterpret_cast<uint32_t *>(smem + L::N_LUTM);
+    uint16_t *sh_lute = reinterpret_cast<uint16_t *>(smem + L::N_LUTE);
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
@@ -655,31 +715,53 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 
     if (io_wave) {
         RG_HWID_BEGIN(1);
-        auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        // Addresses. The five columns this loop touches are [round][row] arrays: a row's address is a SCALAR (column base + round * count * size,
+        // 64-bit, computed on the scalar unit) plus the lane's own 32-bit byte offset, which never changes — the form global_load / global_store
+        // take directly (saddr + voffset), no vector address arithmetic in the loop. The bases are kernel arguments; each gets scalar registers
+        // of its own here: left inside the 16-dword argument tuple they are spilled to VGPR lanes as a whole and re-read piecewise (v_readlane)
+        // at every use, 30 vector instructions per round (round 3 measured that as free — it was, while this wavefront was not what a round
+        // waits for and the SIMD it shares with a deciding wavefront had issue slots to spare; neither holds any more: profiles/r04e_probe.txt).
+        // (launch_compact refuses batches of 2^28 rows per round or more: the lane offset must fit 32 bits)
+        uint64_t b_head = reinterpret_cast<uint64_t>(p.head), b_q = reinterpret_cast<uint64_t>(p.abcd32), b_reply = reinterpret_cast<uint64_t>(p.reply),
+                 b_logfx = reinterpret_cast<uint64_t>(p.logfx), b_persist = reinterpret_cast<uint64_t>(p.persist);
+        RG_OWN_SGPRS(b_head); RG_OWN_SGPRS(b_q); RG_OWN_SGPRS(b_reply); RG_OWN_SGPRS(b_logfx); RG_OWN_SGPRS(b_persist);
+        const uint64_t round_rows = p.count;
+        const uint32_t off8 = ir * 8u, off16 = ir * 16u;
         auto fetch = [&](uint32_t r, Row32 &x) {
-            const size_t row = row_of(r);
-            x.h = nt_load8(reinterpret_cast<const U32x2 *>(p.head) + row);
-            x.q = nt_load16(p.abcd32 + row);
+            const uint64_t rb = (uint64_t)(r < p.rounds ? r : last_round) * round_rows;
+            x.h = nt_load_at<U32x2>(b_head + rb * 8u, off8);
+            x.q = nt_load_at<I32x4>(b_q + rb * 16u, off16);
         };
+        // the tables (only this wavefront reads them: no barrier needed, its own LDS operations are ordered)
+#pragma unroll
+        for (int k = 0; k < 4; k++) sh_lutc[lane + 64u * k] = class_entry(p, lane + 64u * k);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t i7 = lane + 64u * k;
+            sh_lutm[i7] = expand_predicates(i7);                                              // (no election bit set)
+            sh_lute[i7] = (uint16_t)(expand_predicates((i7 << 7) | 0x42u) & 0xFFFFu);       // (main bits of "no main class": fa_n and fc_n set)
+        }
+        __builtin_amdgcn_wave_barrier();                 // (every lane reads entries other lanes wrote: ordered on the hardware, a meeting point for the host emulation's lane threads)
         auto publish = [&](uint32_t slot, const Row32 &x) {
-            sh_evh[slot][lane] = U32x2{decorate_narrow(p, x), x.h.y};
+            sh_evh[slot][lane] = class_word(sh_lutc, x);
             sh_evq[slot][lane] = x.q;
         };
         Tally tally;
         auto retire = [&](uint32_t r, uint32_t hdr) {
             const uint32_t slot = r & 1u;
-            const size_t row = (size_t)r * p.count + ir;
+            const uint64_t rb16 = (uint64_t)r * round_rows * 16u;
             const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
-            const uint32_t flags_all = (uint32_t)o0.y, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
+            // the deciding wavefront hands over truth values, not flags (rg_tier1n.hpp): the flags, the role field and the "valid iff REPLIED" rule are made here
+            const uint32_t flags_all = expand_by_table(sh_lutm, sh_lute, (uint32_t)o0.y) | ((uint32_t)o1.w << RG_F_ROLE_SHIFT), flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
             rg_reply_t rep;
-            rep.resp_term = (int64_t)o0.x; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
-            if (active) nt_store16(p.reply + row, rep);
+            rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
+            if (active) nt_store_at(b_reply + rb16, off16, rep);
             const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-            if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)o0.w, (int64_t)o1.x});
+            if (w_lfx) nt_store_at(b_logfx + rb16, off16, I64x2{(int64_t)o0.w, (int64_t)o1.x});
             if (active & ((flags & RG_F_PERSIST) != 0)) {
                 rg_persist_t per;
                 per.term = (int64_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
-                nt_store16(p.persist + row, per);
+                nt_store_at(b_persist + rb16, off16, per);
             }
             tally.add(RG_HDR_KIND(hdr), flags, status);
         };
@@ -732,20 +814,23 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     __builtin_amdgcn_s_setprio(3);
     RG_HWID_BEGIN(0);
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
-    Group32 g;
+    GroupN g;
     PeersNarrow<F> pe;
     pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false;
+    const bool FAST = p.fast_paths != 0;
     bool in_domain;
     {
         Group g64;
         load_group(p.t, gi, g64);
-        in_domain = fits32(g64, EV_LIMIT) & (p.force_wide == 0);
-        g = narrow(g64);
-        in_domain = in_domain & stage_peers<F>(p.t, gi, g.prepared, pe);
+        // (role epochs grow by at most two per round: a launch of fewer than 2^24 rounds cannot take one out of s_ne()'s domain)
+        in_domain = fits32(g64, EV_LIMIT) & small_fields_fit(g64) & (p.force_wide == 0) & (p.rounds < (1u << 24));
+        narrow_into(g, g64);
+        g.nallow = FAST ? 0 : -1;
+        g.recache();
+        in_domain = in_domain & stage_peers<F>(p.t, gi, g64.prepared, pe);
     }
     bool bailed = __builtin_amdgcn_ballot_w64(!in_domain) != 0;
     if (lane == 0) *sh_bail = bailed ? 1u : 0u;
-    const bool FAST = p.fast_paths != 0;
     bool blocked = false;
     lds_barrier();
     if (bailed) return false;
@@ -753,58 +838,63 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     // One round. The event of round r is in registers (h, q) when the round starts: it was read from the ring a round earlier — it has been
     // there since round r-2 — so the round does not open with an LDS round trip; this round reads event r+1 into (hn, qn). The two register
     // sets swap roles every round: the loop is written out twice (no copies).
-    auto round = [&](const uint32_t r, const U32x2 &h, const I32x4 &q, U32x2 &hn, I32x4 &qn) {
+    auto round = [&](const uint32_t r, const I32x4 &h, const I32x4 &q, I32x4 &hn, I32x4 &qn) {
         if constexpr (PREFETCH) {
             hn = sh_evh[(r + 1u) & 3u][lane];
             qn = sh_evq[(r + 1u) & 3u][lane];
         }
         RG_PROBE_MARK(0);
-        const uint32_t hdr = h.x, aux = h.y, kind = RG_HDR_KIND(hdr);
-        const bool skip = blocked & (kind != RG_EV_NONE);
-        FxT<int32_t> fx{0u, RG_OK, 0, 0};
-        const bool done = tier1<F, int32_t, PeersNarrow<F>>(p, g, pe, fx, FAST & !skip, hdr, aux, q.x, q.y, q.z, q.w, (int32_t)aux);
-        const bool slow = !done & !skip;
-        if (skip) fx = FxT<int32_t>{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
+        OutN out;
+        const sw done = tier1n<F>(p, g, pe, out, h.x, (uint32_t)h.y, h.z, q.x, q.y, q.z, q.w);
+        const bool open = done >= 0;                     // not decided by tier 1: the general handlers — or nothing, for a group blocked after a NEED_HOST
         RG_PROBE_MARK(1);
-        RG_NOTE_SLOW(slow, lane == 0);
-        if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+        RG_NOTE_SLOW(open & !(blocked & (RG_HDR_KIND((uint32_t)h.w) != RG_EV_NONE)), lane == 0);
+        if (__builtin_amdgcn_ballot_w64(open) != 0) {
+            // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
+            const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
+            const bool skip = open & blocked & (kind != RG_EV_NONE);
+            const bool slow = open & !skip;
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {
                 Group g64 = widen(g);
                 Stepper<F, PeersNarrow<F>> st(p, g64, pe);
                 const Entries en = entries_of<true>(p, hdr, aux, 0, 0, 0, 0);
                 st.run(hdr, aux, (int64_t)q.x, (int64_t)q.y, (int64_t)q.z, (int64_t)q.w, false, 0, 0, en, entries_readable(p, en, aux, RG_HDR_N(hdr)));
-                bail = !fits32(g64, STATE_LIMIT) | pe.overflow | (((uint64_t)st.fx.resp_term | (uint64_t)st.fx.log_from) >= (uint64_t)STATE_LIMIT);
-                g = narrow(g64);
-                fx = FxT<int32_t>{st.fx.flags, st.fx.status, (int32_t)st.fx.resp_term, (int32_t)st.fx.log_from};
+                bail = !fits32(g64, STATE_LIMIT) | !small_fields_fit(g64) | pe.overflow |
+                       (((uint64_t)st.fx.resp_term | (uint64_t)st.fx.log_from) >= (uint64_t)STATE_LIMIT);
+                narrow_into(g, g64);
+                if (st.fx.status == RG_NEED_HOST) blocked = true;
+                g.nallow = (FAST & !blocked) ? 0 : -1;
+                g.recache();
+                out.pw = PW_SLOW | st.fx.flags | (st.fx.status << RG_F_STATUS_SHIFT);
+                out.resp = (int32_t)st.fx.resp_term; out.log_from = (int32_t)st.fx.log_from;
             }
+            if (skip) { out.pw = PW_SLOW | ((uint32_t)RG_SKIPPED_AFTER_NEED_HOST << RG_F_STATUS_SHIFT); out.resp = 0; out.log_from = 0; }
             if (__builtin_amdgcn_ballot_w64(bail) != 0) {
                 if (lane == 0) *sh_bail = r + 2u;
                 bailed = true;
             }
         }
-        const uint32_t status = fx.status, flags = fx.flags;
-        if (status == RG_NEED_HOST) blocked = true;
-        const uint32_t flags_all = flags | ((uint32_t)g.role << RG_F_ROLE_SHIFT) | (status << RG_F_STATUS_SHIFT);
         const uint32_t slot = r & 1u;
-        sh_o0[slot][lane] = I32x4{(flags & RG_F_REPLIED) ? fx.resp_term : 0, (int32_t)flags_all, (int32_t)g.role_epoch, g.commit};
-        sh_o1[slot][lane] = I32x4{fx.log_from, g.term, g.voted_for, g.role};
+        sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
+        sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
         RG_PROBE_MARK(2);
         lds_barrier();
         RG_PROBE_MARK(3);
     };
     if constexpr (PREFETCH) {
-        U32x2 h0 = sh_evh[0][lane], h1{0u, 0u};
+        I32x4 h0 = sh_evh[0][lane], h1{0, 0, 0, 0};
         I32x4 q0 = sh_evq[0][lane], q1{0, 0, 0, 0};
         for (uint32_t r = 0; r < p.rounds; r += 2u) {
             round(r, h0, q0, h1, q1);
-            if (bailed | (r + 1u >= p.rounds)) break;
+            if (bailed) break;
+            if (r + 1u >= p.rounds) break;
             round(r + 1u, h1, q1, h0, q0);
             if (bailed) break;
         }
     } else {                                             // the 128-VGPR budget has no room for a second event: read it where it is used
         for (uint32_t r = 0; r < p.rounds; r++) {
-            U32x2 h = sh_evh[r & 3u][lane], hn;
+            I32x4 h = sh_evh[r & 3u][lane], hn;
             I32x4 q = sh_evq[r & 3u][lane], qn;
             round(r, h, q, hn, qn);
             if (bailed) break;
@@ -863,6 +953,7 @@ static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s
 {
     const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
     if (blocks == 0) return hipSuccess;
+    if (p.count >= (1u << 28)) return hipErrorInvalidValue;       // the I/O wavefront addresses a row as scalar base + 32-bit lane offset
     const bool many = blocks > 1024u;                    // more than one workgroup per pair of SIMDs on a 256-CU part
     if (sparse) {
         if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);

@@ -1,0 +1,351 @@
+// rg_tier1n.hpp — tier 1 of the 32-bit body (step32_kernel's deciding wavefront), written in SIGN WORDS. Included by rg_step.hpp only.
+//
+// Why a second statement of tier 1. The deciding wavefront is alone on its SIMD: a round costs (instructions) x (4-5 cycles) plus whatever
+// latency nothing hides, and profiles/r04b_issue_bench.txt prices the idiom the compiler makes of `bool` predicates — v_cmp into an SGPR pair,
+// s_and / s_or on the pairs, v_cndmask on the result — at 9.5 cycles per instruction when the three depend on each other (the scalar unit
+// waits for the vector pipeline and back), against 4.4 for a chain that stays in the vector unit. rg_device.hpp's tier1<> spends ~100 v_cmp +
+// ~100 s_and/s_or + ~110 v_cndmask per round that way. Here a predicate is a 32-bit WORD whose SIGN BIT is the truth value ("sign word",
+// `sw`): an order test is one subtraction (`x - y` is negative iff x < y — every value of this body is below 2^30 + 2^29, so the difference
+// cannot wrap), an equality test is one v_xad_u32 ((x ^ y) + 0x7fffffff is negative iff x != y), a header bit is one shift, and ANY boolean
+// function of three of them is ONE v_bitop3_b32 — the compiler forms it from plain `&`, `|`, `~` on the words; only the sign bits mean
+// anything, the low 31 bits are noise. A word becomes a lane mask (one v_cmp against zero) only where a value is selected.
+//
+// The row classes and their preconditions are those of tier1<> (rg_device.hpp), statement for statement; each is a strict special case of
+// Stepper::run, and a row that misses a precondition is left untouched for it. What is new besides the encoding:
+//   * the state-only part of every precondition ("a Follower that has a log above its epoch", "a prepared Leader", ...) is kept in three cached
+//     words (GroupN::stf_n / stl_n / stc_n), refreshed where a row can change them — the rare blocks, the election block, the general handlers;
+//   * the state-independent part comes from the I/O wavefront as ONE class word per row (CW_* below) beside {aux, n, header};
+//   * the outcome flags are not assembled here: the truth values they are made of are shifted into a PREDICATE WORD (one v_alignbit each)
+//     that the I/O wavefront expands while it stores the row (expand_predicates) — its issue slots are spare, these are not.
+// Reference code decided here (paths under /root/reference/src/main/java/io/lubricant/consensus/raft/): member/Follower.java:35-88 (AppendEntries),
+// member/Leader.java:218-237 + member/Leadership.java:75-130 + member/Leader.java:247-280 (ack, majorIndices, tryCommit), member/Leader.java:128-140
+// (client append), member/Candidate.java:121-134 / member/Follower.java:258-270 (vote replies), member/Follower.java:156-168 / Candidate.java:82-88 /
+// Leader.java:120-126 (timeouts), member/Follower.java:91-127,193-207 (vote requests), context/RaftRoutine.java:140-216 (conversions).
+#pragma once
+#include "rg_device.hpp"
+
+namespace rg {
+
+typedef int32_t sw;                 // sign word: bit 31 is the truth value, bits 30..0 are noise
+
+__device__ __forceinline__ sw s_lt(int32_t x, int32_t y) { return (int32_t)((uint32_t)x - (uint32_t)y); }                  // x < y   (|x - y| < 2^31)
+__device__ __forceinline__ sw s_ne(int32_t x, int32_t y) { return (int32_t)(((uint32_t)x ^ (uint32_t)y) + 0x7FFFFFFFu); }   // x != y  (x ^ y < 2^31: operands that differ in bit 31 read as EQUAL)
+__device__ __forceinline__ sw s_pos(int32_t x) { return (int32_t)(0u - (uint32_t)x); }                                      // x > 0   (x > -2^31)
+__device__ __forceinline__ bool on(sw w) { return w < 0; }
+__device__ __forceinline__ uint32_t push_bit(uint32_t acc, sw w) { return (acc << 1) | ((uint32_t)w >> 31); }              // v_alignbit_b32
+
+// ---- the class word of a row (made by the I/O wavefront: class_word() in rg_step.hpp) --------------------------------------
+// bit 31 .. 19: one bit per state-independent fact; 12..10: follower index j of an ack's responder (0 for every other row); 8..5: slot;
+// 4..0: 31 - j (the shift that brings bit j of `pending` to the sign position)
+constexpr int CW_ACK = 31;          // AE_ACK from a remote peer
+constexpr int CW_AE = 30;           // HDR_AE_OK
+constexpr int CW_CLIENT = 29;       // CLIENT_APPEND with n >= 1
+constexpr int CW_ACKANY = 28;       // AE_ACK / IS_ACK from a remote peer
+constexpr int CW_FLAG = 27;         // the header's flag bit
+constexpr int CW_ELK = 26;          // RV_REQ .. TIMEOUT
+constexpr int CW_VR = 25;           // RV_REPLY / PV_REPLY from a remote peer
+constexpr int CW_PV = 24;           // PV_REPLY
+constexpr int CW_TO = 23;           // TIMEOUT
+constexpr int CW_VQ = 22;           // RV_REQ / PV_REQ with slot < cluster
+constexpr int CW_PVQ = 21;          // PV_REQ
+constexpr int CW_NONE = 19;         // row not addressed this round
+constexpr uint32_t CW_J_MASK = 7u << 10;
+__device__ __forceinline__ sw cw_bit(int32_t cw, int bit) { return (int32_t)((uint32_t)cw << (31 - bit)); }
+
+// ---- the predicate word of a decided row (expanded by the I/O wavefront: expand_predicates() below) -------------------------
+// main block, bits 6..0 (pushed in this order, so the first is the highest): fa_n, x_ct, conv, append, commit, fc_n, drop
+// election block, bits 13..7 (same rule): vq, vq_success, reset, conv, to_lead, to_pre, to_candidate
+constexpr uint32_t PW_SLOW = 1u << 31;     // not a predicate word: bits 23..0 are the flags | status << 16 of a general handler
+__device__ __forceinline__ uint32_t expand_predicates(uint32_t w)
+{
+    auto m = [&](int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); };     // v_bfe_i32: 0 / ~0
+    const uint32_t fa = ~m(6), contains = ~m(5), conv = m(4) | m(10), app = m(3), commit = m(2), hb = ~m(1) | m(9), drop = m(0);
+    const uint32_t vq = m(13), succ = (fa & contains) | m(12), reset = fa | m(11) | conv, to_pre = m(8), cand = m(7);
+    const uint32_t fast = (succ & RG_F_SUCCESS) | ((fa | vq) & RG_F_REPLIED) | (conv & (RG_F_PERSIST | RG_F_ROLE_CHANGED)) | (reset & RG_F_RESET_TIMER) |
+                          (commit & RG_F_COMMIT) | (app & RG_F_LOG_APPEND) | (hb & (RG_EMIT_HEARTBEAT << RG_F_EMIT_SHIFT)) |
+                          (to_pre & (RG_EMIT_PREVOTE << RG_F_EMIT_SHIFT)) | (cand & (RG_EMIT_REQVOTE << RG_F_EMIT_SHIFT)) |
+                          (drop & ((uint32_t)RG_DROPPED_STALE_ROLE << RG_F_STATUS_SHIFT));
+    return (w & PW_SLOW) ? (w & 0x00FFFFFFu) : fast;
+}
+
+// ---- the group image of the 32-bit body ------------------------------------------------------------------------------------------
+// GroupT<int32_t>'s fields with the four booleans as sign words (0 / -1 wherever this file writes them) and the cached precondition words.
+struct GroupN {
+    int32_t term, commit, epoch_index, epoch_term, first, last, elected_term;
+    int32_t s0, s1, s2, s3, t0, t1, t2, t3, lt, top;
+    int32_t voted_for, leader, votes, role, rc;
+    uint32_t role_epoch, elected_epoch, pending;
+    sw td, prepared, log_dirty, peers_dirty;
+    sw nallow;                      // tier 1 is off for this lane: the launch runs the general handlers only, or the group is blocked after a NEED_HOST
+    sw stf_n, stl_n, stc_n;         // NOT (allowed & ...): a Follower with a log above its epoch that is not `prepared` / a prepared Leader / a Leader with a log
+
+    __device__ __forceinline__ void recache()
+    {
+        const int32_t r = role, n = rc, l = last, e = epoch_index;
+        const sw na = nallow, pr = prepared;
+        const sw not_l = s_ne(r, RG_LEADER), no_log = s_lt(n, 1);
+        stf_n = na | s_pos(r) | pr | no_log | ~s_lt(e, l);
+        stl_n = na | not_l | ~pr;
+        stc_n = na | not_l | no_log;
+    }
+    // GroupT::push (db.put(last+1, t)) for a log that has entries, same statements — except that `last` is the caller's (tier 1 has set it to
+    // the index of the row's last entry by the time it comes here)
+    __device__ __forceinline__ void push_run(int32_t index, int32_t t)
+    {
+        int n = rc;
+        int32_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, y0 = t0, y1 = t1, y2 = t2, y3 = t3;
+        const int32_t f = first, cur_lt = lt, cur_top = top;
+        const bool empty = n == 0;
+        const bool newrun = empty | (cur_lt != t);
+        const bool shift = newrun & (n == K);
+        x0 = shift ? x1 : x0; y0 = shift ? y1 : y0;
+        x1 = shift ? x2 : x1; y1 = shift ? y2 : y1;
+        x2 = shift ? x3 : x2; y2 = shift ? y3 : y2;
+        n = shift ? K - 1 : n;
+        const bool w0 = newrun & (n == 0), w1 = newrun & (n == 1), w2 = newrun & (n == 2), w3 = newrun & (n == 3);
+        x0 = w0 ? index : x0; y0 = w0 ? t : y0;
+        x1 = w1 ? index : x1; y1 = w1 ? t : y1;
+        x2 = w2 ? index : x2; y2 = w2 ? t : y2;
+        x3 = w3 ? index : x3; y3 = w3 ? t : y3;
+        n += newrun ? 1 : 0;
+        s0 = x0; s1 = x1; s2 = x2; s3 = x3; t0 = y0; t1 = y1; t2 = y2; t3 = y3;
+        lt = t; top = newrun ? index : cur_top;
+        rc = n;
+        first = empty ? index : f;
+        log_dirty = -1;
+    }
+};
+
+__device__ __forceinline__ Group widen(const GroupN &n)
+{
+    Group g;
+    g.term = n.term; g.commit = n.commit; g.epoch_index = n.epoch_index; g.epoch_term = n.epoch_term; g.first = n.first; g.last = n.last;
+    g.elected_term = n.elected_term;
+    g.s0 = n.s0; g.s1 = n.s1; g.s2 = n.s2; g.s3 = n.s3; g.t0 = n.t0; g.t1 = n.t1; g.t2 = n.t2; g.t3 = n.t3; g.lt = n.lt; g.top = n.top;
+    g.voted_for = n.voted_for; g.leader = n.leader; g.votes = n.votes; g.role = n.role; g.rc = n.rc;
+    g.role_epoch = n.role_epoch; g.elected_epoch = n.elected_epoch; g.pending = n.pending;
+    g.td = n.td < 0; g.prepared = n.prepared < 0; g.log_dirty = n.log_dirty < 0; g.peers_dirty = n.peers_dirty < 0;
+    return g;
+}
+// (the caller sets nallow and calls recache())
+__device__ __forceinline__ void narrow_into(GroupN &n, const Group &g)
+{
+    n.term = (int32_t)g.term; n.commit = (int32_t)g.commit; n.epoch_index = (int32_t)g.epoch_index; n.epoch_term = (int32_t)g.epoch_term;
+    n.first = (int32_t)g.first; n.last = (int32_t)g.last; n.elected_term = (int32_t)g.elected_term;
+    n.s0 = (int32_t)g.s0; n.s1 = (int32_t)g.s1; n.s2 = (int32_t)g.s2; n.s3 = (int32_t)g.s3;
+    n.t0 = (int32_t)g.t0; n.t1 = (int32_t)g.t1; n.t2 = (int32_t)g.t2; n.t3 = (int32_t)g.t3; n.lt = (int32_t)g.lt; n.top = (int32_t)g.top;
+    n.voted_for = g.voted_for; n.leader = g.leader; n.votes = g.votes; n.role = g.role; n.rc = g.rc;
+    n.role_epoch = g.role_epoch; n.elected_epoch = g.elected_epoch; n.pending = g.pending;
+    n.td = g.td ? -1 : 0; n.prepared = g.prepared ? -1 : 0; n.log_dirty = g.log_dirty ? -1 : 0; n.peers_dirty = g.peers_dirty ? -1 : 0;
+}
+// The small fields this file compares with sign words have a domain of their own (beside fits32 for the terms and indices): epochs and the
+// vote count in [0, 2^30), node ids in [-1, 2^30) — s_ne() needs operands that agree in bit 31, and NO_NODE is the one exception it is used with.
+__device__ __forceinline__ bool small_fields_fit(const Group &g)
+{
+    const uint32_t w = g.role_epoch | g.elected_epoch | (uint32_t)g.votes | (uint32_t)(g.leader + 1) | (uint32_t)(g.voted_for + 1);
+    return (w < EV_LIMIT) & ((uint32_t)g.role <= (uint32_t)RG_LEADER);
+}
+
+// what a decided row hands to the I/O wavefront
+struct OutN {
+    uint32_t pw;                    // predicate word, or PW_SLOW | flags | status << 16
+    int32_t resp;                   // RaftResponse.term (read iff REPLIED)
+    int32_t log_from;               // (read iff LOG_APPEND / LOG_TRUNC)
+};
+
+// MUST be called by every lane of the wavefront (converged code). Returns a sign word: the row was decided here.
+template <int F>
+__device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow<F> &pe, OutN &out, int32_t cw, uint32_t aux_u, int32_t n,
+                                     int32_t a, int32_t b, int32_t c, int32_t d)
+{
+    const int32_t aux = (int32_t)aux_u;
+    const int32_t term = g.term, last = g.last, commit = g.commit, epoch = g.epoch_index, lt = g.lt, top = g.top;
+    const int32_t role = g.role, rc = g.rc, leader = g.leader, votes = g.votes, voted = g.voted_for;
+    const int32_t repoch = (int32_t)g.role_epoch;
+    const sw td = g.td, prep = g.prepared, nallow = g.nallow, stl_n = g.stl_n;
+    const int32_t slot = (int32_t)(((uint32_t)cw >> 5) & 15u);
+    const sw flg = cw_bit(cw, CW_FLAG);
+    const sw x_ta = s_lt(term, a);                                  // a > currentTerm
+    const sw x_aux = s_ne(aux, repoch);                             // the row names another participant (AsyncHead aborted)
+    const sw x_tl = s_ne(lt, term);                                 // the tail entry is not of currentTerm
+    // The ack block's LDS reads are issued first and the AppendEntries block — which needs nothing from LDS — is placed between them and
+    // their use: left to itself the scheduler opens the round with the ack block and a wait for the reads.
+    const uint32_t j = ((uint32_t)cw >> 10) & 7u;                   // follower index of an ack's responder, 0 for any other row
+    const I32x4 st = pe.rec[j * BLOCK];
+    int32_t m[F];
+    pe.load_matches(m);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- AppendEntries request at a follower (member/Follower.java:35-88) ---------------------------------------------------------
+    const sw x_ct = s_ne(c, lt);                                    // NOT contains: prevLogTerm != term of the tail
+    const sw rf = x_ta | td;                                        // refresh: switchTo(Follower, term, lastCandidate)
+    const bool contains = x_ct >= 0;
+    const int32_t n_eff = contains ? n : 0;
+    const int32_t ae_last = last + n_eff;                           // (b == last wherever this is used)
+    const int32_t ae_x = vmin<int32_t>(d, ae_last);
+    const sw x_de = s_lt(epoch, d);                                 // leaderCommit > epoch.index
+    // NOT: an allowed row at such a Follower | term >= currentTerm | the known leader, or none, or a refresh | prevLogIndex == last |
+    //      no commit roll-back
+    const sw fa_n = (~cw_bit(cw, CW_AE) | g.stf_n | s_lt(a, term)) | ((s_ne(leader, slot) & ~rf) | s_ne(b, last)) |
+                    (~x_ct & x_de & s_lt(ae_x, commit));
+    const bool m_fa = fa_n >= 0;
+    const sw ae_ref = ~fa_n & rf;
+    const bool m_ref = ae_ref < 0;
+    const sw ae_wc = ~fa_n & ~x_ct & x_de;                          // commits up to min(leaderCommit, last)
+    const sw app_ae = ~fa_n & s_pos(n_eff);
+
+    // ---- AppendEntries ack at a prepared leader (member/Leader.java:218-237, Leadership.java:75-130, Leader.java:247-280) --------
+    __builtin_amdgcn_sched_barrier(0);
+    const int32_t s_epoch = st.x, s_next = st.y, s_match = st.z, s_rej = st.w;
+    const sw pend = (int32_t)(g.pending << ((uint32_t)cw & 31u));   // bit j of `pending`
+    const sw adv = flg & s_lt(s_match, c);
+    const bool m_adv = adv < 0;
+    const int32_t n_match = m_adv ? c : s_match;
+    const int32_t n_next = m_adv ? (int32_t)((uint32_t)c + 1u) : s_next;
+#pragma unroll
+    for (int i = 0; i < F; i++) m[i] = (j == (uint32_t)i) ? n_match : m[i];
+    int32_t full, major;
+    major_indices<F, int32_t>(m, full, major);
+    const sw lookup = flg & s_pos(major);
+    const sw bad_major = lookup & (s_lt(rc, 1) | s_lt(major, top) | s_lt(last, major));      // the quorum index is outside the newest run
+    const int32_t ct0 = (lt == term) ? major : full;
+    const sw rollback = lookup & s_pos(ct0) & s_lt(ct0, commit);
+    const sw fk_n = (~cw | stl_n | x_aux) | (x_ta | s_ne(b, s_epoch) | pend) | (s_lt(c, s_match) | (~flg & ~s_pos(s_match))) |
+                    (~s_lt(b, n_next) | bad_major | rollback);
+    const bool m_fk = fk_n >= 0;
+    const bool m_ct = (~fk_n & lookup) < 0;
+    const int32_t ack_ct = m_ct ? ct0 : 0;                          // commit_to; 0, or >= commitIndex
+    const sw ackany = cw_bit(cw, CW_ACKANY) & ~nallow;
+    const sw drop = ackany & x_aux;
+
+    // ---- client append at a leader (member/Leader.java:128-140) ---------------------------------------------------------------------
+    const int32_t last_n = last + n;
+    const sw fc_n = ~cw_bit(cw, CW_CLIENT) | g.stc_n | ~s_lt(last_n, (int32_t)STATE_LIMIT);
+    const bool m_fc = fc_n >= 0;
+
+    // ---- apply -----------------------------------------------------------------------------------------------------------------------
+    // (the record is written back by every lane — its own values where the row is no such ack: cheaper than an exec-mask branch around two stores)
+    pe.store_ack(j, s_epoch, m_fk ? n_next : s_next, m_fk ? n_match : s_match, m_fk ? ((flg < 0) ? 0 : (int32_t)((uint32_t)s_rej + 1u)) : s_rej);
+    g.term = m_fa ? a : term;
+    g.role_epoch = (uint32_t)repoch + (m_ref ? 1u : 0u);
+    g.td = td & ~ae_ref;
+    g.votes = m_ref ? 1 : votes;
+    g.leader = m_fa ? slot : leader;
+    g.last = m_fa ? ae_last : (m_fc ? last_n : last);
+    const sw app = app_ae | ~fc_n;
+    g.log_dirty = g.log_dirty | app;
+    g.peers_dirty = g.peers_dirty | ~fk_n;
+    const int32_t cand = (ae_wc < 0) ? ae_x : ack_ct;
+    const int32_t new_commit = vmax<int32_t>(commit, cand);
+    g.commit = new_commit;
+    uint32_t pw = push_bit(0u, fa_n);
+    pw = push_bit(pw, x_ct);
+    pw = push_bit(pw, ae_ref);
+    pw = push_bit(pw, app);
+    pw = push_bit(pw, s_lt(commit, new_commit));
+    pw = push_bit(pw, fc_n);
+    out.resp = a;
+    out.log_from = last + 1;
+    sw done = ~fa_n | ~fk_n | ~fc_n | drop | (cw_bit(cw, CW_NONE) & ~nallow);
+    sw any_drop = drop;
+    uint32_t pw_el = 0u;
+
+    // ---- what steady replication does not carry, behind ONE wave-uniform branch -------------------------------------------------------
+    // rare: a new term run at the log tail (the first entries of a new leader's term), prepareReplication after a leader's first entry;
+    // election traffic: decided AND applied here (a lane is in at most one class, and the classes above left the state of every other
+    // lane as it was: the snapshot is still valid)
+    const sw x_pl = s_ne(aux, lt);                                  // the carried entries are not of the tail's term
+    const sw rare = (app_ae & x_pl) | (~fc_n & (x_tl | ~prep));
+    const sw ack_down = ackany & ~x_aux & ~stl_n & x_ta;            // Leader -> Follower(result.term, responder)
+    const sw election = (cw_bit(cw, CW_ELK) & ~nallow) | ack_down;
+    if (__builtin_amdgcn_ballot_w64((rare | election) < 0) != 0) {
+    if (__builtin_amdgcn_ballot_w64(rare < 0) != 0) {
+        const bool ae_newrun = (app_ae & x_pl) < 0, fc_newrun = (~fc_n & x_tl) < 0, fc_prepare = (~fc_n & ~prep) < 0;
+        if (ae_newrun | fc_newrun) g.push_run(last + 1, ae_newrun ? aux : term);
+        if (fc_prepare) {                                           // Leader.prepareReplication after the FIRST new entry: nextIndex = that entry + 1
+            pe.store_prepare(epoch, last + 2);
+            g.pending = 0;
+            g.prepared = -1; g.peers_dirty = -1;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(election < 0) != 0) {
+        const int32_t term1 = term + 1, el_term = g.elected_term, el_epoch = (int32_t)g.elected_epoch;
+        const sw is_pv = cw_bit(cw, CW_PV), is_pvq = cw_bit(cw, CW_PVQ);
+        const sw not_f = s_pos(role), not_c = s_ne(role, RG_CANDIDATE), not_l = s_ne(role, RG_LEADER);
+        // vote replies (member/Candidate.java:121-134, member/Follower.java:258-270)
+        const sw vr_shape = cw_bit(cw, CW_VR) & ~nallow;
+        const sw sender_bad = (is_pv & (not_f | ~td)) | (~is_pv & not_c);
+        const int32_t T = (is_pv < 0) ? term1 : term;
+        const sw vr_cur = vr_shape & ~x_aux & ~sender_bad;
+        const sw x_Ta = s_lt(T, a);
+        const sw vr_higher = vr_cur & x_Ta;
+        const sw vr_grant = vr_cur & ~x_Ta & flg;
+        const sw vr_win = vr_grant & ~s_lt(votes + 1, p.majority);
+        const sw win_rv = vr_win & ~is_pv;
+        const sw x_lt = s_lt(el_term, a);
+        const sw late = vr_shape & ~is_pv & x_aux & (s_pos(el_epoch) & ~s_ne(aux, el_epoch));
+        const sw late_higher = late & x_lt;                         // head.abortRequests(); Follower if that is "better"
+        const sw late_noop = late & ~x_lt & (~flg | s_lt(el_term, term) | (~s_ne(el_term, term) & ~not_l));
+        const sw vote_drop = vr_shape & x_aux & ~late;
+        // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
+        const sw to_kind = cw_bit(cw, CW_TO) & ~nallow;
+        const sw to_stale = to_kind & s_pos(aux) & x_aux;
+        const sw to_live = to_kind & ~to_stale;
+        const sw pre = (p.pre_vote != 0) ? -1 : 0;
+        const sw to_pre = to_live & ~not_f & pre;
+        const sw to_cand = to_live & ((~not_f & ~pre) | ~not_c);
+        const sw to_lead = to_live & ~not_l;
+        // RequestVote / PreVote at a Follower that has a log (member/Follower.java:91-127, 193-207)
+        const sw vq = cw_bit(cw, CW_VQ) & ~nallow & ~not_f & ~s_lt(rc, 1);
+        const sw x_cl = s_lt(lt, c);
+        const sw utd = x_cl | (~s_ne(c, lt) & ~s_lt(b, last));      // Follower.logUpToDate with a last entry
+        const sw pv_judge = vq & is_pvq & x_ta & td;                // else failure(currentTerm), no timer touched
+        const sw rv_new = vq & ~is_pvq & x_ta;
+        const sw rv_same = vq & ~is_pvq & ~x_ta & ~s_lt(a, term);
+        const sw voted_other = s_ne(voted, slot) | voted;           // (votedFor == NO_NODE is nobody's slot)
+        const sw vq_success = ((pv_judge | rv_new) & utd) | (rv_same & ~voted_other);
+        // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`
+        const sw conv_self = vr_win | to_cand;                      // ballot = self
+        const sw conv = (vr_higher | conv_self | (late_higher & ~s_lt(a, term))) | (to_pre | rv_new | ack_down);
+        const sw to_c = (vr_win & is_pv) | to_cand;                 // -> Candidate
+        const sw lead_prepare = to_lead & ~prep;                    // a new Leader's first tick: Leader.prepareReplication (member/Leader.java:30-50)
+        const sw el_fast = (vr_cur | late_higher | late_noop) | (vote_drop | to_kind | vq) | ack_down;
+        //   (vr_cur = higher | win | quiet; to_kind = stale | pre | cand | lead: a timeout always lands in one of them)
+        const bool m_conv = conv < 0, m_winrv = win_rv < 0;
+        const int32_t new_role = (win_rv < 0) ? RG_LEADER : ((to_c < 0) ? RG_CANDIDATE : RG_FOLLOWER);
+        const int32_t new_term = (to_c < 0) ? term1 : (((win_rv | to_pre) < 0) ? term : a);
+        const int32_t new_vote = (conv_self < 0) ? p.self : ((to_pre < 0) ? voted : (((rv_new & ~utd) < 0) ? RG_NO_NODE : slot));
+        if (lead_prepare < 0) {
+            pe.store_prepare(epoch, ((rc > 0) ? last : epoch) + 1);
+            g.pending = 0;
+        }
+        g.elected_epoch = m_winrv ? (uint32_t)repoch : ((late_higher < 0) ? 0u : (uint32_t)el_epoch);      // Candidate.java:75-79 / head.abortRequests()
+        g.elected_term = m_winrv ? term : el_term;
+        g.term = m_conv ? new_term : g.term;
+        g.role = m_conv ? new_role : g.role;
+        g.voted_for = m_conv ? new_vote : g.voted_for;
+        g.role_epoch = g.role_epoch + (m_conv ? 1u : 0u);
+        g.td = (g.td & ~conv) | to_pre;
+        g.votes = m_conv ? 1 : (g.votes + (((vr_grant & ~vr_win) < 0) ? 1 : 0));
+        g.leader = m_conv ? RG_NO_NODE : g.leader;
+        g.prepared = (g.prepared & ~conv) | lead_prepare;
+        g.peers_dirty = g.peers_dirty | lead_prepare;
+        out.resp = ((vq & ~rv_new) < 0) ? term : a;                 // (only read for the vote requests)
+        pw_el = push_bit(0u, vq);
+        pw_el = push_bit(pw_el, vq_success);
+        pw_el = push_bit(pw_el, pv_judge | to_lead);
+        pw_el = push_bit(pw_el, conv);
+        pw_el = push_bit(pw_el, to_lead);
+        pw_el = push_bit(pw_el, to_pre);
+        pw_el = push_bit(pw_el, to_c);
+        any_drop = drop | vote_drop | to_stale;
+        done = done | el_fast;
+    }
+    g.recache();
+    }
+    pw = push_bit(pw, any_drop);
+    out.pw = pw | (pw_el << 7);
+    return done;
+}
+
+}  // namespace rg

@@ -128,6 +128,16 @@ unsigned long long wave_first(unsigned long long v)
     });
 }
 
+unsigned long long wave_lane_value(unsigned long long v, int lane)
+{
+    if (!my_wave) return v;
+    return my_wave->meet(my_lane, v, [lane](const std::vector<unsigned long long> &out, const std::vector<char> &here) {
+        return lane >= 0 && (size_t)lane < out.size() && here[lane] ? out[lane] : 0ull;
+    });
+}
+
+int wave_lane_index() { return my_wave ? my_lane : 0; }
+
 void workgroup_barrier(bool required)
 {
     if (!my_block) {

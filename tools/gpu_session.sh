@@ -74,6 +74,14 @@ for step in "$@"; do
           python tools/placement.py $OUT/hwid_$T.bin | tee -a $OUT/placement.txt; done ;;
     base) for C in "--config 3" "--config 4" "--config 2" "--config 5 --groups-per-gpu 65536" "--config 5"; do
           $B --steps 20 --warmup 3 $C 2>>$OUT/base.err | tee -a $OUT/base.jsonl | line "base $C"; done ;;
+    ab4) for i in 1 2 3; do for L in ${LIBS}; do RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 2>>$OUT/ab4.err | tee -a $OUT/ab4.jsonl | line "c3 $L"; done; done      # LIBS="a.so b.so": same-box A/B over the four configurations
+        for C in "--config 5 --groups-per-gpu 65536" "--config 4" "--config 2" "--config 5"; do for i in 1 2; do for L in ${LIBS}; do
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 $C 2>>$OUT/ab4.err | tee -a $OUT/ab4.jsonl | line "$C $L"; done; done; done ;;
+    ab5) for i in 1 2; do for L in ${LIBS}; do RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 2>>$OUT/ab5.err | tee -a $OUT/ab5.jsonl | line "c3 $L"; done; done      # the short form of ab4
+        for C in "--config 5 --groups-per-gpu 65536" "--config 4" "--config 2" "--config 5"; do for L in ${LIBS}; do
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 $C 2>>$OUT/ab5.err | tee -a $OUT/ab5.jsonl | line "$C $L"; done; done ;;
+    probe2) for L in ${LIBS}; do for C in "--config 2" "" "--config 4" "--config 5 --groups-per-gpu 65536"; do echo "== $L $C" | tee -a $OUT/probe2.txt     # -DRG_PROBE libraries: section timers per round
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 $C 2>>$OUT/probe2.err | tee -a $OUT/probe2.jsonl | python tools/probe.py | tee -a $OUT/probe2.txt; done; done ;;
     issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac

@@ -17,7 +17,11 @@ sys.path.insert(0, ROOT)
 from rafting_amd import abi, workload  # noqa: E402
 
 CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048, 32),
-         ("config3_full_size", 3, 65536, 16), ("config5_full_shard", 5, 131072, 8)]
+         ("config3_full_size", 3, 65536, 16), ("config5_full_shard", 5, 131072, 8),
+         # round 4: what is benchmarked — the first launch of bench.py's default stream (config 3, 65 536 groups x 64 rounds; bench.py
+         # compares its own first launch with this digest: "golden": "ok"), a shard of config 4 as `bench.py --gpus 8` gives every GPU, config 2's
+         # mirrored follower view
+         ("config3_bench_launch", 3, 65536, 64), ("config4_shard", 4, 131072, 8), ("config2f", "2f", 4096, 24)]
 
 
 def canonical_outcome_digest(out):

@@ -1,33 +1,71 @@
 #!/usr/bin/env python3
-"""spine.py file.s kernel_mangled -> instruction count of step32_kernel's deciding-wavefront round from the loop header to the branch that
-skips the general handlers ("spine": tier 1 with its election block and its rare blocks in line). The loop is the first depth-1 loop of the
-kernel; its first s_cbranch_vccz skips the election block, its second the general handlers (tools/spine.sh prints what it finds — read the
-number as a static proxy, and check the two branches still mean that after a change of the round loop)."""
+"""spine.py file.s kernel_mangled -> instruction counts of ONE ROUND of step32_kernel's deciding wavefront, walked along the paths a cluster in
+operation takes: from the header of the round loop to its first s_barrier, with the wave-uniform branches (s_cbranch_vccz: {rare block | election block}, inside it
+the rare block and the election block, then the general handlers) decided as named and every exec-mask branch (s_cbranch_execz) falling through — its body is executed.
+  main     : no rare block, no election row, nothing for the general handlers  (steady replication)
+  election : the same with the election block
+The static proxy for ticks per round (the deciding wavefront is alone on its SIMD, instructions are what it pays for)."""
 import re
 import sys
 
-L = open(sys.argv[1]).read().split('\n')
-k = sys.argv[2]
-start = next(i for i, l in enumerate(L) if l.startswith(k + ':'))
-end = next(i for i in range(start, len(L)) if '.end_amdhsa_kernel' in L[i])
-K = L[start:end]
-isinstr = lambda l: l.startswith('\t') and not l.strip().startswith(';') and not l.strip().startswith('.')   # noqa: E731
-hdr = next(i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l)
-vccz = [i for i in range(hdr, len(K)) if re.search(r's_cbranch_vccz\s+\.LBB', K[i])][:2]
-bar = next(i for i in range(hdr, len(K)) if 's_barrier' in K[i])
-loop_end = next((i for i in range(hdr + 1, len(K)) if 'Loop Header: Depth=1' in K[i]), len(K))
-spine = [l for l in K[hdr:vccz[1] + 1] if isinstr(l)]
-election = [l for l in K[vccz[0] + 1:vccz[1] + 1] if isinstr(l)]
-target = re.search(r'(\.LBB\d+_\d+)', K[vccz[1]]).group(1)
-t0 = next(i for i, l in enumerate(K) if l.startswith(target + ':'))
-tail = []
-for l in K[t0 + 1:]:
-    if l.startswith('.LBB'):
-        break
-    if isinstr(l):
-        tail.append(l)
-movs = sum(1 for l in spine if l.split()[0].startswith('v_mov'))
-lanes = sum(1 for l in spine if 'lane_b32' in l.split()[0])
-print("spine %d instructions (election block and what follows it: %d; + %d in the block the skip lands in); v_mov %d, read/writelane %d; "
-      "first s_barrier %d instructions after the loop header in layout order; loop total %d"
-      % (len(spine), len(election), len(tail), movs, lanes, sum(1 for l in K[hdr:bar] if isinstr(l)), sum(1 for l in K[hdr:loop_end] if isinstr(l))))
+
+def kernel_lines(path, k):
+    L = open(path).read().split('\n')
+    start = next(i for i, l in enumerate(L) if l.startswith(k + ':'))
+    end = next(i for i in range(start, len(L)) if '.end_amdhsa_kernel' in L[i])
+    return L[start:end]
+
+
+def isinstr(l):
+    return l.startswith('\t') and not l.strip().startswith(';') and not l.strip().startswith('.')
+
+
+def walk(K, hdr, decisions):
+    """decisions: for the successive s_cbranch_vccz / s_cbranch_vccnz met on the path, True = taken"""
+    labels = {l.split(':')[0]: i for i, l in enumerate(K) if l.startswith('.LBB')}
+    i, n, d, ops = hdr, 0, 0, {}
+    while True:
+        if n > 20000 or i >= len(K):
+            return -1, ops                      # no barrier on this path: the loop's branch structure is not the one this walker knows
+        l = K[i]
+        if isinstr(l):
+            op = l.split()[0]
+            n += 1
+            ops[op] = ops.get(op, 0) + 1
+            if op == 's_barrier':
+                return n, ops
+            m = re.search(r'(\.LBB\d+_\d+)', l)
+            if op in ('s_cbranch_vccz', 's_cbranch_vccnz', 's_cbranch_scc0', 's_cbranch_scc1'):
+                taken = decisions[d] if d < len(decisions) else True
+                d += 1
+                if taken:
+                    i = labels[m.group(1)]
+                    continue
+            elif op == 's_branch':
+                i = labels[m.group(1)]
+                continue
+        i += 1
+
+
+def main():
+    K = kernel_lines(sys.argv[1], sys.argv[2])
+    hdr = next(i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l)
+    a, opsa = walk(K, hdr, [True, True, True])                   # skip {rare, election}, skip the general handlers
+    b, opsb = walk(K, hdr, [False, True, False, True, True])     # enter that branch, skip rare, enter election, skip the general handlers
+    # the I/O wavefront's round: the longest barrier-to-barrier stretch that loads two rows' worth of columns and stores up to three
+    # (its loop is unrolled by four; the stretches differ by a few instructions)
+    bars = [i for i, l in enumerate(K) if isinstr(l) and l.split()[0] == 's_barrier']
+    io = 0
+    for x, y in zip(bars, bars[1:]):
+        seg = [l.split()[0] for l in K[x:y] if isinstr(l)]
+        if sum(o.startswith('global_load') for o in seg) == 2 and sum(o.startswith('global_store') for o in seg) == 3 and len(seg) < 600:
+            io = max(io, len(seg))
+    cls = lambda ops, p: sum(v for k, v in ops.items() if k.startswith(p))   # noqa: E731
+    print("I/O wavefront: %d instructions per round (longest of the unrolled four)" % io)
+    print("main %d instructions (v_cmp %d, v_cndmask %d, s_and/s_or %d, ds_ %d, v_mov %d); election %d (v_cmp %d, v_cndmask %d, s_and/s_or %d, v_mov %d)"
+          % (a, cls(opsa, 'v_cmp'), cls(opsa, 'v_cndmask'), cls(opsa, 's_and') + cls(opsa, 's_or'), cls(opsa, 'ds_'), cls(opsa, 'v_mov'),
+             b, cls(opsb, 'v_cmp'), cls(opsb, 'v_cndmask'), cls(opsb, 's_and') + cls(opsb, 's_or'), cls(opsb, 'v_mov')))
+
+
+if __name__ == '__main__':
+    main()
