@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--copy-bytes", type=int, default=1 << 30, help="size of the plain-copy measurement (tests on the host emulation shrink it)")
     ap.add_argument("--pcie-batches", type=int, default=12, help="host-memory legs: batches per leg (the first two size the staging buffers)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
+    ap.add_argument("--no-int64-pass", action="store_true", help="skip the extra timed pass with the compact kernel's 64-bit body forced (RG_FORCE_WIDE=1)")
     ap.add_argument("--dist-backend", default="gloo", help="how the three result scalars are added up: gloo (default, host sum — the "
                     "data path has no collective) or nccl (= RCCL)")
     ap.add_argument("--device", type=int, default=None, help="test only: HIP device for every rank (default LOCAL_RANK)")
@@ -194,6 +195,31 @@ def main():
 
     copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
 
+    # ---- the stream's FIRST launch against the committed digest of the reference's own run of it (tests/golden/replay_digests.json, made by
+    # tools/make_golden.py from oracle/_ref: no oracle in this loop), and what this row / table layout must move per launch -----------------
+    golden = None
+    floor_bytes = None
+    if rank == 0:
+        try:
+            from tools import make_golden
+            first_out = dbatches[0].outcome()
+            if not args.override:
+                for name, c in json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.json")))["cases"].items():
+                    if (str(c["number"]), c["groups"], c["rounds"]) == (str(args.config), gpg, args.rounds) and first_gid == 0:
+                        golden = {"case": name, "outcomes": "ok" if make_golden.canonical_outcome_digest(first_out) == c["outcomes"] else "MISMATCH"}
+            # layout floor: event rows in (8 + 16 B, or 40 B + entry terms on wide rows), reply rows out (16 B), the log / commit and persist rows that
+            # exist (16 B each, counted on the stream's first launch), the table once per launch (5 + 4 columns of 16 B in, 5 out, run columns
+            # and the follower records of leading groups when dirty: bounded here by "all of them")
+            f0 = first_out.reply["flags"]
+            rows0 = len(f0)
+            lfx_rows = int(np.count_nonzero((f0 & (abi.F_COMMIT | abi.F_LOG_APPEND | abi.F_LOG_TRUNC)) != 0))
+            per_rows = int(np.count_nonzero((f0 & abi.F_PERSIST) != 0))
+            ev_bytes = dbatches[0].bytes_in if hasattr(dbatches[0], "bytes_in") else rows0 * 40
+            state_bytes = gpg * (9 * 16 + 5 * 16 + 4 * 16) + int(gpg * cfg.leader_frac) * F * 32 * 2
+            floor_bytes = ev_bytes + rows0 * 16 + (lfx_rows + per_rows) * 16 + state_bytes
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            print("bench: golden / layout-floor leg failed: %r" % (e,), file=sys.stderr)
+
     # ---- the same step with caller-owned HOST buffers (PCIe both ways): reported, never `value` -----------------------------
     # Three ways over the link, each from the same table state with the same FRESH batches of the stream (B0, B1 size the staging
     # buffers, the rest are timed):  serial = rg_submit(RG_MEM_HOST), H2D -> kernel -> D2H back to back;  pipelined = rg_submit_async,
@@ -326,6 +352,31 @@ def main():
             cpu["reference_translated"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             print("bench: translated-reference leg failed: %r" % (e,), file=sys.stderr)
 
+    # ---- the same timed steps with the compact kernel's 64-bit body forced (RG_FORCE_WIDE=1): what the step costs when a value of the
+    # workgroup has left the 32-bit tier's domain (>= 2^30). Same batches, a second table from the same initial state; its decision counters must
+    # equal the first pass's (the outcome rows are bit-identical: tests/test_gpu_parity.py::test_compact_multi_round_launch_and_domain_exits).
+    int64_pass = None
+    if rank == 0 and world == 1 and not args.wide_rows and not args.no_int64_pass:
+        os.environ["RG_FORCE_WIDE"] = "1"
+        try:
+            t2 = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+        finally:
+            os.environ.pop("RG_FORCE_WIDE", None)
+        t2.load_state(st0)
+        for i in range(args.warmup):
+            t2.submit_device(dbatches[i])
+        t2.sync()
+        t2.counters(reset=True)
+        t2.timing_begin()
+        for i in range(args.warmup, nb):
+            t2.submit_device(dbatches[i])
+        ms2 = t2.timing_end()
+        t2.sync()
+        c2 = t2.counters()
+        int64_pass = {"ms": ms2 / max(args.steps, 1), "value": decisions / (ms2 * 1e-3) if ms2 > 0 else None,
+                      "counters_equal_first_pass": [int(x) for x in c2] == [int(x) for x in counters]}
+        t2.close()
+
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate
         # passes, gfx950 x2 fetch correction applied; tools/prof.sh writes profiles/traffic.json) — quoted only when the entry
@@ -387,7 +438,18 @@ def main():
                 "algorithmic_bytes_per_launch": alg_per_launch,
                 "algorithmic_bytes_per_decision": alg_bytes / max(decisions, 1),
                 "measured_copy_gbps": copy_gbps,
+                # what this row / table layout has to move per launch whatever the kernel does (events in, replies and the effect rows that exist
+                # out, the table once): a denominator that cannot be beaten, unlike the algorithmic bytes of `frac`, which charge every decision its
+                # group's state although the state stays in registers across the rounds of a launch. frac_of_layout_floor <= 1 by construction.
+                "layout_floor_bytes": floor_bytes,
+                "layout_floor_gbps": None if floor_bytes is None else floor_bytes / avg_kernel_s / 1e9,
+                "frac_of_layout_floor": None if floor_bytes is None else floor_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBPS,
+                "model_overcharges": bool(achieved > HBM_PEAK_GBPS),        # frac > 1: the 8(d) byte model, not the kernel, is off (state is register-resident)
+                "ms_int64_body": None if int64_pass is None else int64_pass["ms"],
+                "value_int64_body": None if int64_pass is None else int64_pass["value"],
+                "int64_body_counters_equal": None if int64_pass is None else int64_pass["counters_equal_first_pass"],
             },
+            "golden": golden,
             "cpu_baseline": cpu,
             "pcie_inclusive_value": pcie_packed if pcie_packed is not None else (pcie_pipe if pcie_pipe is not None else pcie),
             "pcie_inclusive": {"serial_rg_submit": pcie, "pipelined_rg_submit_async": pcie_pipe, "pipelined_rg_submit_async_packed": pcie_packed,

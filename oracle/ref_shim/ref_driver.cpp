@@ -51,6 +51,7 @@ struct ref_table {
     std::vector<std::unique_ptr<RefEnv>> g;
     const int64_t *clock = nullptr;
     int64_t election_ms = 900, heartbeat_ms = 300; uint64_t timer_seed = 0;
+    bool hold = false;                                // ref_hold(): play() leaves what the row queued on the loop undrained (see there)
 };
 
 static RefEnv *g_env = nullptr;
@@ -371,7 +372,12 @@ static void play(ref_table *t, RefEnv &e, const rg_batch_t *in, size_t row, rg_r
     } catch (const Throwable &th) {
         note(e, status_of(th));
     }
-    drain(e);
+    // Delivery modes. Normally the loop is drained right after the row: the one interleaving in which nothing else of this group runs between
+    // a callback's off-loop part (the CAS of the membership filter, context/RaftRoutine.java:140-151) and the loop task it queues at the head
+    // (context/RaftContext.java:205-215, support/EventLoop.java:87-101). With ref_hold() the queue is LEFT AS IT IS: the next row of the group
+    // then runs its handler first — the loop thread was already inside that task when the callback's thread did its CAS — and only then
+    // drains, the held urgent tasks first. (tests/test_ref_parity.py: the interleaving differential)
+    if (!t->hold) drain(e);
     if (e.status == RG_OK && last_error_fmt()) {
         if (strstr(last_error_fmt(), "try commit failed")) e.status = RG_NPE_MAJOR_NULL;    // member/Leader.java:277-279
         else { if (getenv("REF_TRACE")) fprintf(stderr, "ref: swallowed: %s\n", last_error_fmt()); e.status = REF_SWALLOWED_EXCEPTION; }
@@ -593,6 +599,7 @@ int ref_submit(ref_table *t, const rg_batch_t *in, const rg_outcome_t *out)
 }
 
 int ref_clock(ref_table *t, const int64_t *now_per_round) { if (!t) return -1; t->clock = now_per_round; return 0; }
+int ref_hold(ref_table *t, int on) { if (!t) return -1; t->hold = on != 0; return 0; }
 
 
 // ---- N1: Leader.replicateLog (member/Leader.java:142-245) — what the reference itself sends ----------------------------

@@ -374,16 +374,19 @@ hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t 
 constexpr int COPY_UNROLL = 4;
 __global__ __launch_bounds__(256) void copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + (COPY_UNROLL - 1) * stride < n; i += COPY_UNROLL * stride) {
+    // every workgroup walks its own contiguous slice, COPY_UNROLL x 4 KiB at a time, non-temporal both ways: the best of the access shapes
+    // tools/membench.hip tried on an MI355X (5.49 TB/s where the grid-stride form of rounds 1-3 gave 4.3-4.9; profiles/r03a_membench.txt)
+    const size_t per = (n + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    size_t i = lo + threadIdx.x;
+    for (; i + (COPY_UNROLL - 1) * 256 < hi; i += COPY_UNROLL * 256) {
         u32x4 v[COPY_UNROLL];
 #pragma unroll
-        for (int k = 0; k < COPY_UNROLL; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+        for (int k = 0; k < COPY_UNROLL; k++) v[k] = __builtin_nontemporal_load(src + i + k * 256);
 #pragma unroll
-        for (int k = 0; k < COPY_UNROLL; k++) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+        for (int k = 0; k < COPY_UNROLL; k++) __builtin_nontemporal_store(v[k], dst + i + k * 256);
     }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (; i < hi; i += 256) dst[i] = src[i];
 }
 
 // ---- compact transfer formats of the pipelined host path (rg_submit_async_packed, include/raftgpu.h) ---------------------------

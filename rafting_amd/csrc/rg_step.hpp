@@ -57,18 +57,21 @@ template <class T> __device__ __forceinline__ void nt_store16(T *p, const T &x)
 #ifndef RG_GLOBAL_AS                // (the host emulation of tests/devemu defines these away)
 #define RG_GLOBAL_AS __attribute__((address_space(1)))
 #define RG_OWN_SGPRS(v) asm volatile("; %0 in scalar registers of its own" : "+s"(v))
+#define RG_FRESH_VGPR(v) asm volatile("; %0 recomputed from here on" : "+v"(v))   // what is derived from v after this point is not the value derived before it
 #endif
-template <class T> __device__ __forceinline__ T nt_load_at(uint64_t base, uint32_t byte_offset)
+// row `index` of the T-array at `base`; with a scalar base and an index known to be below 2^28 this is global_load / global_store's own
+// addressing form (saddr + 32-bit voffset): no vector address arithmetic
+template <class T> __device__ __forceinline__ T nt_load_at(uint64_t base, uint32_t index)
 {
     typedef uint32_t vec_t __attribute__((vector_size(sizeof(T))));
-    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const RG_GLOBAL_AS vec_t *>(reinterpret_cast<const RG_GLOBAL_AS char *>(base) + byte_offset));
+    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const RG_GLOBAL_AS vec_t *>(base) + index);
     T r; __builtin_memcpy(&r, &v, sizeof(T)); return r;
 }
-template <class T> __device__ __forceinline__ void nt_store_at(uint64_t base, uint32_t byte_offset, const T &x)
+template <class T> __device__ __forceinline__ void nt_store_at(uint64_t base, uint32_t index, const T &x)
 {
     typedef uint32_t vec_t __attribute__((vector_size(sizeof(T))));
     vec_t v; __builtin_memcpy(&v, &x, sizeof(T));
-    __builtin_nontemporal_store(v, reinterpret_cast<RG_GLOBAL_AS vec_t *>(reinterpret_cast<RG_GLOBAL_AS char *>(base) + byte_offset));
+    __builtin_nontemporal_store(v, reinterpret_cast<RG_GLOBAL_AS vec_t *>(base) + index);
 }
 
 // -DRG_PROBE (experiment build, tools/probe.py): s_memtime deltas per section of a round, summed per wavefront and reported through the
@@ -297,6 +300,7 @@ __device__ __forceinline__ void store_group(const DevTable &t, uint32_t gi, cons
 // the eight decision counters of include/raftgpu.h, kept per lane by whoever sees the outcome rows
 struct Tally {
     uint32_t rows = 0, replied = 0, conv = 0, commit = 0, asserts = 0, need = 0, stale = 0, append = 0;
+    uint32_t packed = 0;             // add_packed(): REPLIED, ROLE_CHANGED, COMMIT, LOG_APPEND as four byte counters
     __device__ __forceinline__ void add(uint32_t kind, uint32_t flags, uint32_t status)
     {
         rows += kind != RG_EV_NONE ? 1u : 0u;
@@ -304,9 +308,28 @@ struct Tally {
         conv += (flags >> 3) & 1u;                  // RG_F_ROLE_CHANGED
         commit += (flags >> 5) & 1u;                // RG_F_COMMIT
         append += (flags >> 7) & 1u;                // RG_F_LOG_APPEND
+        add_status(status);
+    }
+    __device__ __forceinline__ void add_status(uint32_t status)
+    {
         asserts += (status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u;
         need += status == RG_NEED_HOST ? 1u : 0u;
         stale += status == RG_DROPPED_STALE_ROLE ? 1u : 0u;
+    }
+    // The same with the four flag counters in one register (the 32-bit body's I/O wavefront, whose instructions count): flag bits 1, 3, 5, 7
+    // land in bits 0, 8, 16, 24 of one product — ((flags >> 1) & 0x55) * (1 + 2^6 + 2^12 + 2^18): bit i goes to i, i + 6, i + 12, i + 18, only
+    // i + 3i reaches a multiple of 8, and no position collects more than two terms, so no carry reaches one either. Call spill() at least
+    // every 255 rows.
+    __device__ __forceinline__ void add_packed(uint32_t kind, uint32_t flags, uint32_t status)
+    {
+        rows += kind != RG_EV_NONE ? 1u : 0u;
+        packed += ((((flags >> 1) & 0x55u) * 0x41041u) & 0x01010101u);
+        add_status(status);
+    }
+    __device__ __forceinline__ void spill()
+    {
+        replied += packed & 0xFFu; conv += (packed >> 8) & 0xFFu; commit += (packed >> 16) & 0xFFu; append += packed >> 24;
+        packed = 0u;
     }
     // Wavefront reduction: butterfly over the 64 lanes, then the wave adds into its workgroup's own 64-byte slot of the counter
     // table with a plain read-modify-write (8 atomics per wave onto 8 shared words cost ~60 us per launch at 1024 waves).
@@ -614,7 +637,11 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
         sh_out[slot][OUT_VOTE][lane] = (uint64_t)(uint32_t)g.voted_for | ((uint64_t)(uint32_t)g.role << 32);
         lds_barrier();
     }
-    if (active) store_group(p.t, gi, g, pe, F);
+    // (the table's column addresses are formed again here: kept from load_group across the round loop they cost the 128-VGPR variant of
+    // step32_kernel four registers' worth of scratch spills)
+    uint32_t gi_out = gi;
+    RG_FRESH_VGPR(gi_out);
+    if (active) store_group(p.t, gi_out, g, pe, F);
 }
 
 template <int F, bool SPARSE>
@@ -626,15 +653,15 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 
 // ---- the 32-bit body on compact rows ------------------------------------------------------------------------------------------
 // Same protocol as split_body, with everything that crosses LDS half as wide and one round more of slack:
-//   event   r+2 : {hdr', aux} as one 8-byte and {a, b, c, d} as one 16-byte LDS store into a FOUR-slot ring, written two rounds ahead (the
-//                 I/O wavefront is never the one that is waited for). With the register budget of launches up to 65 536 rows (PREFETCH) the
-//                 deciding wavefront reads event r+1 while it decides event r, into a second register set — the round loop is written out
-//                 twice so that the two sets swap roles without a copy (as a rotating set the six registers cost 53 copies per round):
-//                 a round no longer opens with an LDS round trip (same-box A/B 0.0961 -> 0.0940 ms at config 3, profiles/r03m_event_prefetch_ab.jsonl)
-//   outcome r-1 : {resp_term, flags, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows (two-slot ring)
+//   event   r+2 : {class word, aux, n, header} and {a, b, c, d} as two 16-byte LDS stores into a FOUR-slot ring, written two rounds ahead (the
+//                 I/O wavefront is never the one that is waited for). (Round 3 had the deciding wavefront read event r+1 while it decided
+//                 event r, into a second register set, the round loop written out twice: worth 2 % then, nothing since tier 1 went to
+//                 sign words — the two copies of the loop disagree about the registers of the group image, 11 copies per round —
+//                 profiles/r04g_io_trims_and_prefetch_ab.jsonl. Gone.)
+//   outcome r-1 : {resp_term, predicate word, role_epoch, commit} and {log_from, term, votedFor, role} as two 16-byte rows (two-slot ring)
 // and no header-addressed loads at all: the term shared by the carried entries is IN the row (RG_HDR_SAME_TERM), so the I/O wavefront's
 // stream is two loads per row, issued six rounds ahead of the decision, four rows in registers (the loop is unrolled by four: no copies).
-// The deciding wavefront keeps a GroupT<int32_t>; a row that tier 1 does not decide is handed to the general handlers on a widened copy
+// The deciding wavefront keeps a GroupN (rg_tier1n.hpp); a row that tier 1 does not decide is handed to the general handlers on a widened copy
 // of the image and the result is narrowed back.
 // Returns false when the workgroup left the 32-bit domain (a group or a Leadership.State value at or above 2^30 at load, a row field
 // outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
@@ -688,7 +715,7 @@ __device__ __forceinline__ uint32_t expand_by_table(const uint32_t *lutm, const 
     return ((int32_t)w < 0) ? (w & 0x00FFFFFFu) : fast;
 }
 
-template <int F, bool SPARSE, bool PREFETCH>
+template <int F, bool SPARSE>
 __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
     typedef SplitLds<F, true> L;
@@ -726,11 +753,11 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                  b_logfx = reinterpret_cast<uint64_t>(p.logfx), b_persist = reinterpret_cast<uint64_t>(p.persist);
         RG_OWN_SGPRS(b_head); RG_OWN_SGPRS(b_q); RG_OWN_SGPRS(b_reply); RG_OWN_SGPRS(b_logfx); RG_OWN_SGPRS(b_persist);
         const uint64_t round_rows = p.count;
-        const uint32_t off8 = ir * 8u, off16 = ir * 16u;
+        const uint32_t irm = ir & 0x0FFFFFFFu;           // (spelled out for the instruction selector: ir < count < 2^28)
         auto fetch = [&](uint32_t r, Row32 &x) {
             const uint64_t rb = (uint64_t)(r < p.rounds ? r : last_round) * round_rows;
-            x.h = nt_load_at<U32x2>(b_head + rb * 8u, off8);
-            x.q = nt_load_at<I32x4>(b_q + rb * 16u, off16);
+            x.h = nt_load_at<U32x2>(b_head + rb * 8u, irm);
+            x.q = nt_load_at<I32x4>(b_q + rb * 16u, irm);
         };
         // the tables (only this wavefront reads them: no barrier needed, its own LDS operations are ordered)
 #pragma unroll
@@ -754,16 +781,19 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             // the deciding wavefront hands over truth values, not flags (rg_tier1n.hpp): the flags, the role field and the "valid iff REPLIED" rule are made here
             const uint32_t flags_all = expand_by_table(sh_lutm, sh_lute, (uint32_t)o0.y) | ((uint32_t)o1.w << RG_F_ROLE_SHIFT), flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
             rg_reply_t rep;
-            rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
-            if (active) nt_store_at(b_reply + rb16, off16, rep);
-            const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-            if (w_lfx) nt_store_at(b_logfx + rb16, off16, I64x2{(int64_t)o0.w, (int64_t)o1.x});
-            if (active & ((flags & RG_F_PERSIST) != 0)) {
+            // (every term / index of this body is in [0, 2^31): zero-extended below, no v_ashr)
+            rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)(uint32_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
+            // (lanes past the end of the batch shadow its last row in everything — same group, same events, same outcome: they store it again,
+            // to the same address; an exec mask around three stores costs more than the duplicates of one workgroup)
+            nt_store_at(b_reply + rb16, irm, rep);
+            const bool w_lfx = ((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST);
+            if (w_lfx) nt_store_at(b_logfx + rb16, irm, I64x2{(int64_t)(uint32_t)o0.w, (int64_t)(uint32_t)o1.x});
+            if ((flags & RG_F_PERSIST) != 0) {
                 rg_persist_t per;
-                per.term = (int64_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
-                nt_store_at(b_persist + rb16, off16, per);
+                per.term = (int64_t)(uint32_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
+                nt_store_at(b_persist + rb16, irm, per);
             }
-            tally.add(RG_HDR_KIND(hdr), flags, status);
+            tally.add_packed(RG_HDR_KIND(hdr), flags, status);
         };
         // Rows r+2 .. r+5 are in registers at the top of round r, row k in buf[k & 3]; the loop is unrolled by four so that the indices are
         // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
@@ -777,9 +807,14 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         }
         lds_barrier();                                   // events 0, 1 and the mark of the state load are visible
         { const uint32_t seen0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(seen0) == 1u) return false; }
+        // The mark is READ right after a barrier and LOOKED AT just before the next one: the read's latency is spent on this round's own work,
+        // and a workgroup that is leaving has published an event and stored an outcome row too many — nothing anybody reads (the 64-bit body
+        // rewrites every outcome row).
         bool bailed = false;
+        uint32_t seen = 0u;                              // the mark as it stood after the previous barrier
         RG_PROBE_BEGIN();
         for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
+            if ((r0 & 127u) == 124u) tally.spill();       // (the byte counters of add_packed)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t r = r0 + (uint32_t)k;
@@ -791,15 +826,17 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                 hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
                 fetch(r + 6u, x);
                 RG_PROBE_MARK(1);
+                const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);      // round r - 1 (or earlier) left the domain: mark <= r + 1
+                if ((mark != 0u) & (mark <= r + 1u)) { bailed = true; break; }
                 lds_barrier();
                 RG_PROBE_MARK(2);
-                const uint32_t seen = *sh_bail;
-                const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);
-                if ((mark != 0u) & (mark <= r + 2u)) { bailed = true; break; }
+                seen = *sh_bail;
             }
         }
         if (bailed) return false;
+        { const uint32_t mark = __builtin_amdgcn_readfirstlane(seen); if (mark != 0u) return false; }      // the last round did
         retire(last_round, hdr_m1);
+        tally.spill();
 #if defined(RG_PROBE)
         RG_PROBE_FLUSH(0);
 #elif defined(RG_PROBE_HWID)
@@ -835,14 +872,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     lds_barrier();
     if (bailed) return false;
     RG_PROBE_BEGIN();
-    // One round. The event of round r is in registers (h, q) when the round starts: it was read from the ring a round earlier — it has been
-    // there since round r-2 — so the round does not open with an LDS round trip; this round reads event r+1 into (hn, qn). The two register
-    // sets swap roles every round: the loop is written out twice (no copies).
-    auto round = [&](const uint32_t r, const I32x4 &h, const I32x4 &q, I32x4 &hn, I32x4 &qn) {
-        if constexpr (PREFETCH) {
-            hn = sh_evh[(r + 1u) & 3u][lane];
-            qn = sh_evq[(r + 1u) & 3u][lane];
-        }
+    auto round = [&](const uint32_t r) {
+        const I32x4 h = sh_evh[r & 3u][lane], q = sh_evq[r & 3u][lane];
         RG_PROBE_MARK(0);
         OutN out;
         const sw done = tier1n<F>(p, g, pe, out, h.x, (uint32_t)h.y, h.z, q.x, q.y, q.z, q.w);
@@ -882,30 +913,18 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         lds_barrier();
         RG_PROBE_MARK(3);
     };
-    if constexpr (PREFETCH) {
-        I32x4 h0 = sh_evh[0][lane], h1{0, 0, 0, 0};
-        I32x4 q0 = sh_evq[0][lane], q1{0, 0, 0, 0};
-        for (uint32_t r = 0; r < p.rounds; r += 2u) {
-            round(r, h0, q0, h1, q1);
-            if (bailed) break;
-            if (r + 1u >= p.rounds) break;
-            round(r + 1u, h1, q1, h0, q0);
-            if (bailed) break;
-        }
-    } else {                                             // the 128-VGPR budget has no room for a second event: read it where it is used
-        for (uint32_t r = 0; r < p.rounds; r++) {
-            I32x4 h = sh_evh[r & 3u][lane], hn;
-            I32x4 q = sh_evq[r & 3u][lane], qn;
-            round(r, h, q, hn, qn);
-            if (bailed) break;
-        }
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        round(r);
+        if (bailed) break;
     }
     if (bailed) return false;
     RG_PROBE_FLUSH(4);
     RG_HWID_END(0);
     if (active) {
         const Group g64 = widen(g);
-        store_group(p.t, gi, g64, pe, F);
+        uint32_t gi_out = gi;
+        RG_FRESH_VGPR(gi_out);
+        store_group(p.t, gi_out, g64, pe, F);
     }
     return true;
 }
@@ -922,7 +941,7 @@ template <int F, bool SPARSE, int WAVES>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    if (narrow_body<F, SPARSE, WAVES == 1>(p, smem)) return;
+    if (narrow_body<F, SPARSE>(p, smem)) return;
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
     // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic
     split_body<F, SPARSE, true>(p, smem);

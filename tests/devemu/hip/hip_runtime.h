@@ -77,6 +77,7 @@ extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kern
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define RG_GLOBAL_AS                 /* rg_step.hpp: global-memory pointers made from integers */
 #define RG_OWN_SGPRS(v) ((void)0)
+#define RG_FRESH_VGPR(v) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) (::hipemu::lane_yield())
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
 #define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */

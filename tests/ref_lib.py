@@ -38,6 +38,7 @@ def lib():
         L.ref_read_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
         L.ref_submit.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
         L.ref_clock.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_hold.argtypes = [C.c_void_p, C.c_int]
         L.ref_replicate.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 5
         L.ref_health_failure.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.ref_ready.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
@@ -109,6 +110,19 @@ class RefTable:
         if rc:
             raise ValueError("ref_submit failed: %d" % rc)
         return out
+
+    def submit_held(self, first, then):
+        """`first` (one round of response callbacks) is delivered WITHOUT draining the groups' event loops — the callbacks' off-loop halves have
+        run (the CAS of the membership filter, ...), the loop tasks they queued at the head have not — then `then` (one round) runs its handlers
+        and the loops are drained: the interleaving in which the loop thread was already inside the second task when the callback's thread
+        came by (context/RaftContext.java:205-215, support/EventLoop.java:87-101). Returns both outcomes."""
+        assert first.rounds == 1 and then.rounds == 1
+        assert lib().ref_hold(self._h, 1) == 0
+        try:
+            a = self.submit(first)
+        finally:
+            lib().ref_hold(self._h, 0)
+        return a, self.submit(then)
 
     def submit_timed(self, batch, now, fill=0):
         return self.submit(batch, fill=fill, now=now)

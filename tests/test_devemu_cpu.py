@@ -58,6 +58,10 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     assert legs["packed_bytes_per_decision"] < legs["wide_bytes_per_decision"]
     rt = d["cpu_baseline"].get("reference_translated")
     assert rt is None or "error" not in rt, rt
+    r = d["roofline"]                                                           # round 4: a denominator that cannot exceed 1, the 64-bit body timed beside the 32-bit one
+    assert r["layout_floor_bytes"] > 0 and 0 < r["frac_of_layout_floor"] and r["layout_floor_bytes"] < r["algorithmic_bytes_per_launch"]
+    assert r["ms_int64_body"] > 0 and r["value_int64_body"] > 0 and r["int64_body_counters_equal"] is True
+    assert "golden" in d and "model_overcharges" in r
 
 
 def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):

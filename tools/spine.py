@@ -52,16 +52,17 @@ def main():
     hdr = next(i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l)
     a, opsa = walk(K, hdr, [True, True, True])                   # skip {rare, election}, skip the general handlers
     b, opsb = walk(K, hdr, [False, True, False, True, True])     # enter that branch, skip rare, enter election, skip the general handlers
-    # the I/O wavefront's round: the longest barrier-to-barrier stretch that loads two rows' worth of columns and stores up to three
-    # (its loop is unrolled by four; the stretches differ by a few instructions)
+    # the I/O wavefront's round: the barrier-to-barrier stretches that load a row (two columns) and store up to three (its loop is unrolled by four)
     bars = [i for i, l in enumerate(K) if isinstr(l) and l.split()[0] == 's_barrier']
-    io = 0
+    ios = []
     for x, y in zip(bars, bars[1:]):
         seg = [l.split()[0] for l in K[x:y] if isinstr(l)]
         if sum(o.startswith('global_load') for o in seg) == 2 and sum(o.startswith('global_store') for o in seg) == 3 and len(seg) < 600:
-            io = max(io, len(seg))
+            ios.append(len(seg))
+    ios = ios[:4]                              # (a fifth such stretch belongs to the 64-bit body)
+    io = (sum(ios) + len(ios) - 1) // max(len(ios), 1)
     cls = lambda ops, p: sum(v for k, v in ops.items() if k.startswith(p))   # noqa: E731
-    print("I/O wavefront: %d instructions per round (longest of the unrolled four)" % io)
+    print("I/O wavefront: %d instructions per round (mean of the unrolled four: %s)" % (io, ios))
     print("main %d instructions (v_cmp %d, v_cndmask %d, s_and/s_or %d, ds_ %d, v_mov %d); election %d (v_cmp %d, v_cndmask %d, s_and/s_or %d, v_mov %d)"
           % (a, cls(opsa, 'v_cmp'), cls(opsa, 'v_cndmask'), cls(opsa, 's_and') + cls(opsa, 's_or'), cls(opsa, 'ds_'), cls(opsa, 'v_mov'),
              b, cls(opsb, 'v_cmp'), cls(opsb, 'v_cndmask'), cls(opsb, 's_and') + cls(opsb, 's_or'), cls(opsb, 'v_mov')))
