@@ -947,6 +947,16 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES
     split_body<F, SPARSE, true>(p, smem);
 }
 
+// RG_FORCE_WIDE=1 (differential tests; bench.py's int64-body pass): the 64-bit body on compact rows from the start, as a kernel of its own name —
+// a profile of a run that has both lists them apart (the 32-bit body's launches are what `roofline` describes)
+template <int F, bool SPARSE, int WAVES>
+__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_wide_kernel(const StepParams p)
+{
+    __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
+    if (threadIdx.x == 0) RG_NOTE_FALLBACK();
+    split_body<F, SPARSE, true>(p, smem);
+}
+
 template <int F>
 static hipError_t launch_single(const StepParams &p, bool sparse, hipStream_t s)
 {
@@ -974,6 +984,16 @@ static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s
     if (blocks == 0) return hipSuccess;
     if (p.count >= (1u << 28)) return hipErrorInvalidValue;       // the I/O wavefront addresses a row as scalar base + 32-bit lane offset
     const bool many = blocks > 1024u;                    // more than one workgroup per pair of SIMDs on a 256-CU part
+    if (p.force_wide != 0) {
+        if (sparse) {
+            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+            else      hipLaunchKernelGGL((step32_wide_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        } else {
+            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, false, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+            else      hipLaunchKernelGGL((step32_wide_kernel<F, false, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        }
+        return hipGetLastError();
+    }
     if (sparse) {
         if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
         else      hipLaunchKernelGGL((step32_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);

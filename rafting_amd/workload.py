@@ -54,6 +54,8 @@ class ReplayConfig:
     p_vote_req: float = 0.002     # RequestVote / PreVote requests reaching a follower from some other candidate
     p_q5: float = 0.0             # a running candidate receives a higher-term RequestVote (Candidate.java:69-71)
     stale_cand_frac: float = 0.2  # RequestVote senders whose log is behind
+    role_sorted: bool = False     # experiment: the leader-view groups are the FIRST leader_frac of the slots instead of a hash of the group
+                                  # id — what a host gets that keeps the groups it leads in slots of their own (wavefronts become single-role)
     grant_prob: float = 0.9
     p_client: float = 0.2         # leader rounds that are client appends rather than acks
     p_reject: float = 0.02
@@ -126,7 +128,8 @@ class ReplayGenerator:
     def _init_model(self):
         n, F, cfg = self.n, self.F, self.cfg
         self.round_no = -1                       # draws for the initial state live in "round -1"
-        self.mode = np.where(self._u(0) < cfg.leader_frac, LEAD, FOLLOW).astype(np.int64)
+        lead = (np.arange(self.first, self.first + self.n) < int(cfg.leader_frac * cfg.groups)) if cfg.role_sorted else (self._u(0) < cfg.leader_frac)
+        self.mode = np.where(lead, LEAD, FOLLOW).astype(np.int64)
         self.term = 1 + self._ri(1, 8)
         self.last = 8 + self._ri(2, 1 << 20)
         self.last_term = self.term.copy()

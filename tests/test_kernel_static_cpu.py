@@ -17,7 +17,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 K32 = "_ZN2rg13step32_kernelILi4ELb0ELi%dEEEvNS_10StepParamsE"
-STEP_KERNELS = [K32 % 1, K32 % 4, "_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE", "_ZN2rg11step_kernelILi4ELb0EEEvNS_10StepParamsE"]
+STEP_KERNELS = [K32 % 1, K32 % 4, (K32 % 1).replace("13step32_kernel", "18step32_wide_kernel"), (K32 % 4).replace("13step32_kernel", "18step32_wide_kernel"), "_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE", "_ZN2rg11step_kernelILi4ELb0EEEvNS_10StepParamsE"]
 
 
 @pytest.fixture(scope="module")

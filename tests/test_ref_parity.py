@@ -153,6 +153,26 @@ def test_baseline_replays_oracle_vs_reference_code(number, groups, rounds):
     compare_states(canonical_state(ref.read_state()), canonical_state(orc.read_state()), "config %d" % number)
 
 
+@pytest.mark.slow
+def test_ten_million_rows_of_config3_oracle_vs_reference_code():
+    """>= 10^7 rows of the metric's configuration (65 536 groups x 5, 160 rounds in five launches) through the reference's own
+    code and through the oracle: every outcome row and the final state. About two minutes (the translated reference runs 2.5 x 10^5 rows/s)."""
+    cfg = workload.config(3, 65536)
+    gen = workload.ReplayGenerator(cfg)
+    st0 = gen.initial_state()
+    orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    ref = ref_lib.RefTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc.load_state(st0)
+    ref.load_state(st0)
+    rows = 0
+    for k in range(5):
+        b = gen.next_batch(32)
+        compare_outcomes(ref.submit(b), orc.submit(b), "config 3, launch %d" % k)
+        rows += b.rounds * b.count
+    compare_states(canonical_state(ref.read_state()), canonical_state(orc.read_state()), "config 3 after %d rows" % rows)
+    assert rows >= 10_000_000
+
+
 def test_send_side_oracle_vs_reference_code():
     """N1: what Leader.replicateLog itself ships (recorded by the RaftService stand-in) against orc_replicate, on the
     states a fuzzed run leaves behind, heartbeat and command paths, with in-flight gating"""

@@ -82,6 +82,10 @@ for step in "$@"; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 $C 2>>$OUT/ab5.err | tee -a $OUT/ab5.jsonl | line "$C $L"; done; done ;;
     probe2) for L in ${LIBS}; do for C in "--config 2" "" "--config 4" "--config 5 --groups-per-gpu 65536"; do echo "== $L $C" | tee -a $OUT/probe2.txt     # -DRG_PROBE libraries: section timers per round
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 10 --warmup 2 $C 2>>$OUT/probe2.err | tee -a $OUT/probe2.jsonl | python tools/probe.py | tee -a $OUT/probe2.txt; done; done ;;
+    sorted) for i in 1 2; do for L in ${LIBS}; do for OV in "" "role_sorted=True"; do      # the class-ballot experiment (tools/experiments/class_ballots.patch): hashed vs role-sorted slots
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 ${OV:+--override "$OV"} 2>>$OUT/sorted.err | tee -a $OUT/sorted.jsonl | line "c3 ${OV:-hashed} $L"; done; done; done
+        for L in ${LIBS}; do for OV in "" "role_sorted=True"; do
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --config 4 ${OV:+--override "$OV"} 2>>$OUT/sorted.err | tee -a $OUT/sorted.jsonl | line "c4 ${OV:-hashed} $L"; done; done ;;
     issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac
