@@ -86,6 +86,8 @@ for step in "$@"; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 ${OV:+--override "$OV"} 2>>$OUT/sorted.err | tee -a $OUT/sorted.jsonl | line "c3 ${OV:-hashed} $L"; done; done; done
         for L in ${LIBS}; do for OV in "" "role_sorted=True"; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --config 4 ${OV:+--override "$OV"} 2>>$OUT/sorted.err | tee -a $OUT/sorted.jsonl | line "c4 ${OV:-hashed} $L"; done; done ;;
+    shards) for C in "--config 4" "--config 5" ""; do for L in ${LIBS}; do       # experiment libraries on the 131 072-group shards (and config 3)
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --no-int64-pass $C 2>>$OUT/shards.err | tee -a $OUT/shards.jsonl | line "${C:-c3} $L"; done; done ;;
     issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac
