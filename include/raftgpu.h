@@ -336,7 +336,12 @@ int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outco
  * outcome columns, per-row status), same results: the kernel decides a workgroup's 64 groups on 32-bit values while every value of
  * those groups and of their rows is below 2^30 and restarts that workgroup's rounds in 64-bit arithmetic at the first value that is
  * not — nothing was written to the table by then, outcome rows are written again — so a table may hold any int64 state.
- * Rows whose values do not fit int32 cannot be expressed in this format at all: submit those batches through rg_submit. */
+ * Rows whose values do not fit int32 cannot be expressed in this format at all: submit those batches through rg_submit.
+ * The 32-bit tier's domain also covers the small fields it compares: role epochs, elected epochs and vote counts below 2^30, node ids >= -1,
+ * `aux` below 2^30 where it is a role epoch or the entries' term, fewer than 2^24 rounds per launch — anything else is decided by the 64-bit
+ * body as well, with the same results. Limit of the format: at most 2^28 - 1 rows per round (a row is addressed as scalar base + 32-bit lane
+ * offset); larger batches are refused (-2, rg_last_error). RG_FORCE_WIDE=1 in the environment of rg_table_create makes every compact batch of
+ * that table take the 64-bit body ("rg::step32_wide_kernel" in a profile): differential tests, and bench.py's int64-body pass. */
 int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, int memspace);
 /* Host-side packer (no device involved): rewrites a wide batch into caller buffers head[rows], abcd[rows], entry_terms[<= in->entry_count].
  * AppendEntries rows whose entries all have one term get RG_HDR_SAME_TERM and carry it in aux; the others keep their terms, renumbered.

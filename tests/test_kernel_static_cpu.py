@@ -67,3 +67,18 @@ def test_a_round_stays_within_its_instruction_budget(assembly):
     # tables: 186 / 336 and 139. Every instruction is four cycles of every round of every SIMD.
     assert 0 < main <= 195 and 0 < election <= 345, p.stdout
     assert 0 < io <= 150, p.stdout
+
+
+def test_sign_word_primitives_and_the_io_wavefronts_tables(tmp_path):
+    """tests/native/tier1n_tables.cpp, compiled for the host through the header shim of tests/devemu: s_lt / s_ne / s_pos on the borders of their
+    domain (and the NO_NODE exception tier 1 relies on), the predicate word's two tables against expand_predicates() for every 14-bit word,
+    the class word (table entry + per-row corrections) against the plain definition of every class bit for 7.3 M (cluster, self, kind, slot,
+    flag, same-term, n, aux, field) combinations in and out of the 32-bit tier's domain."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "tier1n_tables")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "tests", "devemu"), "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "native", "tier1n_tables.cpp"), os.path.join(ROOT, "tests", "devemu", "emu_runtime.cpp"), "-pthread", "-o", exe],
+                   check=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "tier1n tables ok" in p.stdout, p.stdout[-3000:]
