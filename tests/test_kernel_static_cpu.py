@@ -48,14 +48,12 @@ def test_step_kernels_use_no_flat_memory_instructions(assembly, kernel):
 
 
 def test_register_and_scratch_budgets(assembly):
-    bench = kernel_text(assembly, K32 % 1)                # launches up to 65 536 rows: three wavefronts per SIMD, nothing in scratch
-    assert descriptor(bench, ".amdhsa_private_segment_fixed_size") == 0
-    assert descriptor(bench, ".amdhsa_next_free_vgpr") <= 168
-    shard = kernel_text(assembly, K32 % 4)                # beyond: four wavefronts per SIMD (eight workgroups per CU)
-    assert descriptor(shard, ".amdhsa_next_free_vgpr") <= 128
-    assert descriptor(shard, ".amdhsa_private_segment_fixed_size") <= 32     # (spills of the 64-bit fallback's prologue only)
-    for k in (K32 % 1, K32 % 4):
-        assert descriptor(kernel_text(assembly, k), ".amdhsa_group_segment_fixed_size") <= 20 * 1024       # eight workgroups per CU fit 160 KB
+    wide = lambda k: k.replace("13step32_kernel", "18step32_wide_kernel")     # noqa: E731
+    for k in (K32 % 1, K32 % 4, wide(K32 % 1), wide(K32 % 4)):
+        text = kernel_text(assembly, k)
+        assert descriptor(text, ".amdhsa_private_segment_fixed_size") == 0, k       # nothing in scratch, in either body of either variant
+        assert descriptor(text, ".amdhsa_next_free_vgpr") <= 128, k                  # four wavefronts per SIMD: eight workgroups per CU
+        assert descriptor(text, ".amdhsa_group_segment_fixed_size") <= 20 * 1024, k  # ... whose LDS fits 160 KB
 
 
 def test_a_round_stays_within_its_instruction_budget(assembly):
