@@ -30,9 +30,9 @@
 //   tier 1  tier1<V> — the rows a cluster produces in operation (AppendEntries at a follower whose prevLog is the log tail,
 //           acks at a prepared leader, client appends, the whole election traffic: timeouts, vote requests at a follower,
 //           vote replies that count / win / carry a higher term / arrive late, a leader stepping down on a higher-term ack)
-//           with selects only, under preconditions that make every one of them a strict special case of tier 2.
-//           V = int64_t: any values. V = int32_t: the same statements on 32-bit values, used by the compact-format kernel
-//           while every value of a workgroup's groups and rows is below 2^30 (rg_kernels.hip: step32_kernel).
+//           with selects only, under preconditions that make every one of them a strict special case of tier 2. Instantiated at
+//           V = int64_t by the 64-bit bodies. The compact-format kernel's 32-bit body has its own statement of the same classes, in
+//           sign words: rg_tier1n.hpp (tier1n), used while every value of a workgroup's groups and rows is below 2^30.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -324,20 +324,6 @@ struct GroupT {
     }
 };
 typedef GroupT<int64_t> Group;
-typedef GroupT<int32_t> Group32;
-
-// 32-bit image <-> 64-bit image (the general handlers always work on the 64-bit one)
-__device__ __forceinline__ Group widen(const Group32 &n)
-{
-    Group g;
-    g.term = n.term; g.commit = n.commit; g.epoch_index = n.epoch_index; g.epoch_term = n.epoch_term; g.first = n.first; g.last = n.last;
-    g.elected_term = n.elected_term;
-    g.s0 = n.s0; g.s1 = n.s1; g.s2 = n.s2; g.s3 = n.s3; g.t0 = n.t0; g.t1 = n.t1; g.t2 = n.t2; g.t3 = n.t3; g.lt = n.lt; g.top = n.top;
-    g.voted_for = n.voted_for; g.leader = n.leader; g.votes = n.votes; g.role = n.role; g.rc = n.rc;
-    g.role_epoch = n.role_epoch; g.elected_epoch = n.elected_epoch; g.pending = n.pending;
-    g.td = n.td; g.prepared = n.prepared; g.log_dirty = n.log_dirty; g.peers_dirty = n.peers_dirty;
-    return g;
-}
 // every term / index of the image is in [0, limit)
 __device__ __forceinline__ bool fits32(const Group &g, uint32_t limit)
 {
@@ -348,19 +334,6 @@ __device__ __forceinline__ bool fits32(const Group &g, uint32_t limit)
     w = mx(w, mx(mx(mx((uint64_t)g.s0, (uint64_t)g.s1), mx((uint64_t)g.s2, (uint64_t)g.s3)), mx(mx((uint64_t)g.t0, (uint64_t)g.t1), mx((uint64_t)g.t2, (uint64_t)g.t3))));
     return w < (uint64_t)limit;
 }
-__device__ __forceinline__ Group32 narrow(const Group &g)
-{
-    Group32 n;
-    n.term = (int32_t)g.term; n.commit = (int32_t)g.commit; n.epoch_index = (int32_t)g.epoch_index; n.epoch_term = (int32_t)g.epoch_term;
-    n.first = (int32_t)g.first; n.last = (int32_t)g.last; n.elected_term = (int32_t)g.elected_term;
-    n.s0 = (int32_t)g.s0; n.s1 = (int32_t)g.s1; n.s2 = (int32_t)g.s2; n.s3 = (int32_t)g.s3;
-    n.t0 = (int32_t)g.t0; n.t1 = (int32_t)g.t1; n.t2 = (int32_t)g.t2; n.t3 = (int32_t)g.t3; n.lt = (int32_t)g.lt; n.top = (int32_t)g.top;
-    n.voted_for = g.voted_for; n.leader = g.leader; n.votes = g.votes; n.role = g.role; n.rc = g.rc;
-    n.role_epoch = g.role_epoch; n.elected_epoch = g.elected_epoch; n.pending = g.pending;
-    n.td = g.td; n.prepared = g.prepared; n.log_dirty = g.log_dirty; n.peers_dirty = g.peers_dirty;
-    return n;
-}
-
 // ---- Leadership.State of this lane's group in LDS -------------------------------------------------------------------
 // Wide: four [follower][lane] columns of 64-bit values. Narrow (32-bit body): one 16-byte record {lastEpoch, nextIndex, matchIndex,
 // recentRejection} per follower as [follower][lane], plus the F matchIndex values again as one [lane] row of 16 (F <= 4) or 32
@@ -950,7 +923,6 @@ template <int F, class V, class PE>
 __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe, FxT<V> &fx, bool allow, uint32_t hdr, uint32_t aux,
                                       V a, V b, V c, V d, V pe0)
 {
-    constexpr bool NARROW = sizeof(V) == 4;
     const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
     const bool flag = RG_HDR_FLAG(hdr) != 0;
     const uint32_t self = (uint32_t)p.self;
@@ -1004,8 +976,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     const bool ack_drop = ack_any & (aux != g_repoch);               // AsyncHead aborted: response dropped
 
     // ---- client append at a leader ----------------------------------------------------------------
-    bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
-    if constexpr (NARROW) fc = fc & ((uint32_t)g_last + n < STATE_LIMIT);     // (n < 2^20: the sum cannot wrap)
+    const bool fc = allow & (kind == RG_EV_CLIENT_APPEND) & (role == RG_LEADER) & (n >= 1u) & has_log;
     const bool fc_newrun = fc & (lt != g_term);
     const bool fc_prepare = fc & !g_prep;
 
