@@ -10,7 +10,7 @@ import pytest
 
 from rafting_amd import abi, engine
 from tests import fuzz, kat_scenarios, oracle_lib
-from tests.helpers import compare_outcomes, compare_states, make_state, simple_log
+from tests.helpers import set_group, compare_outcomes, compare_states, make_state, simple_log
 
 pytestmark = pytest.mark.gpu
 
@@ -619,6 +619,33 @@ def compact_multi_round_case(G, P, rounds):
             else:
                 b.put(r, g, abi.EV_TIMEOUT)
     _compact_vs_oracle(G3, 3, 0, st, b, "client appends towards 2^31", expect_fallbacks=1)
+
+    # round 4: the small fields the sign words of rg_tier1n.hpp compare have a domain too. Workgroup 0: leaders and candidates whose role epoch lies
+    # at 2^30 + k from the start (the state load leaves the domain), answered by acks / vote replies that name it, and that do not; workgroup 1:
+    # the same with small epochs but rows whose `aux` — a role epoch there — is 2^30 or 2^31 + 5 (the row leaves the domain: s_ne() would read an
+    # operand that differs in bit 31 as EQUAL); workgroup 2: the same traffic entirely inside the domain, which must stay in the 32-bit body.
+    G4, R4 = 192, 6
+    st = abi.GroupState(G4, 5)
+    log = (1, [(1, 4), (51, 5)], 100)
+    for g in range(G4):
+        big = g < 64
+        ep = (LIM + g) if big else 3 + (g % 5)
+        if g % 2:
+            set_group(st, g, role=abi.CANDIDATE, term=6, voted_for=0, role_epoch=ep, votes=1 + (g % 3), log=log, commit=40)
+        else:
+            set_group(st, g, role=abi.LEADER, term=5, voted_for=0, role_epoch=ep, repl_prepared=1, log=log, peers=[(0, 101, 90, 0, 0)] * 4, commit=40)
+    b = abi.Batch(R4, G4)
+    for r in range(R4):
+        for g in range(G4):
+            ep = int(st.role_epoch[g])
+            aux = ep if (g + r) % 3 else ep + 1                          # mostly the live participant, sometimes a fenced one
+            if 64 <= g < 128 and r == 3:
+                aux = LIM if g % 4 else (1 << 31) + 5                    # a row out of the domain in the middle of the launch
+            if g % 2:
+                b.put(r, g, abi.EV_RV_REPLY, slot=1 + (r % 4), flag=int(r % 2 == 0), a=6, aux=aux)
+            else:
+                b.put(r, g, abi.EV_AE_ACK, slot=1 + (r % 4), flag=1, a=5, b=0, c=100, aux=aux)
+    _compact_vs_oracle(G4, 5, 0, st, b, "role epochs at and above 2^30", expect_fallbacks=2)
 
 
 def set_state_follower(st, g, term, leader, last):
