@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <stdexcept>
+#include <thread>
 
 using raftgpu::host::Entry;
 using raftgpu::host::RaftLog;
@@ -13,9 +14,14 @@ namespace wire {
 
 IngressFlusher::IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<RaftLog &(uint32_t)> log_of,
                                std::vector<int64_t> term_of_group, StableStore *store, bool wide_kernel)
-    : table_(table), ing_(ing), codec_(codec), log_of_(std::move(log_of)), term_(std::move(term_of_group)), store_(store), wide_kernel_(wide_kernel)
+    : IngressFlusher(std::vector<rg_table_t *>{table}, ing, codec, std::move(log_of), std::move(term_of_group), store, wide_kernel) {}
+
+IngressFlusher::IngressFlusher(std::vector<rg_table_t *> tables, Ingress &ing, const KryoBodyCodec &codec, std::function<RaftLog &(uint32_t)> log_of,
+                               std::vector<int64_t> term_of_group, StableStore *store, bool wide_kernel)
+    : tables_(std::move(tables)), ing_(ing), codec_(codec), log_of_(std::move(log_of)), term_(std::move(term_of_group)), store_(store), wide_kernel_(wide_kernel)
 {
-    if (ing_.shards() != 1) throw std::invalid_argument("IngressFlusher serves ONE table: a sharded ingress is sealed once and its shards are decided by their tables side by side (SealedBatch::shard)");
+    if (ing_.shards() != tables_.size()) throw std::invalid_argument("IngressFlusher: one table per shard of the ingress");
+    rep_.resize(tables_.size()); lfx_.resize(tables_.size()); per_.resize(tables_.size());
     ing_.retain_bodies(true);
 }
 
@@ -49,30 +55,62 @@ void IngressFlusher::apply(uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b
     if (on_row) reactions_.push_back(Reaction{gid, head, rep});
 }
 
-struct IngressFlusher::Host : RepairHost {
+struct IngressFlusher::Host : RepairHost {               // (the gids repair_need_host hands over are the TABLE's: + first for the host's)
     IngressFlusher &fl;
     const SealedBatch &b;
     std::vector<StableStore::Record> &dirty;
-    Host(IngressFlusher &f, const SealedBatch &batch, std::vector<StableStore::Record> &d) : fl(f), b(batch), dirty(d) {}
-    int64_t term_at(uint32_t gid, int64_t index) override { auto e = fl.log_of_(gid).get(index); return e ? e->term : -1; }
-    int64_t conflict(uint32_t gid, int64_t first, const int64_t *terms, uint32_t n) override
+    uint32_t shard, first;
+    Host(IngressFlusher &f, const SealedBatch &batch, std::vector<StableStore::Record> &d, uint32_t s) : fl(f), b(batch), dirty(d), shard(s), first(batch.shard[s].first_gid) {}
+    int64_t term_at(uint32_t gid, int64_t index) override { auto e = fl.log_of_(first + gid).get(index); return e ? e->term : -1; }
+    int64_t conflict(uint32_t gid, int64_t first_index, const int64_t *terms, uint32_t n) override
     {
         std::vector<Entry> es;
-        for (uint32_t k = 0; k < n; k++) es.push_back(Entry{first + (int64_t)k, terms[k]});
-        auto c = fl.log_of_(gid).conflict(es);
+        for (uint32_t k = 0; k < n; k++) es.push_back(Entry{first_index + (int64_t)k, terms[k]});
+        auto c = fl.log_of_(first + gid).conflict(es);
         return c ? c->index : 0;
     }
-    int64_t epoch_index(uint32_t gid) override { return fl.log_of_(gid).epoch().index; }
-    int submit(const rg_batch_t &in, const rg_outcome_t &out) override { return rg_submit(fl.table_, &in, &out, RG_MEM_HOST); }
+    int64_t epoch_index(uint32_t gid) override { return fl.log_of_(first + gid).epoch().index; }
+    int submit(const rg_batch_t &in, const rg_outcome_t &out) override { return rg_submit(fl.tables_[shard], &in, &out, RG_MEM_HOST); }
     void applied(uint32_t gid, size_t cell, const rg_reply_t &rep, const rg_logfx_t &lfx, const rg_persist_t &per) override
     {
         size_t n = 0;
-        const char *body = fl.ing_.body(b, 0, cell, n);
-        const rg_ev_quad32_t q = b.batch.abcd[cell];
-        fl.apply(gid, b.batch.head[cell], q.a, q.b, body, n, rep, lfx, per, dirty);
+        const char *body = fl.ing_.body(b, shard, cell, n);
+        const rg_ev_quad32_t q = b.shard[shard].batch.abcd[cell];
+        fl.apply(first + gid, b.shard[shard].batch.head[cell], q.a, q.b, body, n, rep, lfx, per, dirty);
         fl.st_.repaired++;
     }
 };
+
+// the launch of one shard on its table (synchronous: the outcome rows are in rep_ / lfx_ / per_[s] when it returns)
+int IngressFlusher::submit_shard(const SealedBatch &b, uint32_t s)
+{
+    const rg_batch32_t &sb = b.shard[s].batch;
+    const uint32_t G = sb.count, R = sb.rounds;
+    const size_t cells = (size_t)G * R;
+    rep_[s].assign(cells, rg_reply_t{0, 0, 0}); lfx_[s].assign(cells, rg_logfx_t{0, 0}); per_[s].assign(cells, rg_persist_t{0, 0, 0});
+    if (cells == 0) return 0;
+    const rg_outcome_t o{rep_[s].data(), lfx_[s].data(), per_[s].data()};
+    if (!wide_kernel_) return rg_submit32(tables_[s], &sb, &o, RG_MEM_HOST);
+    // the same rows as an rg_batch_t (the inverse of rg_batch32_pack)
+    std::vector<rg_ev_head_t> head(sb.head, sb.head + cells);
+    std::vector<rg_ev_pair_t> ab(cells), cd(cells);
+    std::vector<int64_t> terms;
+    for (size_t i = 0; i < cells; i++) {
+        const rg_ev_quad32_t q = sb.abcd[i];
+        ab[i] = rg_ev_pair_t{q.a, q.b}; cd[i] = rg_ev_pair_t{q.c, q.d};
+        const uint32_t n = RG_HDR_N(head[i].hdr);
+        if (RG_HDR_KIND(head[i].hdr) == RG_EV_AE_REQ && n > 0) {
+            const uint32_t at = (uint32_t)terms.size();
+            for (uint32_t k = 0; k < n; k++) terms.push_back((head[i].hdr & RG_HDR_SAME_TERM) ? (int64_t)head[i].aux : (int64_t)sb.entry_terms[head[i].aux + k]);
+            head[i].hdr &= ~RG_HDR_SAME_TERM;
+            head[i].aux = at;
+        }
+    }
+    rg_batch_t in{};
+    in.rounds = R; in.count = G; in.head = head.data(); in.ab = ab.data(); in.cd = cd.data();
+    in.entry_terms = terms.empty() ? nullptr : terms.data(); in.entry_count = terms.size();
+    return rg_submit(tables_[s], &in, &o, RG_MEM_HOST);
+}
 
 int64_t IngressFlusher::flush(std::vector<std::string> &out)
 {
@@ -82,54 +120,45 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
     // every way out recycles the sealed batch: the next flush() seals again (an error leaves the table and the logs where the failed call left
     // them — the caller stops, as with any table error — but does not turn the NEXT call into a logic_error out of seal())
     struct Recycle { Ingress &ing; const SealedBatch &b; bool armed = true; ~Recycle() { if (armed) ing.recycle(b); } } recycle{ing_, b};
-    const uint32_t G = b.batch.count, R = b.batch.rounds;
-    const size_t cells = (size_t)G * R;
+    const uint32_t S = (uint32_t)tables_.size();
     std::vector<StableStore::Record> dirty;
     int64_t decided = 0;
-    if (cells) {
-        rep_.assign(cells, rg_reply_t{0, 0, 0}); lfx_.assign(cells, rg_logfx_t{0, 0}); per_.assign(cells, rg_persist_t{0, 0, 0});
-        const rg_outcome_t o{rep_.data(), lfx_.data(), per_.data()};
-        int rc;
-        if (!wide_kernel_) rc = rg_submit32(table_, &b.batch, &o, RG_MEM_HOST);
-        else {                                                     // the same rows as an rg_batch_t (the inverse of rg_batch32_pack)
-            std::vector<rg_ev_head_t> head(b.batch.head, b.batch.head + cells);
-            std::vector<rg_ev_pair_t> ab(cells), cd(cells);
-            std::vector<int64_t> terms;
-            for (size_t i = 0; i < cells; i++) {
-                const rg_ev_quad32_t q = b.batch.abcd[i];
-                ab[i] = rg_ev_pair_t{q.a, q.b}; cd[i] = rg_ev_pair_t{q.c, q.d};
-                const uint32_t n = RG_HDR_N(head[i].hdr);
-                if (RG_HDR_KIND(head[i].hdr) == RG_EV_AE_REQ && n > 0) {
-                    const uint32_t at = (uint32_t)terms.size();
-                    for (uint32_t k = 0; k < n; k++) terms.push_back((head[i].hdr & RG_HDR_SAME_TERM) ? (int64_t)head[i].aux : (int64_t)b.batch.entry_terms[head[i].aux + k]);
-                    head[i].hdr &= ~RG_HDR_SAME_TERM;
-                    head[i].aux = at;
-                }
-            }
-            rg_batch_t in{};
-            in.rounds = R; in.count = G; in.head = head.data(); in.ab = ab.data(); in.cd = cd.data();
-            in.entry_terms = terms.empty() ? nullptr : terms.data(); in.entry_count = terms.size();
-            rc = rg_submit(table_, &in, &o, RG_MEM_HOST);
-        }
-        if (rc != 0) { err_ = rg_last_error(table_); return -1; }
+    {
+        // the shards' launches side by side: tables are independent (one stream each); the first on this thread
+        std::vector<int> rc(S, 0);
+        std::vector<std::thread> side;
+        for (uint32_t s = 1; s < S; s++) side.emplace_back([&, s] { rc[s] = submit_shard(b, s); });
+        rc[0] = submit_shard(b, 0);
+        for (auto &t : side) t.join();
+        for (uint32_t s = 0; s < S; s++) if (rc[s] != 0) { err_ = rg_last_error(tables_[s]); return -1; }
+    }
+    for (uint32_t s = 0; s < S; s++) {
+        const rg_batch32_t &sb = b.shard[s].batch;
+        const uint32_t G = sb.count, first = b.shard[s].first_gid;
+        const size_t cells = (size_t)G * sb.rounds;
+        if (cells == 0) continue;
         // the rows the launch applied, in (round, group) order = every group's own order
         for (size_t cell = 0; cell < cells; cell++) {
-            if (RG_HDR_KIND(b.batch.head[cell].hdr) == RG_EV_NONE) continue;
+            if (RG_HDR_KIND(sb.head[cell].hdr) == RG_EV_NONE) continue;
             decided++;
-            const uint32_t s = RG_F_STATUS(rep_[cell].flags);
-            if (s == RG_NEED_HOST || s == RG_SKIPPED_AFTER_NEED_HOST) continue;
+            const uint32_t st = RG_F_STATUS(rep_[s][cell].flags);
+            if (st == RG_NEED_HOST || st == RG_SKIPPED_AFTER_NEED_HOST) continue;
             size_t n = 0;
-            const char *body = ing_.body(b, 0, cell, n);
-            const rg_ev_quad32_t q = b.batch.abcd[cell];
-            apply((uint32_t)(cell % G), b.batch.head[cell], q.a, q.b, body, n, rep_[cell], lfx_[cell], per_[cell], dirty);
+            const char *body = ing_.body(b, s, cell, n);
+            const rg_ev_quad32_t q = sb.abcd[cell];
+            apply(first + (uint32_t)(cell % G), sb.head[cell], q.a, q.b, body, n, rep_[s][cell], lfx_[s][cell], per_[s][cell], dirty);
         }
-        Host host(*this, b, dirty);
-        if (repair_need_host(b, rep_.data(), lfx_.data(), false, host) < 0) { err_ = std::string("repair: ") + rg_last_error(table_); return -1; }
+        Host host(*this, b, dirty, s);
+        if (repair_need_host(b, rep_[s].data(), lfx_[s].data(), false, host, s) < 0) { err_ = std::string("repair: ") + rg_last_error(tables_[s]); return -1; }
     }
     // rows beside the batch (a value beyond 2^31 ...): one sparse row each, the same hint protocol
     std::vector<std::pair<size_t, rg_reply_t>> wide_replies;
     for (size_t i = 0; i < b.wide.size(); i++) {
         const HeldRow &w = b.wide[i];
+        uint32_t ws = S - 1;                                       // the shard (table) the row's group lives in
+        while (ws > 0 && b.shard[ws].first_gid > w.gid) ws--;
+        const uint32_t tgid = w.gid - b.shard[ws].first_gid;
+        rg_table_t *tbl = tables_[ws];
         rg_ev_head_t h = w.head;
         h.hdr &= ~(RG_HDR_SAME_TERM | RG_HDR_HINT_BIT);
         h.aux = RG_HDR_KIND(h.hdr) == RG_EV_AE_REQ ? 0u : h.aux;
@@ -137,10 +166,10 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
         rg_reply_t rep{0, 0, 0}; rg_logfx_t lfx{0, 0}; rg_persist_t per{0, 0, 0};
         for (int attempt = 0; attempt < 2; attempt++) {
             rg_batch_t in{};
-            in.rounds = 1; in.count = 1; in.gid = &w.gid; in.head = &h; in.ab = &ab; in.cd = &cd;
+            in.rounds = 1; in.count = 1; in.gid = &tgid; in.head = &h; in.ab = &ab; in.cd = &cd;
             in.entry_terms = w.terms.empty() ? nullptr : w.terms.data(); in.entry_count = w.terms.size(); in.hint = &hint;
             const rg_outcome_t o{&rep, &lfx, &per};
-            if (rg_submit(table_, &in, &o, RG_MEM_HOST) != 0) { err_ = rg_last_error(table_); return -1; }
+            if (rg_submit(tbl, &in, &o, RG_MEM_HOST) != 0) { err_ = rg_last_error(tbl); return -1; }
             if (RG_F_STATUS(rep.flags) != RG_NEED_HOST) break;
             if (attempt == 1) { err_ = "a row beside the batch still answers RG_NEED_HOST after its hint"; return -1; }     // as repair_need_host does
             RaftLog &log = log_of_(w.gid);
@@ -163,7 +192,8 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
     }
     if (store_ && !dirty.empty()) { store_->persist(dirty); st_.persisted += dirty.size(); }      // N3: before any reply of this batch leaves
     for (const Reaction &r : reactions_) on_row(r.gid, r.head, r.reply);                           // ... and before anything on_row sends
-    if (cells) st_.frames += ing_.emit(b, rep_.data(), out);
+    for (uint32_t s = 0; s < S; s++)
+        if (!rep_[s].empty()) st_.frames += ing_.emit(b, rep_[s].data(), out, 0, (size_t)-1, NO_CONN, s);
     for (auto &wr : wide_replies) {
         const HeldRow &w = b.wide[wr.first];
         if (w.from.conn < out.size()) st_.frames += ing_.emit_wide(w, wr.second, out[w.from.conn]) != NO_CONN;

@@ -3,6 +3,8 @@
 // every group misses the device's cached term runs in its second row -> the repair reads the hints from real MemoryLogs (six term runs each,
 // the device caches four) and applies the effects of the repaired rows one by one -> a row beyond int32 beside the batch -> the durability
 // journal before any reply -> response frames. At the end every MemoryLog, the table and the responses agree with what the requests said.
+// With a third argument S > 1 the same flow runs through a SHARDED ingress in front of S tables (block partition of the groups, one table per shard,
+// one IngressFlusher for all of them): same requests, same expectations, every table read back.
 // TEST INFRASTRUCTURE (tests/test_devemu_cpu.py). prints "ingress flusher ok=1"
 #include <cstdio>
 #include <cstdlib>
@@ -17,17 +19,22 @@ using raftgpu::host::Entry;
 using raftgpu::host::MemoryLog;
 using raftgpu::host::StableStore;
 
-#define RG(call) do { if ((call) != 0) { fprintf(stderr, "%s: %s\n", #call, rg_last_error(table)); return 1; } } while (0)
+#define RG(call) do { if ((call) != 0) { fprintf(stderr, "%s failed\n", #call); return 1; } } while (0)
 
 int main(int argc, char **argv)
 {
     const uint32_t G = argc > 1 ? (uint32_t)atoi(argv[1]) : 70;
     const char *journal = argc > 2 ? argv[2] : "/tmp/ingress_flusher_flow.journal";
+    const uint32_t S = argc > 3 ? (uint32_t)atoi(argv[3]) : 1;              // tables behind the ingress
+    const uint32_t PER = (G + S - 1) / S;                                   // groups per shard (the last one may hold fewer)
     const int P = 3, SELF = 1, F = P - 1, RUNS = 6;
     const int64_t TERM = 7, PER_RUN = 10, LAST0 = RUNS * PER_RUN;          // indices 1..60, terms 2..7; the device caches the runs from index 21 on
     const uint32_t SPECIAL = 5;                                             // the group that gets ONE request whose term lies beyond int32
-    rg_table_t *table = nullptr;
-    if (rg_table_create(0, G, P, SELF, 1, &table) != 0) { fprintf(stderr, "rg_table_create: %s\n", rg_last_error(nullptr)); return 1; }
+    std::vector<rg_table_t *> tables(S, nullptr);
+    for (uint32_t s = 0; s < S; s++) {
+        const uint32_t n = std::min(PER, G - s * PER);
+        if (rg_table_create(0, n, P, SELF, 1, &tables[s]) != 0) { fprintf(stderr, "rg_table_create: %s\n", rg_last_error(nullptr)); return 1; }
+    }
     std::vector<std::unique_ptr<MemoryLog>> logs;
     {
         std::vector<int64_t> term(G, TERM), elected_term(G, 0), commit(G, LAST0), eidx(G, 0), eterm(G, 0), first(G, 1), last(G, LAST0);
@@ -56,23 +63,26 @@ int main(int argc, char **argv)
         st.run_count = run_count.data(); st.run_offset = run_offset.data(); st.run_start = run_start.data(); st.run_term = run_term.data();
         st.peer_last_epoch = pe.data(); st.peer_next_index = pn.data(); st.peer_match_index = pm.data(); st.peer_rejection = pr.data();
         st.peer_pending = pp.data();
-        RG(rg_load_state(table, 0, G, &st));
+        for (uint32_t s = 0; s < S; s++) {                                    // shard s = groups [s * PER, ...): the columns are uniform, the run offsets per table
+            const uint32_t n = std::min(PER, G - s * PER);
+            RG(rg_load_state(tables[s], 0, n, &st));
+        }
     }
     const KryoBodyCodec codec({{"10.3.0.1", 7301}, {"10.3.0.2", 7302}, {"10.3.0.3", 7303}});
     ContextIndex index(G);
     std::vector<std::string> ids(G);
     for (uint32_t g = 0; g < G; g++) { ids[g] = "ledger/" + std::to_string(g); if (!index.insert(ids[g].data(), ids[g].size(), g)) return 2; }
     const uint32_t R = 8;
-    const size_t cells = (size_t)G * R;
+    const size_t cells = (size_t)PER * S * R;
     std::vector<rg_ev_head_t> head[2] = {std::vector<rg_ev_head_t>(cells), std::vector<rg_ev_head_t>(cells)};
     std::vector<rg_ev_quad32_t> abcd[2] = {std::vector<rg_ev_quad32_t>(cells), std::vector<rg_ev_quad32_t>(cells)};
     std::vector<int32_t> terms[2] = {std::vector<int32_t>(4096), std::vector<int32_t>(4096)};
     Ingress ing(G, R, 1, codec, index, Ingress::Buffers{head[0].data(), abcd[0].data(), terms[0].data(), terms[0].size()},
-                Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()});
+                Ingress::Buffers{head[1].data(), abcd[1].data(), terms[1].data(), terms[1].size()}, 1u << 16, S);
     ing.set_peer(0, 0);
     remove(journal);
     StableStore store(journal);
-    IngressFlusher flusher(table, ing, codec, [&](uint32_t g) -> raftgpu::host::RaftLog & { return *logs[g]; }, std::vector<int64_t>(G, TERM), &store, true);
+    IngressFlusher flusher(tables, ing, codec, [&](uint32_t g) -> raftgpu::host::RaftLog & { return *logs[g]; }, std::vector<int64_t>(G, TERM), &store, true);
 
     uint64_t seen_rows = 0, timer_resets = 0;
     flusher.on_row = [&](uint32_t, const rg_ev_head_t &, const rg_reply_t &r) { seen_rows++; timer_resets += (r.flags & RG_F_RESET_TIMER) != 0; };
@@ -130,7 +140,17 @@ int main(int argc, char **argv)
     st.run_count = run_count.data(); st.run_offset = run_offset.data(); st.run_start = run_start.data(); st.run_term = run_term.data();
     st.peer_last_epoch = pe.data(); st.peer_next_index = pn.data(); st.peer_match_index = pm.data(); st.peer_rejection = pr.data();
     st.peer_pending = pp.data();
-    RG(rg_read_state(table, 0, G, &st));
+    for (uint32_t s = 0; s < S; s++) {                                        // every table's groups into their place of the global columns
+        const uint32_t n = std::min(PER, G - s * PER), at = s * PER;
+        rg_group_state_t part = st;
+        part.current_term += at; part.voted_for += at; part.role += at; part.current_leader += at; part.timeout_detected += at; part.repl_prepared += at;
+        part.role_epoch += at; part.votes += at; part.elected_epoch += at; part.elected_term += at; part.commit_index += at; part.epoch_index += at;
+        part.epoch_term += at; part.first_index += at; part.last_index += at; part.run_count += at; part.run_offset += at;
+        part.run_start += (size_t)at * RG_TERM_RUNS; part.run_term += (size_t)at * RG_TERM_RUNS;
+        part.peer_last_epoch += (size_t)at * F; part.peer_next_index += (size_t)at * F; part.peer_match_index += (size_t)at * F;
+        part.peer_rejection += (size_t)at * F; part.peer_pending += (size_t)at * F;
+        RG(rg_read_state(tables[s], 0, n, &part));
+    }
     for (uint32_t g = 0; g < G; g++) {
         const int64_t want_last = g == SPECIAL ? LAST0 + 1 : LAST0 + 3, want_commit = g == SPECIAL ? LAST0 : LAST0 + 3;
         const int64_t want_term = g == SPECIAL ? ((int64_t)1 << 33) + TERM : TERM;
@@ -149,6 +169,6 @@ int main(int argc, char **argv)
            "%llu of %llu requests answered (%llu success), %llu wrong\n", (int)ok, (unsigned long long)s.rows, (unsigned long long)s.batches, (unsigned long long)s.repaired,
            (unsigned long long)s.wide, (unsigned long long)s.appended, (unsigned long long)s.committed, (unsigned long long)s.persisted, (unsigned long long)answers,
            (unsigned long long)requests, (unsigned long long)successes, (unsigned long long)wrong);
-    rg_table_destroy(table);
+    for (rg_table_t *t : tables) rg_table_destroy(t);
     return ok ? 0 : 1;
 }

@@ -162,8 +162,9 @@ def test_ingress_flusher_repairs_from_real_logs_and_applies_effects_on_the_emula
     subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(ROOT, "include"), os.path.join(EMU, "ingress_flusher_flow.cpp")] +
                    [os.path.join(host, f) for f in ("ingress_flusher.cpp", "ingress.cpp", "wire.cpp", "kryo_body.cpp", "raft_host.cpp", "stable_store.cpp")] +
                    ["-L" + EMU, "-l:libraftgpu_emu.so", "-Wl,-rpath," + EMU, "-pthread", "-o", exe], check=True)
-    p = subprocess.run([exe, "70", str(tmp_path / "journal")], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "ingress flusher ok=1" in p.stdout, p.stdout + p.stderr
+    for args in (["70"], ["70", "2"], ["130", "3"], ["12", "3"]):         # one table; a sharded ingress in front of 2 / 3 tables (the row beside the batch in shard 0 / 1)
+        p = subprocess.run([exe, args[0], str(tmp_path / "journal")] + args[1:], env=dict(os.environ, RG_SPLIT="0"), capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "ingress flusher ok=1" in p.stdout, p.stdout + p.stderr
 
 
 def test_three_nodes_that_exchange_nothing_but_wire_bytes_on_the_emulation(emulation_library, tmp_path):
