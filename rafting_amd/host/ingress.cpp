@@ -260,6 +260,7 @@ void Ingress::hold(Conn &c, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t 
     h.terms.assign(terms, terms + n_terms);
     if (body_len) h.body.assign(body, body_len);
     c.held.push_back(std::move(h));
+    c.held_count.store(c.held.size(), std::memory_order_relaxed);      // (what held_on() reads: the vector itself belongs to its reader and to seal())
 }
 
 // true: the row sits in the bank (or in its wide list); false: the caller keeps it for the next batch
@@ -422,16 +423,16 @@ const char *Ingress::body(const SealedBatch &b, uint32_t shard, size_t cell, siz
 }
 
 namespace {
-struct StandBack {                                                // feeders do not start a new read while the flusher wants the exclusive lock
-    std::atomic<bool> &f;
-    explicit StandBack(std::atomic<bool> &x) : f(x) { f.store(true, std::memory_order_release); }
-    ~StandBack() { f.store(false, std::memory_order_release); }
+struct StandBack {                                                // feeders do not start a new read while somebody wants the exclusive lock
+    std::atomic<uint32_t> &f;                                     // (a COUNT: seal() and held() may both be asking — ADVICE r3: with one flag the first to finish
+    explicit StandBack(std::atomic<uint32_t> &x) : f(x) { f.fetch_add(1, std::memory_order_acq_rel); }     // let the feeders loose on the other)
+    ~StandBack() { f.fetch_sub(1, std::memory_order_acq_rel); }
 };
 }  // namespace
 
 int Ingress::feed(uint32_t conn, const uint8_t *data, size_t n)
 {
-    while (sealing_.load(std::memory_order_acquire)) std::this_thread::yield();
+    while (sealing_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
     c.queued = 0;
@@ -485,7 +486,7 @@ size_t Ingress::encode_sends(uint32_t conn, int32_t self_slot, uint32_t count, c
 
 void Ingress::add_row(uint32_t conn, uint32_t gid, rg_ev_head_t head, int64_t a, int64_t b, int64_t c4, int64_t d, Origin reply_to)
 {
-    while (sealing_.load(std::memory_order_acquire)) std::this_thread::yield();
+    while (sealing_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     std::shared_lock<std::shared_mutex> lk(mu_);
     Conn &c = c_[conn];
     const uint32_t kind = RG_HDR_KIND(head.hdr);                 // (AppendEntries: entries travel in frames; NONE / unknown kinds are no rows)
@@ -538,6 +539,7 @@ const SealedBatch &Ingress::seal()
         for (HeldRow &h : c_[i].held) fresh.push_back(Waiting{std::move(h), i});
         c_[i].backlogged.fetch_add(c_[i].held.size(), std::memory_order_relaxed);
         c_[i].held.clear();
+        c_[i].held_count.store(0, std::memory_order_relaxed);
     }
     std::sort(fresh.begin(), fresh.end(), [](const Waiting &x, const Waiting &y) { return x.row.ticket < y.row.ticket; });
     for (Waiting &w : fresh) backlog_[w.row.gid].push_back(std::move(w));

@@ -200,7 +200,7 @@ public:
 
     // rows of `conn` waiting for the next batch (the reader thread of that connection asks: a reader whose rows pile up because the flusher is
     // behind stops reading its socket until the next seal — TCP pushes back on the peer — instead of letting the list grow)
-    size_t held_on(uint32_t conn) const { return c_[conn].held.size() + c_[conn].backlogged.load(std::memory_order_relaxed); }
+    size_t held_on(uint32_t conn) const { return c_[conn].held_count.load(std::memory_order_relaxed) + c_[conn].backlogged.load(std::memory_order_relaxed); }
     uint64_t refused() const { return refused_.load(std::memory_order_relaxed); }     // frames that were no decision row (unknown context, ...)
     uint64_t held() const;                                                            // rows waiting for the next batch
 
@@ -222,6 +222,7 @@ private:
         int32_t peer = RG_NO_NODE;
         std::unique_ptr<PendingRing> ring;
         std::vector<HeldRow> held;                               // held back since the last seal, in arrival order
+        std::atomic<size_t> held_count{0};                       // held.size(), for held_on() from other threads
         std::atomic<size_t> backlogged{0};                       // its rows in backlog_ (seal() moves them there)
         std::string bodies[2];                                   // (retain_bodies) request bodies of its rows, per bank
         Request q;                                               // decode scratch
@@ -260,7 +261,7 @@ private:
     SealedBatch sealed_[2];
     int fill_ = 0;                                               // bank being filled (changed under the exclusive lock)
     mutable std::shared_mutex mu_;
-    mutable std::atomic<bool> sealing_{false};                           // seal() is waiting for / holds the exclusive lock: feeders stand back (the rwlock
+    mutable std::atomic<uint32_t> sealing_{0};                           // seal() is waiting for / holds the exclusive lock: feeders stand back (the rwlock
                                                                  // alone prefers readers, a stream of overlapping feed() calls would starve the flusher)
     std::atomic<uint64_t> refused_{0}, ticket_{0};
 };
