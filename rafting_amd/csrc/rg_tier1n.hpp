@@ -31,7 +31,6 @@ typedef int32_t sw;                 // sign word: bit 31 is the truth value, bit
 __device__ __forceinline__ sw s_lt(int32_t x, int32_t y) { return (int32_t)((uint32_t)x - (uint32_t)y); }                  // x < y   (|x - y| < 2^31)
 __device__ __forceinline__ sw s_ne(int32_t x, int32_t y) { return (int32_t)(((uint32_t)x ^ (uint32_t)y) + 0x7FFFFFFFu); }   // x != y  (x ^ y < 2^31: operands that differ in bit 31 read as EQUAL)
 __device__ __forceinline__ sw s_pos(int32_t x) { return (int32_t)(0u - (uint32_t)x); }                                      // x > 0   (x > -2^31)
-__device__ __forceinline__ bool on(sw w) { return w < 0; }
 __device__ __forceinline__ uint32_t push_bit(uint32_t acc, sw w) { return (acc << 1) | ((uint32_t)w >> 31); }              // v_alignbit_b32
 
 // ---- the class word of a row (made by the I/O wavefront: class_word() in rg_step.hpp) --------------------------------------
@@ -49,7 +48,6 @@ constexpr int CW_TO = 23;           // TIMEOUT
 constexpr int CW_VQ = 22;           // RV_REQ / PV_REQ with slot < cluster
 constexpr int CW_PVQ = 21;          // PV_REQ
 constexpr int CW_NONE = 19;         // row not addressed this round
-constexpr uint32_t CW_J_MASK = 7u << 10;
 __device__ __forceinline__ sw cw_bit(int32_t cw, int bit) { return (int32_t)((uint32_t)cw << (31 - bit)); }
 
 // ---- the predicate word of a decided row (expanded by the I/O wavefront: expand_predicates() below) -------------------------
@@ -69,7 +67,7 @@ __device__ __forceinline__ uint32_t expand_predicates(uint32_t w)
 }
 
 // ---- the group image of the 32-bit body ------------------------------------------------------------------------------------------
-// GroupT<int32_t>'s fields with the four booleans as sign words (0 / -1 wherever this file writes them) and the cached precondition words.
+// GroupT's fields in 32 bits, the four booleans as sign words (0 / -1 wherever this file writes them) and the cached precondition words.
 struct GroupN {
     int32_t term, commit, epoch_index, epoch_term, first, last, elected_term;
     int32_t s0, s1, s2, s3, t0, t1, t2, t3, lt, top;
