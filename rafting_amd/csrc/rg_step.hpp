@@ -478,7 +478,7 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // LDS of a two-wavefront workgroup. The 64-bit body and the 32-bit body never run at the same time: one buffer, two layouts. On compact rows
-// (EV32) the 64-bit body's event ring carries five fields instead of eleven (no hint, the entry term is `aux`): 18 KB per workgroup at F = 4,
+// (EV32) the 64-bit body's event ring carries five fields instead of eleven (no hint, the entry term is `aux`): 18 KB per workgroup at F = 4 (19 KB with the 32-bit body's tables),
 // eight workgroups per CU instead of six.
 template <int F, bool EV32>
 struct SplitLds {
@@ -933,10 +933,11 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 #define RG_NOTE_FALLBACK() ((void)0)
 #endif
 
-// Two register budgets. WAVES = 1: whatever the allocator wants (3 wavefronts per SIMD: enough while a launch has at most one workgroup
-// per pair of SIMDs, 65 536 rows). WAVES = 4: at most 128 VGPRs, so that eight workgroups (18 KB of LDS each) are resident per CU — a
-// launch of 131 072 rows then runs in ONE pass with two deciding wavefronts per SIMD instead of a pass and a third (same-box A/B at config
-// 4's shard: 0.1994 -> 0.1307 ms per launch, profiles/r03d_w4_ab.jsonl; at 65 536 rows the smaller budget costs 2 %).
+// Two register budgets. WAVES = 1: whatever the allocator wants (launches of at most one workgroup per pair of SIMDs, 65 536 rows). WAVES = 4:
+// at most 128 VGPRs, so that eight workgroups (19 KB of LDS each) are resident per CU — a launch of 131 072 rows then runs in ONE pass with two
+// deciding wavefronts per SIMD instead of a pass and a third (round 3's same-box A/B at config 4's shard: 0.1994 -> 0.1307 ms per launch,
+// profiles/r03d_w4_ab.jsonl). Since round 4 the allocator asks for 113 / 112 VGPRs: both variants fit either budget, the two are kept for the
+// bound itself (a change that needs more registers shows up as spills in the second, not as a launch that takes two passes).
 template <int F, bool SPARSE, int WAVES>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {

@@ -1,7 +1,7 @@
 // rg_tier1n.hpp — tier 1 of the 32-bit body (step32_kernel's deciding wavefront), written in SIGN WORDS. Included by rg_step.hpp only.
 //
-// Why a second statement of tier 1. The deciding wavefront is alone on its SIMD: a round costs (instructions) x (4-5 cycles) plus whatever
-// latency nothing hides, and profiles/r04b_issue_bench.txt prices the idiom the compiler makes of `bool` predicates — v_cmp into an SGPR pair,
+// Why a second statement of tier 1. A round costs (vector instructions of the wavefronts that share a SIMD) x 4 cycles plus whatever latency
+// nothing hides, and profiles/r04b_issue_bench.txt prices the idiom the compiler makes of `bool` predicates — v_cmp into an SGPR pair,
 // s_and / s_or on the pairs, v_cndmask on the result — at 9.5 cycles per instruction when the three depend on each other (the scalar unit
 // waits for the vector pipeline and back), against 4.4 for a chain that stays in the vector unit. rg_device.hpp's tier1<> spends ~100 v_cmp +
 // ~100 s_and/s_or + ~110 v_cndmask per round that way. Here a predicate is a 32-bit WORD whose SIGN BIT is the truth value ("sign word",
@@ -16,7 +16,7 @@
 //     words (GroupN::stf_n / stl_n / stc_n), refreshed where a row can change them — the rare blocks, the election block, the general handlers;
 //   * the state-independent part comes from the I/O wavefront as ONE class word per row (CW_* below) beside {aux, n, header};
 //   * the outcome flags are not assembled here: the truth values they are made of are shifted into a PREDICATE WORD (one v_alignbit each)
-//     that the I/O wavefront expands while it stores the row (expand_predicates) — its issue slots are spare, these are not.
+//     that the I/O wavefront expands through two LDS tables while it stores the row (expand_predicates, expand_by_table in rg_step.hpp).
 // Reference code decided here (paths under /root/reference/src/main/java/io/lubricant/consensus/raft/): member/Follower.java:35-88 (AppendEntries),
 // member/Leader.java:218-237 + member/Leadership.java:75-130 + member/Leader.java:247-280 (ack, majorIndices, tryCommit), member/Leader.java:128-140
 // (client append), member/Candidate.java:121-134 / member/Follower.java:258-270 (vote replies), member/Follower.java:156-168 / Candidate.java:82-88 /
