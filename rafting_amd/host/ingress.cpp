@@ -570,6 +570,28 @@ uint64_t Ingress::held() const
     return n;
 }
 
+size_t Ingress::drop_rows_of(uint32_t gid)
+{
+    StandBack standing_back(sealing_);
+    std::unique_lock<std::shared_mutex> lk(mu_);
+    size_t n = 0;
+    for (Conn &c : c_) {
+        const size_t before = c.held.size();
+        c.held.erase(std::remove_if(c.held.begin(), c.held.end(), [gid](const HeldRow &h) { return h.gid == gid; }), c.held.end());
+        n += before - c.held.size();
+        c.held_count.store(c.held.size(), std::memory_order_relaxed);
+    }
+    auto it = backlog_.find(gid);
+    if (it != backlog_.end()) {
+        for (const Waiting &w : it->second) c_[w.conn].backlogged.fetch_sub(1, std::memory_order_relaxed);
+        n += it->second.size();
+        backlog_.erase(it);
+        if (gid < groups_) bank_[fill_].depth[gid].fetch_and(~CLOSED, std::memory_order_relaxed);     // (it was closed for this batch because of that backlog)
+    }
+    refused_.fetch_add(n, std::memory_order_relaxed);
+    return n;
+}
+
 size_t Ingress::emit(const SealedBatch &b, const rg_reply_t *reply, std::vector<std::string> &out, size_t cell_begin, size_t cell_end, uint32_t only_conn,
                      uint32_t shard) const
 {

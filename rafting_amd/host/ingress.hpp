@@ -203,6 +203,11 @@ public:
     size_t held_on(uint32_t conn) const { return c_[conn].held_count.load(std::memory_order_relaxed) + c_[conn].backlogged.load(std::memory_order_relaxed); }
     uint64_t refused() const { return refused_.load(std::memory_order_relaxed); }     // frames that were no decision row (unknown context, ...)
     uint64_t held() const;                                                            // rows waiting for the next batch
+    // The context behind `gid` was erased (ContextIndex::erase): the rows of it that are still waiting outside a batch — held back by a reader,
+    // queued in the backlog — are dropped and counted as refused, so that the group id can be reclaimed and given to ANOTHER context without that
+    // context's group deciding the old one's rows. Rows already placed in the batch being filled are decided with it, by the old
+    // context's group. Call it after erase() and before reclaim(); excludes the feeders like seal() does. Returns the rows dropped.
+    size_t drop_rows_of(uint32_t gid);
 
 private:
     struct Bank {

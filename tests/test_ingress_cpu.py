@@ -312,3 +312,19 @@ def test_a_send_whose_previous_entry_lies_below_the_cached_runs_is_completed_fro
     assert scope == b"appendEntries:g" and (q[0], q[1], q[2], q[3]) == (7, 0, 15, 3) and q[5] == [term_of(0, 16 + k) for k in range(n)] and n > 0
     whole, frames0, from_log0 = ing.encode_sends(0, 0, head, send[:, 0], term_of)      # the complete row gives the same request (under the next sequence number)
     assert (frames0, from_log0) == (1, 0) and wirelib.split_frames(whole)[0][3] == body and wirelib.split_frames(whole)[0][1] == seq + 1
+
+
+def test_rows_of_an_erased_context_do_not_reach_the_next_owner_of_its_group(tmp_path):
+    """ADVICE r3 (low): held and backlogged rows are keyed by group id; after ContextIndex::erase + reclaim + insert of ANOTHER context under that id they
+    would have been decided by the new context's group. Ingress::drop_rows_of (called between erase and reclaim) drops and counts them; the rows
+    already in the batch being filled are decided with it (tests/native/ingress_drop_rows.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "rafting_amd", "host")
+    exe = str(tmp_path / "ingress_drop_rows")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-I" + host, "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "tests", "native", "ingress_drop_rows.cpp"), os.path.join(host, "ingress.cpp"), os.path.join(host, "wire.cpp"),
+                    os.path.join(host, "kryo_body.cpp"), "-pthread", "-o", exe], check=True, timeout=600)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "drop rows ok" in p.stdout, p.stdout + p.stderr
