@@ -11,6 +11,8 @@ g++ -O1 -g -std=c++17 -fPIC -shared -w -pthread -fsanitize=undefined -fno-saniti
 g++ -O1 -g -std=c++17 -fPIC -shared -w -pthread -fsanitize=address $INC -x c++ $SRC -o $OUT/asan/libraftgpu_emu.so
 cd $ROOT
 echo "== UBSan"; RG_LIB=$OUT/ubsan/libraftgpu_emu.so RG_SPLIT=0 RG_ALLOW_HOST_EMULATION=1 python -m pytest tests/devemu/emu_cases.py -q -x -p no:cacheprovider | tail -2
+echo "== UBSan, emulated wavefronts (the compact-row kernel: rg_tier1n.hpp's sign words and shifts, the I/O wavefront's tables)"
+RG_LIB=$OUT/ubsan/libraftgpu_emu.so RG_SPLIT=1 RG_EMU_WAVES=1 RG_ALLOW_HOST_EMULATION=1 python -m pytest tests/devemu/emu_cases_waves.py -q -x -p no:cacheprovider | tail -2
 # the "split kernel is refused" case throws a C++ exception through the preloaded runtime: left out under ASan
 echo "== ASan"; LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 RG_LIB=$OUT/asan/libraftgpu_emu.so RG_SPLIT=0 RG_ALLOW_HOST_EMULATION=1 \
     python -m pytest tests/devemu/emu_cases.py -q -x -p no:cacheprovider -k "not refused" | tail -2
