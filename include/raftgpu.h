@@ -57,8 +57,9 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      3     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
-                                     3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows */
+#define RG_ABI_VERSION      4     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
+                                     3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows
+                                     4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -158,6 +159,8 @@ typedef struct {
                                          context/RaftRoutine.java:101-107) and returned or threw before the un-muting call — Follower.java:43 then
                                          the throw at :48-50, Follower.java:118 then the throw in logUpToDate, Follower.java:134 then :136-139.
                                          The timer does not fire until a later handler re-arms it. Only set together with RG_F_RESET_TIMER */
+#define RG_F_WIDE_VALUES  (1u << 13)  /* rg_out32_t rows only: a value of this row does not fit int32 — the row's numbers are the low 32 bits only,
+                                         the full ones are in the wide columns of rg_outcome32_t at the same row index (when the caller gave any) */
 #define RG_F_STATUS_SHIFT 16
 #define RG_F_STATUS(f)    (((f) >> RG_F_STATUS_SHIFT) & 0xFFu)
 #define RG_F_EMIT(f)      (((f) & RG_F_EMIT_MASK) >> RG_F_EMIT_SHIFT)
@@ -262,6 +265,13 @@ int         rg_table_create(int device, uint32_t groups, uint32_t cluster, uint3
                             int pre_vote, rg_table_t **out);
 int         rg_table_destroy(rg_table_t *t);
 const char *rg_last_error(const rg_table_t *t);      /* t may be NULL for create failures */
+/* Table options. RG_OPT_REQUIRE_FENCED_TIMEOUTS (default 0): with 1, an RG_EV_TIMEOUT row whose aux is 0 ("whoever is current") is refused as
+ * RG_BAD_EVENT instead of being resolved against the participant of the moment. The reference's timer thread checks ticket.participant() ==
+ * context.participant() BEFORE the event loop sees the task (context/RaftRoutine.java:65-77); a serial engine can only reproduce that when the
+ * row names the participant whose ticket fired (rg_timers_expired_epochs supplies it) — the ordering contract of INTEGRATION.md section 1,
+ * enforced instead of merely stated. The C++ host's IngressFlusher turns it on. */
+enum { RG_OPT_REQUIRE_FENCED_TIMEOUTS = 1 };
+int         rg_table_option(rg_table_t *t, int option, int value);
 uint32_t    rg_table_groups(const rg_table_t *t);
 uint32_t    rg_table_cluster(const rg_table_t *t);
 
@@ -348,6 +358,36 @@ int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, 
  * Returns the entry_count of the compact batch, or < 0: -1 missing column, -2 the batch has hints, -3 a value outside [0, 2^31),
  * -4 entry_terms needed but NULL. rounds / count / gid are the wide batch's. */
 int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms);
+/* COMPACT OUTCOME ROWS (ABI 4). What a reply carries is RaftResponse(term, success) (RaftResponse.java:8-24) plus instructions; while a
+ * group's values are below 2^31 all of it fits ONE 16-byte row per event that every lane stores unconditionally — instead of a 16-byte reply
+ * plus a conditional 16-byte effect row that half of the lanes store (32-byte write granules: measured 1.17x inflation) — and the role epoch,
+ * which only changes with a conversion, moves into the persist row that a conversion writes anyway. Per 64-round launch of 65 536 groups the
+ * outcome stream shrinks from ~125 MB to ~68 MB.
+ *   rg_out32_t      always written.  resp_term: RaftResponse.term, 0 unless RG_F_REPLIED.  flags: as rg_reply_t.flags.  commit_index:
+ *                   RaftLog.lastCommitted() AFTER the row, whatever the flags say (rg_logfx_t only has it for rows that carry an effect).
+ *                   log_from: as rg_logfx_t.log_from, 0 unless the row carries RG_F_LOG_APPEND / RG_F_LOG_TRUNC or the status RG_NEED_HOST.
+ *   rg_persist32_t  written iff RG_F_PERSIST (every conversion sets it: RaftMember.<init> persists, member/RaftMember.java:25): the durable
+ *                   pair, the role, and the role epoch AFTER the row — the tag for the RPCs the host emits from now on. A row without
+ *                   RG_F_PERSIST leaves the group's role epoch where it was.
+ *   wide            optional (all three columns or none, [rounds*count] each): where a workgroup that left the 32-bit domain (the 64-bit body,
+ *                   see rg_submit32) puts the full rows of an event whose values do not fit — such a row carries RG_F_WIDE_VALUES and the
+ *                   low 32 bits. The columns are not touched otherwise. Without them the full values of such a row are lost to the caller
+ *                   (rg_read_state still has the group's state).
+ * Same batches, same decisions, same table state as rg_submit32; dense batches only (gid == NULL). rg_timers_update / rg_health_update read
+ * rg_reply_t rows: a host that runs the device-side timers unpacks first (or uses rg_submit32). */
+typedef struct { int32_t resp_term; uint32_t flags; int32_t commit_index; int32_t log_from; } rg_out32_t;          /* 16 B */
+typedef struct { int32_t term; int32_t voted_for; uint32_t role_epoch; int32_t role; } rg_persist32_t;            /* 16 B */
+typedef struct {
+    rg_out32_t     *row;       /* [rounds*count], required */
+    rg_persist32_t *persist;   /* [rounds*count], required */
+    rg_outcome_t    wide;      /* optional overflow columns */
+} rg_outcome32_t;
+int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *out, int memspace);
+/* Host-side (no device involved): compact outcome rows -> the wide columns, for callers written against rg_outcome_t. `in` and `out` are HOST
+ * arrays of rounds*count rows (out->logfx / out->persist rows that carry nothing are zeroed, like rg_submit's). role_epoch: [count], the role
+ * epoch of every group BEFORE the batch (rg_group_state_t.role_epoch); updated in place to the epochs after it. Rows flagged
+ * RG_F_WIDE_VALUES are copied from in->wide (-3 when that is missing). Returns 0, or < 0. */
+int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const rg_outcome_t *out);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
  * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel";
  * compact batches (rg_submit32, rg_submit_async_packed) are always decided by "rg::step32_kernel" */

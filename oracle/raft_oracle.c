@@ -58,6 +58,7 @@ struct orc_table {
     uint64_t timer_seed;
     uint32_t groups, cluster, self, followers;
     int      pre_vote;
+    int      require_fence;      /* RG_OPT_REQUIRE_FENCED_TIMEOUTS (a contract of the C-ABI, not reference behaviour): TIMEOUT rows with aux == 0 are RG_BAD_EVENT */
     int      majority;           /* RaftContext.majority()  context/RaftContext.java:170 */
     const int64_t *clock;        /* N4b: System.currentTimeMillis() per round of the next orc_submit (orc_health_clock) */
     group_t *g;
@@ -589,6 +590,7 @@ static void on_install_snapshot(const orc_table_t *t, group_t *g, fx_t *fx, int6
  * Only run for the participant whose ticket fired (context/RaftRoutine.java:57,70): `ticket_epoch` 0 = whoever is current. */
 static void on_timeout(const orc_table_t *t, group_t *g, fx_t *fx, uint32_t ticket_epoch)
 {
+    if (ticket_epoch == 0 && t->require_fence) { fx->status = RG_BAD_EVENT; return; }
     if (ticket_epoch != 0 && ticket_epoch != g->role_epoch) { fx->status = RG_DROPPED_STALE_ROLE; return; }
     if (g->role == RG_FOLLOWER) {
         if (t->pre_vote) {
@@ -714,6 +716,13 @@ orc_table_t *orc_table_create(uint32_t groups, uint32_t cluster, uint32_t self_s
         t->g[i].votes = 1;
     }
     return t;
+}
+
+int orc_table_option(orc_table_t *t, int option, int value)
+{
+    if (!t || option != RG_OPT_REQUIRE_FENCED_TIMEOUTS) return -1;
+    t->require_fence = value != 0;
+    return 0;
 }
 
 void orc_table_destroy(orc_table_t *t)

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MIN_CLUSTER, MAX_CLUSTER = 2, 7
 TERM_RUNS = 4
 NO_NODE = -1
@@ -28,6 +28,7 @@ F_EMIT_SHIFT, F_EMIT_MASK = 8, 3 << 8
 EMIT_NONE, EMIT_PREVOTE, EMIT_REQVOTE, EMIT_HEARTBEAT = 0, 1, 2, 3
 F_ROLE_SHIFT, F_ROLE_MASK = 10, 3 << 10
 F_TIMER_MUTED = 1 << 12
+F_WIDE_VALUES = 1 << 13    # rg_out32_t rows only: the row's numbers are low 32 bits, the full rows are in the overflow columns
 F_STATUS_SHIFT = 16
 
 OK = 0
@@ -40,6 +41,7 @@ A_INSTALL_BEFORE_AE, A_NO_DOWNGRADE = 20, 21
 NEED_HOST, SKIPPED_AFTER_NEED_HOST, BAD_EVENT, UNSUPPORTED_LOG_STATE = 32, 33, 34, 35
 
 MEM_HOST, MEM_DEVICE = 0, 1
+OPT_REQUIRE_FENCED_TIMEOUTS = 1
 NUM_COUNTERS = 8
 
 HEAD_DT = np.dtype([("hdr", "<u4"), ("aux", "<u4")])
@@ -100,6 +102,10 @@ class COutcome(C.Structure):
 class CBatch32(C.Structure):           # rg_batch32_t
     _fields_ = [("rounds", C.c_uint32), ("count", C.c_uint32), ("gid", C.c_void_p), ("head", C.c_void_p), ("abcd", C.c_void_p),
                 ("entry_terms", C.c_void_p), ("entry_count", C.c_uint64)]
+
+
+class COutcome32(C.Structure):         # rg_outcome32_t
+    _fields_ = [("row", C.c_void_p), ("persist", C.c_void_p), ("wide", COutcome)]
 
 
 class COutcomePacked(C.Structure):     # rg_outcome_packed_t
@@ -263,6 +269,32 @@ class Batch32:
         b.entry_terms = _ptr(self.entry_terms) if self.entry_count else None
         b.entry_count = self.entry_count
         return b
+
+
+OUT32_DT = np.dtype([("resp_term", "<i4"), ("flags", "<u4"), ("commit_index", "<i4"), ("log_from", "<i4")])
+PERSIST32_DT = np.dtype([("term", "<i4"), ("voted_for", "<i4"), ("role_epoch", "<u4"), ("role", "<i4")])
+assert OUT32_DT.itemsize == 16 and PERSIST32_DT.itemsize == 16
+
+
+class Outcome32:
+    """Host image of an rg_outcome32_t (compact outcome rows, ABI 4): one rg_out32_t per event, an rg_persist32_t where the row carries
+    RG_F_PERSIST, and optionally the wide overflow columns for rows flagged RG_F_WIDE_VALUES."""
+
+    def __init__(self, rows, fill=0, wide=True):
+        self.rows = rows
+        self.row = np.zeros(rows, dtype=OUT32_DT)
+        self.persist = np.zeros(rows, dtype=PERSIST32_DT)
+        self.wide = Outcome(rows, fill) if wide else None
+        if fill:
+            self.row.view(np.uint8)[:] = fill
+            self.persist.view(np.uint8)[:] = fill
+
+    def as_struct(self):
+        o = COutcome32()
+        o.row, o.persist = _ptr(self.row), _ptr(self.persist)
+        if self.wide is not None:
+            o.wide = self.wide.as_struct()
+        return o
 
 
 def has_logfx(flags):

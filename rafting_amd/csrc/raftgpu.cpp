@@ -56,7 +56,8 @@ struct rg_table {
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
     int force_wide = 0;                         // RG_FORCE_WIDE=1: the compact-format kernel skips its 32-bit body (differential tests)
-    Staging st_abcd32, st_terms32;
+    int require_fence = 0;                      // rg_table_option(RG_OPT_REQUIRE_FENCED_TIMEOUTS)
+    Staging st_abcd32, st_terms32, st_out32, st_persist32;
     int lanes = -1;                             // -1: pick per launch; 0: split kernel; 64: single-wavefront kernel (RG_SPLIT env forces one)
     uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
     Staging st_gid, st_head, st_ab, st_cd, st_hint, st_terms, st_reply, st_logfx, st_persist, st_hb, st_fl, st_sh, st_ss;
@@ -148,6 +149,15 @@ const char *rg_last_error(const rg_table_t *t) { return t ? t->err.c_str() : g_c
 uint32_t rg_table_groups(const rg_table_t *t) { return t ? t->G : 0; }
 uint32_t rg_table_cluster(const rg_table_t *t) { return t ? t->P : 0; }
 
+int rg_table_option(rg_table_t *t, int option, int value)
+{
+    if (!t) return -1;
+    switch (option) {
+    case RG_OPT_REQUIRE_FENCED_TIMEOUTS: t->require_fence = value != 0; return 0;
+    default: return fail(t, -1, "rg_table_option: unknown option %d", option);
+    }
+}
+
 int rg_table_destroy(rg_table_t *t)
 {
     if (!t) return 0;
@@ -158,7 +168,7 @@ int rg_table_destroy(rg_table_t *t)
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
                     t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline,
                     t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
-                    t->health_fail, t->health_recent};
+                    t->health_fail, t->health_recent, t->st_abcd32.ptr, t->st_terms32.ptr, t->st_out32.ptr, t->st_persist32.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
     for (PipeSlot &sl : t->pipe) {
         if (sl.down) (void)hipEventSynchronize(sl.down);
@@ -463,6 +473,7 @@ static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
     p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
     p.fast_paths = t->fast_paths;
     p.force_wide = t->force_wide;
+    p.require_fence = t->require_fence;
     return p;
 }
 
@@ -712,6 +723,100 @@ int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, 
     HIP_TRY(t, hipMemcpyAsync(out->logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+/* compact rows in, compact outcome rows out (ABI 4): see include/raftgpu.h */
+int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *out, int memspace)
+{
+    if (!t) return -1;
+    if (!in || !out) return fail(t, -1, "rg_submit32c: NULL batch or outcome");
+    if (!in->head || !in->abcd || !out->row || !out->persist) return fail(t, -1, "rg_submit32c: head, abcd, row and persist are required");
+    if (in->gid) return fail(t, -1, "rg_submit32c: dense batches only (gid must be NULL)");
+    const int wides = (out->wide.reply != nullptr) + (out->wide.logfx != nullptr) + (out->wide.persist != nullptr);
+    if (wides != 0 && wides != 3) return fail(t, -1, "rg_submit32c: the overflow columns come as all three or none");
+    rg_batch_t wide{};                              // the same shape rules as every other submission (rounds, count, entry bound)
+    wide.rounds = in->rounds; wide.count = in->count; wide.head = in->head;
+    wide.ab = wide.cd = reinterpret_cast<const rg_ev_pair_t *>(in->abcd);      // presence only: check_batch does not read event fields
+    wide.entry_terms = reinterpret_cast<const int64_t *>(in->entry_terms); wide.entry_count = in->entry_count;
+    rg_reply_t dummy_r; rg_logfx_t dummy_l; rg_persist_t dummy_p;
+    const rg_outcome_t shape{&dummy_r, &dummy_l, &dummy_p};
+    if (int rc = check_batch(t, &wide, &shape, memspace == RG_MEM_HOST)) return rc;
+    if (in->count == 0) return 0;
+    if (bind(t)) return -2;
+    const size_t rows = (size_t)in->rounds * in->count;
+    rg::StepParams p = step_params(t, &wide);
+    if (memspace == RG_MEM_DEVICE) {
+        p.head = in->head; p.abcd32 = (const rg::I32x4 *)in->abcd;
+        p.entry_terms32 = in->entry_count ? in->entry_terms : nullptr;
+        p.out32 = (rg::I32x4 *)out->row; p.persist32 = (rg::I32x4 *)out->persist;
+        p.reply = out->wide.reply; p.logfx = (I64x2 *)out->wide.logfx; p.persist = out->wide.persist;
+        return launch(t, p, false);
+    }
+    if (memspace != RG_MEM_HOST) return fail(t, -1, "rg_submit32c: unknown memspace %d", memspace);
+    hipStream_t s = t->stream;
+    if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_abcd32, rows * sizeof(rg_ev_quad32_t)) ||
+        reserve(t, t->st_out32, rows * sizeof(rg_out32_t)) || reserve(t, t->st_persist32, rows * sizeof(rg_persist32_t)))
+        return -2;
+    if (wides && (reserve(t, t->st_reply, rows * sizeof(rg_reply_t)) || reserve(t, t->st_logfx, rows * sizeof(I64x2)) ||
+                  reserve(t, t->st_persist, rows * sizeof(rg_persist_t))))
+        return -2;
+    HIP_TRY(t, hipMemcpyAsync(t->st_head.ptr, in->head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(t, hipMemcpyAsync(t->st_abcd32.ptr, in->abcd, rows * sizeof(rg_ev_quad32_t), hipMemcpyHostToDevice, s));
+    p.head = (const rg_ev_head_t *)t->st_head.ptr; p.abcd32 = (const rg::I32x4 *)t->st_abcd32.ptr;
+    if (in->entry_count) {
+        if (reserve(t, t->st_terms32, in->entry_count * sizeof(int32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_terms32.ptr, in->entry_terms, in->entry_count * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        p.entry_terms32 = (const int32_t *)t->st_terms32.ptr;
+    }
+    p.out32 = (rg::I32x4 *)t->st_out32.ptr; p.persist32 = (rg::I32x4 *)t->st_persist32.ptr;
+    HIP_TRY(t, hipMemsetAsync(t->st_persist32.ptr, 0, rows * sizeof(rg_persist32_t), s));       // conditional rows come back zeroed, as rg_submit's
+    if (wides) {
+        p.reply = (rg_reply_t *)t->st_reply.ptr; p.logfx = (I64x2 *)t->st_logfx.ptr; p.persist = (rg_persist_t *)t->st_persist.ptr;
+        HIP_TRY(t, hipMemsetAsync(t->st_reply.ptr, 0, rows * sizeof(rg_reply_t), s));
+        HIP_TRY(t, hipMemsetAsync(t->st_logfx.ptr, 0, rows * sizeof(I64x2), s));
+        HIP_TRY(t, hipMemsetAsync(t->st_persist.ptr, 0, rows * sizeof(rg_persist_t), s));
+    }
+    if (int rc = launch(t, p, false)) return rc;
+    HIP_TRY(t, hipMemcpyAsync(out->row, t->st_out32.ptr, rows * sizeof(rg_out32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(t, hipMemcpyAsync(out->persist, t->st_persist32.ptr, rows * sizeof(rg_persist32_t), hipMemcpyDeviceToHost, s));
+    if (wides) {
+        HIP_TRY(t, hipMemcpyAsync(out->wide.reply, t->st_reply.ptr, rows * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(t, hipMemcpyAsync(out->wide.logfx, t->st_logfx.ptr, rows * sizeof(I64x2), hipMemcpyDeviceToHost, s));
+        HIP_TRY(t, hipMemcpyAsync(out->wide.persist, t->st_persist.ptr, rows * sizeof(rg_persist_t), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+/* host-side: rg_out32_t / rg_persist32_t rows -> the wide columns (no device involved) */
+int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const rg_outcome_t *out)
+{
+    if (!in || !in->row || !in->persist || !role_epoch || !out || !out->reply || !out->logfx || !out->persist) return -1;
+    for (uint32_t r = 0; r < rounds; r++) {
+        for (uint32_t i = 0; i < count; i++) {
+            const size_t row = (size_t)r * count + i;
+            const rg_out32_t c = in->row[row];
+            const uint32_t flags = c.flags & ~RG_F_WIDE_VALUES;
+            const bool has_lfx = (flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0 || RG_F_STATUS(flags) == RG_NEED_HOST;
+            const bool has_from = (flags & (RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0 || RG_F_STATUS(flags) == RG_NEED_HOST;
+            const bool has_per = (flags & RG_F_PERSIST) != 0;
+            if (c.flags & RG_F_WIDE_VALUES) {
+                if (!in->wide.reply || !in->wide.logfx || !in->wide.persist) return -3;
+                out->reply[row] = in->wide.reply[row];
+                out->logfx[row] = has_lfx ? in->wide.logfx[row] : rg_logfx_t{0, 0};
+                out->persist[row] = has_per ? in->wide.persist[row] : rg_persist_t{0, 0, 0};
+                if (out->reply[row].flags != flags) return -4;          // the two copies of a row disagree
+                role_epoch[i] = out->reply[row].role_epoch;
+                continue;
+            }
+            if (has_per) role_epoch[i] = in->persist[row].role_epoch;
+            out->reply[row] = rg_reply_t{(flags & RG_F_REPLIED) ? (int64_t)c.resp_term : 0, flags, role_epoch[i]};
+            out->logfx[row] = has_lfx ? rg_logfx_t{(int64_t)c.commit_index, has_from ? (int64_t)c.log_from : 0} : rg_logfx_t{0, 0};
+            out->persist[row] = has_per ? rg_persist_t{(int64_t)in->persist[row].term, in->persist[row].voted_for, in->persist[row].role}
+                                        : rg_persist_t{0, 0, 0};
+        }
+    }
     return 0;
 }
 

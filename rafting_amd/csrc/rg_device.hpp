@@ -84,10 +84,13 @@ struct StepParams {
     rg_reply_t *reply;
     I64x2 *logfx;
     rg_persist_t *persist;
+    I32x4 *out32, *persist32;       // compact outcome rows (rg_submit32c): rg_out32_t always, rg_persist32_t iff PERSIST; reply / logfx / persist are then
+                                    // the optional overflow columns of rows flagged RG_F_WIDE_VALUES (all three, or all null)
     unsigned long long *counters;   // [workgroups][RG_NUM_COUNTERS]
     int32_t self, cluster, majority, pre_vote;
     int32_t fast_paths;             // 0: general handlers only
     int32_t force_wide;             // compact-format kernel: skip the 32-bit body (tests)
+    int32_t require_fence;          // RG_OPT_REQUIRE_FENCED_TIMEOUTS: a TIMEOUT row with aux == 0 is RG_BAD_EVENT
 };
 
 struct ReplicateParams {             // N1: Leader.replicateLog for many groups (rg_kernels.hip: replicate_kernel)
@@ -808,7 +811,9 @@ struct Stepper {
 
     __device__ __forceinline__ void on_timeout(uint32_t ticket_epoch)
     {
-        // context/RaftRoutine.java:57,70: only the participant whose ticket fired runs onTimeout (0 = whoever is current)
+        // context/RaftRoutine.java:57,70: only the participant whose ticket fired runs onTimeout (0 = whoever is current — refused when the table
+        // requires fenced timeouts: RG_OPT_REQUIRE_FENCED_TIMEOUTS)
+        if (ticket_epoch == 0u && p.require_fence != 0) { fx.status = RG_BAD_EVENT; return; }
         if (ticket_epoch != 0u && ticket_epoch != g.role_epoch) { fx.status = RG_DROPPED_STALE_ROLE; return; }
         if (g.role == RG_FOLLOWER) {
             if (p.pre_vote) {
@@ -1040,7 +1045,7 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
         const bool late_noop = late & (a <= el_term) & (!flag | (el_term < g_term) | ((el_term == g_term) & (role == RG_LEADER)));
         const bool vote_drop = vr_shape & !cur_epoch & !late;
         // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
-        const bool to_kind = allow & (kind == RG_EV_TIMEOUT);
+        const bool to_kind = allow & (kind == RG_EV_TIMEOUT) & ((aux != 0u) | (p.require_fence == 0));      // (an un-fenced row where fences are required: general handlers, RG_BAD_EVENT)
         const bool to_stale = to_kind & (aux != 0u) & (aux != g_repoch);
         const bool to_live = to_kind & !to_stale;
         const bool to_pre = to_live & (role == RG_FOLLOWER) & (p.pre_vote != 0);

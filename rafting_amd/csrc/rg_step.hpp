@@ -497,9 +497,12 @@ struct SplitLds {
 };
 
 // The 64-bit body of a two-wavefront workgroup, on wide (EV32 = false) or compact (EV32 = true) rows.
-template <int F, bool SPARSE, bool EV32>
+// OUT32 (compact rows only): the outcome goes out as rg_out32_t / rg_persist32_t rows (rg_submit32c); an event whose values do not fit int32 is
+// flagged RG_F_WIDE_VALUES and its full rows go to the overflow columns p.reply / p.logfx / p.persist, when the caller gave them.
+template <int F, bool SPARSE, bool EV32, bool OUT32 = false>
 __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *smem)
 {
+    static_assert(EV32 || !OUT32, "compact outcome rows belong to the compact-row kernels");
     typedef SplitLds<F, EV32> L;
     int64_t *sh_epoch = reinterpret_cast<int64_t *>(smem + L::W_EPOCH), *sh_next = reinterpret_cast<int64_t *>(smem + L::W_NEXT),
             *sh_match = reinterpret_cast<int64_t *>(smem + L::W_MATCH);
@@ -535,14 +538,28 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
             const uint32_t flags_all = (uint32_t)fe, flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
             rg_reply_t rep;
             rep.resp_term = (int64_t)sh_out[slot][OUT_RESP][lane]; rep.flags = flags_all; rep.role_epoch = (uint32_t)(fe >> 32);
-            if (active) nt_store16(p.reply + row, rep);
             const bool w_lfx = active & (((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST));
-            if (w_lfx) nt_store16(p.logfx + row, I64x2{(int64_t)sh_out[slot][OUT_COMMIT][lane], (int64_t)sh_out[slot][OUT_FROM][lane]});
-            if (active & ((flags & RG_F_PERSIST) != 0)) {
-                const uint64_t v = sh_out[slot][OUT_VOTE][lane];
-                rg_persist_t per;
-                per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
-                nt_store16(p.persist + row, per);
+            const bool w_per = active & ((flags & RG_F_PERSIST) != 0);
+            const I64x2 lfx{(int64_t)sh_out[slot][OUT_COMMIT][lane], (int64_t)sh_out[slot][OUT_FROM][lane]};
+            const uint64_t v = sh_out[slot][OUT_VOTE][lane];
+            rg_persist_t per;
+            per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
+            if constexpr (OUT32) {
+                const uint64_t bits = (uint64_t)rep.resp_term | (uint64_t)lfx.x | (w_lfx ? (uint64_t)lfx.y : 0ull) | (w_per ? (uint64_t)per.term : 0ull);
+                const bool wide = bits >= (1ull << 31);
+                if (active) {
+                    nt_store16(p.out32 + row, I32x4{(int32_t)rep.resp_term, (int32_t)(flags_all | (wide ? RG_F_WIDE_VALUES : 0u)), (int32_t)lfx.x, (int32_t)lfx.y});
+                    if (w_per) nt_store16(p.persist32 + row, I32x4{(int32_t)per.term, per.voted_for, (int32_t)rep.role_epoch, per.role});
+                    if (wide & (p.reply != nullptr)) {
+                        nt_store16(p.reply + row, rep);
+                        if (w_lfx) nt_store16(p.logfx + row, lfx);
+                        if (w_per) nt_store16(p.persist + row, per);
+                    }
+                }
+            } else {
+                if (active) nt_store16(p.reply + row, rep);
+                if (w_lfx) nt_store16(p.logfx + row, lfx);
+                if (w_per) nt_store16(p.persist + row, per);
             }
             tally.add(RG_HDR_KIND(hdr), flags, status);
         };
@@ -715,7 +732,10 @@ __device__ __forceinline__ uint32_t expand_by_table(const uint32_t *lutm, const 
     return ((int32_t)w < 0) ? (w & 0x00FFFFFFu) : fast;
 }
 
-template <int F, bool SPARSE>
+// IOW = 2 (experiment, -DRG_IOW2: launches of at most one workgroup per pair of SIMDs): the I/O work of a workgroup on TWO wavefronts — wave 1 fetches
+// and publishes events, wave 2 retires outcomes and keeps the tallies — so that neither is ever what the deciding wavefront waits for at the
+// barrier; all three meet at the same s_barrier every round.
+template <int F, bool SPARSE, bool OUT32, int IOW = 1>
 __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
     typedef SplitLds<F, true> L;
@@ -742,6 +762,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 
     if (io_wave) {
         RG_HWID_BEGIN(1);
+        // (wave-uniform roles: with one I/O wavefront it has both)
+        const bool do_pub = IOW == 1 || __builtin_amdgcn_readfirstlane(threadIdx.x) < 2u * BLOCK;
+        const bool do_ret = IOW == 1 || !do_pub;
         // Addresses. The five columns this loop touches are [round][row] arrays: a row's address is a SCALAR (column base + round * count * size,
         // 64-bit, computed on the scalar unit) plus the lane's own 32-bit byte offset, which never changes — the form global_load / global_store
         // take directly (saddr + voffset), no vector address arithmetic in the loop. The bases are kernel arguments; each gets scalar registers
@@ -749,8 +772,11 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         // at every use, 30 vector instructions per round (round 3 measured that as free — it was, while this wavefront was not what a round
         // waits for and the SIMD it shares with a deciding wavefront had issue slots to spare; neither holds any more: profiles/r04e_probe.txt).
         // (launch_compact refuses batches of 2^28 rows per round or more: the lane offset must fit 32 bits)
-        uint64_t b_head = reinterpret_cast<uint64_t>(p.head), b_q = reinterpret_cast<uint64_t>(p.abcd32), b_reply = reinterpret_cast<uint64_t>(p.reply),
-                 b_logfx = reinterpret_cast<uint64_t>(p.logfx), b_persist = reinterpret_cast<uint64_t>(p.persist);
+        // (OUT32: the always-written column is rg_out32_t, the conditional one rg_persist32_t; there is no third)
+        uint64_t b_head = reinterpret_cast<uint64_t>(p.head), b_q = reinterpret_cast<uint64_t>(p.abcd32),
+                 b_reply = OUT32 ? reinterpret_cast<uint64_t>(p.out32) : reinterpret_cast<uint64_t>(p.reply),
+                 b_logfx = reinterpret_cast<uint64_t>(p.logfx),
+                 b_persist = OUT32 ? reinterpret_cast<uint64_t>(p.persist32) : reinterpret_cast<uint64_t>(p.persist);
         RG_OWN_SGPRS(b_head); RG_OWN_SGPRS(b_q); RG_OWN_SGPRS(b_reply); RG_OWN_SGPRS(b_logfx); RG_OWN_SGPRS(b_persist);
         const uint64_t round_rows = p.count;
         const uint32_t irm = ir & 0x0FFFFFFFu;           // (spelled out for the instruction selector: ir < count < 2^28)
@@ -780,18 +806,25 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
             // the deciding wavefront hands over truth values, not flags (rg_tier1n.hpp): the flags, the role field and the "valid iff REPLIED" rule are made here
             const uint32_t flags_all = expand_by_table(sh_lutm, sh_lute, (uint32_t)o0.y) | ((uint32_t)o1.w << RG_F_ROLE_SHIFT), flags = flags_all & 0xFFFFu, status = RG_F_STATUS(flags_all);
-            rg_reply_t rep;
-            // (every term / index of this body is in [0, 2^31): zero-extended below, no v_ashr)
-            rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)(uint32_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
             // (lanes past the end of the batch shadow its last row in everything — same group, same events, same outcome: they store it again,
             // to the same address; an exec mask around three stores costs more than the duplicates of one workgroup)
-            nt_store_at(b_reply + rb16, irm, rep);
-            const bool w_lfx = ((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST);
-            if (w_lfx) nt_store_at(b_logfx + rb16, irm, I64x2{(int64_t)(uint32_t)o0.w, (int64_t)(uint32_t)o1.x});
-            if ((flags & RG_F_PERSIST) != 0) {
-                rg_persist_t per;
-                per.term = (int64_t)(uint32_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
-                nt_store_at(b_persist + rb16, irm, per);
+            if constexpr (OUT32) {
+                // ONE row that every lane stores: {RaftResponse.term, flags, commitIndex after the row, log_from} — every value of this body fits,
+                // so RG_F_WIDE_VALUES never appears here; log_from is only meaningful under its flags (rg_out32_t), no select spent on it
+                nt_store_at(b_reply + rb16, irm, I32x4{(flags & RG_F_REPLIED) ? o0.x : 0, (int32_t)flags_all, o0.w, o1.x});
+                if ((flags & RG_F_PERSIST) != 0) nt_store_at(b_persist + rb16, irm, I32x4{o1.y, o1.z, o0.z, o1.w});
+            } else {
+                rg_reply_t rep;
+                // (every term / index of this body is in [0, 2^31): zero-extended below, no v_ashr)
+                rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)(uint32_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
+                nt_store_at(b_reply + rb16, irm, rep);
+                const bool w_lfx = ((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST);
+                if (w_lfx) nt_store_at(b_logfx + rb16, irm, I64x2{(int64_t)(uint32_t)o0.w, (int64_t)(uint32_t)o1.x});
+                if ((flags & RG_F_PERSIST) != 0) {
+                    rg_persist_t per;
+                    per.term = (int64_t)(uint32_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
+                    nt_store_at(b_persist + rb16, irm, per);
+                }
             }
             tally.add_packed(RG_HDR_KIND(hdr), flags, status);
         };
@@ -799,17 +832,20 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
         Row32 buf[4];
         uint32_t hdr_m1 = 0u, hdr_0, hdr_1;              // headers of rounds r-1, r, r+1 (the tallies need the kind of a retired row)
-        {
+        if (do_pub) {
             Row32 e0, e1;
             fetch(0, e0); fetch(1, e1); fetch(2, buf[2]); fetch(3, buf[3]); fetch(4, buf[0]); fetch(5, buf[1]);
             publish(0u, e0); publish(1u, e1);
             hdr_0 = e0.h.x; hdr_1 = e1.h.x;
+        } else {
+            hdr_0 = hdr_1 = 0u;
+            for (int k = 0; k < 4; k++) { buf[k].h = U32x2{0u, 0u}; buf[k].q = I32x4{0, 0, 0, 0}; }
         }
         lds_barrier();                                   // events 0, 1 and the mark of the state load are visible
         { const uint32_t seen0 = *sh_bail; if (__builtin_amdgcn_readfirstlane(seen0) == 1u) return false; }
         // The mark is READ right after a barrier and LOOKED AT just before the next one: the read's latency is spent on this round's own work,
-        // and a workgroup that is leaving has published an event and stored an outcome row too many — nothing anybody reads (the 64-bit body
-        // rewrites every outcome row).
+        // and a workgroup that is leaving has published an event and stored an outcome row too many: the outcome row is rewritten by the 64-bit
+        // body, the event lands in LDS that body is about to reuse — hence the barrier between the two bodies in step32_kernel.
         bool bailed = false;
         uint32_t seen = 0u;                              // the mark as it stood after the previous barrier
         RG_PROBE_BEGIN();
@@ -820,11 +856,16 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                 const uint32_t r = r0 + (uint32_t)k;
                 if (r >= p.rounds) break;
                 Row32 &x = buf[(k + 2) & 3];
-                publish((r + 2u) & 3u, x);
+                if (do_pub) publish((r + 2u) & 3u, x);
                 RG_PROBE_MARK(0);
-                if (r > 0) retire(r - 1u, hdr_m1);
-                hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
-                fetch(r + 6u, x);
+                if constexpr (IOW == 1) {
+                    if (r > 0) retire(r - 1u, hdr_m1);
+                    hdr_m1 = hdr_0; hdr_0 = hdr_1; hdr_1 = x.h.x;
+                } else {
+                    // (the retiring wavefront never saw the row: its kind is still in the event ring — slot (r - 1) & 3 is rewritten in round r + 1)
+                    if (do_ret && r > 0) retire(r - 1u, (uint32_t)sh_evh[(r - 1u) & 3u][lane].w);
+                }
+                if (do_pub) fetch(r + 6u, x);
                 RG_PROBE_MARK(1);
                 const uint32_t mark = __builtin_amdgcn_readfirstlane(seen);      // round r - 1 (or earlier) left the domain: mark <= r + 1
                 if ((mark != 0u) & (mark <= r + 1u)) { bailed = true; break; }
@@ -835,14 +876,15 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         }
         if (bailed) return false;
         { const uint32_t mark = __builtin_amdgcn_readfirstlane(seen); if (mark != 0u) return false; }      // the last round did
-        retire(last_round, hdr_m1);
+        if constexpr (IOW == 1) retire(last_round, hdr_m1);
+        else if (do_ret) retire(last_round, (uint32_t)sh_evh[last_round & 3u][lane].w);
         tally.spill();
 #if defined(RG_PROBE)
-        RG_PROBE_FLUSH(0);
+        if (do_pub) RG_PROBE_FLUSH(0);
 #elif defined(RG_PROBE_HWID)
-        RG_HWID_END(1);
+        if (do_pub) RG_HWID_END(1);
 #else
-        tally.flush(p, lane, active);
+        if (do_ret) tally.flush(p, lane, active);
 #endif
         return true;
     }
@@ -938,24 +980,35 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 // deciding wavefronts per SIMD instead of a pass and a third (round 3's same-box A/B at config 4's shard: 0.1994 -> 0.1307 ms per launch,
 // profiles/r03d_w4_ab.jsonl). Since round 4 the allocator asks for 113 / 112 VGPRs: both variants fit either budget, the two are kept for the
 // bound itself (a change that needs more registers shows up as spills in the second, not as a launch that takes two passes).
-template <int F, bool SPARSE, int WAVES>
-__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
+template <int F, bool SPARSE, int WAVES, bool OUT32, int IOW = 1>
+__global__ __launch_bounds__((1 + IOW) * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    if (narrow_body<F, SPARSE>(p, smem)) return;
+    if (narrow_body<F, SPARSE, OUT32, IOW>(p, smem)) return;
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
-    // both wavefronts come here together, right after a barrier: start over in 64-bit arithmetic
-    split_body<F, SPARSE, true>(p, smem);
+    if constexpr (IOW == 2) {
+        // the 64-bit body knows two wavefronts: the third only keeps the barriers' count (one to get here, one per staging, one per round)
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 2u * BLOCK) {
+            for (uint32_t k = 0; k < p.rounds + 2u; k++) lds_barrier();
+            return;
+        }
+    }
+    // Both wavefronts left the 32-bit body after the same number of barriers, but not at the same moment: the I/O wavefront looks at the bail
+    // mark one round late (narrow_body) and has by then published one more event into N_EVH / N_EVQ — memory the 64-bit body's follower
+    // records (W_MATCH, W_REJ) overlap. Meet once more before anybody stages anything (never executed on the 32-bit path).
+    lds_barrier();
+    // start over in 64-bit arithmetic
+    split_body<F, SPARSE, true, OUT32>(p, smem);
 }
 
 // RG_FORCE_WIDE=1 (differential tests; bench.py's int64-body pass): the 64-bit body on compact rows from the start, as a kernel of its own name —
 // a profile of a run that has both lists them apart (the 32-bit body's launches are what `roofline` describes)
-template <int F, bool SPARSE, int WAVES>
+template <int F, bool SPARSE, int WAVES, bool OUT32>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_wide_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
     if (threadIdx.x == 0) RG_NOTE_FALLBACK();
-    split_body<F, SPARSE, true>(p, smem);
+    split_body<F, SPARSE, true, OUT32>(p, smem);
 }
 
 template <int F>
@@ -985,22 +1038,38 @@ static hipError_t launch_compact(const StepParams &p, bool sparse, hipStream_t s
     if (blocks == 0) return hipSuccess;
     if (p.count >= (1u << 28)) return hipErrorInvalidValue;       // the I/O wavefront addresses a row as scalar base + 32-bit lane offset
     const bool many = blocks > 1024u;                    // more than one workgroup per pair of SIMDs on a 256-CU part
+    const dim3 grid(blocks), wg(2 * BLOCK);
+    if (p.out32 != nullptr) {                            // compact outcome rows (rg_submit32c): dense batches only
+        if (sparse) return hipErrorInvalidValue;
+        if (p.force_wide != 0) {
+            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, false, 4, true>), grid, wg, 0, s, p);
+            else      hipLaunchKernelGGL((step32_wide_kernel<F, false, 1, true>), grid, wg, 0, s, p);
+        } else {
+            if (many) hipLaunchKernelGGL((step32_kernel<F, false, 4, true>), grid, wg, 0, s, p);
+#ifdef RG_IOW2
+            else      hipLaunchKernelGGL((step32_kernel<F, false, 1, true, 2>), grid, dim3(3 * BLOCK), 0, s, p);
+#else
+            else      hipLaunchKernelGGL((step32_kernel<F, false, 1, true>), grid, wg, 0, s, p);
+#endif
+        }
+        return hipGetLastError();
+    }
     if (p.force_wide != 0) {
         if (sparse) {
-            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-            else      hipLaunchKernelGGL((step32_wide_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, true, 4, false>), grid, wg, 0, s, p);
+            else      hipLaunchKernelGGL((step32_wide_kernel<F, true, 1, false>), grid, wg, 0, s, p);
         } else {
-            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, false, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-            else      hipLaunchKernelGGL((step32_wide_kernel<F, false, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+            if (many) hipLaunchKernelGGL((step32_wide_kernel<F, false, 4, false>), grid, wg, 0, s, p);
+            else      hipLaunchKernelGGL((step32_wide_kernel<F, false, 1, false>), grid, wg, 0, s, p);
         }
         return hipGetLastError();
     }
     if (sparse) {
-        if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-        else      hipLaunchKernelGGL((step32_kernel<F, true, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        if (many) hipLaunchKernelGGL((step32_kernel<F, true, 4, false>), grid, wg, 0, s, p);
+        else      hipLaunchKernelGGL((step32_kernel<F, true, 1, false>), grid, wg, 0, s, p);
     } else {
-        if (many) hipLaunchKernelGGL((step32_kernel<F, false, 4>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
-        else      hipLaunchKernelGGL((step32_kernel<F, false, 1>), dim3(blocks), dim3(2 * BLOCK), 0, s, p);
+        if (many) hipLaunchKernelGGL((step32_kernel<F, false, 4, false>), grid, wg, 0, s, p);
+        else      hipLaunchKernelGGL((step32_kernel<F, false, 1, false>), grid, wg, 0, s, p);
     }
     return hipGetLastError();
 }

@@ -244,7 +244,9 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     pw = push_bit(pw, fc_n);
     out.resp = a;
     out.log_from = last + 1;
-    sw done = ~fa_n | ~fk_n | ~fc_n | drop | (cw_bit(cw, CW_NONE) & ~nallow);
+    // (a row that is not addressed is done whatever the lane's mode: after a NEED_HOST the host parks the group — RG_EV_NONE rows — and a wavefront
+    // that visited the general handlers for each of them would pay a slow round per parked round; their answer for such a row is this one)
+    sw done = ~fa_n | ~fk_n | ~fc_n | drop | cw_bit(cw, CW_NONE);
     sw any_drop = drop;
     uint32_t pw_el = 0u;
 
@@ -267,76 +269,101 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
             }
         }
         if (__builtin_amdgcn_ballot_w64(election < 0) != 0) {
-            const int32_t term1 = term + 1, el_term = g.elected_term, el_epoch = (int32_t)g.elected_epoch;
-            const sw is_pv = cw_bit(cw, CW_PV), is_pvq = cw_bit(cw, CW_PVQ);
+            // One sub-block per row class, each behind its own ballot, and the conversion tail behind one more: three election rows of four are
+            // vote replies that are merely counted (config 3: 1.19 % of the rows, 54 % of the wave-rounds; timeouts 12 %, vote requests 9 %), and a
+            // launch ends with its slowest workgroup — the one that meets such a row in 61 of its 64 rounds.
+            const int32_t term1 = term + 1;
+            const sw is_pv = cw_bit(cw, CW_PV);
             const sw not_f = s_pos(role), not_c = s_ne(role, RG_CANDIDATE), not_l = s_ne(role, RG_LEADER);
+            sw conv = ack_down, conv_self = 0, to_c = 0, win_rv = 0, late_higher = 0, count = 0, el_fast = ack_down;
+            sw to_pre = 0, to_lead = 0, vq = 0, vq_success = 0, reset = 0, rv_new = 0, no_vote = 0;
             // vote replies (member/Candidate.java:121-134, member/Follower.java:258-270)
             const sw vr_shape = cw_bit(cw, CW_VR) & ~nallow;
-            const sw sender_bad = (is_pv & (not_f | ~td)) | (~is_pv & not_c);
-            const int32_t T = (is_pv < 0) ? term1 : term;
-            const sw vr_cur = vr_shape & ~x_aux & ~sender_bad;
-            const sw x_Ta = s_lt(T, a);
-            const sw vr_higher = vr_cur & x_Ta;
-            const sw vr_grant = vr_cur & ~x_Ta & flg;
-            const sw vr_win = vr_grant & ~s_lt(votes + 1, p.majority);
-            const sw win_rv = vr_win & ~is_pv;
-            const sw x_lt = s_lt(el_term, a);
-            const sw late = vr_shape & ~is_pv & x_aux & (s_pos(el_epoch) & ~s_ne(aux, el_epoch));
-            const sw late_higher = late & x_lt;                         // head.abortRequests(); Follower if that is "better"
-            const sw late_noop = late & ~x_lt & (~flg | s_lt(el_term, term) | (~s_ne(el_term, term) & ~not_l));
-            const sw vote_drop = vr_shape & x_aux & ~late;
-            // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
-            const sw to_kind = cw_bit(cw, CW_TO) & ~nallow;
-            const sw to_stale = to_kind & s_pos(aux) & x_aux;
-            const sw to_live = to_kind & ~to_stale;
-            const sw pre = (p.pre_vote != 0) ? -1 : 0;
-            const sw to_pre = to_live & ~not_f & pre;
-            const sw to_cand = to_live & ((~not_f & ~pre) | ~not_c);
-            const sw to_lead = to_live & ~not_l;
-            // RequestVote / PreVote at a Follower that has a log (member/Follower.java:91-127, 193-207)
-            const sw vq = cw_bit(cw, CW_VQ) & ~nallow & ~not_f & ~s_lt(rc, 1);
-            const sw x_cl = s_lt(lt, c);
-            const sw utd = x_cl | (~s_ne(c, lt) & ~s_lt(b, last));      // Follower.logUpToDate with a last entry
-            const sw pv_judge = vq & is_pvq & x_ta & td;                // else failure(currentTerm), no timer touched
-            const sw rv_new = vq & ~is_pvq & x_ta;
-            const sw rv_same = vq & ~is_pvq & ~x_ta & ~s_lt(a, term);
-            const sw voted_other = s_ne(voted, slot) | voted;           // (votedFor == NO_NODE is nobody's slot)
-            const sw vq_success = ((pv_judge | rv_new) & utd) | (rv_same & ~voted_other);
-            // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`
-            const sw conv_self = vr_win | to_cand;                      // ballot = self
-            const sw conv = (vr_higher | conv_self | (late_higher & ~s_lt(a, term))) | (to_pre | rv_new | ack_down);
-            const sw to_c = (vr_win & is_pv) | to_cand;                 // -> Candidate
-            const sw lead_prepare = to_lead & ~prep;                    // a new Leader's first tick: Leader.prepareReplication (member/Leader.java:30-50)
-            const sw el_fast = (vr_cur | late_higher | late_noop) | (vote_drop | to_kind | vq) | ack_down;
-            //   (vr_cur = higher | win | quiet; to_kind = stale | pre | cand | lead: a timeout always lands in one of them)
-            const bool m_conv = conv < 0, m_winrv = win_rv < 0;
-            const int32_t new_role = (win_rv < 0) ? RG_LEADER : ((to_c < 0) ? RG_CANDIDATE : RG_FOLLOWER);
-            const int32_t new_term = (to_c < 0) ? term1 : (((win_rv | to_pre) < 0) ? term : a);
-            const int32_t new_vote = (conv_self < 0) ? p.self : ((to_pre < 0) ? voted : (((rv_new & ~utd) < 0) ? RG_NO_NODE : slot));
-            if (lead_prepare < 0) {
-                pe.store_prepare(epoch, ((rc > 0) ? last : epoch) + 1);
-                g.pending = 0;
+            if (__builtin_amdgcn_ballot_w64(vr_shape < 0) != 0) {
+                const int32_t el_term = g.elected_term, el_epoch = (int32_t)g.elected_epoch;
+                const sw sender_bad = (is_pv & (not_f | ~td)) | (~is_pv & not_c);
+                const int32_t T = (is_pv < 0) ? term1 : term;
+                const sw vr_cur = vr_shape & ~x_aux & ~sender_bad;
+                const sw x_Ta = s_lt(T, a);
+                const sw vr_grant = vr_cur & ~x_Ta & flg;
+                const sw vr_win = vr_grant & ~s_lt(votes + 1, p.majority);
+                const sw x_lt = s_lt(el_term, a);
+                const sw late = vr_shape & ~is_pv & x_aux & (s_pos(el_epoch) & ~s_ne(aux, el_epoch));
+                const sw late_noop = late & ~x_lt & (~flg | s_lt(el_term, term) | (~s_ne(el_term, term) & ~not_l));
+                const sw vote_drop = vr_shape & x_aux & ~late;
+                late_higher = late & x_lt;                              // head.abortRequests(); Follower if that is "better"
+                win_rv = vr_win & ~is_pv;
+                conv_self = vr_win;
+                to_c = vr_win & is_pv;
+                count = vr_grant & ~vr_win;
+                conv = conv | (vr_cur & x_Ta) | vr_win | (late_higher & ~s_lt(a, term));
+                el_fast = el_fast | vr_cur | late_higher | late_noop | vote_drop;
+                any_drop = any_drop | vote_drop;
             }
-            g.elected_epoch = m_winrv ? (uint32_t)repoch : ((late_higher < 0) ? 0u : (uint32_t)el_epoch);      // Candidate.java:75-79 / head.abortRequests()
-            g.elected_term = m_winrv ? term : el_term;
-            g.term = m_conv ? new_term : g.term;
-            g.role = m_conv ? new_role : g.role;
-            g.voted_for = m_conv ? new_vote : g.voted_for;
-            g.role_epoch = g.role_epoch + (m_conv ? 1u : 0u);
-            g.td = (g.td & ~conv) | to_pre;
-            g.votes = m_conv ? 1 : (g.votes + (((vr_grant & ~vr_win) < 0) ? 1 : 0));
-            g.leader = m_conv ? RG_NO_NODE : g.leader;
-            g.prepared = (g.prepared & ~conv) | lead_prepare;
-            g.peers_dirty = g.peers_dirty | lead_prepare;
+            // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
+            const sw to_kind = cw_bit(cw, CW_TO) & ~nallow & (s_pos(aux) | ((p.require_fence != 0) ? 0 : -1));      // (an un-fenced row where fences are required: general handlers, RG_BAD_EVENT)
+            if (__builtin_amdgcn_ballot_w64(to_kind < 0) != 0) {
+                const sw to_stale = to_kind & s_pos(aux) & x_aux;
+                const sw to_live = to_kind & ~to_stale;
+                const sw pre = (p.pre_vote != 0) ? -1 : 0;
+                const sw to_cand = to_live & ((~not_f & ~pre) | ~not_c);
+                to_pre = to_live & ~not_f & pre;
+                to_lead = to_live & ~not_l;
+                conv_self = conv_self | to_cand;
+                to_c = to_c | to_cand;
+                conv = conv | to_cand | to_pre;
+                reset = to_lead;
+                el_fast = el_fast | to_kind;                            // (stale | pre | cand | lead: a timeout always lands in one of them)
+                any_drop = any_drop | to_stale;
+            }
+            // RequestVote / PreVote at a Follower that has a log (member/Follower.java:91-127, 193-207)
+            const sw vq_shape = cw_bit(cw, CW_VQ) & ~nallow;
+            if (__builtin_amdgcn_ballot_w64(vq_shape < 0) != 0) {
+                const sw is_pvq = cw_bit(cw, CW_PVQ);
+                vq = vq_shape & ~not_f & ~s_lt(rc, 1);
+                const sw utd = s_lt(lt, c) | (~s_ne(c, lt) & ~s_lt(b, last));      // Follower.logUpToDate with a last entry
+                const sw pv_judge = vq & is_pvq & x_ta & td;            // else failure(currentTerm), no timer touched
+                const sw rv_same = vq & ~is_pvq & ~x_ta & ~s_lt(a, term);
+                const sw voted_other = s_ne(voted, slot) | voted;       // (votedFor == NO_NODE is nobody's slot)
+                rv_new = vq & ~is_pvq & x_ta;
+                no_vote = rv_new & ~utd;
+                vq_success = ((pv_judge | rv_new) & utd) | (rv_same & ~voted_other);
+                reset = reset | pv_judge;
+                conv = conv | rv_new;
+                el_fast = el_fast | vq;
+            }
+            // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`; what else a row changes beyond the vote count
+            const sw lead_prepare = to_lead & ~prep;                    // a new Leader's first tick: Leader.prepareReplication (member/Leader.java:30-50)
+            if (__builtin_amdgcn_ballot_w64((conv | lead_prepare | late_higher) < 0) != 0) {
+                const bool m_conv = conv < 0, m_winrv = win_rv < 0;
+                const int32_t new_role = (win_rv < 0) ? RG_LEADER : ((to_c < 0) ? RG_CANDIDATE : RG_FOLLOWER);
+                const int32_t new_term = (to_c < 0) ? term1 : (((win_rv | to_pre) < 0) ? term : a);
+                const int32_t new_vote = (conv_self < 0) ? p.self : ((to_pre < 0) ? voted : ((no_vote < 0) ? RG_NO_NODE : slot));
+                if (lead_prepare < 0) {
+                    pe.store_prepare(epoch, ((rc > 0) ? last : epoch) + 1);
+                    g.pending = 0;
+                }
+                g.elected_epoch = m_winrv ? (uint32_t)repoch : ((late_higher < 0) ? 0u : g.elected_epoch);      // Candidate.java:75-79 / head.abortRequests()
+                g.elected_term = m_winrv ? term : g.elected_term;
+                g.term = m_conv ? new_term : g.term;
+                g.role = m_conv ? new_role : g.role;
+                g.voted_for = m_conv ? new_vote : g.voted_for;
+                g.role_epoch = g.role_epoch + (m_conv ? 1u : 0u);
+                g.td = (g.td & ~conv) | to_pre;
+                g.votes = m_conv ? 1 : g.votes;
+                g.leader = m_conv ? RG_NO_NODE : g.leader;
+                g.prepared = (g.prepared & ~conv) | lead_prepare;
+                g.peers_dirty = g.peers_dirty | lead_prepare;
+            }
+            g.votes = g.votes + (int32_t)((uint32_t)count >> 31);       // (a counted vote never converts)
             out.resp = ((vq & ~rv_new) < 0) ? term : a;                 // (only read for the vote requests)
             pw_el = push_bit(0u, vq);
             pw_el = push_bit(pw_el, vq_success);
-            pw_el = push_bit(pw_el, pv_judge | to_lead);
+            pw_el = push_bit(pw_el, reset);
             pw_el = push_bit(pw_el, conv);
             pw_el = push_bit(pw_el, to_lead);
             pw_el = push_bit(pw_el, to_pre);
             pw_el = push_bit(pw_el, to_c);
-            any_drop = drop | vote_drop | to_stale;
             done = done | el_fast;
         }
         g.recache();

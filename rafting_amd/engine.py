@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -85,10 +85,13 @@ def lib():
         L.rg_table_groups.argtypes = [vp]
         L.rg_table_cluster.restype = u32
         L.rg_table_cluster.argtypes = [vp]
+        L.rg_table_option.argtypes = [vp, i32, i32]
         L.rg_load_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_read_state.argtypes = [vp, u32, u32, C.POINTER(abi.CGroupState)]
         L.rg_submit.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome), i32]
         L.rg_submit32.argtypes = [vp, C.POINTER(abi.CBatch32), C.POINTER(abi.COutcome), i32]
+        L.rg_submit32c.argtypes = [vp, C.POINTER(abi.CBatch32), C.POINTER(abi.COutcome32), i32]
+        L.rg_outcome32_unpack.argtypes = [C.POINTER(abi.COutcome32), u32, u32, vp, C.POINTER(abi.COutcome)]
         L.rg_batch32_pack.restype = C.c_int64
         L.rg_batch32_pack.argtypes = [C.POINTER(abi.CBatch), vp, vp, vp]
         L.rg_submit_async.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
@@ -235,6 +238,20 @@ class PackedBatch:
         self._owners = []
 
 
+def unpack32(out32, rounds, count, role_epoch_before):
+    """abi.Outcome32 -> abi.Outcome through the library's host-side rg_outcome32_unpack. `role_epoch_before`: the groups' role epochs before the
+    batch (GroupState.role_epoch); returns (outcome, role epochs after the batch)."""
+    out = abi.Outcome(rounds * count)
+    ep = np.ascontiguousarray(role_epoch_before, dtype=np.uint32).copy()
+    assert len(ep) == count and out32.rows == rounds * count
+    i, o = out32.as_struct(), out.as_struct()
+    rc = lib().rg_outcome32_unpack(C.byref(i), rounds, count, ep.ctypes.data, C.byref(o))
+    if rc:
+        raise EngineError("rg_outcome32_unpack: %d (%s)" % (rc, {-1: "missing column", -3: "a row is flagged RG_F_WIDE_VALUES but there are no overflow columns",
+                                                                 -4: "the compact and the wide copy of a row disagree"}.get(rc, "?")))
+    return out, ep
+
+
 class DeviceBuffer:
     """A block of HBM owned through rg_dev_alloc."""
 
@@ -305,9 +322,11 @@ class DeviceBatch:
 
 
 class DeviceBatch32:
-    """An rg_batch32_t + rg_outcome_t resident in HBM (rg_submit32, RG_MEM_DEVICE): built once from an abi.Batch, submitted many times."""
+    """An rg_batch32_t + rg_outcome_t resident in HBM (rg_submit32, RG_MEM_DEVICE): built once from an abi.Batch, submitted many times.
+    compact=True: the outcome is an rg_outcome32_t instead (rg_submit32c: one 16-byte row per event + persist rows; `wide` adds the overflow
+    columns) — outcome32() reads it back, outcome(role_epoch_before) unpacks it into the wide image."""
 
-    def __init__(self, table, batch):
+    def __init__(self, table, batch, compact=False, wide=True):
         b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
         self.table, self.rounds, self.count = table, b32.rounds, b32.count
         rows = b32.rounds * b32.count
@@ -317,9 +336,12 @@ class DeviceBatch32:
         self.head, self.abcd = mk(b32.head), mk(b32.abcd)
         self.entry_count = b32.entry_count
         self.entry_terms = mk(b32.entry_terms[: b32.entry_count]) if b32.entry_count else None
-        self.reply = DeviceBuffer(table, rows * abi.REPLY_DT.itemsize)
-        self.logfx = DeviceBuffer(table, rows * abi.LOGFX_DT.itemsize)
-        self.persist = DeviceBuffer(table, rows * abi.PERSIST_DT.itemsize)
+        self.compact = compact
+        self.reply = self.logfx = self.persist = self.row32 = self.persist32 = None
+        if not compact or wide:
+            self.reply = DeviceBuffer(table, rows * abi.REPLY_DT.itemsize)
+            self.logfx = DeviceBuffer(table, rows * abi.LOGFX_DT.itemsize)
+            self.persist = DeviceBuffer(table, rows * abi.PERSIST_DT.itemsize)
         b = abi.CBatch32()
         b.rounds, b.count = b32.rounds, b32.count
         b.gid = self.gid.ptr if self.gid else None
@@ -327,11 +349,32 @@ class DeviceBatch32:
         b.entry_terms = self.entry_terms.ptr if self.entry_terms else None
         b.entry_count = self.entry_count
         o = abi.COutcome()
-        o.reply, o.logfx, o.persist = self.reply.ptr, self.logfx.ptr, self.persist.ptr
+        if self.reply is not None:
+            o.reply, o.logfx, o.persist = self.reply.ptr, self.logfx.ptr, self.persist.ptr
+        if compact:
+            self.row32 = DeviceBuffer(table, rows * abi.OUT32_DT.itemsize)
+            self.persist32 = DeviceBuffer(table, rows * abi.PERSIST32_DT.itemsize)
+            o32 = abi.COutcome32()
+            o32.row, o32.persist, o32.wide = self.row32.ptr, self.persist32.ptr, o
+            o = o32
         self.c_batch, self.c_out = b, o
         self.bytes_in = b32.head.nbytes + b32.abcd.nbytes + 4 * b32.entry_count
 
-    def outcome(self):
+    def outcome32(self):
+        assert self.compact
+        out = abi.Outcome32(self.rows, wide=self.reply is not None)
+        out.row = self.row32.to_host(abi.OUT32_DT, self.rows)
+        out.persist = self.persist32.to_host(abi.PERSIST32_DT, self.rows)
+        if out.wide is not None:
+            out.wide.reply = self.reply.to_host(abi.REPLY_DT, self.rows)
+            out.wide.logfx = self.logfx.to_host(abi.LOGFX_DT, self.rows)
+            out.wide.persist = self.persist.to_host(abi.PERSIST_DT, self.rows)
+        return out
+
+    def outcome(self, role_epoch_before=None):
+        if self.compact:
+            assert role_epoch_before is not None, "compact outcome rows carry the role epoch only where it changes: pass the epochs before the batch"
+            return unpack32(self.outcome32(), self.rounds, self.count, role_epoch_before)[0]
         out = abi.Outcome(self.rows)
         out.reply = self.reply.to_host(abi.REPLY_DT, self.rows)
         out.logfx = self.logfx.to_host(abi.LOGFX_DT, self.rows)
@@ -339,7 +382,7 @@ class DeviceBatch32:
         return out
 
     def free(self):
-        for b in (self.gid, self.head, self.abcd, self.entry_terms, self.reply, self.logfx, self.persist):
+        for b in (self.gid, self.head, self.abcd, self.entry_terms, self.reply, self.logfx, self.persist, self.row32, self.persist32):
             if b is not None:
                 b.free()
 
@@ -372,6 +415,10 @@ class Table:
         except Exception:
             pass
 
+    def set_option(self, option, value):
+        """rg_table_option, e.g. (abi.OPT_REQUIRE_FENCED_TIMEOUTS, 1)"""
+        self._check(lib().rg_table_option(self._h, option, int(value)))
+
     # state ---------------------------------------------------------------------------------------
     def load_state(self, state, first=0):
         s = state.as_struct()
@@ -399,6 +446,19 @@ class Table:
         b, o = b32.as_struct(), out.as_struct()
         self._check(lib().rg_submit32(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
         return out
+
+    def submit32c(self, batch, out32=None, fill=0, wide=True):
+        """Host-buffer submission of compact rows with COMPACT OUTCOME rows (rg_submit32c, RG_MEM_HOST) -> abi.Outcome32"""
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
+        out32 = abi.Outcome32(b32.rounds * b32.count, fill, wide=wide) if out32 is None else out32
+        b, o = b32.as_struct(), out32.as_struct()
+        self._check(lib().rg_submit32c(self._h, C.byref(b), C.byref(o), abi.MEM_HOST))
+        return out32
+
+    def submit32c_unpacked(self, batch, role_epoch_before, fill=0):
+        """rg_submit32c, then rg_outcome32_unpack: the wide image of the compact outcome rows (what rg_submit32 would have returned)"""
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
+        return unpack32(self.submit32c(b32, fill=fill), b32.rounds, b32.count, role_epoch_before)[0]
 
     def submit_async(self, batch, out):
         """Pipelined host-buffer submission (rg_submit_async): returns at once; `batch` and `out` must stay alive and untouched
@@ -432,7 +492,9 @@ class Table:
 
     def submit_device(self, dbatch):
         """HBM-resident submission (RG_MEM_DEVICE): asynchronous on the table's stream. DeviceBatch -> rg_submit, DeviceBatch32 -> rg_submit32."""
-        if isinstance(dbatch, DeviceBatch32):
+        if isinstance(dbatch, DeviceBatch32) and dbatch.compact:
+            self._check(lib().rg_submit32c(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
+        elif isinstance(dbatch, DeviceBatch32):
             self._check(lib().rg_submit32(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))
         else:
             self._check(lib().rg_submit(self._h, C.byref(dbatch.c_batch), C.byref(dbatch.c_out), abi.MEM_DEVICE))

@@ -23,6 +23,8 @@ IngressFlusher::IngressFlusher(std::vector<rg_table_t *> tables, Ingress &ing, c
     if (ing_.shards() != tables_.size()) throw std::invalid_argument("IngressFlusher: one table per shard of the ingress");
     rep_.resize(tables_.size()); lfx_.resize(tables_.size()); per_.resize(tables_.size());
     ing_.retain_bodies(true);
+    // the ordering contract of INTEGRATION.md section 1, enforced: a timeout row names the participant whose ticket fired (context/RaftRoutine.java:65-77)
+    for (rg_table_t *t : tables_) rg_table_option(t, RG_OPT_REQUIRE_FENCED_TIMEOUTS, 1);
 }
 
 // One applied row -> the host-owned plugins, in the handler's order.
@@ -125,12 +127,23 @@ int64_t IngressFlusher::flush(std::vector<std::string> &out)
     int64_t decided = 0;
     {
         // the shards' launches side by side: tables are independent (one stream each); the first on this thread
+        // (the side threads are joined on EVERY way out of this block — an exception out of shard 0's submit, e.g. bad_alloc, would
+        // otherwise destroy joinable threads (std::terminate) while they still read the sealed batch; what a shard throws is reported, not lost)
         std::vector<int> rc(S, 0);
+        std::vector<std::string> thrown(S);
         std::vector<std::thread> side;
-        for (uint32_t s = 1; s < S; s++) side.emplace_back([&, s] { rc[s] = submit_shard(b, s); });
-        rc[0] = submit_shard(b, 0);
+        struct Join { std::vector<std::thread> &ts; ~Join() { for (auto &t : ts) if (t.joinable()) t.join(); } } join_all{side};
+        auto run = [&](uint32_t s) {
+            try { rc[s] = submit_shard(b, s); }
+            catch (const std::exception &e) { rc[s] = -1; thrown[s] = e.what(); }
+        };
+        for (uint32_t s = 1; s < S; s++) side.emplace_back(run, s);
+        run(0);
         for (auto &t : side) t.join();
-        for (uint32_t s = 0; s < S; s++) if (rc[s] != 0) { err_ = rg_last_error(tables_[s]); return -1; }
+        std::string all;
+        for (uint32_t s = 0; s < S; s++)
+            if (rc[s] != 0) all += (all.empty() ? "" : "; ") + ("shard " + std::to_string(s) + ": ") + (thrown[s].empty() ? std::string(rg_last_error(tables_[s])) : thrown[s]);
+        if (!all.empty()) { err_ = all; return -1; }
     }
     for (uint32_t s = 0; s < S; s++) {
         const rg_batch32_t &sb = b.shard[s].batch;

@@ -61,6 +61,10 @@ class ReplayConfig:
     p_reject: float = 0.02
     p_conflict: float = 0.0       # higher-term AppendEntries (a subset of p_higher_term) whose entries OVERWRITE the last 1-3 uncommitted
                                   # entries of the follower: prevLogIndex below the tail, conflict -> truncate -> append (general handlers)
+    p_miss: float = 0.0           # adverse mix (bench.py's value_adverse_mix): follower rows that are a RETRANSMITTED heartbeat of the current leader whose
+                                  # prevLogIndex lies below the device's cached term runs (the logs then start with five runs) -> RG_NEED_HOST. The row
+                                  # changes nothing whether it is applied or not (but Follower.currentLeader where that was still null); the host PARKS the group (RG_EV_NONE rows) for the rest of the launch —
+                                  # what RG_SKIPPED_AFTER_NEED_HOST would do to its rows anyway — and drops the duplicate instead of resubmitting it
     ae_entries: tuple = (0, 1, 2, 4)   # entries per AppendEntries request, equiprobable
     self_slot: int = 0
     pre_vote: bool = True
@@ -148,6 +152,21 @@ class ReplayGenerator:
         self.late_k = np.full(n, F, dtype=np.int64)              # next late RequestVote reply of a won election
         self.late_epoch = np.zeros(n, dtype=np.int64)
         self.needs_append = np.zeros(n, dtype=bool)
+        self.parked = np.zeros(n, dtype=bool)                    # p_miss: groups that met a cache miss in the launch being built
+        self.miss_rows = 0
+        if cfg.p_miss > 0.0:
+            # five term runs per log: [1, last - 44] of term t - 4, three one-entry runs, then [last - 40, last] of term t. The device caches the newest
+            # four: an index below last0 - 43 is a miss for the rest of the stream (later runs only push the cached window further up)
+            self.term = self.term + 4
+            self.last = np.maximum(self.last, 64)
+            self.last_term = self.term.copy()
+            self.commit = np.maximum(self.commit, self.last - 3)
+            self.match = np.maximum(self.match, (self.last - 3)[:, None])
+            self.tail_run_start = self.last - 40
+            self.cur_term_start = self.last - 40
+            self.miss_below = self.last - 43
+            self.run_starts = np.stack([np.ones(n, dtype=np.int64), self.last - 43, self.last - 42, self.last - 41, self.last - 40], axis=1)
+            self.run_terms = self.term[:, None] + np.arange(-4, 1, dtype=np.int64)[None, :]
         self.round_no = 0
 
     def initial_state(self):
@@ -167,6 +186,22 @@ class ReplayGenerator:
         st.run_term[0::abi.TERM_RUNS] = self.term
         st.peer_match_index[:] = np.where(lead[:, None], self.match, 0).reshape(-1)
         st.peer_next_index[:] = np.where(lead[:, None], self.match + 1, 0).reshape(-1)
+        if cfg.p_miss > 0.0:                                      # five runs per group: the table keeps the newest RG_TERM_RUNS
+            st = abi.GroupState(n, self.P, runs_total=5 * n)
+            st.role[:] = np.where(lead, abi.LEADER, abi.FOLLOWER)
+            st.current_term[:] = self.term
+            st.voted_for[:] = np.where(lead, cfg.self_slot, self.leader)
+            st.current_leader[:] = np.where(lead, abi.NO_NODE, self.leader)
+            st.repl_prepared[:] = lead
+            st.commit_index[:] = self.commit
+            st.first_index[:] = 1
+            st.last_index[:] = self.last
+            st.run_count[:] = 5
+            st.run_offset[:] = np.arange(n, dtype=np.uint32) * 5
+            st.run_start[:] = self.run_starts.reshape(-1)
+            st.run_term[:] = self.run_terms.reshape(-1)
+            st.peer_match_index[:] = np.where(lead[:, None], self.match, 0).reshape(-1)
+            st.peer_next_index[:] = np.where(lead[:, None], self.match + 1, 0).reshape(-1)
         return st
 
     # -- one round -------------------------------------------------------------------------------
@@ -185,6 +220,17 @@ class ReplayGenerator:
         u0, u1, u2, u3 = self._u(0), self._u(1), self._u(2), self._u(3)
         mode = self.mode.copy()                                   # decisions below use the mode at round start
         other = self.others[self._ri(4, F)]
+        if cfg.p_miss > 0.0:
+            mode[self.parked] = -1                                # parked until the launch ends: RG_EV_NONE rows, no model change
+            miss = (mode == FOLLOW) & (self._u(10) < cfg.p_miss)
+            mode[miss] = -1
+            kind[miss] = abi.EV_AE_REQ                            # the leader's heartbeat once more, with a prevLog far behind: (term, leader, prev, prevTerm, [], 0)
+            slot[miss] = self.leader[miss]
+            a[miss] = self.term[miss]
+            bb[miss] = (self.miss_below - 1 - self._ri(11, 4))[miss]
+            c[miss] = self.run_terms[miss, 0]
+            self.parked |= miss
+            self.miss_rows += int(np.count_nonzero(miss))
 
         # ---- follower view ----------------------------------------------------------------------
         fol = mode == FOLLOW
@@ -345,6 +391,7 @@ class ReplayGenerator:
         """The next `rounds` rounds as one dense multi-round batch (entry offsets local to the batch)."""
         b = abi.Batch(rounds, self.n)
         self._ents, self._ent_count = [], 0
+        self.parked[:] = False
         for r in range(rounds):
             self._round(b, r)
         b.entry_terms = np.concatenate(self._ents) if self._ents else np.zeros(0, dtype=np.int64)

@@ -75,12 +75,13 @@ def test_packed_pipeline_formats():
 
 
 # ---- compact rows (rg_batch32_t) through step32_kernel: the 32-bit body, and the 64-bit body it falls back to ------------------------
-@pytest.fixture(params=["narrow", "forced-wide"])
+@pytest.fixture(params=["narrow", "forced-wide", "narrow-out32", "forced-wide-out32"])
 def compact_route(request, monkeypatch):
-    """Table.submit packs every batch that fits (no hints, values < 2^31) and sends it through rg_submit32"""
-    if request.param == "forced-wide":
+    """Table.submit packs every batch that fits (no hints, values < 2^31) and sends it through rg_submit32 — or, `out32`, through rg_submit32c
+    (compact outcome rows, ABI 4) and back through rg_outcome32_unpack"""
+    if request.param.startswith("forced-wide"):
         monkeypatch.setenv("RG_FORCE_WIDE", "1")
-    T.route_through_compact(monkeypatch)
+    T.route_through_compact(monkeypatch, out32=request.param.endswith("out32"))
     return request.param
 
 
@@ -89,6 +90,12 @@ def test_kat_on_compact_rows(scenario, monkeypatch):
     # (the 32-bit body; the 64-bit body of the same kernel answers the fuzz cases below on this emulation and every scenario on the GPU:
     # tests/test_gpu_parity.py runs all of them on both routes)
     T.route_through_compact(monkeypatch)
+    scenario(T.mk_gpu)
+
+
+@pytest.mark.parametrize("scenario", kat_scenarios.SCENARIOS, ids=lambda f: f.__name__)
+def test_kat_on_compact_rows_with_compact_outcomes(scenario, monkeypatch):
+    T.route_through_compact(monkeypatch, out32=True)
     scenario(T.mk_gpu)
 
 
@@ -111,6 +118,22 @@ def test_compact_multi_round_launch_and_domain_exits():
 
 def test_compact_workload_replays():
     T.compact_workload_case(groups=200, rounds=12)
+
+
+@pytest.mark.parametrize("route", ["wide-rows", "narrow", "forced-wide", "narrow-out32"])
+def test_unfenced_timeouts_are_refused_where_the_table_requires_fences(route, monkeypatch):
+    if route != "wide-rows":
+        T.route_through_compact(monkeypatch, out32=route.endswith("out32"))
+    if route == "forced-wide":
+        monkeypatch.setenv("RG_FORCE_WIDE", "1")
+    T.fenced_timeouts_case()
+
+
+@pytest.mark.parametrize("forced_wide", [False, True])
+def test_adverse_mix_stream(forced_wide, monkeypatch):
+    if forced_wide:
+        monkeypatch.setenv("RG_FORCE_WIDE", "1")
+    T.adverse_mix_case(320, 16)
 
 
 def test_ingress_batches_are_decided_like_the_history_row_by_row():

@@ -151,6 +151,37 @@ def compare_outcomes(ref, got, where=""):
         _same(ref.persist[k][pf], got.persist[k][pf], "persist." + k, where)
 
 
+def check_out32_rows(raw, unpacked, before, after, rounds, count):
+    """What include/raftgpu.h promises about rg_out32_t / rg_persist32_t rows beyond what rg_outcome32_unpack carries over: commit_index is
+    RaftLog.lastCommitted() after EVERY row (it moves exactly where RG_F_COMMIT says, and ends at the table's value), resp_term is 0 unless
+    RG_F_REPLIED, a persist row names the role its reply names, and the role epochs end at the table's. Rows flagged RG_F_WIDE_VALUES
+    (the 64-bit body met a value beyond int32) are exempt from the numeric checks: their truth is in the overflow columns."""
+    fl = raw.row["flags"].reshape(rounds, count)
+    wide = (fl & abi.F_WIDE_VALUES) != 0
+    commit = raw.row["commit_index"].astype(np.int64).reshape(rounds, count)
+    prev = np.vstack([before.commit_index[None, :], commit[:-1]])
+    moved = (fl & abi.F_COMMIT) != 0
+    ok = wide | np.vstack([np.zeros((1, count), bool), wide[:-1]]) | np.where(moved, commit > prev, commit == prev)
+    if not ok.all():
+        r, g = np.argwhere(~ok)[0]
+        raise AssertionError("rg_out32_t.commit_index of round %d group %d is %d after %d (RG_F_COMMIT %s)" % (r, g, commit[r, g], prev[r, g], bool(moved[r, g])))
+    small = (after.commit_index < (1 << 31)) & ~wide[-1]
+    assert np.array_equal(commit[-1][small], after.commit_index[small]), "the last rows' commit_index is not the table's"
+    silent = ((fl & abi.F_REPLIED) == 0) & ~wide
+    assert not raw.row["resp_term"].reshape(rounds, count)[silent].any(), "resp_term of a row without RG_F_REPLIED"
+    per = (fl & abi.F_PERSIST) != 0
+    assert np.array_equal(raw.persist["role"].reshape(rounds, count)[per].astype(np.uint32), abi.flags_role(fl[per])), "persist.role != the reply's role"
+    ep = before.role_epoch.copy()
+    pe = raw.persist["role_epoch"].reshape(rounds, count)
+    wr = None if raw.wide is None else raw.wide.reply["role_epoch"].reshape(rounds, count)
+    for r in range(rounds):
+        ep = np.where(per[r], pe[r], ep)
+        if wr is not None:
+            ep = np.where(wide[r], wr[r], ep)
+    assert np.array_equal(ep, after.role_epoch), "role epochs carried by the persist rows do not end at the table's"
+    _same(unpacked.reply["role_epoch"].reshape(rounds, count)[-1], after.role_epoch, "unpacked role_epoch (last round)", "rg_outcome32_unpack")
+
+
 def _same(a, b, what, where):
     a, b = np.asarray(a), np.asarray(b)
     if a.shape != b.shape or not np.array_equal(a, b):

@@ -1,0 +1,128 @@
+/*
+ * jni_harness.c — TEST INFRASTRUCTURE: drives integration/jni/raftgpu_jni.c through a FAKE JNIEnv (tests/jni_stub/jni.h: a stand-in, no JVM
+ * here) on whatever libraftgpu.so it is linked against — the host emulation of the kernels in the CPU suite — and holds the shim to the
+ * C-ABI called directly: the same batch through Java_..._GpuTable_submit and through rg_submit must give byte-identical outcome columns and
+ * table state.  A "direct ByteBuffer" here is a struct {address, capacity}; an "Object[]" a struct {n, elements}.
+ */
+#include <jni.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "raftgpu.h"
+
+struct _jobject { int kind; void *addr; jlong cap; jsize n; jobject *elems; const char *text; };
+enum { K_BUFFER = 1, K_ARRAY, K_CLASS, K_STRING };
+static char thrown[256];
+
+static jclass fake_FindClass(JNIEnv *env, const char *name) { (void)env; static struct _jobject c = {K_CLASS, 0, 0, 0, 0, 0}; c.text = name; return &c; }
+static jint fake_ThrowNew(JNIEnv *env, jclass c, const char *msg) { (void)env; (void)c; snprintf(thrown, sizeof thrown, "%s", msg ? msg : ""); return 0; }
+static jstring fake_NewStringUTF(JNIEnv *env, const char *utf) { (void)env; jobject o = calloc(1, sizeof *o); o->kind = K_STRING; o->text = utf; return o; }
+static jsize fake_GetArrayLength(JNIEnv *env, jarray a) { (void)env; return a->n; }
+static jobject fake_GetObjectArrayElement(JNIEnv *env, jobjectArray a, jsize i) { (void)env; return a->elems[i]; }
+static jobject fake_NewDirectByteBuffer(JNIEnv *env, void *p, jlong cap) { (void)env; jobject o = calloc(1, sizeof *o); o->kind = K_BUFFER; o->addr = p; o->cap = cap; return o; }
+static void *fake_GetDirectBufferAddress(JNIEnv *env, jobject b) { (void)env; return b->kind == K_BUFFER ? b->addr : NULL; }
+static jlong fake_GetDirectBufferCapacity(JNIEnv *env, jobject b) { (void)env; return b->cap; }
+
+static const struct JNINativeInterface_ table = {fake_FindClass, fake_ThrowNew, fake_NewStringUTF, fake_GetArrayLength, fake_GetObjectArrayElement,
+                                                 fake_NewDirectByteBuffer, fake_GetDirectBufferAddress, fake_GetDirectBufferCapacity};
+static JNIEnv env_ = &table;
+static JNIEnv *env = &env_;
+
+#define J(cls, name) Java_io_lubricant_consensus_raft_gpu_##cls##_##name
+jint J(GpuTable, abiVersion)(JNIEnv *, jclass);
+jlong J(GpuTable, create)(JNIEnv *, jclass, jint, jint, jint, jint, jboolean);
+void J(GpuTable, destroy)(JNIEnv *, jclass, jlong);
+jstring J(GpuTable, lastError)(JNIEnv *, jclass, jlong);
+jint J(GpuTable, option)(JNIEnv *, jclass, jlong, jint, jint);
+jobject J(GpuTable, hostAlloc)(JNIEnv *, jclass, jlong, jlong);
+jint J(GpuTable, hostFree)(JNIEnv *, jclass, jlong, jobject);
+jint J(GpuTable, loadState)(JNIEnv *, jclass, jlong, jint, jint, jobjectArray);
+jint J(GpuTable, readState)(JNIEnv *, jclass, jlong, jint, jint, jobjectArray);
+jint J(GpuTable, submit)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject);
+jint J(GpuTable, submit32c)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject, jobject);
+
+enum { G = 96, P = 3, NCOL = sizeof(rg_group_state_t) / sizeof(void *) };
+
+/* the 24 columns of rg_group_state_t for G fresh followers with a small log (what RaftContext.initialize would restore) */
+static void make_state(rg_group_state_t *s)
+{
+    const size_t sizes[NCOL] = {8, 4, 4, 4, 1, 1, 4, 4, 4, 8, 8, 8, 8, 8, 8, 4, 4, 8 * RG_TERM_RUNS, 8 * RG_TERM_RUNS, 8 * (P - 1), 8 * (P - 1), 8 * (P - 1), 4 * (P - 1), 1 * (P - 1)};
+    void **f = (void **)s;
+    for (int i = 0; i < NCOL; i++) f[i] = calloc(G, sizes[i]);
+    for (uint32_t g = 0; g < G; g++) {
+        s->current_term[g] = 3; s->voted_for[g] = 1; s->role[g] = RG_FOLLOWER; s->current_leader[g] = 1; s->role_epoch[g] = 1; s->votes[g] = 1;
+        s->commit_index[g] = 8; s->first_index[g] = 1; s->last_index[g] = 10 + g; s->run_count[g] = 1; s->run_offset[g] = g * RG_TERM_RUNS;
+        s->run_start[g * RG_TERM_RUNS] = 1; s->run_term[g * RG_TERM_RUNS] = 3;
+    }
+}
+
+static jobject buf(void *p, size_t n) { return fake_NewDirectByteBuffer(env, p, (jlong)n); }
+
+int main(void)
+{
+    if (J(GpuTable, abiVersion)(env, NULL) != RG_ABI_VERSION) { fprintf(stderr, "abi\n"); return 1; }
+    /* a refused create throws IllegalStateException with the library's message and returns 0 */
+    if (J(GpuTable, create)(env, NULL, 0, G, 99, 0, 1) != 0 || !strstr(thrown, "cluster")) { fprintf(stderr, "create(bad cluster) did not throw: '%s'\n", thrown); return 1; }
+    const jlong h = J(GpuTable, create)(env, NULL, 0, G, P, 0, 1);
+    rg_table_t *direct = NULL;
+    if (!h || rg_table_create(0, G, P, 0, 1, &direct) != 0) { fprintf(stderr, "create: %s\n", thrown); return 1; }
+    if (J(GpuTable, option)(env, NULL, h, RG_OPT_REQUIRE_FENCED_TIMEOUTS, 1) != 0 || rg_table_option(direct, RG_OPT_REQUIRE_FENCED_TIMEOUTS, 1) != 0) return 1;
+    if (J(GpuTable, option)(env, NULL, h, 12345, 1) == 0 || !strstr(J(GpuTable, lastError)(env, NULL, h)->text, "option")) { fprintf(stderr, "unknown option accepted\n"); return 1; }
+
+    rg_group_state_t st;
+    make_state(&st);
+    jobject cols[NCOL];
+    const size_t sizes[NCOL] = {8, 4, 4, 4, 1, 1, 4, 4, 4, 8, 8, 8, 8, 8, 8, 4, 4, 8 * RG_TERM_RUNS, 8 * RG_TERM_RUNS, 8 * (P - 1), 8 * (P - 1), 8 * (P - 1), 4 * (P - 1), 1 * (P - 1)};
+    for (int i = 0; i < NCOL; i++) cols[i] = buf(((void **)&st)[i], G * sizes[i]);
+    struct _jobject arr = {K_ARRAY, 0, 0, NCOL, cols, 0}, short_arr = {K_ARRAY, 0, 0, NCOL - 1, cols, 0};
+    if (J(GpuTable, loadState)(env, NULL, h, 0, G, &short_arr) == 0 || !strstr(thrown, "24 columns")) { fprintf(stderr, "short column list accepted\n"); return 1; }
+    if (J(GpuTable, loadState)(env, NULL, h, 0, G, &arr) != 0 || rg_load_state(direct, 0, G, &st) != 0) { fprintf(stderr, "loadState: %s\n", rg_last_error(direct)); return 1; }
+
+    /* one round: AppendEntries at the log tail with two entries (even groups), an un-fenced and a fenced timeout (odd groups) */
+    rg_ev_head_t head[G]; rg_ev_pair_t ab[G], cd[G]; int64_t terms[2 * G]; uint64_t nterms = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        if (g % 2 == 0) {
+            head[g].hdr = RG_HDR_MAKE(RG_EV_AE_REQ, 1, 0, 2); head[g].aux = (uint32_t)nterms;
+            terms[nterms++] = 3; terms[nterms++] = 3;
+            ab[g].x = 3; ab[g].y = 10 + g; cd[g].x = 3; cd[g].y = 11 + g;
+        } else {
+            head[g].hdr = RG_HDR_MAKE(RG_EV_TIMEOUT, 0, 0, 0); head[g].aux = (g % 4 == 1) ? 0u : 1u;
+            ab[g].x = ab[g].y = cd[g].x = cd[g].y = 0;
+        }
+    }
+    rg_reply_t rep_j[G], rep_d[G]; rg_logfx_t lfx_j[G], lfx_d[G]; rg_persist_t per_j[G], per_d[G];
+    memset(rep_j, 0, sizeof rep_j); memset(rep_d, 0, sizeof rep_d);
+    const jint rc = J(GpuTable, submit)(env, NULL, h, 1, G, NULL, buf(head, sizeof head), buf(ab, sizeof ab), buf(cd, sizeof cd), buf(terms, sizeof terms), (jlong)nterms, NULL,
+                                        buf(rep_j, sizeof rep_j), buf(lfx_j, sizeof lfx_j), buf(per_j, sizeof per_j));
+    rg_batch_t in = {1, G, NULL, head, ab, cd, terms, nterms, NULL};
+    rg_outcome_t out = {rep_d, lfx_d, per_d};
+    if (rc != 0 || rg_submit(direct, &in, &out, RG_MEM_HOST) != 0) { fprintf(stderr, "submit: %d %s\n", rc, rg_last_error(direct)); return 1; }
+    if (memcmp(rep_j, rep_d, sizeof rep_j) || memcmp(lfx_j, lfx_d, sizeof lfx_j) || memcmp(per_j, per_d, sizeof per_j)) { fprintf(stderr, "outcomes differ\n"); return 1; }
+    unsigned ok = 0, bad = 0, app = 0;
+    for (uint32_t g = 0; g < G; g++) {
+        const uint32_t status = RG_F_STATUS(rep_j[g].flags);
+        ok += status == RG_OK; bad += status == RG_BAD_EVENT; app += (rep_j[g].flags & RG_F_LOG_APPEND) != 0;
+    }
+    if (bad != G / 4 || ok != G - G / 4 || app != G / 2) { fprintf(stderr, "unexpected decisions: ok %u bad %u append %u\n", ok, bad, app); return 1; }
+
+    /* the same state through readState: both tables hold the same image */
+    rg_group_state_t a, b;
+    make_state(&a); make_state(&b);
+    jobject cols_a[NCOL];
+    for (int i = 0; i < NCOL; i++) cols_a[i] = buf(((void **)&a)[i], G * sizes[i]);
+    struct _jobject arr_a = {K_ARRAY, 0, 0, NCOL, cols_a, 0};
+    if (J(GpuTable, readState)(env, NULL, h, 0, G, &arr_a) != 0 || rg_read_state(direct, 0, G, &b) != 0) return 1;
+    for (int i = 0; i < NCOL; i++) if (memcmp(((void **)&a)[i], ((void **)&b)[i], G * sizes[i])) { fprintf(stderr, "state column %d differs\n", i); return 1; }
+
+    /* page-locked memory as a direct buffer, and back */
+    jobject pinned = J(GpuTable, hostAlloc)(env, NULL, h, 4096);
+    if (!pinned || pinned->cap != 4096 || !pinned->addr) return 1;
+    memset(pinned->addr, 0x5A, 4096);
+    if (J(GpuTable, hostFree)(env, NULL, h, pinned) != 0) return 1;
+
+    J(GpuTable, destroy)(env, NULL, h);
+    rg_table_destroy(direct);
+    printf("jni shim ok: %u rows decided identically through the shim and through the C-ABI (%u refused as un-fenced timeouts)\n", G, bad);
+    return 0;
+}

@@ -31,6 +31,7 @@ def lib():
         L.orc_table_create.restype = C.c_void_p
         L.orc_table_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.orc_table_destroy.argtypes = [C.c_void_p]
+        L.orc_table_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_load_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
         L.orc_read_state.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(abi.CGroupState)]
         L.orc_submit.argtypes = [C.c_void_p, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
@@ -78,6 +79,10 @@ class OracleTable:
         if self._h:
             lib().orc_table_destroy(self._h)
             self._h = None
+
+    def set_option(self, option, value):
+        if lib().orc_table_option(self._h, option, int(value)):
+            raise ValueError("orc_table_option(%d) refused" % option)
 
     def __del__(self):
         self.close()

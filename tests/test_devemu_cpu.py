@@ -58,10 +58,16 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     assert legs["packed_bytes_per_decision"] < legs["wide_bytes_per_decision"]
     rt = d["cpu_baseline"].get("reference_translated")
     assert rt is None or "error" not in rt, rt
-    r = d["roofline"]                                                           # round 4: a denominator that cannot exceed 1, the 64-bit body timed beside the 32-bit one
-    assert r["layout_floor_bytes"] > 0 and 0 < r["frac_of_layout_floor"] and r["layout_floor_bytes"] < r["algorithmic_bytes_per_launch"]
+    r = d["roofline"]                                                           # round 5: `frac` is moved bytes over time over the peak (the PMC quotation, or — here, no
+    assert r["layout_estimate_bytes"] > 0 and r["layout_estimate_bytes"] < r["algorithmic_bytes_per_launch"]     # entry for an emulation build — the layout estimate, named as such)
+    assert r["traffic"] is None and r["frac_basis"].startswith("layout estimate") and abs(r["frac"] - r["frac_of_layout_estimate"]) < 1e-12
+    assert r["traffic_measured_in_this_run"] is False and r["work_rate_algorithmic_gbps"] > 0 and r["outcome_format"] == "rg_outcome32_t"
     assert r["ms_int64_body"] > 0 and r["value_int64_body"] > 0 and r["int64_body_counters_equal"] is True
     assert "golden" in d and "model_overcharges" in r
+    adv = d["adverse_mix"]                                                      # round 5: the adverse mix as a line of the default run
+    assert "error" not in adv, adv
+    assert d["value_adverse_mix"] > 0 and adv["need_host_as_expected"] is True and adv["counters"]["need_host"] > 0 and adv["counters"]["asserts"] == 0
+    assert 0.02 < adv["mix"]["election_rows_share"] < 0.2 and 0.0 < adv["mix"]["rows_parked_share"] < 0.5
 
 
 def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):

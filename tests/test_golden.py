@@ -12,15 +12,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.json")))["cases"]
 
 
-@pytest.mark.parametrize("name", sorted(GOLDEN))
+# Round 5: the 16 shard launches of `bench.py --gpus N` (131 072 groups x 64 rounds each, 8.4 M rows; tools/make_golden.py SHARD_CASES). Every rank of a
+# multi-GPU bench run checks its own; the suites re-derive a sample so that they stay within minutes: the oracle four of them, the translated
+# reference two (about 40 s each; the other fourteen are marked slow: RG_RUN_SLOW=1), the GPU four.
+SHARDS = {n for n, c in GOLDEN.items() if "shard" in c}
+ORACLE_SAMPLE = {"config4_shard0_bench_launch", "config4_shard7_bench_launch", "config5_shard3_bench_launch", "config5_shard6_bench_launch"}
+REFERENCE_SAMPLE = {"config4_shard5_bench_launch", "config5_shard2_bench_launch"}
+GPU_SAMPLE = {"config4_shard0_bench_launch", "config4_shard6_bench_launch", "config5_shard1_bench_launch", "config5_shard7_bench_launch"}
+
+
+def _replay(mk, c):
+    return make_golden.replay(mk, c["number"], c["groups"], c["rounds"], c.get("shard"))
+
+
+def _cases(sample):
+    return [pytest.param(n, marks=pytest.mark.slow) if (n in SHARDS and n not in sample) else n for n in sorted(GOLDEN)]
+
+
+@pytest.mark.parametrize("name", _cases(ORACLE_SAMPLE))
 def test_oracle_reproduces_committed_digests(name):
     from tests import oracle_lib
     c = GOLDEN[name]
-    got = make_golden.replay(lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    got = _replay(lambda g, p, s, v: oracle_lib.OracleTable(g, p, s, v), c)
     assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
 
 
-SLOW_FOR_THE_REFERENCE = {"config3_bench_launch"}          # 4.2 M rows = 45 s of the translated reference: RG_RUN_SLOW=1 (the oracle and the GPU reproduce it in every run)
+SLOW_FOR_THE_REFERENCE = {"config3_bench_launch"} | (SHARDS - REFERENCE_SAMPLE)          # 4.2 M rows = 45 s of the translated reference: RG_RUN_SLOW=1 (the oracle and the GPU reproduce it in every run)
 
 
 @pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.slow) if n in SLOW_FOR_THE_REFERENCE else n for n in sorted(GOLDEN)])
@@ -29,14 +46,14 @@ def test_reference_code_reproduces_committed_digests(name):           # (the ful
     if not ref_lib.available():
         pytest.skip("oracle/_ref/libref.so needs the reference checkout to be built")
     c = GOLDEN[name]
-    got = make_golden.replay(lambda g, p, s, v: ref_lib.RefTable(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    got = _replay(lambda g, p, s, v: ref_lib.RefTable(g, p, s, v), c)
     assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(GOLDEN))
+@pytest.mark.parametrize("name", _cases(GPU_SAMPLE))
 def test_gpu_reproduces_committed_digests(name):
     from rafting_amd import engine
     c = GOLDEN[name]
-    got = make_golden.replay(lambda g, p, s, v: engine.Table(g, p, s, v), c["number"], c["groups"], c["rounds"])
+    got = _replay(lambda g, p, s, v: engine.Table(g, p, s, v), c)
     assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}

@@ -10,34 +10,46 @@ import pytest
 
 from rafting_amd import abi, engine
 from tests import fuzz, kat_scenarios, oracle_lib
-from tests.helpers import set_group, compare_outcomes, compare_states, make_state, simple_log
+from tests.helpers import set_group, compare_outcomes, compare_states, make_state, simple_log, check_out32_rows
 
 pytestmark = pytest.mark.gpu
 
 
-def route_through_compact(monkeypatch):
+def route_through_compact(monkeypatch, out32=False):
     """Table.submit packs every batch that can travel as compact rows (no hint column, every value in [0, 2^31)) with the library's
-    rg_batch32_pack and hands it to rg_submit32 — so whatever a test does through submit() is decided by step32_kernel."""
+    rg_batch32_pack and hands it to rg_submit32 — so whatever a test does through submit() is decided by step32_kernel. out32: dense batches
+    go through rg_submit32c instead (compact OUTCOME rows, ABI 4) and come back through rg_outcome32_unpack, with the raw rows held to what
+    include/raftgpu.h says about them (helpers.check_out32_rows)."""
     wide_submit = engine.Table.submit
 
     def submit(self, batch, out=None, fill=0):
         if batch.hint is None and abi.batch_fits_32(batch):
+            if out32 and batch.gid is None:
+                before = self.read_state()
+                raw = self.submit32c(batch, fill=fill)
+                got, _ = engine.unpack32(raw, batch.rounds, batch.count, before.role_epoch)
+                check_out32_rows(raw, got, before, self.read_state(), batch.rounds, batch.count)
+                if out is not None:
+                    out.reply[:], out.logfx[:], out.persist[:] = got.reply, got.logfx, got.persist
+                    return out
+                return got
             return self.submit32(batch, out, fill)
         return wide_submit(self, batch, out, fill)
     monkeypatch.setattr(engine.Table, "submit", submit)
 
 
-@pytest.fixture(autouse=True, params=["split", "single", "compact", "compact-forced-wide"])
+@pytest.fixture(autouse=True, params=["split", "single", "compact", "compact-forced-wide", "compact-out32", "compact-out32-forced-wide"])
 def step_kernel_variant(request, monkeypatch):
     """Every test of this module runs against every step kernel: `split` = decide + I/O wavefront per 64 groups on wide rows (what the
     library picks up to one wavefront of groups per SIMD), `single` = one wavefront does both (picked beyond that), `compact` = the
     compact-format kernel (32-bit body wherever the values allow it), `compact-forced-wide` = the same kernel made to take its 64-bit
-    body from the start (RG_FORCE_WIDE=1)."""
+    body from the start (RG_FORCE_WIDE=1), `compact-out32*` = the same two with compact outcome rows (rg_submit32c)."""
     monkeypatch.setenv("RG_SPLIT", "0" if request.param == "single" else "1")
     if request.param.startswith("compact"):
-        route_through_compact(monkeypatch)
-        if request.param == "compact-forced-wide":
+        route_through_compact(monkeypatch, out32="out32" in request.param)
+        if request.param.endswith("forced-wide"):
             monkeypatch.setenv("RG_FORCE_WIDE", "1")
+    return request.param
 
 
 def mk_gpu(groups, cluster, self_slot, pre_vote):
@@ -227,6 +239,47 @@ def test_sparse_rows_only_touch_their_groups():
     with pytest.raises(engine.EngineError):
         bad = abi.Batch(1, 2, gid=np.array([5, 5], dtype=np.uint32))
         gpu.submit(bad)
+
+
+def fenced_timeouts_case(G=192):
+    """RG_OPT_REQUIRE_FENCED_TIMEOUTS (ABI 4): with the option a TIMEOUT row whose aux is 0 is RG_BAD_EVENT and changes nothing, a row
+    that names the participant whose ticket fired is decided as ever, a row that names a replaced one is RG_DROPPED_STALE_ROLE; without the option
+    aux = 0 still means "whoever is current" (context/RaftRoutine.java:65-77 checks the ticket's participant on the timer thread, before the loop)."""
+    st = abi.GroupState(G, 3)
+    for g in range(G):
+        set_state_follower(st, g, term=4, leader=1, last=20 + g)
+        st.role_epoch[g] = 5 + g % 3
+        if g % 4 == 1:
+            st.role[g], st.voted_for[g], st.current_leader[g] = abi.CANDIDATE, 0, abi.NO_NODE
+        if g % 4 == 2:
+            st.role[g], st.voted_for[g], st.current_leader[g] = abi.LEADER, 0, abi.NO_NODE
+    b = abi.Batch(3, G)
+    for g in range(G):
+        b.put(0, g, abi.EV_TIMEOUT, aux=0)                                   # un-fenced
+        b.put(1, g, abi.EV_TIMEOUT, aux=int(st.role_epoch[g]) + (7 if g % 5 == 0 else 0))     # fenced: the live participant, or one that is gone
+        b.put(2, g, abi.EV_TIMEOUT, aux=0)
+    for required in (True, False):
+        gpu, orc = engine.Table(G, 3, 0, True), oracle_lib.OracleTable(G, 3, 0, True)
+        for t in (gpu, orc):
+            t.set_option(abi.OPT_REQUIRE_FENCED_TIMEOUTS, required)
+            t.load_state(st)
+        ref, got = orc.submit(b), gpu.submit(b)
+        compare_outcomes(ref, got, "fenced timeouts (required=%s)" % required)
+        compare_states(orc.read_state(), gpu.read_state(), "fenced timeouts (required=%s)" % required)
+        status = abi.flags_status(got.reply["flags"]).reshape(3, G)
+        if required:
+            assert np.all(status[0] == abi.BAD_EVENT) and np.all(status[2] == abi.BAD_EVENT)
+            assert not np.any(got.reply["flags"].reshape(3, G)[0] & (abi.F_PERSIST | abi.F_ROLE_CHANGED | abi.F_RESET_TIMER | abi.F_EMIT_MASK))
+            stale = np.arange(G) % 5 == 0                                    # (round 0 changed nothing: the epochs of round 1 are judged against the loaded ones)
+            assert np.all(status[1][stale] == abi.DROPPED_STALE_ROLE) and np.all(status[1][~stale] == abi.OK)
+        else:
+            assert np.all(status[0] == abi.OK) and np.all(status[2] == abi.OK)
+        gpu.close()
+        orc.close()
+
+
+def test_unfenced_timeouts_are_refused_where_the_table_requires_fences():
+    fenced_timeouts_case()
 
 
 def test_api_misuse_is_reported():
@@ -715,8 +768,67 @@ def compact_workload_case(groups, rounds):
         orc.close()
 
 
+def adverse_mix_case(groups, rounds, launches=3):
+    """bench.py's adverse mix (conflicting AppendEntries, election churn, 1 % of the follower rows a retransmitted heartbeat whose prevLog lies below
+    the four cached term runs) through rg_submit32c against the oracle: every row but the misses bit-identical; a miss row answers RG_NEED_HOST on
+    the device and plain success at the oracle's lossless log — it changes nothing either way, and the stream parks the group (RG_EV_NONE) until
+    the launch ends — so the final states agree as well."""
+    import dataclasses
+    from rafting_amd import workload
+    cfg = dataclasses.replace(workload.config(3, groups), p_conflict=0.005, p_miss=0.01, p_timeout=0.03, p_vote_req=0.008, name="config3 adverse mix")
+    gen = workload.ReplayGenerator(cfg)
+    st0 = gen.initial_state()
+    gpu = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    orc = oracle_lib.OracleTable(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    ep = st0.role_epoch
+    misses = 0
+    G_adv = cfg.groups
+    missed_any = np.zeros(G_adv, dtype=bool)
+    for k in range(launches):
+        b = gen.next_batch(rounds)
+        ref = orc.submit(b)
+        db = engine.DeviceBatch32(gpu, b, compact=True)
+        gpu.submit_device(db)
+        gpu.sync()
+        got, ep = engine.unpack32(db.outcome32(), db.rounds, db.count, ep)
+        db.free()
+        miss = abi.flags_status(got.reply["flags"]) == abi.NEED_HOST
+        misses += int(miss.sum())
+        missed_any |= miss.reshape(b.rounds, b.count).any(axis=0)
+        # the oracle applied those rows: a successful AppendEntries reply that re-arms the timer and changes nothing
+        assert np.all(abi.flags_status(ref.reply["flags"][miss]) == abi.OK) and np.all(ref.reply["flags"][miss] & abi.F_SUCCESS)
+        assert not np.any(ref.reply["flags"][miss] & (abi.F_COMMIT | abi.F_LOG_APPEND | abi.F_LOG_TRUNC | abi.F_PERSIST))
+        for o in (ref, got):                          # ... and is compared everywhere else
+            o.reply["flags"][miss] = 0; o.reply["resp_term"][miss] = 0
+            o.logfx[miss] = (0, 0)
+        compare_outcomes(ref, got, "adverse mix, launch %d" % k)
+        # parked: every row of the group after its miss is RG_EV_NONE
+        kinds = (b.head["hdr"] & 0xF).reshape(b.rounds, b.count)
+        after = np.cumsum(miss.reshape(b.rounds, b.count), axis=0) - miss.reshape(b.rounds, b.count) > 0
+        assert not kinds[after].any()
+    assert misses == gen.miss_rows and misses > 0
+    assert gpu.counters()[5] == misses
+    # the one thing the retransmitted heartbeat does where it IS applied: Follower.currentLeader = leaderId (member/Follower.java:54) — visible only in a group
+    # that had not heard from its leader since its last conversion; the next AppendEntries sets it on both sides
+    ref_st, got_st = orc.read_state(), gpu.read_state()
+    late = missed_any & (got_st.current_leader == abi.NO_NODE) & (ref_st.current_leader != abi.NO_NODE)
+    assert late.sum() < 0.01 * G_adv
+    ref_st.current_leader[late] = abi.NO_NODE
+    compare_states(ref_st, got_st, "adverse mix final")
+    gpu.close()
+    orc.close()
+
+
 def test_compact_multi_round_launch_and_domain_exits():
     compact_multi_round_case(1024, 5, 48)
+
+
+def test_adverse_mix_stream_matches_the_oracle_but_for_its_cache_misses(step_kernel_variant):
+    if step_kernel_variant not in ("compact-out32", "compact-out32-forced-wide"):
+        pytest.skip("one stream, the compact-outcome route: on the 32-bit body and on the 64-bit body")
+    adverse_mix_case(4096, 24)
 
 
 def test_compact_workload_replays():

@@ -16,8 +16,10 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-K32 = "_ZN2rg13step32_kernelILi4ELb0ELi%dEEEvNS_10StepParamsE"
-STEP_KERNELS = [K32 % 1, K32 % 4, (K32 % 1).replace("13step32_kernel", "18step32_wide_kernel"), (K32 % 4).replace("13step32_kernel", "18step32_wide_kernel"), "_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE", "_ZN2rg11step_kernelILi4ELb0EEEvNS_10StepParamsE"]
+K32 = "_ZN2rg13step32_kernelILi4ELb0ELi%dELb0ELi1EEEvNS_10StepParamsE"      # <F = 4, dense, WAVES, wide outcome columns, one I/O wavefront>
+K32C = K32.replace("ELb0ELi1EEEv", "ELb1ELi1EEEv")      # the same with compact outcome rows (rg_submit32c)
+WIDE = lambda k: k.replace("13step32_kernel", "18step32_wide_kernel").replace("ELi1EEEv", "EEEv")     # noqa: E731  (the 64-bit body as a kernel of its own: no I/O-wavefront parameter)
+STEP_KERNELS = [K32 % 1, K32 % 4, K32C % 1, K32C % 4, WIDE(K32C % 1), WIDE(K32 % 1), WIDE(K32 % 4), "_ZN2rg17step_split_kernelILi4ELb0EEEvNS_10StepParamsE", "_ZN2rg11step_kernelILi4ELb0EEEvNS_10StepParamsE"]
 
 
 @pytest.fixture(scope="module")
@@ -48,8 +50,7 @@ def test_step_kernels_use_no_flat_memory_instructions(assembly, kernel):
 
 
 def test_register_and_scratch_budgets(assembly):
-    wide = lambda k: k.replace("13step32_kernel", "18step32_wide_kernel")     # noqa: E731
-    for k in (K32 % 1, K32 % 4, wide(K32 % 1), wide(K32 % 4)):
+    for k in (K32 % 1, K32 % 4, WIDE(K32 % 1), WIDE(K32 % 4), K32C % 1, K32C % 4, WIDE(K32C % 1), WIDE(K32C % 4)):
         text = kernel_text(assembly, k)
         assert descriptor(text, ".amdhsa_private_segment_fixed_size") == 0, k       # nothing in scratch, in either body of either variant
         assert descriptor(text, ".amdhsa_next_free_vgpr") <= 128, k                  # four wavefronts per SIMD: eight workgroups per CU
@@ -57,14 +58,22 @@ def test_register_and_scratch_budgets(assembly):
 
 
 def test_a_round_stays_within_its_instruction_budget(assembly):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spine.py"), assembly, K32 % 1], capture_output=True, text=True, timeout=120)
-    assert p.returncode == 0, p.stderr[-2000:]
-    main, election = (int(x) for x in re.search(r"main (\d+) instructions.*election (\d+) ", p.stdout).groups())
-    io = int(re.search(r"I/O wavefront: (\d+) instructions", p.stdout).group(1))
+    def spine(kernel):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "spine.py"), assembly, kernel], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]
+        main, election = (int(x) for x in re.search(r"main (\d+) instructions.*election (\d+) ", p.stdout).groups())
+        io = int(re.search(r"I/O wavefront: (\d+) instructions", p.stdout).group(1))
+        counted, all_classes = (int(x) for x in re.search(r"vote reply counted (\d+),.*all classes (\d+)", p.stdout).groups())
+        return main, election, io, counted, all_classes, p.stdout
+    main, election, io, counted, all_classes, text = spine(K32 % 1)
     # round 3's tier 1 (bool predicates: v_cmp + s_and + v_cndmask): 322 / 534 and 148; the sign-word tier of rg_tier1n.hpp with the I/O wavefront's
-    # tables: 186 / 336 and 139. Every instruction is four cycles of every round of every SIMD.
-    assert 0 < main <= 195 and 0 < election <= 345, p.stdout
-    assert 0 < io <= 150, p.stdout
+    # tables: 186 / 336 and 139; round 5, one block per election row class: a round with a vote reply that is merely counted — three election
+    # rounds of four — 268, every class at once 344. Every instruction is four cycles of every round of every SIMD.
+    assert 0 < main <= 195 and 0 < counted <= 285 and election == all_classes and 0 < all_classes <= 360, text
+    assert 0 < io <= 150, text
+    # compact outcome rows (rg_submit32c): one unconditional 16-byte store instead of a reply and a conditional effect row
+    main_c, _, io_c, counted_c, _, text_c = spine(K32C % 1)
+    assert main_c == main and counted_c == counted and 0 < io_c <= 130, text_c
 
 
 def test_sign_word_primitives_and_the_io_wavefronts_tables(tmp_path):

@@ -11,7 +11,7 @@ for l in sys.stdin:
     l=l.strip()
     if not l.startswith('{'): continue
     d=json.loads(l); r=d['roofline']
-    print('%-34s %.4f ms  frac %.3f  copy %s  %s  value %.3e' % ('$1', r['avg_kernel_ms'], r['frac'], r.get('measured_copy_gbps'), r['kernel'], d['value']))"; }
+    print('%-44s %.4f ms  frac %s  work-rate %.3f  copy %.0f  %s  value %.3e' % ('$1', r['avg_kernel_ms'], ('%.3f' % r['frac']) if r.get('frac') is not None else 'n/a', r.get('work_rate_algorithmic_over_peak', 0.0), r.get('measured_copy_gbps') or 0.0, r['kernel'], d['value']))"; }
 for step in "$@"; do
   case $step in
     membench) timeout 300 build/membench > $OUT/membench.txt 2>&1; tail -50 $OUT/membench.txt ;;
@@ -88,6 +88,12 @@ for step in "$@"; do
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --config 4 ${OV:+--override "$OV"} 2>>$OUT/sorted.err | tee -a $OUT/sorted.jsonl | line "c4 ${OV:-hashed} $L"; done; done ;;
     shards) for C in "--config 4" "--config 5" ""; do for L in ${LIBS}; do       # experiment libraries on the 131 072-group shards (and config 3)
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --no-int64-pass $C 2>>$OUT/shards.err | tee -a $OUT/shards.jsonl | line "${C:-c3} $L"; done; done ;;
+    out32) for i in 1 2; do for W in "" "--wide-outcomes"; do       # round 5: compact outcome rows (rg_submit32c, the default) against rg_submit32's columns, same library
+          $B --steps 20 --warmup 3 --no-int64-pass --no-adverse $W 2>>$OUT/out32.err | tee -a $OUT/out32.jsonl | line "c3 ${W:-compact-outcomes}"; done; done
+        for C in "--config 4" "--config 5 --groups-per-gpu 65536" "--config 5"; do for W in "" "--wide-outcomes"; do
+          $B --steps 20 --warmup 3 --no-int64-pass --no-adverse $C $W 2>>$OUT/out32.err | tee -a $OUT/out32.jsonl | line "$C ${W:-compact-outcomes}"; done; done ;;
+    abq) for C in "" "--config 4"; do for i in 1 2; do for L in ${LIBS}; do       # quick same-box A/B on the two configurations that matter (config 3, config 4's shard)
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --no-int64-pass --no-adverse $C ${AB_ARGS} 2>>$OUT/abq.err | tee -a $OUT/abq.jsonl | line "${C:-c3} $L"; done; done; done ;;
     issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac

@@ -22,6 +22,10 @@ CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048
          # compares its own first launch with this digest: "golden": "ok"), a shard of config 4 as `bench.py --gpus 8` gives every GPU, config 2's
          # mirrored follower view
          ("config3_bench_launch", 3, 65536, 64), ("config4_shard", 4, 131072, 8), ("config2f", "2f", 4096, 24)]
+# round 5: what `bench.py --gpus N` runs on EVERY rank — the first 64-round launch of shards 0..7 (131 072 groups each, streams keyed by
+# global group id) of the 1 048 576-group tables of configs 4 and 5; rank r of a multi-GPU run compares its own first launch with case r and the
+# line carries the verdicts. (name, config number, groups, rounds, shard index)
+SHARD_CASES = [("config%d_shard%d_bench_launch" % (number, k), number, 131072, 64, k) for number in (4, 5) for k in range(8)]
 
 
 def canonical_outcome_digest(out):
@@ -51,10 +55,14 @@ def state_digest(st):
     return h.hexdigest()
 
 
-def replay(make_table, number, groups, rounds):
-    cfg = workload.config(number, groups)
-    gen = workload.ReplayGenerator(cfg)
-    t = make_table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+def replay(make_table, number, groups, rounds, shard=None):
+    if shard is None:
+        cfg = workload.config(number, groups)
+        gen = workload.ReplayGenerator(cfg)
+    else:                                  # block `shard` of THE config's table (what bench.py --gpus N gives rank `shard`)
+        cfg = workload.CONFIGS[number]
+        gen = workload.ReplayGenerator(cfg, first_gid=shard * groups, count=groups)
+    t = make_table(gen.n, cfg.cluster, cfg.self_slot, cfg.pre_vote)
     t.load_state(gen.initial_state())
     b = gen.next_batch(rounds)
     inputs = hashlib.sha256(b.head.tobytes() + b.ab.tobytes() + b.cd.tobytes() + b.entry_terms[: b.entry_count].tobytes()).hexdigest()
@@ -62,14 +70,34 @@ def replay(make_table, number, groups, rounds):
     return {"inputs": inputs, "outcomes": canonical_outcome_digest(out), "state": state_digest(t.read_state())}
 
 
-def main():
+def _one(case):
     from tests import ref_lib
     mk = lambda g, p, s, v: ref_lib.RefTable(g, p, s, v)   # noqa: E731
+    name, number, groups, rounds = case[:4]
+    shard = case[4] if len(case) > 4 else None
+    d = dict(number=number, groups=groups, rounds=rounds, **replay(mk, number, groups, rounds, shard))
+    if shard is not None:
+        d["shard"] = shard
+    return name, d
+
+
+def main():
+    """python tools/make_golden.py [--shards-only] [--jobs N]: every case is one single-threaded run of the translated reference (the 16 shard
+    launches are 8.4 M rows each, about a minute apiece), run in N processes"""
+    import multiprocessing
+    path = os.path.join(ROOT, "tests", "golden", "replay_digests.json")
+    jobs = int(sys.argv[sys.argv.index("--jobs") + 1]) if "--jobs" in sys.argv else max(1, (os.cpu_count() or 2) - 1)
     doc = {"generator": "tools/make_golden.py over oracle/_ref/libref.so (the reference's Java decision classes, "
                         "mechanically translated by tools/make_ref.py)", "cases": {}}
-    for name, number, groups, rounds in CASES:
-        doc["cases"][name] = dict(number=number, groups=groups, rounds=rounds, **replay(mk, number, groups, rounds))
-    path = os.path.join(ROOT, "tests", "golden", "replay_digests.json")
+    cases = list(SHARD_CASES)
+    if "--shards-only" in sys.argv:
+        doc = json.load(open(path))        # keep the other cases as committed
+    else:
+        cases = list(CASES) + cases
+    with multiprocessing.get_context("spawn").Pool(jobs) as pool:
+        for name, d in pool.imap_unordered(_one, cases):
+            doc["cases"][name] = d
+            print("done", name, flush=True)
     json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
 

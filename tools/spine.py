@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """spine.py file.s kernel_mangled -> instruction counts of ONE ROUND of step32_kernel's deciding wavefront, walked along the paths a cluster in
-operation takes: from the header of the round loop to its first s_barrier, with the wave-uniform branches (s_cbranch_vccz: {rare block | election block}, inside it
-the rare block and the election block, then the general handlers) decided as named and every exec-mask branch (s_cbranch_execz) falling through — its body is executed.
+operation takes: from the header of the round loop to its first s_barrier, with the wave-uniform branches (the ballots: {rare block | election block}, inside it
+the rare block and the election block, inside that one block per row class, then the general handlers) decided as named and every exec-mask branch
+(s_cbranch_execz) falling through — its body is executed.
   main     : no rare block, no election row, nothing for the general handlers  (steady replication)
-  election : the same with the election block
+  election : the same with the election block and every class block in it; per class on the last line
 The static proxy for ticks per round (the deciding wavefront is alone on its SIMD, instructions are what it pays for)."""
 import re
 import sys
@@ -20,8 +21,9 @@ def isinstr(l):
     return l.startswith('\t') and not l.strip().startswith(';') and not l.strip().startswith('.')
 
 
-def walk(K, hdr, decisions):
-    """decisions: for the successive s_cbranch_vccz / s_cbranch_vccnz met on the path, True = taken"""
+def walk(K, hdr, enters):
+    """enters: for the successive wave-uniform ballot branches met on the path (s_cbranch_vccz / vccnz / scc0 / scc1), True = the block behind the
+    ballot is entered. The compiler lays a block out either behind a vccz that skips it or at the target of a vccnz that enters it."""
     labels = {l.split(':')[0]: i for i, l in enumerate(K) if l.startswith('.LBB')}
     i, n, d, ops = hdr, 0, 0, {}
     while True:
@@ -36,9 +38,9 @@ def walk(K, hdr, decisions):
                 return n, ops
             m = re.search(r'(\.LBB\d+_\d+)', l)
             if op in ('s_cbranch_vccz', 's_cbranch_vccnz', 's_cbranch_scc0', 's_cbranch_scc1'):
-                taken = decisions[d] if d < len(decisions) else True
+                enter = enters[d] if d < len(enters) else False
                 d += 1
-                if taken:
+                if enter == (op.endswith('nz') or op.endswith('scc1')):
                     i = labels[m.group(1)]
                     continue
             elif op == 's_branch':
@@ -50,14 +52,20 @@ def walk(K, hdr, decisions):
 def main():
     K = kernel_lines(sys.argv[1], sys.argv[2])
     hdr = next(i for i, l in enumerate(K) if 'Loop Header: Depth=1' in l)
-    a, opsa = walk(K, hdr, [True, True, True])                   # skip {rare, election}, skip the general handlers
-    b, opsb = walk(K, hdr, [False, True, False, True, True])     # enter that branch, skip rare, enter election, skip the general handlers
+    a, opsa = walk(K, hdr, [])                                   # no {rare, election} block, no general handlers
+    # the ballots in program order: {rare | election}, rare, election, then (round 5: one sub-block per row class, each behind its own ballot) vote
+    # replies, timeouts, vote requests, the conversion tail; then the general handlers
+    b, opsb = walk(K, hdr, [True, False, True, True, True, True, True])       # every class and the conversion tail: the worst round
+    c, _ = walk(K, hdr, [True, False, True, True, False, False, False])       # a vote reply that is merely counted: three election rounds of four
+    d, _ = walk(K, hdr, [True, False, True, True, False, False, True])        # a vote reply that converts
+    e, _ = walk(K, hdr, [True, False, True, False, True, False, True])        # a timeout (always converts or prepares)
+    f, _ = walk(K, hdr, [True, False, True, False, False, True, True])        # a vote request that converts
     # the I/O wavefront's round: the barrier-to-barrier stretches that load a row (two columns) and store up to three (its loop is unrolled by four)
     bars = [i for i, l in enumerate(K) if isinstr(l) and l.split()[0] == 's_barrier']
     ios = []
     for x, y in zip(bars, bars[1:]):
         seg = [l.split()[0] for l in K[x:y] if isinstr(l)]
-        if sum(o.startswith('global_load') for o in seg) == 2 and sum(o.startswith('global_store') for o in seg) == 3 and len(seg) < 600:
+        if sum(o.startswith('global_load') for o in seg) == 2 and sum(o.startswith('global_store') for o in seg) in (2, 3) and len(seg) < 600:      # (two stores: compact outcome rows)
             ios.append(len(seg))
     ios = ios[:4]                              # (a fifth such stretch belongs to the 64-bit body)
     io = (sum(ios) + len(ios) - 1) // max(len(ios), 1)
@@ -66,6 +74,7 @@ def main():
     print("main %d instructions (v_cmp %d, v_cndmask %d, s_and/s_or %d, ds_ %d, v_mov %d); election %d (v_cmp %d, v_cndmask %d, s_and/s_or %d, v_mov %d)"
           % (a, cls(opsa, 'v_cmp'), cls(opsa, 'v_cndmask'), cls(opsa, 's_and') + cls(opsa, 's_or'), cls(opsa, 'ds_'), cls(opsa, 'v_mov'),
              b, cls(opsb, 'v_cmp'), cls(opsb, 'v_cndmask'), cls(opsb, 's_and') + cls(opsb, 's_or'), cls(opsb, 'v_mov')))
+    print("election rounds by class: vote reply counted %d, vote reply converting %d, timeout %d, vote request converting %d, all classes %d" % (c, d, e, f, b))
 
 
 if __name__ == '__main__':

@@ -5,4 +5,5 @@
 set -e
 OUT=${OUT:-/tmp/spine}; mkdir -p $OUT
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -mllvm -amdgpu-sched-strategy=max-ilp -DRG_BUILD_ONLY_F4 "$@" -S --cuda-device-only -o $OUT/rg.s $(dirname $0)/../rafting_amd/csrc/rg_kernels.hip 2>/dev/null
-python3 $(dirname $0)/spine.py $OUT/rg.s _ZN2rg13step32_kernelILi4ELb0ELi1EEEvNS_10StepParamsE
+python3 $(dirname $0)/spine.py $OUT/rg.s _ZN2rg13step32_kernelILi4ELb0ELi1ELb0ELi1EEEvNS_10StepParamsE
+python3 $(dirname $0)/spine.py $OUT/rg.s _ZN2rg13step32_kernelILi4ELb0ELi1ELb1ELi1EEEvNS_10StepParamsE      # compact outcome rows
