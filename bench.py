@@ -65,6 +65,8 @@ def parse():
                     "and persist rows) instead of the default compact outcome rows (rg_submit32c: one 16-byte row per event + persist rows)")
     ap.add_argument("--no-adverse", action="store_true", help="skip the adverse-mix leg (value_adverse_mix: conflicts + cache misses + election churn on the same configuration)")
     ap.add_argument("--adverse-batches", type=int, default=8, help="launches of the adverse-mix leg (the first two are warm-up)")
+    ap.add_argument("--index-base-batches", type=int, default=6, help="launches of the long-lived-groups leg (every log compacted at 2^40, index bases set; the first two are "
+                    "warm-up; 0 skips the leg)")
     ap.add_argument("--wide-rows", action="store_true", help="stage the batches as rg_batch_t (40 B + 8n per row, 64-bit fields) and decide them with the "
                     "wide-row kernels instead of the default compact rows (rg_batch32_t, 24 B per row) / rg::step32_kernel")
     return ap.parse_args()
@@ -193,6 +195,8 @@ def main():
         table.submit_device(dbatches[i])
     table.sync()
     table.counters(reset=True)
+    if not args.wide_rows:
+        table.wide_body_workgroups(reset=True)
     barrier()
     t0 = time.perf_counter()
     table.timing_begin()                 # one HIP event pair on the table's stream around the K launches
@@ -204,6 +208,7 @@ def main():
     elapsed = time.perf_counter() - t0
     launches = args.steps
     counters = table.counters()
+    wide_wgs = None if args.wide_rows else table.wide_body_workgroups()       # workgroups of the timed launches that left the 32-bit domain (0 on this stream)
 
     decisions = sum(s[0] for s in stats[args.warmup:])
     alg_bytes = sum(s[1] for s in stats[args.warmup:])
@@ -468,6 +473,60 @@ def main():
             adverse = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             print("bench: adverse-mix leg failed: %r" % (e,), file=sys.stderr)
 
+    # ---- the same configuration for LONG-LIVED groups: every log compacted at 2^40 (epoch.index = 2^40, all live indices above it), the
+    # table's index bases at 2^40 - 1, rows packed relative to them (rg_batch32_pack_rel). The 32-bit body must carry it at the headline's speed: no
+    # workgroup on the 64-bit body. The first launch is checked against the oracle, which works on the absolute values.
+    long_lived = None
+    if rank == 0 and world == 1 and args.index_base_batches > 2 and not args.wide_rows and not args.override:
+        try:
+            import dataclasses
+            OFF = 1 << 40
+            lcfg = dataclasses.replace(cfg, name=cfg.name + " [index base 2^40]", index_base=OFF)
+            lgen = workload.ReplayGenerator(lcfg, first_gid=first_gid, count=count)
+            lbase = np.full(gpg, OFF - 1, dtype=np.int64)
+            t4 = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+            t4.set_index_base(lbase)
+            lst0 = lgen.initial_state()
+            t4.load_state(lst0)
+            lbatches, ldec, first_host = [], 0, None
+            for i in range(args.index_base_batches):
+                b = lgen.next_batch(args.rounds)
+                if i == 0:
+                    first_host = b
+                if i >= 2:
+                    ldec += workload.batch_stats(b, F)[0]
+                lbatches.append(engine.DeviceBatch32(t4, engine.pack32(b, index_base=lbase), compact=compact_out, wide=False))
+            for i in range(2):
+                t4.submit_device(lbatches[i])
+            t4.sync()
+            checked = None
+            if not args.no_cpu_baseline:
+                from tests import oracle_lib
+                from tests.helpers import compare_outcomes
+                orc = oracle_lib.OracleTable(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+                orc.load_state(lst0)
+                _, ref0 = orc.submit_threads(first_host, max(4, min(os.cpu_count() or 4, 64)), abi.Outcome(first_host.rounds * first_host.count))
+                got0 = engine.unpack32(lbatches[0].outcome32(), lbatches[0].rounds, lbatches[0].count, lst0.role_epoch, index_base=lbase)[0] if compact_out \
+                    else lbatches[0].outcome()
+                compare_outcomes(ref0, got0, "long-lived groups, first launch vs oracle")
+                orc.close()
+                checked = "first launch (%d rows) bit-identical to the oracle on the absolute stream" % (first_host.rounds * first_host.count)
+            t4.wide_body_workgroups(reset=True)
+            t4.timing_begin()
+            for i in range(2, args.index_base_batches):
+                t4.submit_device(lbatches[i])
+            lms = t4.timing_end()
+            t4.sync()
+            n_l = args.index_base_batches - 2
+            long_lived = {"value": ldec / (lms * 1e-3), "avg_kernel_ms": lms / n_l, "launches": n_l, "index_base": OFF - 1, "epoch_index": OFF,
+                          "int64_body_workgroups": t4.wide_body_workgroups(), "checked": checked}
+            for db in lbatches:
+                db.free()
+            t4.close()
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            long_lived = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench: long-lived-groups leg failed: %r" % (e,), file=sys.stderr)
+
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate
         # passes, gfx950 x2 fetch correction applied; tools/prof.sh writes profiles/traffic.json) — quoted only when the entry
@@ -551,6 +610,9 @@ def main():
                 "value_int64_body": None if int64_pass is None else int64_pass["value"],
                 "int64_body_counters_equal": None if int64_pass is None else int64_pass["counters_equal_first_pass"],
             },
+            "int64_body_workgroups": wide_wgs,
+            "value_long_lived_groups": None if not long_lived or "value" not in long_lived else long_lived["value"],
+            "long_lived_groups": long_lived,
             "value_adverse_mix": None if not adverse or "value" not in adverse else adverse["value"],
             "adverse_mix": adverse,
             "golden": golden,

@@ -59,7 +59,7 @@ extern "C" {
 
 #define RG_ABI_VERSION      4     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
                                      3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows
-                                     4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option */
+                                     4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option; the index base of the compact formats (rg_index_base_set) */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -358,6 +358,23 @@ int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, 
  * Returns the entry_count of the compact batch, or < 0: -1 missing column, -2 the batch has hints, -3 a value outside [0, 2^31),
  * -4 entry_terms needed but NULL. rounds / count / gid are the wide batch's. */
 int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms);
+
+/* THE INDEX BASE OF THE COMPACT FORMATS (ABI 4). Every quantity of the path is a Java long (command/RaftLog.java:72-132); terms stay small (one per
+ * election) but a group that lives long enough pushes its log indices past 2^30, which — with absolute 32-bit rows — would put it beyond the compact
+ * formats and its whole workgroup on the 64-bit body for good. So every group has an index base (0 after rg_table_create), and in rg_batch32_t rows
+ * and rg_out32_t rows a log index x of group g travels RELATIVE to it:
+ *       x == 0 ("none": prevLogIndex of an empty log, leaderCommit 0, matchIndex of a follower that has not answered)  ->  0
+ *       any other x                                                                                                      ->  x - base[g], in [1, 2^31)
+ * The index fields of a row are: AE_REQ b, d; AE_ACK b, c; IS_ACK b; RV_REQ / PV_REQ b; LOG_FLUSH a; IS_REQ b (terms, n and aux travel as they are);
+ * of an rg_out32_t row: commit_index and log_from. rg_outcome_t columns, rg_group_state_t and rg_send_t always speak absolute values.
+ * The host keeps the base BELOW every non-zero index the group can meet — in practice a little below epoch.index, moved up after a compaction
+ * (RaftLog.flush, command/storage/RocksLog.java:228-242) between two launches; a group whose epoch.index is 0 keeps base 0. Decisions never depend
+ * on the base: the 32-bit body works on the relative image while every non-zero index of the group lies in (base, base + 2^30) and epoch.index > base,
+ * the 64-bit body on absolute values otherwise (a value without an image in an rg_out32_t row: RG_F_WIDE_VALUES). base = 0 is ABI 3's format. */
+int rg_index_base_set(rg_table_t *t, uint32_t first, uint32_t count, const int64_t *base);
+int rg_index_base_get(rg_table_t *t, uint32_t first, uint32_t count, int64_t *base);
+/* rg_batch32_pack with bases: index_base[g] for every group of the table (NULL: all 0); -3 also when an index lies at or below its group's base */
+int64_t rg_batch32_pack_rel(const rg_batch_t *in, const int64_t *index_base, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms);
 /* COMPACT OUTCOME ROWS (ABI 4). What a reply carries is RaftResponse(term, success) (RaftResponse.java:8-24) plus instructions; while a
  * group's values are below 2^31 all of it fits ONE 16-byte row per event that every lane stores unconditionally — instead of a 16-byte reply
  * plus a conditional 16-byte effect row that half of the lanes store (32-byte write granules: measured 1.17x inflation) — and the role epoch,
@@ -388,6 +405,8 @@ int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *ou
  * epoch of every group BEFORE the batch (rg_group_state_t.role_epoch); updated in place to the epochs after it. Rows flagged
  * RG_F_WIDE_VALUES are copied from in->wide (-3 when that is missing). Returns 0, or < 0. */
 int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const rg_outcome_t *out);
+/* the same for a table with index bases (below): index_base[count] puts commit_index / log_from back on the groups' bases (NULL: all 0) */
+int rg_outcome32_unpack_rel(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const int64_t *index_base, const rg_outcome_t *out);
 /* which step kernel a batch of `count` rows per round is decided by: "rg::step_split_kernel" (a deciding and an I/O
  * wavefront per 64 groups; chosen while the batch has at most one wavefront of groups per SIMD) or "rg::step_kernel";
  * compact batches (rg_submit32, rg_submit_async_packed) are always decided by "rg::step32_kernel" */
@@ -508,6 +527,10 @@ int rg_timing_end(rg_table_t *t, double *elapsed_ms);
  * [4]=assert statuses, [5]=NEED_HOST, [6]=dropped stale, [7]=log appends. */
 #define RG_NUM_COUNTERS 8
 int rg_counters_read(rg_table_t *t, uint64_t counters[RG_NUM_COUNTERS], int reset);
+/* Workgroups (64 groups each) of compact-row launches (rg_submit32 / rg_submit32c / rg_submit_async_packed) that were decided by the 64-bit body since the
+ * last reset: a value of theirs left the 32-bit image (include/raftgpu.h, rg_submit32; with index bases: "the index base of the compact formats"). Results
+ * are the same either way; the count tells a host that groups have outgrown their bases. Waits for the stream. */
+int rg_wide_body_workgroups(rg_table_t *t, uint64_t *count, int reset);
 /* Plain streaming-copy kernel over `bytes` of scratch on this device: returns achieved GB/s
  * (read+write) — the measured-copy roofline reported next to the 8 TB/s spec. */
 int rg_copy_bandwidth(rg_table_t *t, size_t bytes, int iters, double *gbps);

@@ -53,6 +53,7 @@ struct rg_table {
     hipStream_t stream = nullptr;
     DevTable dt{};
     unsigned long long *counters = nullptr;     // [counter_slots][RG_NUM_COUNTERS], one slot per wave of a dense launch
+    unsigned long long *wide_bodies = nullptr;  // one word (rg_wide_body_workgroups)
     size_t counter_slots = 0;
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
     int force_wide = 0;                         // RG_FORCE_WIDE=1: the compact-format kernel skips its 32-bit body (differential tests)
@@ -164,7 +165,7 @@ int rg_table_destroy(rg_table_t *t)
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
     void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
-                    t->dt.peer_en, t->dt.peer_m, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
+                    t->dt.peer_en, t->dt.peer_m, t->dt.ibase, t->wide_bodies, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
                     t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline,
                     t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
@@ -222,6 +223,9 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->dt.runs, G * rg::K * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_en, G * F * sizeof(I64x2)));
     CREATE_TRY(hipMalloc((void **)&t->dt.peer_m, G * F * sizeof(rg::Match)));
+    CREATE_TRY(hipMalloc((void **)&t->dt.ibase, G * sizeof(int64_t)));
+    CREATE_TRY(hipMalloc((void **)&t->wide_bodies, sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(t->wide_bodies, 0, sizeof(unsigned long long), t->stream));
     {
         hipDeviceProp_t prop;
         CREATE_TRY(hipGetDeviceProperties(&prop, device));
@@ -251,6 +255,7 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMemsetAsync(t->dt.runs, 0, G * rg::K * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.peer_en, 0, G * F * sizeof(I64x2), t->stream));
     CREATE_TRY(hipMemsetAsync(t->dt.peer_m, 0, G * F * sizeof(rg::Match), t->stream));
+    CREATE_TRY(hipMemsetAsync(t->dt.ibase, 0, G * sizeof(int64_t), t->stream));
     CREATE_TRY(hipMemsetAsync(t->counters, 0, t->counter_slots * RG_NUM_COUNTERS * sizeof(unsigned long long), t->stream));
     {   // fresh groups = what RaftContext.initialize leaves: Follower, term 0, no vote, empty log
         std::vector<rg::Ident> id(G, rg::Ident{RG_NO_NODE, RG_NO_NODE, 1u, 0u});
@@ -470,6 +475,7 @@ static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
     p.rounds = in->rounds; p.count = in->count;
     p.entry_count = in->entry_count;
     p.counters = t->counters;
+    p.wide_bodies = t->wide_bodies;
     p.self = (int32_t)t->self; p.cluster = (int32_t)t->P; p.majority = (int32_t)(t->P / 2 + 1); p.pre_vote = t->pre_vote;
     p.fast_paths = t->fast_paths;
     p.force_wide = t->force_wide;
@@ -726,6 +732,57 @@ int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, 
     return 0;
 }
 
+int rg_wide_body_workgroups(rg_table_t *t, uint64_t *count, int reset)
+{
+    if (!t || !count) return -1;
+    if (bind(t)) return -2;
+    unsigned long long v = 0;
+    HIP_TRY(t, hipMemcpyAsync(&v, t->wide_bodies, sizeof v, hipMemcpyDeviceToHost, t->stream));
+    if (reset) HIP_TRY(t, hipMemsetAsync(t->wide_bodies, 0, sizeof v, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    *count = v;
+    return 0;
+}
+
+/* the index base of the compact formats: see include/raftgpu.h */
+int rg_index_base_set(rg_table_t *t, uint32_t first, uint32_t count, const int64_t *base)
+{
+    if (!t) return -1;
+    if (!base) return fail(t, -1, "rg_index_base_set: NULL base");
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_index_base_set: groups [%u, %u) of %u", first, first + count, t->G);
+    for (uint32_t i = 0; i < count; i++)
+        if (base[i] < 0) return fail(t, -1, "rg_index_base_set: base[%u] = %lld is negative", i, (long long)base[i]);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(t->dt.ibase + first, base, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int rg_index_base_get(rg_table_t *t, uint32_t first, uint32_t count, int64_t *base)
+{
+    if (!t) return -1;
+    if (!base) return fail(t, -1, "rg_index_base_get: NULL base");
+    if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_index_base_get: groups [%u, %u) of %u", first, first + count, t->G);
+    if (count == 0) return 0;
+    if (bind(t)) return -2;
+    HIP_TRY(t, hipMemcpyAsync(base, t->dt.ibase + first, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+/* which of a row's fields a, b, c, d (bits 0..3) are log indices (rg_device.hpp: index_fields) */
+static uint32_t host_index_fields(uint32_t kind)
+{
+    switch (kind) {
+    case RG_EV_AE_REQ: return 0xAu;
+    case RG_EV_AE_ACK: return 0x6u;
+    case RG_EV_IS_ACK: case RG_EV_RV_REQ: case RG_EV_PV_REQ: case RG_EV_IS_REQ: return 0x2u;
+    case RG_EV_LOG_FLUSH: return 0x1u;
+    default: return 0u;
+    }
+}
+
 /* compact rows in, compact outcome rows out (ABI 4): see include/raftgpu.h */
 int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *out, int memspace)
 {
@@ -792,7 +849,13 @@ int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *ou
 /* host-side: rg_out32_t / rg_persist32_t rows -> the wide columns (no device involved) */
 int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const rg_outcome_t *out)
 {
+    return rg_outcome32_unpack_rel(in, rounds, count, role_epoch, nullptr, out);
+}
+
+int rg_outcome32_unpack_rel(const rg_outcome32_t *in, uint32_t rounds, uint32_t count, uint32_t *role_epoch, const int64_t *index_base, const rg_outcome_t *out)
+{
     if (!in || !in->row || !in->persist || !role_epoch || !out || !out->reply || !out->logfx || !out->persist) return -1;
+    auto absolute = [&](int32_t v, uint32_t i) { return v == 0 ? (int64_t)0 : (int64_t)v + (index_base ? index_base[i] : 0); };
     for (uint32_t r = 0; r < rounds; r++) {
         for (uint32_t i = 0; i < count; i++) {
             const size_t row = (size_t)r * count + i;
@@ -812,7 +875,7 @@ int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t coun
             }
             if (has_per) role_epoch[i] = in->persist[row].role_epoch;
             out->reply[row] = rg_reply_t{(flags & RG_F_REPLIED) ? (int64_t)c.resp_term : 0, flags, role_epoch[i]};
-            out->logfx[row] = has_lfx ? rg_logfx_t{(int64_t)c.commit_index, has_from ? (int64_t)c.log_from : 0} : rg_logfx_t{0, 0};
+            out->logfx[row] = has_lfx ? rg_logfx_t{absolute(c.commit_index, i), has_from ? absolute(c.log_from, i) : 0} : rg_logfx_t{0, 0};
             out->persist[row] = has_per ? rg_persist_t{(int64_t)in->persist[row].term, in->persist[row].voted_for, in->persist[row].role}
                                         : rg_persist_t{0, 0, 0};
         }
@@ -823,6 +886,11 @@ int rg_outcome32_unpack(const rg_outcome32_t *in, uint32_t rounds, uint32_t coun
 /* host-side packer: rg_batch_t -> rg_batch32_t (no device involved) */
 int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms)
 {
+    return rg_batch32_pack_rel(in, nullptr, head, abcd, entry_terms);
+}
+
+int64_t rg_batch32_pack_rel(const rg_batch_t *in, const int64_t *index_base, rg_ev_head_t *head, rg_ev_quad32_t *abcd, int32_t *entry_terms)
+{
     if (!in || !in->head || !in->ab || !in->cd || !head || !abcd) return -1;
     if (in->hint) return -2;                                    // hints answer RG_NEED_HOST rows: those batches stay wide
     const size_t rows = (size_t)in->rounds * in->count;
@@ -830,7 +898,16 @@ int64_t rg_batch32_pack(const rg_batch_t *in, rg_ev_head_t *head, rg_ev_quad32_t
     uint64_t out_terms = 0;
     for (size_t r = 0; r < rows; r++) {
         const uint32_t hdr = in->head[r].hdr & ~(RG_HDR_HINT_BIT | RG_HDR_SAME_TERM | (1u << 11)), aux = in->head[r].aux;
-        const int64_t a = in->ab[r].x, b = in->ab[r].y, c = in->cd[r].x, d = in->cd[r].y;
+        int64_t a = in->ab[r].x, b = in->ab[r].y, c = in->cd[r].x, d = in->cd[r].y;
+        if (RG_HDR_KIND(hdr) == RG_EV_NONE) a = b = c = d = 0;      // a row that is not addressed carries nothing: whatever its fields hold does not travel
+        if (index_base) {                                       // a log index x of group g travels as x - base[g]; 0 ("none") as 0; anything at or below the base has no image
+            const size_t i = r % in->count;
+            const int64_t base = index_base[in->gid ? in->gid[i] : i];
+            const uint32_t ix = host_index_fields(RG_HDR_KIND(hdr));
+            int64_t *f[4] = {&a, &b, &c, &d};
+            for (int k = 0; k < 4; k++)
+                if (((ix >> k) & 1u) && *f[k] != 0) { if (*f[k] <= base) return -3; *f[k] -= base; }
+        }
         if (!fits(a) || !fits(b) || !fits(c) || !fits(d)) return -3;
         abcd[r] = rg_ev_quad32_t{(int32_t)a, (int32_t)b, (int32_t)c, (int32_t)d};
         head[r].hdr = hdr; head[r].aux = aux;

@@ -68,6 +68,7 @@ struct DevTable {
     I64x2 *runs;          // [K][G] {start, term}
     I64x2 *peer_en;       // [F][G] {lastEpoch, nextIndex}
     Match *peer_m;        // [F][G]
+    int64_t *ibase;       // [G] index base of the compact formats (rg_index_base_set; 0 unless the host set one): see to_rel()
     uint32_t groups;
 };
 
@@ -87,6 +88,7 @@ struct StepParams {
     I32x4 *out32, *persist32;       // compact outcome rows (rg_submit32c): rg_out32_t always, rg_persist32_t iff PERSIST; reply / logfx / persist are then
                                     // the optional overflow columns of rows flagged RG_F_WIDE_VALUES (all three, or all null)
     unsigned long long *counters;   // [workgroups][RG_NUM_COUNTERS]
+    unsigned long long *wide_bodies;// one word: workgroups of compact-row launches that were decided by the 64-bit body (rg_wide_body_workgroups)
     int32_t self, cluster, majority, pre_vote;
     int32_t fast_paths;             // 0: general handlers only
     int32_t force_wide;             // compact-format kernel: skip the 32-bit body (tests)
@@ -337,6 +339,36 @@ __device__ __forceinline__ bool fits32(const Group &g, uint32_t limit)
     w = mx(w, mx(mx(mx((uint64_t)g.s0, (uint64_t)g.s1), mx((uint64_t)g.s2, (uint64_t)g.s3)), mx(mx((uint64_t)g.t0, (uint64_t)g.t1), mx((uint64_t)g.t2, (uint64_t)g.t3))));
     return w < (uint64_t)limit;
 }
+// ---- the index base of the compact formats (ABI 4) -------------------------------------------------------------------------
+// Every quantity of the path is a Java long (command/RaftLog.java:72-132), and a group that lives long enough pushes its log indices past
+// 2^30 — which would send its workgroup to the 64-bit body for good. Terms stay small (one per election); only INDICES grow. So the compact
+// formats and the 32-bit image carry an index x of group g RELATIVE to a base the host sets for that group (rg_index_base_set):
+//     0 travels as 0 ("none": matchIndex of a follower that has not answered, leaderCommit of a fresh leader, prevLogIndex of an empty log),
+//     any other x as x - base[g], which must lie in [1, 2^30) for the 32-bit body (in [1, 2^31) for the format).
+// Order, equality, "is it zero" and adding a positive count to a non-zero index all survive the mapping as long as EVERY non-zero index of
+// the group lies above the base — what tier 1 of the 32-bit body (rg_tier1n.hpp) does with indices is exactly that; the one place that
+// computes from a possibly-zero index, prepareReplication's `epoch.index + 1`, is covered by requiring epoch.index > base where base != 0.
+// The general handlers run on ABSOLUTE values (converted on the way in and out), the table holds absolute int64 state, and anything that does not
+// fit sends the workgroup to the 64-bit body as before. base = 0 (the default) is the format of ABI 3, bit for bit.
+__device__ __forceinline__ int64_t to_rel(int64_t x, int64_t base) { const int64_t d = x - base; return x == 0 ? 0 : (d == 0 ? -1 : d); }      // (x == base != 0 has no image: -1 fails every range check)
+__device__ __forceinline__ int64_t to_abs(int64_t r, int64_t base) { return r == 0 ? 0 : r + base; }
+template <class Fn> __device__ __forceinline__ Group map_indices(const Group &g, Fn f)
+{
+    Group r = g;
+    r.commit = f(g.commit); r.epoch_index = f(g.epoch_index); r.first = f(g.first); r.last = f(g.last);
+    r.s0 = f(g.s0); r.s1 = f(g.s1); r.s2 = f(g.s2); r.s3 = f(g.s3); r.top = f(g.top);
+    return r;
+}
+__device__ __forceinline__ Group group_to_rel(const Group &g, int64_t base) { return map_indices(g, [base](int64_t x) { return to_rel(x, base); }); }
+__device__ __forceinline__ Group group_to_abs(const Group &g, int64_t base) { return map_indices(g, [base](int64_t x) { return to_abs(x, base); }); }
+// which of a row's fields a, b, c, d (bits 0..3) are log indices, by event kind: AE_REQ b d, AE_ACK b c, IS_ACK b, RV_REQ / PV_REQ b, LOG_FLUSH a, IS_REQ b
+__device__ __forceinline__ uint32_t index_fields(uint32_t kind)
+{
+    constexpr uint64_t LUT = (0xAull << (4 * RG_EV_AE_REQ)) | (0x6ull << (4 * RG_EV_AE_ACK)) | (0x2ull << (4 * RG_EV_IS_ACK)) | (0x2ull << (4 * RG_EV_RV_REQ)) |
+                             (0x2ull << (4 * RG_EV_PV_REQ)) | (0x1ull << (4 * RG_EV_LOG_FLUSH)) | (0x2ull << (4 * RG_EV_IS_REQ));
+    return (uint32_t)(LUT >> (4u * (kind & 15u))) & 15u;
+}
+
 // ---- Leadership.State of this lane's group in LDS -------------------------------------------------------------------
 // Wide: four [follower][lane] columns of 64-bit values. Narrow (32-bit body): one 16-byte record {lastEpoch, nextIndex, matchIndex,
 // recentRejection} per follower as [follower][lane], plus the F matchIndex values again as one [lane] row of 16 (F <= 4) or 32
@@ -382,12 +414,13 @@ struct PeersNarrow {
     I32x4 *rec;                                 // [F][BLOCK], + lane applied
     int32_t *mv;                                // [MV][BLOCK][4], + lane * 4 applied; element i at mv[(i / 4) * BLOCK * 4 + (i % 4)]
     bool overflow;                              // a general handler stored a value that does not fit: the workgroup redoes the launch in 64 bits
+    int64_t base;                               // the records hold indices relative to the group's index base (to_rel); the scalar accessors the general handlers use speak absolute values
     __device__ __forceinline__ int32_t *mslot(int i) const { return mv + (i >> 2) * (BLOCK * 4) + (i & 3); }
-    __device__ __forceinline__ int64_t last_epoch(int j) const { return rec[j * BLOCK].x; }
-    __device__ __forceinline__ int64_t next_index(int j) const { return rec[j * BLOCK].y; }
-    __device__ __forceinline__ int64_t match_index(int j) const { return rec[j * BLOCK].z; }
+    __device__ __forceinline__ int64_t last_epoch(int j) const { return to_abs(rec[j * BLOCK].x, base); }
+    __device__ __forceinline__ int64_t next_index(int j) const { return to_abs(rec[j * BLOCK].y, base); }
+    __device__ __forceinline__ int64_t match_index(int j) const { return to_abs(rec[j * BLOCK].z, base); }
     __device__ __forceinline__ int32_t rejection(int j) const { return rec[j * BLOCK].w; }
-    __device__ __forceinline__ int32_t fit(int64_t v) { overflow = overflow | ((uint64_t)v >= (uint64_t)STATE_LIMIT); return (int32_t)v; }
+    __device__ __forceinline__ int32_t fit(int64_t v) { const int64_t r = to_rel(v, base); overflow = overflow | ((uint64_t)r >= (uint64_t)STATE_LIMIT); return (int32_t)r; }
     __device__ __forceinline__ void set_last_epoch(int j, int64_t v) { rec[j * BLOCK].x = fit(v); }
     __device__ __forceinline__ void set_next_index(int j, int64_t v) { rec[j * BLOCK].y = fit(v); }
     __device__ __forceinline__ void set_match_index(int j, int64_t v) { const int32_t w = fit(v); rec[j * BLOCK].z = w; *mslot(j) = w; }

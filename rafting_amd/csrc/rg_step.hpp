@@ -248,20 +248,22 @@ __device__ __forceinline__ void stage_peers(const DevTable &t, uint32_t gi, cons
         pe.set_match_index(j, m.match_index); pe.set_rejection(j, m.rejection);
     }
 }
-// the same into the 32-bit records; false when a value lies outside [0, EV_LIMIT)
+// the same into the 32-bit records, relative to the group's index base (pe.base); false when a value has no image in [0, EV_LIMIT)
 template <int F>
 __device__ __forceinline__ bool stage_peers(const DevTable &t, uint32_t gi, bool prepared, PeersNarrow<F> &pe)
 {
     if (!prepared) return true;
     const uint32_t G = t.groups;
+    const int64_t base = pe.base;
     uint64_t w = 0;
 #pragma unroll
     for (int j = 0; j < F; j++) {
         const I64x2 en = t.peer_en[(size_t)j * G + gi];
         const Match m = t.peer_m[(size_t)j * G + gi];
-        w |= (uint64_t)en.x | (uint64_t)en.y | (uint64_t)m.match_index;
-        pe.rec[j * BLOCK] = I32x4{(int32_t)en.x, (int32_t)en.y, (int32_t)m.match_index, m.rejection};
-        *pe.mslot(j) = (int32_t)m.match_index;
+        const int64_t ep = to_rel(en.x, base), nx = to_rel(en.y, base), mt = to_rel(m.match_index, base);
+        w |= (uint64_t)ep | (uint64_t)nx | (uint64_t)mt;
+        pe.rec[j * BLOCK] = I32x4{(int32_t)ep, (int32_t)nx, (int32_t)mt, m.rejection};
+        *pe.mslot(j) = (int32_t)mt;
     }
     return w < (uint64_t)EV_LIMIT;
 }
@@ -519,10 +521,15 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
 
     if (io_wave) {
         auto row_of = [&](uint32_t r) { return (size_t)(r < p.rounds ? r : last_round) * p.count + ir; };
+        // compact rows (and compact outcome rows) carry log indices relative to the group's index base (rg_device.hpp: to_rel): this body decides on
+        // absolute values, so the row's index fields are taken off the base as they are handed over, and put back on it in the rows of OUT32
+        int64_t io_base = 0;
+        if constexpr (EV32) io_base = p.t.ibase[SPARSE ? p.gid[ir] : ir];
         auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
             sh_ev[slot][EV_HEAD][lane] = (uint64_t)decorate<EV32>(p, e, t, false) | ((uint64_t)e.aux << 32);
-            sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b;
-            sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
+            const uint32_t ix = EV32 ? index_fields(RG_HDR_KIND(e.hdr)) : 0u;
+            sh_ev[slot][EV_A][lane] = (uint64_t)((ix & 1u) ? to_abs(e.a, io_base) : e.a); sh_ev[slot][EV_B][lane] = (uint64_t)((ix & 2u) ? to_abs(e.b, io_base) : e.b);
+            sh_ev[slot][EV_C][lane] = (uint64_t)((ix & 4u) ? to_abs(e.c, io_base) : e.c); sh_ev[slot][EV_D][lane] = (uint64_t)((ix & 8u) ? to_abs(e.d, io_base) : e.d);
             if constexpr (!EV32) {
                 sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0;
                 sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
@@ -545,10 +552,11 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
             rg_persist_t per;
             per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
             if constexpr (OUT32) {
-                const uint64_t bits = (uint64_t)rep.resp_term | (uint64_t)lfx.x | (w_lfx ? (uint64_t)lfx.y : 0ull) | (w_per ? (uint64_t)per.term : 0ull);
+                const int64_t commit_r = to_rel(lfx.x, io_base), from_r = to_rel(lfx.y, io_base);
+                const uint64_t bits = (uint64_t)rep.resp_term | (uint64_t)commit_r | (w_lfx ? (uint64_t)from_r : 0ull) | (w_per ? (uint64_t)per.term : 0ull);
                 const bool wide = bits >= (1ull << 31);
                 if (active) {
-                    nt_store16(p.out32 + row, I32x4{(int32_t)rep.resp_term, (int32_t)(flags_all | (wide ? RG_F_WIDE_VALUES : 0u)), (int32_t)lfx.x, (int32_t)lfx.y});
+                    nt_store16(p.out32 + row, I32x4{(int32_t)rep.resp_term, (int32_t)(flags_all | (wide ? RG_F_WIDE_VALUES : 0u)), (int32_t)commit_r, (int32_t)from_r});
                     if (w_per) nt_store16(p.persist32 + row, I32x4{(int32_t)per.term, per.voted_for, (int32_t)rep.role_epoch, per.role});
                     if (wide & (p.reply != nullptr)) {
                         nt_store16(p.reply + row, rep);
@@ -780,6 +788,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         RG_OWN_SGPRS(b_head); RG_OWN_SGPRS(b_q); RG_OWN_SGPRS(b_reply); RG_OWN_SGPRS(b_logfx); RG_OWN_SGPRS(b_persist);
         const uint64_t round_rows = p.count;
         const uint32_t irm = ir & 0x0FFFFFFFu;           // (spelled out for the instruction selector: ir < count < 2^28)
+        // the group's index base: only the wide effect rows need it (compact outcome rows carry indices relative to it, like the event rows)
+        int64_t io_base = 0;
+        if constexpr (!OUT32) io_base = p.t.ibase[SPARSE ? p.gid[ir] : ir];
         auto fetch = [&](uint32_t r, Row32 &x) {
             const uint64_t rb = (uint64_t)(r < p.rounds ? r : last_round) * round_rows;
             x.h = nt_load_at<U32x2>(b_head + rb * 8u, irm);
@@ -819,7 +830,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                 rep.resp_term = (flags & RG_F_REPLIED) ? (int64_t)(uint32_t)o0.x : 0; rep.flags = flags_all; rep.role_epoch = (uint32_t)o0.z;
                 nt_store_at(b_reply + rb16, irm, rep);
                 const bool w_lfx = ((flags & (RG_F_COMMIT | RG_F_LOG_APPEND | RG_F_LOG_TRUNC)) != 0) | (status == RG_NEED_HOST);
-                if (w_lfx) nt_store_at(b_logfx + rb16, irm, I64x2{(int64_t)(uint32_t)o0.w, (int64_t)(uint32_t)o1.x});
+                // (rg_logfx_t speaks absolute indices: the image's values go back on the group's base)
+                if (w_lfx) nt_store_at(b_logfx + rb16, irm, I64x2{to_abs((int64_t)(uint32_t)o0.w, io_base), to_abs((int64_t)(uint32_t)o1.x, io_base)});
                 if ((flags & RG_F_PERSIST) != 0) {
                     rg_persist_t per;
                     per.term = (int64_t)(uint32_t)o1.y; per.voted_for = o1.z; per.role = o1.w;
@@ -895,14 +907,17 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     GroupN g;
     PeersNarrow<F> pe;
-    pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false;
+    const int64_t base = p.t.ibase[gi];                 // the group's index base (0 unless the host set one): the image below is relative to it (to_rel)
+    pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false; pe.base = base;
     const bool FAST = p.fast_paths != 0;
     bool in_domain;
     {
         Group g64;
         load_group(p.t, gi, g64);
-        // (role epochs grow by at most two per round: a launch of fewer than 2^24 rounds cannot take one out of s_ne()'s domain)
-        in_domain = fits32(g64, EV_LIMIT) & small_fields_fit(g64) & (p.force_wide == 0) & (p.rounds < (1u << 24));
+        g64 = group_to_rel(g64, base);
+        // (role epochs grow by at most two per round: a launch of fewer than 2^24 rounds cannot take one out of s_ne()'s domain;
+        //  with a base the epoch must lie above it: the one index tier 1 computes from — prepareReplication's epoch.index + 1 — is then never "0 + 1")
+        in_domain = fits32(g64, EV_LIMIT) & small_fields_fit(g64) & (p.force_wide == 0) & (p.rounds < (1u << 24)) & ((base == 0) | (g64.epoch_index > 0)) & (base >= 0);
         narrow_into(g, g64);
         g.nallow = FAST ? 0 : -1;
         g.recache();
@@ -929,11 +944,16 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             const bool slow = open & !skip;
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {
-                Group g64 = widen(g);
+                // the general handlers decide on ABSOLUTE values: the image and the row's index fields are taken off the base, the results put back on it
+                Group g64 = group_to_abs(widen(g), base);
                 Stepper<F, PeersNarrow<F>> st(p, g64, pe);
                 const Entries en = entries_of<true>(p, hdr, aux, 0, 0, 0, 0);
-                st.run(hdr, aux, (int64_t)q.x, (int64_t)q.y, (int64_t)q.z, (int64_t)q.w, false, 0, 0, en, entries_readable(p, en, aux, RG_HDR_N(hdr)));
-                bail = !fits32(g64, STATE_LIMIT) | !small_fields_fit(g64) | pe.overflow |
+                const uint32_t ix = index_fields(kind);
+                st.run(hdr, aux, (ix & 1u) ? to_abs(q.x, base) : (int64_t)q.x, (ix & 2u) ? to_abs(q.y, base) : (int64_t)q.y,
+                       (ix & 4u) ? to_abs(q.z, base) : (int64_t)q.z, (ix & 8u) ? to_abs(q.w, base) : (int64_t)q.w, false, 0, 0, en, entries_readable(p, en, aux, RG_HDR_N(hdr)));
+                g64 = group_to_rel(g64, base);
+                st.fx.log_from = to_rel(st.fx.log_from, base);
+                bail = !fits32(g64, STATE_LIMIT) | !small_fields_fit(g64) | pe.overflow | ((base != 0) & (g64.epoch_index <= 0)) |
                        (((uint64_t)st.fx.resp_term | (uint64_t)st.fx.log_from) >= (uint64_t)STATE_LIMIT);
                 narrow_into(g, g64);
                 if (st.fx.status == RG_NEED_HOST) blocked = true;
@@ -963,10 +983,10 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     RG_PROBE_FLUSH(4);
     RG_HWID_END(0);
     if (active) {
-        const Group g64 = widen(g);
+        const Group g64 = group_to_abs(widen(g), base);
         uint32_t gi_out = gi;
         RG_FRESH_VGPR(gi_out);
-        store_group(p.t, gi_out, g64, pe, F);
+        store_group(p.t, gi_out, g64, pe, F);       // (pe's scalar accessors return absolute values)
     }
     return true;
 }
@@ -985,7 +1005,7 @@ __global__ __launch_bounds__((1 + IOW) * BLOCK) __attribute__((amdgpu_waves_per_
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
     if (narrow_body<F, SPARSE, OUT32, IOW>(p, smem)) return;
-    if (threadIdx.x == 0) RG_NOTE_FALLBACK();
+    if (threadIdx.x == 0) { RG_NOTE_FALLBACK(); atomicAdd(p.wide_bodies, 1ull); }      // (a workgroup that left the 32-bit domain: rare by design, counted so a host can see it)
     if constexpr (IOW == 2) {
         // the 64-bit body knows two wavefronts: the third only keeps the barriers' count (one to get here, one per staging, one per round)
         if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 2u * BLOCK) {
@@ -1007,7 +1027,7 @@ template <int F, bool SPARSE, int WAVES, bool OUT32>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_wide_kernel(const StepParams p)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    if (threadIdx.x == 0) RG_NOTE_FALLBACK();
+    if (threadIdx.x == 0) { RG_NOTE_FALLBACK(); atomicAdd(p.wide_bodies, 1ull); }
     split_body<F, SPARSE, true, OUT32>(p, smem);
 }
 

@@ -31,11 +31,11 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_outcome32_unpack_rel", "rg_index_base_set", "rg_index_base_get", "rg_batch32_pack_rel", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
-        "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_copy_bandwidth",
+        "rg_timing_read", "rg_timing_begin", "rg_timing_end", "rg_counters_read", "rg_wide_body_workgroups", "rg_copy_bandwidth",
     ]
 
 
@@ -92,6 +92,11 @@ def lib():
         L.rg_submit32.argtypes = [vp, C.POINTER(abi.CBatch32), C.POINTER(abi.COutcome), i32]
         L.rg_submit32c.argtypes = [vp, C.POINTER(abi.CBatch32), C.POINTER(abi.COutcome32), i32]
         L.rg_outcome32_unpack.argtypes = [C.POINTER(abi.COutcome32), u32, u32, vp, C.POINTER(abi.COutcome)]
+        L.rg_outcome32_unpack_rel.argtypes = [C.POINTER(abi.COutcome32), u32, u32, vp, vp, C.POINTER(abi.COutcome)]
+        L.rg_index_base_set.argtypes = [vp, u32, u32, vp]
+        L.rg_index_base_get.argtypes = [vp, u32, u32, vp]
+        L.rg_batch32_pack_rel.restype = C.c_int64
+        L.rg_batch32_pack_rel.argtypes = [C.POINTER(abi.CBatch), vp, vp, vp, vp]
         L.rg_batch32_pack.restype = C.c_int64
         L.rg_batch32_pack.argtypes = [C.POINTER(abi.CBatch), vp, vp, vp]
         L.rg_submit_async.argtypes = [vp, C.POINTER(abi.CBatch), C.POINTER(abi.COutcome)]
@@ -124,6 +129,7 @@ def lib():
         L.rg_timing_begin.argtypes = [vp]
         L.rg_timing_end.argtypes = [vp, C.POINTER(C.c_double)]
         L.rg_counters_read.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+        L.rg_wide_body_workgroups.argtypes = [vp, C.POINTER(C.c_uint64), i32]
         L.rg_copy_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
         if L.rg_abi_version() != abi.ABI_VERSION:
             raise EngineError("libraftgpu.so ABI %d != binding ABI %d" % (L.rg_abi_version(), abi.ABI_VERSION))
@@ -145,15 +151,21 @@ def _replicate(call, groups, cluster, gid, heartbeat, in_flight):
     return head, np.ascontiguousarray(send.reshape(F, count).T)
 
 
-def pack32(batch):
-    """abi.Batch -> abi.Batch32 through the library's host-side packer (rg_batch32_pack): AppendEntries rows whose entries share one term
-    carry it in the row (RG_HDR_SAME_TERM). Raises when the batch cannot travel in the compact format (hints, a value outside [0, 2^31))."""
+def pack32(batch, index_base=None):
+    """abi.Batch -> abi.Batch32 through the library's host-side packer (rg_batch32_pack / _rel): AppendEntries rows whose entries share one term
+    carry it in the row (RG_HDR_SAME_TERM). index_base: int64 per GROUP OF THE TABLE — log indices then travel relative to their group's base
+    (include/raftgpu.h, "the index base of the compact formats"). Raises when the batch cannot travel in the compact format (hints, a value
+    outside [0, 2^31), an index at or below its base)."""
     rows = batch.rounds * batch.count
     head = np.zeros(rows, dtype=abi.HEAD_DT)
     abcd = np.zeros(rows, dtype=abi.QUAD32_DT)
     terms = np.zeros(max(batch.entry_count, 1), dtype=np.int32)
     b = batch.as_struct()
-    n = lib().rg_batch32_pack(C.byref(b), head.ctypes.data, abcd.ctypes.data, terms.ctypes.data)
+    if index_base is None:
+        n = lib().rg_batch32_pack(C.byref(b), head.ctypes.data, abcd.ctypes.data, terms.ctypes.data)
+    else:
+        ib = np.ascontiguousarray(index_base, dtype=np.int64)
+        n = lib().rg_batch32_pack_rel(C.byref(b), ib.ctypes.data, head.ctypes.data, abcd.ctypes.data, terms.ctypes.data)
     if n < 0:
         raise EngineError("rg_batch32_pack: %d (%s)" % (n, {-1: "missing column", -2: "the batch carries hints", -3: "a value outside [0, 2^31)",
                                                              -4: "entry_terms needed"}.get(n, "?")))
@@ -238,14 +250,16 @@ class PackedBatch:
         self._owners = []
 
 
-def unpack32(out32, rounds, count, role_epoch_before):
-    """abi.Outcome32 -> abi.Outcome through the library's host-side rg_outcome32_unpack. `role_epoch_before`: the groups' role epochs before the
-    batch (GroupState.role_epoch); returns (outcome, role epochs after the batch)."""
+def unpack32(out32, rounds, count, role_epoch_before, index_base=None):
+    """abi.Outcome32 -> abi.Outcome through the library's host-side rg_outcome32_unpack(_rel). `role_epoch_before`: the groups' role epochs before the
+    batch (GroupState.role_epoch); index_base: the groups' index bases (None: all 0); returns (outcome, role epochs after the batch)."""
     out = abi.Outcome(rounds * count)
     ep = np.ascontiguousarray(role_epoch_before, dtype=np.uint32).copy()
     assert len(ep) == count and out32.rows == rounds * count
     i, o = out32.as_struct(), out.as_struct()
-    rc = lib().rg_outcome32_unpack(C.byref(i), rounds, count, ep.ctypes.data, C.byref(o))
+    ib = None if index_base is None else np.ascontiguousarray(index_base, dtype=np.int64)
+    assert ib is None or len(ib) == count
+    rc = lib().rg_outcome32_unpack_rel(C.byref(i), rounds, count, ep.ctypes.data, None if ib is None else ib.ctypes.data, C.byref(o))
     if rc:
         raise EngineError("rg_outcome32_unpack: %d (%s)" % (rc, {-1: "missing column", -3: "a row is flagged RG_F_WIDE_VALUES but there are no overflow columns",
                                                                  -4: "the compact and the wide copy of a row disagree"}.get(rc, "?")))
@@ -414,6 +428,17 @@ class Table:
             self.close()
         except Exception:
             pass
+
+    def set_index_base(self, base, first=0):
+        """rg_index_base_set: the index base of the compact formats for groups [first, first + len(base))"""
+        b = np.ascontiguousarray(base, dtype=np.int64)
+        self._check(lib().rg_index_base_set(self._h, first, len(b), b.ctypes.data))
+
+    def index_base(self, first=0, count=None):
+        count = self.groups - first if count is None else count
+        b = np.zeros(count, dtype=np.int64)
+        self._check(lib().rg_index_base_get(self._h, first, count, b.ctypes.data))
+        return b
 
     def set_option(self, option, value):
         """rg_table_option, e.g. (abi.OPT_REQUIRE_FENCED_TIMEOUTS, 1)"""
@@ -611,6 +636,12 @@ class Table:
         arr = (C.c_uint64 * abi.NUM_COUNTERS)()
         self._check(lib().rg_counters_read(self._h, arr, int(reset)))
         return list(arr)
+
+    def wide_body_workgroups(self, reset=False):
+        """workgroups of compact-row launches decided by the 64-bit body since the last reset (rg_wide_body_workgroups)"""
+        n = C.c_uint64()
+        self._check(lib().rg_wide_body_workgroups(self._h, C.byref(n), int(reset)))
+        return n.value
 
     def copy_bandwidth(self, nbytes=1 << 30, iters=10):
         g = C.c_double()

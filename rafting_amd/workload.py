@@ -65,6 +65,8 @@ class ReplayConfig:
                                   # prevLogIndex lies below the device's cached term runs (the logs then start with five runs) -> RG_NEED_HOST. The row
                                   # changes nothing whether it is applied or not (but Follower.currentLeader where that was still null); the host PARKS the group (RG_EV_NONE rows) for the rest of the launch —
                                   # what RG_SKIPPED_AFTER_NEED_HOST would do to its rows anyway — and drops the duplicate instead of resubmitting it
+    index_base: int = 0           # long-lived groups: every log was compacted at index_base (epoch = (index_base, 1)), all live indices lie above it — the
+                                  # stream is the same otherwise. With the table's index bases at index_base - 1 the compact formats carry it (rg_index_base_set)
     ae_entries: tuple = (0, 1, 2, 4)   # entries per AppendEntries request, equiprobable
     self_slot: int = 0
     pre_vote: bool = True
@@ -135,7 +137,7 @@ class ReplayGenerator:
         lead = (np.arange(self.first, self.first + self.n) < int(cfg.leader_frac * cfg.groups)) if cfg.role_sorted else (self._u(0) < cfg.leader_frac)
         self.mode = np.where(lead, LEAD, FOLLOW).astype(np.int64)
         self.term = 1 + self._ri(1, 8)
-        self.last = 8 + self._ri(2, 1 << 20)
+        self.last = cfg.index_base + 8 + self._ri(2, 1 << 20)
         self.last_term = self.term.copy()
         self.epoch = np.ones(n, dtype=np.int64)                  # role epoch
         self.leader = self.others[self._ri(3, F)]                # leader slot a follower hears from
@@ -145,8 +147,8 @@ class ReplayGenerator:
             self.match[:, j] = self.last - self._ri(5 + j, 4)
         lead = self.mode == LEAD
         self.commit[lead] = np.sort(self.match[lead], axis=1)[:, F // 2]
-        self.cur_term_start = np.ones(n, dtype=np.int64)         # first log index written in the current term
-        self.tail_run_start = np.ones(n, dtype=np.int64)         # first index of the run of entries that carries last_term
+        self.cur_term_start = np.full(n, cfg.index_base + 1, dtype=np.int64)      # first log index written in the current term
+        self.tail_run_start = np.full(n, cfg.index_base + 1, dtype=np.int64)      # first index of the run of entries that carries last_term
         self.k = np.zeros(n, dtype=np.int64)                     # replies of the running (pre-)election delivered so far
         self.grants = np.zeros(n, dtype=np.int64)
         self.late_k = np.full(n, F, dtype=np.int64)              # next late RequestVote reply of a won election
@@ -179,13 +181,18 @@ class ReplayGenerator:
         st.current_leader[:] = np.where(lead, abi.NO_NODE, self.leader)
         st.repl_prepared[:] = lead
         st.commit_index[:] = self.commit
-        st.first_index[:] = 1
+        st.first_index[:] = cfg.index_base + 1
         st.last_index[:] = self.last
         st.run_count[:] = 1
-        st.run_start[0::abi.TERM_RUNS] = 1
+        st.run_start[0::abi.TERM_RUNS] = cfg.index_base + 1
         st.run_term[0::abi.TERM_RUNS] = self.term
         st.peer_match_index[:] = np.where(lead[:, None], self.match, 0).reshape(-1)
         st.peer_next_index[:] = np.where(lead[:, None], self.match + 1, 0).reshape(-1)
+        if cfg.index_base:
+            assert cfg.p_miss == 0.0
+            st.epoch_index[:] = cfg.index_base
+            st.epoch_term[:] = 1
+            st.peer_last_epoch[:] = np.repeat(np.where(lead, cfg.index_base, 0), F)       # Leader.prepareReplication: lastEpoch = epoch.index
         if cfg.p_miss > 0.0:                                      # five runs per group: the table keeps the newest RG_TERM_RUNS
             st = abi.GroupState(n, self.P, runs_total=5 * n)
             st.role[:] = np.where(lead, abi.LEADER, abi.FOLLOWER)
@@ -318,7 +325,7 @@ class ReplayGenerator:
         slot[ack] = pj[ack]
         flag[ack] = ok[ack]
         a[ack] = np.where(down[ack], self.term[ack] + 1, self.term[ack])
-        bb[ack] = 0                                               # epoch.index at send: no compaction in this model
+        bb[ack] = cfg.index_base                                  # epoch.index at send: no compaction in this model
         c[ack] = sent[ack]
         aux[ack] = self.epoch[ack]
         adv = ack & ~down & ok

@@ -129,6 +129,18 @@ def test_unfenced_timeouts_are_refused_where_the_table_requires_fences(route, mo
     T.fenced_timeouts_case()
 
 
+def test_groups_at_two_to_the_forty_stay_on_the_32_bit_body():
+    T.index_base_case(G=192, rounds=24)
+    T.index_base_workload_case(groups=320, rounds=12)
+
+
+def test_groups_at_two_to_the_forty_on_the_64_bit_body(monkeypatch):
+    """the same traffic with the 64-bit body forced: it takes the relative rows off the bases itself (the fallback of a workgroup that left the domain)"""
+    monkeypatch.setenv("RG_FORCE_WIDE", "1")
+    monkeypatch.setattr(engine.Table, "wide_body_workgroups", lambda self, reset=False: 0)
+    T.index_base_workload_case(groups=192, rounds=8)
+
+
 @pytest.mark.parametrize("forced_wide", [False, True])
 def test_adverse_mix_stream(forced_wide, monkeypatch):
     if forced_wide:

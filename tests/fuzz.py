@@ -258,15 +258,16 @@ class Fuzzer:
                     self._vote_reply(b, r, g, v, pre=False)
 
 
-def random_initial_state(groups, cluster, self_slot, seed):
-    """Mixed-role start: followers/candidates/leaders with logs of 1-3 term runs, epochs, peers."""
+def random_initial_state(groups, cluster, self_slot, seed, offset=0):
+    """Mixed-role start: followers/candidates/leaders with logs of 1-3 term runs, epochs, peers. offset > 0: long-lived groups — every log was
+    compacted at or above `offset` (epoch.index >= offset), so all their live indices are huge while their spans stay small."""
     rng = random.Random(seed ^ 0x5EED)
     st = abi.GroupState(groups, cluster)
     Fn = cluster - 1
     for g in range(groups):
         role = rng.choices([F, C, L], [60, 10, 30])[0]
         term = rng.randint(1, 8)
-        eidx = rng.choice([0, 0, rng.randint(1, 50)])
+        eidx = offset + rng.choice([0, 0, rng.randint(1, 50)])
         eterm = 0 if eidx == 0 else rng.randint(1, term)
         st.role[g], st.current_term[g] = role, term
         st.epoch_index[g], st.epoch_term[g] = eidx, eterm
@@ -293,7 +294,7 @@ def random_initial_state(groups, cluster, self_slot, seed):
             st.repl_prepared[g] = 1
             top = int(st.last_index[g]) if st.run_count[g] else eidx
             for j in range(Fn):
-                m = rng.choice([0, rng.randint(0, top)])
+                m = rng.choice([0, rng.randint(max(eidx - 30, 0) if offset else 0, top)])
                 st.peer_last_epoch[g * Fn + j] = eidx
                 st.peer_match_index[g * Fn + j] = m
                 st.peer_next_index[g * Fn + j] = (m + 1) if m else top + 1

@@ -64,6 +64,9 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     assert r["traffic_measured_in_this_run"] is False and r["work_rate_algorithmic_gbps"] > 0 and r["outcome_format"] == "rg_outcome32_t"
     assert r["ms_int64_body"] > 0 and r["value_int64_body"] > 0 and r["int64_body_counters_equal"] is True
     assert "golden" in d and "model_overcharges" in r
+    ll = d["long_lived_groups"]                                                 # round 5: groups at 2^40 on the 32-bit body (index bases), checked against the oracle in the run
+    assert "error" not in ll, ll
+    assert d["value_long_lived_groups"] > 0 and ll["int64_body_workgroups"] == 0 and d["int64_body_workgroups"] == 0 and "bit-identical" in ll["checked"]
     adv = d["adverse_mix"]                                                      # round 5: the adverse mix as a line of the default run
     assert "error" not in adv, adv
     assert d["value_adverse_mix"] > 0 and adv["need_host_as_expected"] is True and adv["counters"]["need_host"] > 0 and adv["counters"]["asserts"] == 0

@@ -821,8 +821,126 @@ def adverse_mix_case(groups, rounds, launches=3):
     orc.close()
 
 
+def index_base_case(G=256, P=5, rounds=40, seed=77, offset=1 << 40):
+    """Groups whose logs were compacted around 2^40: every live index is huge, every span small. With the table's index bases a little
+    below the epochs the compact formats carry the traffic — rows packed relative to the bases (rg_batch32_pack_rel), compact outcome rows unpacked
+    back onto them — and the 32-bit body decides it: NO workgroup takes the 64-bit body (rg_wide_body_workgroups), every outcome row and the final
+    state bit-identical to the oracle's, which works on the absolute values throughout. A second table without bases takes the same state and the same
+    rows in the wide format: same answers, by the wide-row kernel."""
+    st0 = fuzz.random_initial_state(G, P, 1, seed, offset=offset)
+    base = np.full(G, offset - 1000, dtype=np.int64)
+    gpu, orc = engine.Table(G, P, 1, True), oracle_lib.OracleTable(G, P, 1, True)
+    gpu.set_index_base(base)
+    assert np.array_equal(gpu.index_base(), base)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    fz = fuzz.Fuzzer(G, P, 1, seed, allow_miss=True)
+    gpu.wide_body_workgroups(reset=True)
+    compact = rows_total = hist_ok = misses = 0
+    for r in range(rounds):
+        cur = gpu.read_state()
+        b = abi.Batch(1, G)
+        fz.round(cur, b, 0)
+        # rows the format cannot hold (the fuzzer's dirt: a leaderCommit of 3 for a log that starts at 2^40, ...) travel beside the batch as ONE sparse
+        # wide submit — what the ingress does with them (SealedBatch::wide); the dense compact batch has RG_EV_NONE in their place
+        kind = b.head["hdr"] & 0xF
+        ixf = np.array([0, 0xA, 0x6, 0x2, 0x2, 0x2, 0, 0, 0, 0, 0x1, 0x2, 0, 0, 0, 0], dtype=np.uint32)[kind]
+        cols = (b.ab["x"], b.ab["y"], b.cd["x"], b.cd["y"])
+        beside = np.zeros(G, dtype=bool)
+        for k, col in enumerate(cols):
+            is_ix = ((ixf >> k) & 1) != 0
+            beside |= is_ix & (col != 0) & ((col <= base) | (col - base >= (1 << 31)))
+            beside |= ~is_ix & ((col < 0) | (col >= (1 << 31)))
+        dense = abi.Batch(1, G)
+        dense.head[:], dense.ab[:], dense.cd[:] = b.head, b.ab, b.cd
+        dense.entry_terms, dense.entry_count = b.entry_terms, b.entry_count
+        dense.head["hdr"][beside] = 0
+        b32 = engine.pack32(dense, index_base=base)
+        compact += int(np.count_nonzero(kind[~beside]))
+        rows_total += int(np.count_nonzero(kind))
+        raw = gpu.submit32c(b32, fill=0xAB)
+        assert not np.any(raw.row["flags"] & abi.F_WIDE_VALUES)
+        got, _ = engine.unpack32(raw, 1, G, cur.role_epoch, index_base=base)
+        # the rows really are relative: commitIndex after the row, on the base, is the table's
+        c = raw.row["commit_index"].astype(np.int64)
+        assert np.array_equal(np.where(c == 0, 0, c + base), gpu.read_state().commit_index)
+        if beside.any():
+            rows = np.flatnonzero(beside)
+            o2 = gpu.submit(_subset(b, rows, rows.astype(np.uint32)), fill=0xAB)
+            got.reply[rows], got.logfx[rows], got.persist[rows] = o2.reply, o2.logfx, o2.persist
+        misses += _resolve_need_host(gpu, orc, b, got, cur)      # (hints from the host's log as it stands BEFORE the round: the oracle's, here)
+        ref = orc.submit(b, fill=0xAB)
+        compare_outcomes(ref, got, "index base, round %d" % r)
+        hist_ok += int(np.count_nonzero(ref.status == abi.OK))
+    compare_states(orc.read_state(), gpu.read_state(), "index base final")
+    assert compact >= 0.97 * rows_total, "only %d of %d rows travelled in the compact format" % (compact, rows_total)
+    # (the fuzzer's acks claim arbitrary matchIndex values — 25 billion entries behind the leader, say: such a group has left ANY 2^30 window and takes
+    # its workgroup to the 64-bit body, rightly. The clean stream of index_base_workload_case is where "no workgroup leaves" is asserted.)
+    assert gpu.wide_body_workgroups() <= rounds * ((G + 63) // 64) // 2, "most workgroups of groups at 2^40 with small spans must stay on the 32-bit body"
+    assert hist_ok > rounds * G // 2
+    # without a base the same groups cannot use the compact row format at all, and a compact-format launch on their state takes the 64-bit body
+    plain = engine.Table(G, P, 1, True)
+    plain.load_state(st0)
+    with pytest.raises(engine.EngineError):
+        engine.pack32(b)
+    quiet = abi.Batch(1, G)                               # RG_EV_NONE rows: expressible in any format
+    plain.submit32(quiet)
+    assert plain.wide_body_workgroups() == (G + 63) // 64
+    # a base above a live index: the group leaves the 32-bit domain (its workgroup runs the 64-bit body), decisions unchanged
+    gpu2, orc2 = engine.Table(G, P, 1, True), oracle_lib.OracleTable(G, P, 1, True)
+    bad = base.copy()
+    bad[7] = int(st0.epoch_index[7]) + 5                  # above group 7's epoch
+    gpu2.set_index_base(bad)
+    gpu2.load_state(st0)
+    orc2.load_state(st0)
+    raw = gpu2.submit32c(engine.pack32(quiet, index_base=bad))
+    got, _ = engine.unpack32(raw, 1, G, st0.role_epoch, index_base=bad)
+    compare_outcomes(orc2.submit(quiet), got, "a base above the epoch")
+    assert gpu2.wide_body_workgroups() == 1
+    compare_states(orc2.read_state(), gpu2.read_state(), "a base above the epoch")
+    for t in (gpu, orc, plain, gpu2, orc2):
+        t.close()
+
+
+def index_base_workload_case(groups=2048, rounds=24, offset=1 << 40):
+    """the BASELINE stream with every log compacted at 2^40 (workload index_base): compact rows relative to base = 2^40 - 1 through rg_submit32c in
+    multi-round launches, against the oracle on the absolute stream; no workgroup on the 64-bit body"""
+    import dataclasses
+    from rafting_amd import workload
+    cfg = dataclasses.replace(workload.config(3, groups), index_base=offset, name="config3 at index base 2^40")
+    gen = workload.ReplayGenerator(cfg)
+    st0 = gen.initial_state()
+    base = np.full(groups, offset - 1, dtype=np.int64)
+    gpu, orc = engine.Table(groups, cfg.cluster, cfg.self_slot, cfg.pre_vote), oracle_lib.OracleTable(groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    gpu.set_index_base(base)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    ep = st0.role_epoch
+    for k in range(2):
+        b = gen.next_batch(rounds)
+        ref = orc.submit(b)
+        db = engine.DeviceBatch32(gpu, engine.pack32(b, index_base=base), compact=True)
+        gpu.submit_device(db)
+        gpu.sync()
+        got, ep = engine.unpack32(db.outcome32(), db.rounds, db.count, ep, index_base=base)
+        db.free()
+        compare_outcomes(ref, got, "index base workload, launch %d" % k)
+        assert int(np.count_nonzero(ref.status != abi.OK)) < 0.001 * len(ref.status)
+    compare_states(orc.read_state(), gpu.read_state(), "index base workload final")
+    assert gpu.wide_body_workgroups() == 0
+    gpu.close()
+    orc.close()
+
+
 def test_compact_multi_round_launch_and_domain_exits():
     compact_multi_round_case(1024, 5, 48)
+
+
+def test_groups_at_two_to_the_forty_stay_on_the_32_bit_body(step_kernel_variant):
+    if step_kernel_variant != "compact-out32":
+        pytest.skip("one route: compact rows in, compact outcome rows out, bases set")
+    index_base_case()
+    index_base_workload_case()
 
 
 def test_adverse_mix_stream_matches_the_oracle_but_for_its_cache_misses(step_kernel_variant):

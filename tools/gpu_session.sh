@@ -94,6 +94,8 @@ for step in "$@"; do
           $B --steps 20 --warmup 3 --no-int64-pass --no-adverse $C $W 2>>$OUT/out32.err | tee -a $OUT/out32.jsonl | line "$C ${W:-compact-outcomes}"; done; done ;;
     abq) for C in "" "--config 4"; do for i in 1 2; do for L in ${LIBS}; do       # quick same-box A/B on the two configurations that matter (config 3, config 4's shard)
           RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --no-int64-pass --no-adverse $C ${AB_ARGS} 2>>$OUT/abq.err | tee -a $OUT/abq.jsonl | line "${C:-c3} $L"; done; done; done ;;
+    abc3) for i in 1 2 3; do for L in ${LIBS}; do       # config 3 only, alternating
+          RG_LIB=$(pwd)/rafting_amd/$L $B --steps 20 --warmup 3 --no-int64-pass --no-adverse ${AB_ARGS} 2>>$OUT/abc3.err | tee -a $OUT/abc3.jsonl | line "c3 $L"; done; done ;;
     issue) timeout 120 build/issue_bench > $OUT/issue_bench.txt 2>&1; cat $OUT/issue_bench.txt ;;
     *) echo "unknown step $step" ;;
   esac
