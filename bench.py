@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--adverse-batches", type=int, default=8, help="launches of the adverse-mix leg (the first two are warm-up)")
     ap.add_argument("--index-base-batches", type=int, default=6, help="launches of the long-lived-groups leg (every log compacted at 2^40, index bases set; the first two are "
                     "warm-up; 0 skips the leg)")
+    ap.add_argument("--tick-batches", type=int, default=100, help="single-round ticks per way of the once-per-tick latency leg (the first ten are warm-up; 0 skips the leg)")
     ap.add_argument("--wide-rows", action="store_true", help="stage the batches as rg_batch_t (40 B + 8n per row, 64-bit fields) and decide them with the "
                     "wide-row kernels instead of the default compact rows (rg_batch32_t, 24 B per row) / rg::step32_kernel")
     return ap.parse_args()
@@ -527,6 +528,61 @@ def main():
             long_lived = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             print("bench: long-lived-groups leg failed: %r" % (e,), file=sys.stderr)
 
+    # ---- the once-per-tick path: ONE round per submission, from page-locked host buffers to page-locked host buffers, submit -> wait.
+    # Two ways: rg_submit_async_packed (nine runtime calls per tick) and rg_tick_launch (the same chain recorded once as a HIP graph, one call per tick);
+    # plus what one single-round launch costs on the device when the rows already lie in HBM. A latency figure, never `value`.
+    tick = None
+    if rank == 0 and world == 1 and args.tick_batches > 10 and not args.wide_rows and not args.override:
+        try:
+            def lat(us):
+                us = np.sort(np.asarray(us))
+                return {"p50_us": float(us[len(us) // 2]), "p99_us": float(us[min(len(us) - 1, int(len(us) * 0.99))]), "mean_us": float(us.mean()), "ticks": len(us)}
+            res = {}
+            for way in ("rg_submit_async_packed", "rg_tick_launch"):
+                tg = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
+                tt = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+                tt.load_state(tg.initial_state())
+                ticks = [tg.next_batch(1) for _ in range(args.tick_batches)]
+                cap = max(b.entry_count for b in ticks) + 64
+                pb = engine.PackedBatch(tt, ticks[0], entry_cap=cap)
+                tk = engine.Tick(tt, pb) if way == "rg_tick_launch" else None
+                us = []
+                for i, b in enumerate(ticks):
+                    b32 = engine.pack32(b)
+                    pb.head[:], pb.abcd[:] = b32.head, b32.abcd
+                    pb.entry_terms[:b32.entry_count] = b32.entry_terms[:b32.entry_count]
+                    if tk is None:
+                        pb.c_in.entry_count = b32.entry_count
+                    t1 = time.perf_counter()
+                    if tk is None:
+                        tt.submit_async_packed(pb)
+                        tt.submit_wait()
+                    else:
+                        tk.launch()
+                        tk.wait()
+                    dt = time.perf_counter() - t1
+                    if i >= 10:
+                        us.append(dt * 1e6)
+                res[way] = lat(us)
+                if tk is not None:
+                    tk.close()
+                    # the same single-round launches with the rows resident in HBM: what the device itself spends per tick
+                    dbs = [engine.DeviceBatch32(tt, b, compact=compact_out, wide=False) for b in ticks[:20]]
+                    tt.submit_device(dbs[0]); tt.submit_device(dbs[1]); tt.sync()
+                    tt.timing_begin()
+                    for db in dbs[2:]:
+                        tt.submit_device(db)
+                    res["device_us_per_single_round_launch"] = tt.timing_end() * 1e3 / (len(dbs) - 2)
+                    for db in dbs:
+                        db.free()
+                pb.free()
+                tt.close()
+            tick = dict(res, groups=gpg, rounds_per_tick=1, bytes_up_per_tick=24 * gpg, note="submit -> wait of ONE round over PCIe, page-locked buffers both ways; "
+                        "python call overhead (ctypes, ~2 us per call) included in both ways")
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            tick = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench: once-per-tick leg failed: %r" % (e,), file=sys.stderr)
+
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the SAME command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate
         # passes, gfx950 x2 fetch correction applied; tools/prof.sh writes profiles/traffic.json) — quoted only when the entry
@@ -610,6 +666,7 @@ def main():
                 "value_int64_body": None if int64_pass is None else int64_pass["value"],
                 "int64_body_counters_equal": None if int64_pass is None else int64_pass["counters_equal_first_pass"],
             },
+            "tick_latency": tick,
             "int64_body_workgroups": wide_wgs,
             "value_long_lived_groups": None if not long_lived or "value" not in long_lived else long_lived["value"],
             "long_lived_groups": long_lived,

@@ -341,6 +341,22 @@ typedef struct {
 } rg_outcome_packed_t;
 int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out);
 
+/* THE ONCE-PER-TICK PATH (ABI 4). A host that flushes once per tick (support/EventLoopGroup.java:32-46 drains whatever is queued; a 300 ms-tick cluster queues
+ * one or two events per group) submits small batches of a FIXED shape from the same page-locked buffers over and over, and what it feels is not the kernel
+ * but the driver: rg_submit_async_packed is nine runtime calls per batch (copies up, three kernels, copies down, events). rg_tick_create records that
+ * whole chain ONCE — upload of the compact rows, the step kernel, the packing of the effect lists, the download of the replies — as a HIP graph bound to
+ * the caller's buffers; rg_tick_launch replays it with one call. The host refills `in`'s buffers between a wait and the next launch.
+ *   in      shape and buffers are fixed at creation: rounds, count, gid (NULL = dense), head, abcd; entry_terms with entry_count = its CAPACITY (the whole
+ *           array is uploaded every tick; 0 when every AppendEntries row carries RG_HDR_SAME_TERM). All page-locked (rg_host_alloc).
+ *   out     as for rg_submit_async_packed (reply dense; logfx / persist lists with counts), page-locked.
+ * Same decisions as rg_submit_async_packed on the same rows; launches of one table run in the order they were made, with every other submission
+ * (they share the table's stream). Table options are read at creation. At most one launch of a tick is in flight: rg_tick_launch waits for the previous one. */
+typedef struct rg_tick rg_tick_t;
+int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out, rg_tick_t **tick);
+int rg_tick_launch(rg_tick_t *tick);      /* returns at once */
+int rg_tick_wait(rg_tick_t *tick);        /* the launch has landed in `out` */
+int rg_tick_destroy(rg_tick_t *tick);
+
 /* The compact rows as a batch format of their own — what a host that keeps its batches in HBM (or builds them there) hands over:
  * 24 bytes per event instead of 40 + 8n, no gathered entry-term loads. Same contract as rg_submit (memspace, dense / sparse, rounds,
  * outcome columns, per-row status), same results: the kernel decides a workgroup's 64 groups on 32-bit values while every value of

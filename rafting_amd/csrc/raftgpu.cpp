@@ -616,6 +616,118 @@ int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outco
     return 0;
 }
 
+/* the once-per-tick path: see include/raftgpu.h */
+struct rg_tick {
+    rg_table *t = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    Staging head, abcd, gid, terms, reply, logfx, persist, counts;
+    bool in_flight = false;
+};
+
+int rg_tick_destroy(rg_tick_t *k)
+{
+    if (!k) return 0;
+    if (k->t) { (void)hipSetDevice(k->t->device); if (k->t->stream) (void)hipStreamSynchronize(k->t->stream); }
+    if (k->exec) (void)hipGraphExecDestroy(k->exec);
+    if (k->graph) (void)hipGraphDestroy(k->graph);
+    for (Staging *st : {&k->head, &k->abcd, &k->gid, &k->terms, &k->reply, &k->logfx, &k->persist, &k->counts})
+        if (st->ptr) (void)hipFree(st->ptr);
+    delete k;
+    return 0;
+}
+
+int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out, rg_tick_t **tick)
+{
+    if (!t) return -1;
+    if (!tick) return fail(t, -1, "rg_tick_create: tick is NULL");
+    *tick = nullptr;
+    if (!in || !out) return fail(t, -1, "rg_tick_create: null batch or outcome");
+    if (!in->head || !in->abcd || !out->reply || !out->counts || (out->logfx_cap && !out->logfx) || (out->persist_cap && !out->persist))
+        return fail(t, -1, "rg_tick_create: head, abcd, reply, counts and every list with a capacity are required");
+    if (in->entry_count && !in->entry_terms) return fail(t, -1, "rg_tick_create: entry_count %llu without entry_terms", (unsigned long long)in->entry_count);
+    rg_batch_t wide{};
+    wide.rounds = in->rounds; wide.count = in->count; wide.gid = nullptr; wide.head = in->head;      // (a sparse gid list is read at every launch, not now)
+    wide.ab = wide.cd = reinterpret_cast<const rg_ev_pair_t *>(in->abcd);
+    wide.entry_terms = reinterpret_cast<const int64_t *>(in->entry_terms); wide.entry_count = in->entry_count;
+    rg_logfx_t dummy_l; rg_persist_t dummy_p;
+    const rg_outcome_t shape{out->reply, &dummy_l, &dummy_p};
+    if (in->gid) {
+        if (in->rounds != 1) return fail(t, -1, "rg_tick_create: sparse batches carry exactly one round");
+        if (in->count > t->G || in->count == 0) return fail(t, -1, "rg_tick_create: %u rows for %u groups", in->count, t->G);
+    } else if (int rc = check_batch(t, &wide, &shape, true)) return rc;
+    if (in->rounds == 0 || in->count == 0) return fail(t, -1, "rg_tick_create: an empty shape");
+    const size_t rows64 = (size_t)in->rounds * in->count;
+    if (rows64 >= (1ull << 31)) return fail(t, -1, "rg_tick_create: %zu rows in one batch (limit 2^31 - 1)", rows64);
+    if (bind(t)) return -2;
+    void *d_logfx = nullptr, *d_persist = nullptr, *d_counts = nullptr;
+    if (hipHostGetDevicePointer(&d_counts, out->counts, 0) != hipSuccess ||
+        (out->logfx_cap && hipHostGetDevicePointer(&d_logfx, out->logfx, 0) != hipSuccess) ||
+        (out->persist_cap && hipHostGetDevicePointer(&d_persist, out->persist, 0) != hipSuccess)) {
+        (void)hipGetLastError();
+        return fail(t, -1, "rg_tick_create: counts / logfx / persist must be page-locked memory from rg_host_alloc");
+    }
+    rg_tick *k = new rg_tick();
+    k->t = t;
+    const uint32_t rows = (uint32_t)rows64, waves = (rows + 63u) / 64u;
+    const bool sparse = in->gid != nullptr;
+    if (reserve(t, k->head, rows64 * sizeof(rg_ev_head_t)) || reserve(t, k->abcd, rows64 * sizeof(rg_ev_quad32_t)) || reserve(t, k->reply, rows64 * sizeof(rg_reply_t)) ||
+        reserve(t, k->logfx, rows64 * sizeof(I64x2)) || reserve(t, k->persist, rows64 * sizeof(rg_persist_t)) || reserve(t, k->counts, (size_t)2 * waves * sizeof(uint32_t)) ||
+        (sparse && reserve(t, k->gid, in->count * sizeof(uint32_t))) || (in->entry_count && reserve(t, k->terms, in->entry_count * sizeof(int32_t)))) {
+        rg_tick_destroy(k);
+        return -2;
+    }
+    rg::StepParams p = step_params(t, &wide);
+    p.head = (const rg_ev_head_t *)k->head.ptr; p.abcd32 = (const rg::I32x4 *)k->abcd.ptr;
+    p.gid = sparse ? (const uint32_t *)k->gid.ptr : nullptr;
+    p.entry_terms32 = in->entry_count ? (const int32_t *)k->terms.ptr : nullptr;
+    p.reply = (rg_reply_t *)k->reply.ptr; p.logfx = (I64x2 *)k->logfx.ptr; p.persist = (rg_persist_t *)k->persist.ptr;
+    hipStream_t s = t->stream;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) e = hipMemcpyAsync(k->head.ptr, in->head, rows64 * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(k->abcd.ptr, in->abcd, rows64 * sizeof(rg_ev_quad32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && sparse) e = hipMemcpyAsync(k->gid.ptr, in->gid, in->count * sizeof(uint32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && in->entry_count) e = hipMemcpyAsync(k->terms.ptr, in->entry_terms, in->entry_count * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = rg::launch_step(p, (int)t->F, sparse, 32, s);
+    if (e == hipSuccess) e = rg::launch_outcome_count(p.reply, rows, (uint32_t *)k->counts.ptr, (uint32_t *)d_counts, s);
+    if (e == hipSuccess) e = rg::launch_outcome_emit(p.reply, p.logfx, p.persist, rows, (const uint32_t *)k->counts.ptr, (I64x2 *)d_logfx, out->logfx_cap,
+                                                     (rg_persist_t *)d_persist, out->persist_cap, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(out->reply, k->reply.ptr, rows64 * sizeof(rg_reply_t), hipMemcpyDeviceToHost, s);
+    hipGraph_t g = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s, &g);           // (always: an open capture would poison the stream)
+    k->graph = g;
+    if (e == hipSuccess) e = e2;
+    if (e == hipSuccess) e = hipGraphInstantiate(&k->exec, k->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rg_tick_destroy(k);
+        return fail(t, -2, "rg_tick_create: %s", hipGetErrorString(e));
+    }
+    *tick = k;
+    return 0;
+}
+
+int rg_tick_launch(rg_tick_t *k)
+{
+    if (!k || !k->t) return -1;
+    rg_table *t = k->t;
+    if (bind(t)) return -2;
+    if (k->in_flight) { HIP_TRY(t, hipStreamSynchronize(t->stream)); k->in_flight = false; }
+    HIP_TRY(t, hipGraphLaunch(k->exec, t->stream));
+    k->in_flight = true;
+    return 0;
+}
+
+int rg_tick_wait(rg_tick_t *k)
+{
+    if (!k || !k->t) return -1;
+    rg_table *t = k->t;
+    HIP_TRY(t, hipSetDevice(t->device));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    k->in_flight = false;
+    return 0;
+}
+
 int rg_submit_wait(rg_table_t *t)
 {
     if (!t) return -1;

@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_outcome32_unpack_rel", "rg_index_base_set", "rg_index_base_get", "rg_batch32_pack_rel", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_outcome32_unpack_rel", "rg_index_base_set", "rg_index_base_get", "rg_batch32_pack_rel", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_tick_create", "rg_tick_launch", "rg_tick_wait", "rg_tick_destroy", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -103,6 +103,10 @@ def lib():
         L.rg_submit_wait.argtypes = [vp]
         L.rg_submit_async_packed.argtypes = [vp, vp, vp]
         L.rg_sync.argtypes = [vp]
+        L.rg_tick_create.argtypes = [vp, vp, vp, C.POINTER(vp)]
+        L.rg_tick_launch.argtypes = [vp]
+        L.rg_tick_wait.argtypes = [vp]
+        L.rg_tick_destroy.argtypes = [vp]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_step_kernel.restype = C.c_char_p
         L.rg_step_kernel.argtypes = [vp, u32]
@@ -195,13 +199,15 @@ class PackedBatch:
     """An abi.Batch re-laid in the compact transfer formats of rg_submit_async_packed, in page-locked memory: int32 event fields up,
     dense replies + packed logfx / persist lists down. unpack() rebuilds a dense abi.Outcome (unflagged rows zero) for comparison."""
 
-    def __init__(self, table, batch, logfx_cap=None, persist_cap=None):
+    def __init__(self, table, batch, logfx_cap=None, persist_cap=None, entry_cap=0):
         assert abi.batch_fits_32(batch), "a value outside [0, 2^31) or a hint column: use submit_async for this batch"
         rows = batch.rounds * batch.count
         self.rows, self.table, self._owners = rows, table, []
         b32 = pack32(batch)
         self.head, self.abcd = self._pin(b32.head), self._pin(b32.abcd)
-        self.entry_terms = self._pin(b32.entry_terms[:max(b32.entry_count, 1)])
+        et = np.zeros(max(entry_cap, b32.entry_count, 1), dtype=np.int32)      # entry_cap: room for the entry terms of later batches of the same shape (engine.Tick)
+        et[:b32.entry_count] = b32.entry_terms[:b32.entry_count]
+        self.entry_terms = self._pin(et)
         self.gid = None if batch.gid is None else self._pin(batch.gid)
         self.logfx_cap = rows if logfx_cap is None else logfx_cap
         self.persist_cap = rows if persist_cap is None else persist_cap
@@ -213,7 +219,7 @@ class PackedBatch:
         b.rounds, b.count = batch.rounds, batch.count
         b.gid = None if self.gid is None else self.gid.ctypes.data
         b.head, b.abcd = self.head.ctypes.data, self.abcd.ctypes.data
-        b.entry_terms = self.entry_terms.ctypes.data if b32.entry_count else None
+        b.entry_terms = self.entry_terms.ctypes.data if (b32.entry_count or entry_cap) else None
         b.entry_count = b32.entry_count
         o = abi.COutcomePacked()
         o.reply, o.logfx, o.persist, o.counts = self.reply.ctypes.data, self.logfx.ctypes.data, self.persist.ctypes.data, self.counts.ctypes.data
@@ -264,6 +270,37 @@ def unpack32(out32, rounds, count, role_epoch_before, index_base=None):
         raise EngineError("rg_outcome32_unpack: %d (%s)" % (rc, {-1: "missing column", -3: "a row is flagged RG_F_WIDE_VALUES but there are no overflow columns",
                                                                  -4: "the compact and the wide copy of a row disagree"}.get(rc, "?")))
     return out, ep
+
+
+class Tick:
+    """A prepared once-per-tick submission (rg_tick_create): the PackedBatch's page-locked buffers, a fixed shape, one HIP graph. refill(batch) writes
+    the next tick's rows into the same buffers; launch() / wait() replay the graph; the outcome is read through the PackedBatch (unpack())."""
+
+    def __init__(self, table, pb):
+        self.table, self.pb = table, pb
+        h = C.c_void_p()
+        pb.c_in.entry_count = len(pb.entry_terms) if pb.c_in.entry_terms else 0       # the array's capacity: all of it travels every tick
+        table._check(lib().rg_tick_create(table._h, C.byref(pb.c_in), C.byref(pb.c_out), C.byref(h)))
+        self._h = h
+
+    def refill(self, batch):
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch)
+        assert (b32.rounds, b32.count) == (self.pb.c_in.rounds, self.pb.c_in.count) and b32.entry_count <= self.pb.c_in.entry_count
+        self.pb.head[:], self.pb.abcd[:] = b32.head, b32.abcd
+        self.pb.entry_terms[:b32.entry_count] = b32.entry_terms[:b32.entry_count]
+        if b32.gid is not None:
+            self.pb.gid[:] = b32.gid
+
+    def launch(self):
+        self.table._check(lib().rg_tick_launch(self._h))
+
+    def wait(self):
+        self.table._check(lib().rg_tick_wait(self._h))
+
+    def close(self):
+        if self._h:
+            lib().rg_tick_destroy(self._h)
+            self._h = None
 
 
 class DeviceBuffer:

@@ -129,6 +129,10 @@ def test_unfenced_timeouts_are_refused_where_the_table_requires_fences(route, mo
     T.fenced_timeouts_case()
 
 
+def test_the_once_per_tick_graph_matches_the_oracle():
+    T.tick_path_case(G=128, ticks=12)
+
+
 def test_groups_at_two_to_the_forty_stay_on_the_32_bit_body():
     T.index_base_case(G=192, rounds=24)
     T.index_base_workload_case(groups=320, rounds=12)

@@ -27,6 +27,7 @@ extern "C" long rg_emu_fallbacks(int reset) { return reset ? g_fallbacks.exchang
 namespace hipemu {
 
 thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
+thread_local std::vector<std::function<void()>> *capture_ = nullptr;
 thread_local hipError_t last_error = hipSuccess;
 
 namespace {

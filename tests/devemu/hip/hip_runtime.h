@@ -42,7 +42,11 @@ struct dim3 {
 struct uint4 { unsigned x, y, z, w; };
 
 #include <functional>
+#include <vector>
 namespace hipemu {
+// stream capture (hipStreamBeginCapture .. hipGraphLaunch): while a capture is open, copies, memsets and launches are recorded as closures instead
+// of being executed; hipGraphLaunch replays them in order. One stream is as good as another here (everything is synchronous).
+extern thread_local std::vector<std::function<void()>> *capture_;
 extern thread_local dim3 threadIdx_, blockIdx_, blockDim_, gridDim_;
 struct Deadlock {};
 void pinned_add(void *p, size_t n);
@@ -123,8 +127,31 @@ static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { const hip
 static inline hipError_t hipHostFree(void *p) { ::hipemu::pinned_remove(p); free(p); return hipSuccess; }
 // page-locked memory is mapped at its own address; anything else is not device-visible (as on the real runtime)
 static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { if (!::hipemu::pinned_has(h)) return hipErrorInvalidValue; *d = h; return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t)
+{
+    if (::hipemu::capture_) { ::hipemu::capture_->push_back([=]() { memmove(d, s, n); }); return hipSuccess; }
+    memmove(d, s, n); return hipSuccess;
+}
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t)
+{
+    if (::hipemu::capture_) { ::hipemu::capture_->push_back([=]() { memset(d, v, n); }); return hipSuccess; }
+    memset(d, v, n); return hipSuccess;
+}
+typedef struct hipemu_graph { std::vector<std::function<void()>> ops; } *hipGraph_t, *hipGraphExec_t;
+typedef void *hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { if (::hipemu::capture_) return hipErrorInvalidValue; ::hipemu::capture_ = new std::vector<std::function<void()>>(); return hipSuccess; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g)
+{
+    if (!::hipemu::capture_) return hipErrorInvalidValue;
+    *g = new hipemu_graph{std::move(*::hipemu::capture_)};
+    delete ::hipemu::capture_; ::hipemu::capture_ = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, hipGraphNode_t *, char *, size_t) { *e = new hipemu_graph{g->ops}; return hipSuccess; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) { for (auto &op : e->ops) op(); return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
@@ -135,4 +162,6 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::hipemu::run_grid((grid), (block), [&]() { kernel(__VA_ARGS__); }, #kernel)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) do { \
+        if (::hipemu::capture_) { const dim3 g_ = (grid), b_ = (block); ::hipemu::capture_->push_back([=]() { ::hipemu::run_grid(g_, b_, [=]() { kernel(__VA_ARGS__); }, #kernel); }); } \
+        else ::hipemu::run_grid((grid), (block), [&]() { kernel(__VA_ARGS__); }, #kernel); } while (0)

@@ -64,6 +64,9 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     assert r["traffic_measured_in_this_run"] is False and r["work_rate_algorithmic_gbps"] > 0 and r["outcome_format"] == "rg_outcome32_t"
     assert r["ms_int64_body"] > 0 and r["value_int64_body"] > 0 and r["int64_body_counters_equal"] is True
     assert "golden" in d and "model_overcharges" in r
+    tk = d["tick_latency"]                                                      # round 5: the once-per-tick path, both ways
+    assert "error" not in tk, tk
+    assert tk["rg_tick_launch"]["p50_us"] > 0 and tk["rg_submit_async_packed"]["p99_us"] > 0 and tk["device_us_per_single_round_launch"] > 0
     ll = d["long_lived_groups"]                                                 # round 5: groups at 2^40 on the 32-bit body (index bases), checked against the oracle in the run
     assert "error" not in ll, ll
     assert d["value_long_lived_groups"] > 0 and ll["int64_body_workgroups"] == 0 and d["int64_body_workgroups"] == 0 and "bit-identical" in ll["checked"]

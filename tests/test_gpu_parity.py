@@ -932,6 +932,61 @@ def index_base_workload_case(groups=2048, rounds=24, offset=1 << 40):
     orc.close()
 
 
+def tick_path_case(G=192, P=5, ticks=24, seed=123):
+    """The once-per-tick path (rg_tick_*): ONE prepared submission (a HIP graph over the upload, the step kernel, the list packing and the download),
+    refilled and replayed tick after tick from the same page-locked buffers, against the oracle row for row — dense single-round ticks from the state-aware
+    fuzzer, then a sparse tick shape (a fixed set of groups)."""
+    st0 = fuzz.random_initial_state(G, P, 0, seed)
+    gpu, orc = engine.Table(G, P, 0, True), oracle_lib.OracleTable(G, P, 0, True)
+    gpu.load_state(st0)
+    orc.load_state(st0)
+    fz = fuzz.Fuzzer(G, P, 0, seed, allow_miss=False)
+    shape = abi.Batch(1, G)
+    pb = engine.PackedBatch(gpu, shape, entry_cap=8 * G)
+    tick = engine.Tick(gpu, pb)
+    for r in range(ticks):
+        b = abi.Batch(1, G)
+        fz.round(gpu.read_state(), b, 0)
+        tick.refill(b)
+        tick.launch()
+        tick.wait()
+        compare_outcomes(orc.submit(b), pb.unpack(), "tick %d" % r)
+    compare_states(orc.read_state(), gpu.read_state(), "after %d ticks" % ticks)
+    tick.close()
+    pb.free()
+    # a sparse shape: every third group, one row each
+    gids = np.arange(0, G, 3, dtype=np.uint32)
+    sp = abi.Batch(1, len(gids), gid=gids)
+    pbs = engine.PackedBatch(gpu, sp, entry_cap=8 * len(gids))
+    tk = engine.Tick(gpu, pbs)
+    for r in range(6):
+        full = abi.Batch(1, G)
+        fz.round(gpu.read_state(), full, 0)
+        sub = _subset(full, gids.astype(np.int64), gids)
+        sub.hint = None
+        sub.head["hdr"] &= ~np.uint32(abi.HDR_HINT_BIT)
+        tk.refill(sub)
+        tk.launch()
+        tk.wait()
+        compare_outcomes(orc.submit(sub), pbs.unpack(), "sparse tick %d" % r)
+    compare_states(orc.read_state(), gpu.read_state(), "after the sparse ticks")
+    # misuse: pageable list memory is refused, as by rg_submit_async_packed
+    with pytest.raises(engine.EngineError):
+        bad = engine.PackedBatch(gpu, shape)
+        bad.c_out.counts = np.zeros(2, dtype=np.uint32).ctypes.data
+        engine.Tick(gpu, bad)
+    tk.close()
+    pbs.free()
+    gpu.close()
+    orc.close()
+
+
+def test_the_once_per_tick_graph_matches_the_oracle(step_kernel_variant):
+    if step_kernel_variant != "compact":
+        pytest.skip("one route: the tick path always runs the compact-row kernel")
+    tick_path_case()
+
+
 def test_compact_multi_round_launch_and_domain_exits():
     compact_multi_round_case(1024, 5, 48)
 

@@ -94,11 +94,14 @@ def main():
         doc = json.load(open(path))        # keep the other cases as committed
     else:
         cases = list(CASES) + cases
-    with multiprocessing.get_context("spawn").Pool(jobs) as pool:
+    if "--missing-only" in sys.argv:       # (a run that lost a worker: keep what is there)
+        doc = json.load(open(path))
+        cases = [c for c in cases if c[0] not in doc["cases"]]
+    with multiprocessing.get_context("spawn").Pool(jobs, maxtasksperchild=1) as pool:
         for name, d in pool.imap_unordered(_one, cases):
             doc["cases"][name] = d
+            json.dump(doc, open(path, "w"), indent=1, sort_keys=True)      # after every case: a killed worker costs one case, not the run
             print("done", name, flush=True)
-    json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
 
 
