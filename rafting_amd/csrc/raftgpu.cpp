@@ -58,6 +58,7 @@ struct rg_table {
     int fast_paths = 1;                         // RG_FAST=0: general handlers only (differential tests)
     int force_wide = 0;                         // RG_FORCE_WIDE=1: the compact-format kernel skips its 32-bit body (differential tests)
     int require_fence = 0;                      // rg_table_option(RG_OPT_REQUIRE_FENCED_TIMEOUTS)
+    int has_bases = 0;                          // rg_index_base_set has stored a non-zero base at some time
     Staging st_abcd32, st_terms32, st_out32, st_persist32;
     int lanes = -1;                             // -1: pick per launch; 0: split kernel; 64: single-wavefront kernel (RG_SPLIT env forces one)
     uint32_t simds = 1024;                      // SIMDs of the device (CUs x 4)
@@ -480,6 +481,7 @@ static rg::StepParams step_params(rg_table *t, const rg_batch_t *in)
     p.fast_paths = t->fast_paths;
     p.force_wide = t->force_wide;
     p.require_fence = t->require_fence;
+    p.has_bases = t->has_bases;
     return p;
 }
 
@@ -864,6 +866,7 @@ int rg_index_base_set(rg_table_t *t, uint32_t first, uint32_t count, const int64
     if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_index_base_set: groups [%u, %u) of %u", first, first + count, t->G);
     for (uint32_t i = 0; i < count; i++)
         if (base[i] < 0) return fail(t, -1, "rg_index_base_set: base[%u] = %lld is negative", i, (long long)base[i]);
+    for (uint32_t i = 0; i < count; i++) if (base[i] != 0) t->has_bases = 1;       // (sticky: the kernels read the column from now on)
     if (count == 0) return 0;
     if (bind(t)) return -2;
     HIP_TRY(t, hipMemcpyAsync(t->dt.ibase + first, base, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));

@@ -93,6 +93,7 @@ struct StepParams {
     int32_t fast_paths;             // 0: general handlers only
     int32_t force_wide;             // compact-format kernel: skip the 32-bit body (tests)
     int32_t require_fence;          // RG_OPT_REQUIRE_FENCED_TIMEOUTS: a TIMEOUT row with aux == 0 is RG_BAD_EVENT
+    int32_t has_bases;              // the host has set a non-zero index base at some time (rg_index_base_set): 0 = the ibase column is all zero and is not read
 };
 
 struct ReplicateParams {             // N1: Leader.replicateLog for many groups (rg_kernels.hip: replicate_kernel)

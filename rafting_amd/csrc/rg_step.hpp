@@ -494,7 +494,8 @@ struct SplitLds {
     static constexpr int NEV = 4;
     static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 16,
                             N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16,
-                            N_LUTC = N_BAIL + 16, N_LUTM = N_LUTC + 256 * 4, N_LUTE = N_LUTM + 128 * 4, N_END = N_LUTE + 128 * 2;      // the I/O wavefront's tables (below)
+                            N_LUTC = N_BAIL + 16, N_LUTM = N_LUTC + 256 * 4, N_LUTE = N_LUTM + 128 * 4,      // the I/O wavefront's tables (below)
+                            N_BASE = N_LUTE + 128 * 2, N_END = N_BASE + BLOCK * 8;                           // the groups' index bases (the deciding wavefront's; round 5)
     static constexpr size_t BYTES = EV32 ? (W_END > N_END ? W_END : N_END) : W_END;
 };
 
@@ -524,7 +525,7 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
         // compact rows (and compact outcome rows) carry log indices relative to the group's index base (rg_device.hpp: to_rel): this body decides on
         // absolute values, so the row's index fields are taken off the base as they are handed over, and put back on it in the rows of OUT32
         int64_t io_base = 0;
-        if constexpr (EV32) io_base = p.t.ibase[SPARSE ? p.gid[ir] : ir];
+        if constexpr (EV32) io_base = (p.has_bases != 0) ? p.t.ibase[SPARSE ? p.gid[ir] : ir] : 0;
         auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
             sh_ev[slot][EV_HEAD][lane] = (uint64_t)decorate<EV32>(p, e, t, false) | ((uint64_t)e.aux << 32);
             const uint32_t ix = EV32 ? index_fields(RG_HDR_KIND(e.hdr)) : 0u;
@@ -790,7 +791,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         const uint32_t irm = ir & 0x0FFFFFFFu;           // (spelled out for the instruction selector: ir < count < 2^28)
         // the group's index base: only the wide effect rows need it (compact outcome rows carry indices relative to it, like the event rows)
         int64_t io_base = 0;
-        if constexpr (!OUT32) io_base = p.t.ibase[SPARSE ? p.gid[ir] : ir];
+        if constexpr (!OUT32) io_base = (p.has_bases != 0) ? p.t.ibase[SPARSE ? p.gid[ir] : ir] : 0;
         auto fetch = [&](uint32_t r, Row32 &x) {
             const uint64_t rb = (uint64_t)(r < p.rounds ? r : last_round) * round_rows;
             x.h = nt_load_at<U32x2>(b_head + rb * 8u, irm);
@@ -907,14 +908,22 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     const uint32_t gi = SPARSE ? p.gid[ir] : ir;
     GroupN g;
     PeersNarrow<F> pe;
-    const int64_t base = p.t.ibase[gi];                 // the group's index base (0 unless the host set one): the image below is relative to it (to_rel)
-    pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false; pe.base = base;
+    // The group's index base (0 unless the host set one): the image below is relative to it (to_rel). A table without bases — every wavefront whose 64
+    // bases are all 0 — skips the conversions at both ends of the launch behind ONE wave-uniform flag; where there are bases they wait in LDS for the
+    // general handlers and the write-back (kept in two VGPRs across the round loop they cost it 1.8 %, re-read from the table at the end of the launch a
+    // serialised memory round trip: 3.5 % — same-box A/Bs, profiles/r05e, r05f).
+    int64_t *sh_base = reinterpret_cast<int64_t *>(smem + L::N_BASE) + lane;
+    pe.rec = sh_rec + lane; pe.mv = sh_mv + lane * 4; pe.overflow = false; pe.base = 0;
     const bool FAST = p.fast_paths != 0;
-    bool in_domain;
+    bool in_domain, any_base;
     {
+        const int64_t base = (p.has_bases != 0) ? p.t.ibase[gi] : 0;       // (a table that never had a base: not even the load)
+        any_base = __builtin_amdgcn_ballot_w64(base != 0) != 0;
+        *sh_base = base;
+        pe.base = base;
         Group g64;
         load_group(p.t, gi, g64);
-        g64 = group_to_rel(g64, base);
+        if (any_base) g64 = group_to_rel(g64, base);
         // (role epochs grow by at most two per round: a launch of fewer than 2^24 rounds cannot take one out of s_ne()'s domain;
         //  with a base the epoch must lie above it: the one index tier 1 computes from — prepareReplication's epoch.index + 1 — is then never "0 + 1")
         in_domain = fits32(g64, EV_LIMIT) & small_fields_fit(g64) & (p.force_wide == 0) & (p.rounds < (1u << 24)) & ((base == 0) | (g64.epoch_index > 0)) & (base >= 0);
@@ -945,6 +954,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {
                 // the general handlers decide on ABSOLUTE values: the image and the row's index fields are taken off the base, the results put back on it
+                const int64_t base = any_base ? *sh_base : 0;
+                pe.base = base;
                 Group g64 = group_to_abs(widen(g), base);
                 Stepper<F, PeersNarrow<F>> st(p, g64, pe);
                 const Entries en = entries_of<true>(p, hdr, aux, 0, 0, 0, 0);
@@ -983,7 +994,13 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     RG_PROBE_FLUSH(4);
     RG_HWID_END(0);
     if (active) {
-        const Group g64 = group_to_abs(widen(g), base);
+        Group g64 = widen(g);
+        pe.base = 0;
+        if (any_base) {
+            const int64_t base = *sh_base;
+            pe.base = base;
+            g64 = group_to_abs(g64, base);
+        }
         uint32_t gi_out = gi;
         RG_FRESH_VGPR(gi_out);
         store_group(p.t, gi_out, g64, pe, F);       // (pe's scalar accessors return absolute values)

@@ -258,8 +258,13 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     const sw rare = (app_ae & x_pl) | (~fc_n & (x_tl | ~prep));
     const sw ack_down = ackany & ~x_aux & ~stl_n & x_ta;            // Leader -> Follower(result.term, responder)
     const sw election = (cw_bit(cw, CW_ELK) & ~nallow) | ack_down;
-    if (__builtin_amdgcn_ballot_w64((rare | election) < 0) != 0) {
-        if (__builtin_amdgcn_ballot_w64(rare < 0) != 0) {
+    // The ballots of this block are issued BACK TO BACK ahead of the branches that test them: a ballot whose scalar result is branched on at once costs the
+    // VALU -> SALU round trip (50 ticks for ballot + taken branch against 20 for a taken branch on a scalar that is already there,
+    // profiles/r04b_issue_bench.txt), and an election round has up to seven of them. Same-box: config 3 0.0687 -> 0.0673 ms, config 4's shard 0.1058 -> 0.1047
+    // (profiles/r05i_hoisted_ballots_ab.jsonl).
+    const uint64_t b_rare = __builtin_amdgcn_ballot_w64(rare < 0), b_el = __builtin_amdgcn_ballot_w64(election < 0);
+    if ((b_rare | b_el) != 0) {
+        if (b_rare != 0) {
             const bool ae_newrun = (app_ae & x_pl) < 0, fc_newrun = (~fc_n & x_tl) < 0, fc_prepare = (~fc_n & ~prep) < 0;
             if (ae_newrun | fc_newrun) g.push_run(last + 1, ae_newrun ? aux : term);
             if (fc_prepare) {                                           // Leader.prepareReplication after the FIRST new entry: nextIndex = that entry + 1
@@ -268,7 +273,7 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 g.prepared = -1; g.peers_dirty = -1;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(election < 0) != 0) {
+        if (b_el != 0) {
             // One sub-block per row class, each behind its own ballot, and the conversion tail behind one more: three election rows of four are
             // vote replies that are merely counted (config 3: 1.19 % of the rows, 54 % of the wave-rounds; timeouts 12 %, vote requests 9 %), and a
             // launch ends with its slowest workgroup — the one that meets such a row in 61 of its 64 rounds.
@@ -279,7 +284,10 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
             sw to_pre = 0, to_lead = 0, vq = 0, vq_success = 0, reset = 0, rv_new = 0, no_vote = 0;
             // vote replies (member/Candidate.java:121-134, member/Follower.java:258-270)
             const sw vr_shape = cw_bit(cw, CW_VR) & ~nallow;
-            if (__builtin_amdgcn_ballot_w64(vr_shape < 0) != 0) {
+            const sw to_kind = cw_bit(cw, CW_TO) & ~nallow & (s_pos(aux) | ((p.require_fence != 0) ? 0 : -1));      // (an un-fenced row where fences are required: general handlers, RG_BAD_EVENT)
+            const sw vq_shape = cw_bit(cw, CW_VQ) & ~nallow;
+            const uint64_t b_vr = __builtin_amdgcn_ballot_w64(vr_shape < 0), b_to = __builtin_amdgcn_ballot_w64(to_kind < 0), b_vq = __builtin_amdgcn_ballot_w64(vq_shape < 0);
+            if (b_vr != 0) {
                 const int32_t el_term = g.elected_term, el_epoch = (int32_t)g.elected_epoch;
                 const sw sender_bad = (is_pv & (not_f | ~td)) | (~is_pv & not_c);
                 const int32_t T = (is_pv < 0) ? term1 : term;
@@ -301,8 +309,7 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 any_drop = any_drop | vote_drop;
             }
             // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
-            const sw to_kind = cw_bit(cw, CW_TO) & ~nallow & (s_pos(aux) | ((p.require_fence != 0) ? 0 : -1));      // (an un-fenced row where fences are required: general handlers, RG_BAD_EVENT)
-            if (__builtin_amdgcn_ballot_w64(to_kind < 0) != 0) {
+            if (b_to != 0) {
                 const sw to_stale = to_kind & s_pos(aux) & x_aux;
                 const sw to_live = to_kind & ~to_stale;
                 const sw pre = (p.pre_vote != 0) ? -1 : 0;
@@ -317,8 +324,7 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 any_drop = any_drop | to_stale;
             }
             // RequestVote / PreVote at a Follower that has a log (member/Follower.java:91-127, 193-207)
-            const sw vq_shape = cw_bit(cw, CW_VQ) & ~nallow;
-            if (__builtin_amdgcn_ballot_w64(vq_shape < 0) != 0) {
+            if (b_vq != 0) {
                 const sw is_pvq = cw_bit(cw, CW_PVQ);
                 vq = vq_shape & ~not_f & ~s_lt(rc, 1);
                 const sw utd = s_lt(lt, c) | (~s_ne(c, lt) & ~s_lt(b, last));      // Follower.logUpToDate with a last entry

@@ -128,7 +128,9 @@ def test_kernels_that_need_lanes_to_meet_on_emulated_wavefronts(emulation_librar
     workgroup — the two-wavefront step kernel with its LDS rings, the decision counters, the ballot-compacted timer list."""
     env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT)
     env.pop("RG_FAST", None)
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases_waves.py"), "-x", "-q", "-p", "no:cacheprovider"],
+    # (185 cases, each a grid of OS threads: four pytest-xdist workers where the plugin is there — the cases share nothing)
+    par = ["-n", "4"] if __import__("importlib.util").util.find_spec("xdist") else []
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(EMU, "emu_cases_waves.py"), "-x", "-q", "-p", "no:cacheprovider"] + par,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-6000:] + p.stderr[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout

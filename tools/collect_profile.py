@@ -33,7 +33,7 @@ def main(src, name):
         doc = json.load(open(tpath)) if os.path.exists(tpath) else {"note": "HBM bytes per launch of the step kernel from rocprofv3 PMC passes "
                                                                            "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, KB); bench.py quotes an entry only for the same workload, "
                                                                            "kernel and library build (lib_sha16)", "entries": []}
-        key = lambda x: (x["config"], x["groups_per_gpu"], x["rounds"], x["kernel"])   # noqa: E731
+        key = lambda x: (x["config"], x["groups_per_gpu"], x["rounds"], x["kernel"], x.get("outcome_format", "rg_outcome_t"))   # noqa: E731
         doc["entries"] = [x for x in doc["entries"] if key(x) != key(e)] + [e]
         json.dump(doc, open(tpath, "w"), indent=1)
         print("traffic.json:", key(e), "%.1f MB" % (e["traffic_bytes_per_launch"] / 1e6))

@@ -47,6 +47,7 @@ def main(out):
         from rafting_amd import engine
         entry = {"config": bench["config"].get("config_number"), "groups_per_gpu": bench["config"]["groups_per_gpu"],
                  "rounds": bench["config"]["rounds_per_step"], "kernel": bench["roofline"]["kernel"],
+                 "outcome_format": bench["roofline"].get("outcome_format", "rg_outcome_t"),
                  "fetch_size_kb_per_launch": counters["FETCH_SIZE"], "write_size_kb_per_launch": counters["WRITE_SIZE"],
                  "gfx950_fetch_correction": 2.0,
                  "traffic_bytes_per_launch": (2.0 * counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024.0,

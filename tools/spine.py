@@ -26,6 +26,7 @@ def walk(K, hdr, enters):
     ballot is entered. The compiler lays a block out either behind a vccz that skips it or at the target of a vccnz that enters it."""
     labels = {l.split(':')[0]: i for i, l in enumerate(K) if l.startswith('.LBB')}
     i, n, d, ops = hdr, 0, 0, {}
+    scc_means_zero = True                        # what SCC = 1 says about the ballot last compared: s_cmp_eq_u64 x, 0 -> "no lane", s_cmp_lg_u64 x, 0 -> "some lane"
     while True:
         if n > 20000 or i >= len(K):
             return -1, ops                      # no barrier on this path: the loop's branch structure is not the one this walker knows
@@ -36,11 +37,19 @@ def walk(K, hdr, enters):
             ops[op] = ops.get(op, 0) + 1
             if op == 's_barrier':
                 return n, ops
+            if op.startswith('s_cmp_eq'):
+                scc_means_zero = True
+            elif op.startswith('s_cmp_lg') or op.startswith('s_cmp_ne'):
+                scc_means_zero = False
             m = re.search(r'(\.LBB\d+_\d+)', l)
             if op in ('s_cbranch_vccz', 's_cbranch_vccnz', 's_cbranch_scc0', 's_cbranch_scc1'):
                 enter = enters[d] if d < len(enters) else False
                 d += 1
-                if enter == (op.endswith('nz') or op.endswith('scc1')):
+                if op.startswith('s_cbranch_vcc'):
+                    taken_means_enter = op.endswith('nz')
+                else:                            # (round 5: ballots issued ahead of their branches are tested on the scalar unit: s_cmp + s_cbranch_scc)
+                    taken_means_enter = op.endswith('scc1') != scc_means_zero
+                if enter == taken_means_enter:
                     i = labels[m.group(1)]
                     continue
             elif op == 's_branch':
