@@ -133,8 +133,19 @@ def main():
     red_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-        sync_t = torch.zeros(1, device=red_dev)
+        # (gloo announces its connections on STDOUT — "[Gloo] Rank 0 is connected to ..." — and the contract is ONE JSON line there: while the
+        # process group comes up, and through its first collective, fd 1 points at stderr)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+            sync_t = torch.zeros(1, device=red_dev)
+            dist.all_reduce(sync_t)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from rafting_amd import abi, engine, shard, workload
 

@@ -76,7 +76,6 @@ extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kern
 #define __builtin_amdgcn_s_memtime() (0ull)
 #define __builtin_amdgcn_readfirstlane(x) ((decltype(x))::hipemu::wave_first((unsigned long long)(x)))
 #define __builtin_amdgcn_ballot_w64(x) (::hipemu::wave_ballot(x))
-#define __builtin_amdgcn_inverse_ballot_w64(m) (((((unsigned long long)(m)) >> ::hipemu::wave_lane_index()) & 1ull) != 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define RG_GLOBAL_AS                 /* rg_step.hpp: global-memory pointers made from integers */
@@ -92,19 +91,6 @@ extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kern
 #define __popcll(x) __builtin_popcountll(x)
 template <class T> static inline T __shfl_xor(T v, int lane_xor, int) { return (T)::hipemu::wave_exchange_xor((unsigned long long)v, lane_xor); }
 template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
-
-// v_readlane / v_writelane / the lane's index (rg_device.hpp: lane_get / lane_put / lane_index), supplied here because the product's versions are
-// a clang builtin and inline assembly
-#define RG_LANE_OPS_DEFINED 1
-namespace rg {
-// lane_get(v, l) is only ever used by election_rows(), whose iteration for lane l reads lane l's values and writes lane l's state (`me == l`):
-// the thread that IS lane l gets its own value, which is the right one; every other thread computes that iteration on its own values and
-// throws the result away. No rendezvous per read (a 64-thread meeting per v_readlane made the wavefront emulation six times slower); what
-// keeps the threads together is the trip count, which comes from a ballot. A read of ANOTHER lane's state would go unnoticed here — the GPU
-// parity tests are the gate for that.
-static inline int32_t lane_get(int32_t v, int) { return v; }
-static inline int lane_index() { return ::hipemu::wave_lane_index(); }
-}
 
 // ---- the slice of the runtime API raftgpu.cpp uses -----------------------------------------------------------------
 typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801 } hipError_t;
