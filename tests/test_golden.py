@@ -57,3 +57,27 @@ def test_gpu_reproduces_committed_digests(name):
     c = GOLDEN[name]
     got = _replay(lambda g, p, s, v: engine.Table(g, p, s, v), c)
     assert got == {k: c[k] for k in ("inputs", "outcomes", "state")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,compact_outcomes", [("config4_shard6_bench_launch", True), ("config5_shard1_bench_launch", False)])
+def test_the_bench_launch_shape_on_the_compact_kernel_reproduces_the_reference_digest(name, compact_outcomes):
+    """the shape `bench.py --gpus 8` gives every GPU — 131 072 groups x 64 rounds in ONE launch of step32_kernel's 128-VGPR variant
+    (`WAVES = 4`), HBM-resident compact rows, with compact outcome rows (rg_submit32c) and with the wide columns (rg_submit32) — against the digest the
+    reference's own code produced for that shard (neither oracle nor reference in the loop)."""
+    from rafting_amd import engine, workload
+    c = GOLDEN[name]
+    cfg = workload.CONFIGS[c["number"]]
+    gen = workload.ReplayGenerator(cfg, first_gid=c["shard"] * c["groups"], count=c["groups"])
+    st0 = gen.initial_state()
+    t = engine.Table(c["groups"], cfg.cluster, cfg.self_slot, cfg.pre_vote)
+    t.load_state(st0)
+    db = engine.DeviceBatch32(t, gen.next_batch(c["rounds"]), compact=compact_outcomes, wide=False)
+    t.submit_device(db)
+    t.sync()
+    out = db.outcome(st0.role_epoch) if compact_outcomes else db.outcome()
+    assert make_golden.canonical_outcome_digest(out) == c["outcomes"]
+    assert make_golden.state_digest(t.read_state()) == c["state"]
+    assert t.wide_body_workgroups() == 0
+    db.free()
+    t.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Soak differential fuzz on the GPU box: many seeds x cluster shapes, HIP path vs oracle in lockstep with the hint
 protocol, with and without the fast-path tier, through every step kernel in turn: wide rows on the two-wavefront kernel / on the
-single-wavefront kernel, compact rows (rg_submit32: step32_kernel's 32-bit body), compact rows forced onto the 64-bit body.
+single-wavefront kernel, compact rows (rg_submit32: step32_kernel's 32-bit body), compact rows forced onto the 64-bit body, and the last two again with compact
+outcome rows (rg_submit32c).
 usage: python tools/soak.py [seconds=240]"""
 import os
 import sys
@@ -23,7 +24,17 @@ def compact_submit(self, batch, out=None, fill=0):      # what tests/test_gpu_pa
     return WIDE_SUBMIT(self, batch, out, fill)
 
 
-ROUTES = ("split", "compact", "single", "compact-forced-wide")
+def out32_submit(self, batch, out=None, fill=0):        # route_through_compact(out32=True): rg_submit32c + rg_outcome32_unpack, the raw rows held to their contract
+    if batch.hint is None and abi.batch_fits_32(batch) and batch.gid is None:
+        before = self.read_state()
+        raw = self.submit32c(batch, fill=fill)
+        got, _ = engine.unpack32(raw, batch.rounds, batch.count, before.role_epoch)
+        T.check_out32_rows(raw, got, before, self.read_state(), batch.rounds, batch.count)
+        return got
+    return compact_submit(self, batch, out, fill)
+
+
+ROUTES = ("split", "compact", "single", "compact-forced-wide", "compact-out32", "compact-out32-forced-wide")
 
 
 def main():
@@ -39,8 +50,8 @@ def main():
         os.environ["RG_FAST"] = "0" if runs % 5 == 4 else "1"
         route = ROUTES[(runs // 3) % len(ROUTES)]
         os.environ["RG_SPLIT"] = "0" if route == "single" else "1"
-        os.environ["RG_FORCE_WIDE"] = "1" if route == "compact-forced-wide" else "0"
-        engine.Table.submit = compact_submit if route.startswith("compact") else WIDE_SUBMIT
+        os.environ["RG_FORCE_WIDE"] = "1" if route.endswith("forced-wide") else "0"
+        engine.Table.submit = out32_submit if "out32" in route else (compact_submit if route.startswith("compact") else WIDE_SUBMIT)
         per_route[route] = per_route.get(route, 0) + 1
         # group counts that are not multiples of the wavefront size exercise the shadow lanes of the tail wavefront
         groups, rounds = ((1024, 150), (1000, 150), (257, 400), (65, 600))[runs % 4]
