@@ -328,10 +328,24 @@ struct Tally {
         packed += ((((flags >> 1) & 0x55u) * 0x41041u) & 0x01010101u);
         add_status(status);
     }
+    // The three status tallies the same way, the classification read from a 64-entry LDS table (status_entry) instead of being computed with five
+    // compares per row: asserts | need << 8 | stale << 16.
+    uint32_t packed_status = 0;
+    static __device__ __forceinline__ uint32_t status_entry(uint32_t status)
+    {
+        return ((status != RG_OK && status < RG_NPE_MAJOR_NULL) ? 1u : 0u) | (status == RG_NEED_HOST ? 1u << 8 : 0u) | (status == RG_DROPPED_STALE_ROLE ? 1u << 16 : 0u);
+    }
+    __device__ __forceinline__ void add_packed_lut(uint32_t kind, uint32_t flags, uint32_t status, const uint32_t *lut)
+    {
+        rows += kind != RG_EV_NONE ? 1u : 0u;
+        packed += ((((flags >> 1) & 0x55u) * 0x41041u) & 0x01010101u);
+        packed_status += lut[status & 63u];              // (status codes end at 35)
+    }
     __device__ __forceinline__ void spill()
     {
         replied += packed & 0xFFu; conv += (packed >> 8) & 0xFFu; commit += (packed >> 16) & 0xFFu; append += packed >> 24;
-        packed = 0u;
+        asserts += packed_status & 0xFFu; need += (packed_status >> 8) & 0xFFu; stale += (packed_status >> 16) & 0xFFu;
+        packed = 0u; packed_status = 0u;
     }
     // Wavefront reduction: butterfly over the 64 lanes, then the wave adds into its workgroup's own 64-byte slot of the counter
     // table with a plain read-modify-write (8 atomics per wave onto 8 shared words cost ~60 us per launch at 1024 waves).
@@ -495,7 +509,8 @@ struct SplitLds {
     static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 16,
                             N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16,
                             N_LUTC = N_BAIL + 16, N_LUTM = N_LUTC + 256 * 4, N_LUTE = N_LUTM + 128 * 4,      // the I/O wavefront's tables (below)
-                            N_BASE = N_LUTE + 128 * 2, N_END = N_BASE + BLOCK * 8;                           // the groups' index bases (the deciding wavefront's; round 5)
+                            N_BASE = N_LUTE + 128 * 2, N_LUTS = N_BASE + BLOCK * 8,                           // the groups' index bases (the deciding wavefront's; round 5)
+                            N_END = N_LUTS + 64 * 4;                                                          // the I/O wavefront's status -> tally table
     static constexpr size_t BYTES = EV32 ? (W_END > N_END ? W_END : N_END) : W_END;
 };
 
@@ -761,6 +776,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     uint32_t *sh_bail = reinterpret_cast<uint32_t *>(smem + L::N_BAIL);
     uint32_t *sh_lutc = reinterpret_cast<uint32_t *>(smem + L::N_LUTC), *sh_lutm = reinterpret_cast<uint32_t *>(smem + L::N_LUTM);
     uint16_t *sh_lute = reinterpret_cast<uint16_t *>(smem + L::N_LUTE);
+    uint32_t *sh_luts = reinterpret_cast<uint32_t *>(smem + L::N_LUTS);
 
     const uint32_t lane = threadIdx.x & (BLOCK - 1);
     const bool io_wave = __builtin_amdgcn_readfirstlane(threadIdx.x) >= (uint32_t)BLOCK;       // wave-uniform
@@ -806,6 +822,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             sh_lutm[i7] = expand_predicates(i7);                                              // (no election bit set)
             sh_lute[i7] = (uint16_t)(expand_predicates((i7 << 7) | 0x42u) & 0xFFFFu);       // (main bits of "no main class": fa_n and fc_n set)
         }
+        sh_luts[lane] = Tally::status_entry(lane);
         __builtin_amdgcn_wave_barrier();                 // (every lane reads entries other lanes wrote: ordered on the hardware, a meeting point for the host emulation's lane threads)
         auto publish = [&](uint32_t slot, const Row32 &x) {
             sh_evh[slot][lane] = class_word(sh_lutc, x);
@@ -839,7 +856,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                     nt_store_at(b_persist + rb16, irm, per);
                 }
             }
-            tally.add_packed(RG_HDR_KIND(hdr), flags, status);
+            tally.add_packed_lut(RG_HDR_KIND(hdr), flags, status, sh_luts);
         };
         // Rows r+2 .. r+5 are in registers at the top of round r, row k in buf[k & 3]; the loop is unrolled by four so that the indices are
         // compile-time constants. Round r publishes row r+2 and re-fills its registers with row r+6.
@@ -946,7 +963,14 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         const bool open = done >= 0;                     // not decided by tier 1: the general handlers — or nothing, for a group blocked after a NEED_HOST
         RG_PROBE_MARK(1);
         RG_NOTE_SLOW(open & !(blocked & (RG_HDR_KIND((uint32_t)h.w) != RG_EV_NONE)), lane == 0);
-        if (__builtin_amdgcn_ballot_w64(open) != 0) {
+        // The outcome rows go to LDS BEFORE the branch on "somebody needs the general handlers": the ballot's scalar result is not there yet when the
+        // branch is issued (the VALU -> SALU round trip, profiles/r04b_issue_bench.txt), and these stores are independent work to spend that wait on.
+        // A round that does visit the general handlers writes the rows again afterwards.
+        const uint64_t b_open = __builtin_amdgcn_ballot_w64(open);
+        const uint32_t slot = r & 1u;
+        sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
+        sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
+        if (b_open != 0) {
             // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
             const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
             const bool skip = open & blocked & (kind != RG_EV_NONE);
@@ -978,10 +1002,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                 if (lane == 0) *sh_bail = r + 2u;
                 bailed = true;
             }
+            sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
+            sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
         }
-        const uint32_t slot = r & 1u;
-        sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
-        sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
         RG_PROBE_MARK(2);
         lds_barrier();
         RG_PROBE_MARK(3);
