@@ -41,6 +41,7 @@ jint J(GpuTable, loadState)(JNIEnv *, jclass, jlong, jint, jint, jobjectArray);
 jint J(GpuTable, readState)(JNIEnv *, jclass, jlong, jint, jint, jobjectArray);
 jint J(GpuTable, submit)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject);
 jint J(GpuTable, submit32c)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject, jobject);
+jint J(GpuTable, unpack32)(JNIEnv *, jclass, jint, jint, jobject, jobject, jobject, jobject, jobject, jobject, jobject, jobject, jobject);
 
 enum { G = 96, P = 3, NCOL = sizeof(rg_group_state_t) / sizeof(void *) };
 
@@ -114,6 +115,37 @@ int main(void)
     struct _jobject arr_a = {K_ARRAY, 0, 0, NCOL, cols_a, 0};
     if (J(GpuTable, readState)(env, NULL, h, 0, G, &arr_a) != 0 || rg_read_state(direct, 0, G, &b) != 0) return 1;
     for (int i = 0; i < NCOL; i++) if (memcmp(((void **)&a)[i], ((void **)&b)[i], G * sizes[i])) { fprintf(stderr, "state column %d differs\n", i); return 1; }
+
+    /* compact rows in, compact outcome rows out (ABI 4) through the shim and directly — on tables that hold the state both just reached — and the unpacking.
+     * (step32_kernel is a two-wavefront kernel: the emulation runs it with one OS thread per lane, RG_EMU_WAVES=1; skipped on a lane-serial emulation) */
+    if (getenv("RG_EMU_WAVES") || !getenv("RG_ALLOW_HOST_EMULATION")) {
+        rg_ev_head_t head32[G]; rg_ev_quad32_t abcd[G]; int32_t terms32[2 * G];
+        for (uint32_t g = 0; g < G; g++) {       /* the next AppendEntries at every even group's new tail; a fenced timeout elsewhere */
+            if (g % 2 == 0) { ab[g].y = 12 + g; cd[g].y = 13 + g; }
+            else head[g].aux = rep_j[g].role_epoch;
+        }
+        const int64_t nt = rg_batch32_pack(&in, head32, abcd, terms32);
+        if (nt < 0) { fprintf(stderr, "pack %lld\n", (long long)nt); return 1; }
+        rg_out32_t row_j[G], row_d[G]; rg_persist32_t p32_j[G], p32_d[G];
+        memset(p32_j, 0, sizeof p32_j); memset(p32_d, 0, sizeof p32_d);
+        const jint rc32 = J(GpuTable, submit32c)(env, NULL, h, 1, G, buf(head32, sizeof head32), buf(abcd, sizeof abcd), nt ? buf(terms32, sizeof terms32) : NULL, (jlong)nt,
+                                                 buf(row_j, sizeof row_j), buf(p32_j, sizeof p32_j), NULL, NULL, NULL);
+        rg_batch32_t in32 = {1, G, NULL, head32, abcd, nt ? terms32 : NULL, (uint64_t)nt};
+        rg_outcome32_t out32 = {row_d, p32_d, {NULL, NULL, NULL}};
+        if (rc32 != 0 || rg_submit32c(direct, &in32, &out32, RG_MEM_HOST) != 0) { fprintf(stderr, "submit32c: %d %s\n", rc32, rg_last_error(direct)); return 1; }
+        if (memcmp(row_j, row_d, sizeof row_j) || memcmp(p32_j, p32_d, sizeof p32_j)) { fprintf(stderr, "compact outcome rows differ\n"); return 1; }
+        uint32_t ep_j[G], ep_d[G];
+        for (uint32_t g = 0; g < G; g++) ep_j[g] = ep_d[g] = rep_j[g].role_epoch;
+        rg_outcome32_t src = {row_j, p32_j, {NULL, NULL, NULL}};
+        if (J(GpuTable, unpack32)(env, NULL, 1, G, buf(row_j, sizeof row_j), buf(p32_j, sizeof p32_j), NULL, NULL, NULL, buf(ep_j, sizeof ep_j), buf(rep_j, sizeof rep_j),
+                                  buf(lfx_j, sizeof lfx_j), buf(per_j, sizeof per_j)) != 0 ||
+            rg_outcome32_unpack(&src, 1, G, ep_d, &out) != 0) { fprintf(stderr, "unpack32\n"); return 1; }
+        if (memcmp(rep_j, rep_d, sizeof rep_j) || memcmp(lfx_j, lfx_d, sizeof lfx_j) || memcmp(per_j, per_d, sizeof per_j) || memcmp(ep_j, ep_d, sizeof ep_j)) { fprintf(stderr, "unpacked outcomes differ\n"); return 1; }
+        unsigned appended = 0, converted = 0;
+        for (uint32_t g = 0; g < G; g++) { appended += (rep_j[g].flags & RG_F_LOG_APPEND) != 0; converted += (rep_j[g].flags & RG_F_ROLE_CHANGED) != 0; }
+        if (appended != G / 2 || converted != G / 2) { fprintf(stderr, "compact round: %u appends, %u conversions\n", appended, converted); return 1; }
+        printf("compact outcome rows through the shim: %u appends, %u conversions, identical to the C-ABI\n", appended, converted);
+    }
 
     /* page-locked memory as a direct buffer, and back */
     jobject pinned = J(GpuTable, hostAlloc)(env, NULL, h, 4096);
