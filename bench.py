@@ -245,15 +245,23 @@ def main():
     floor_bytes = None
     first_out = None
     verdict, case_name = -1.0, None                       # -1 no committed case for this launch shape, 1 ok, 0 MISMATCH
+    golden_path = os.environ.get("RG_GOLDEN_FILE") or os.path.join(ROOT, "tests", "golden", "replay_digests.json")     # (RG_GOLDEN_FILE: tests hand in a tampered copy)
+
+    def case_of(shard_index):
+        """the committed case for this launch shape and that block of the table, if there is one: (name, case)"""
+        if args.override:
+            return None, None
+        for name, c in json.load(open(golden_path))["cases"].items():
+            if (str(c["number"]), c["groups"], c["rounds"]) == (str(args.config), gpg, args.rounds) and c.get("shard", 0) == shard_index \
+                    and (("shard" in c) == (cfg.groups != gpg)):
+                return name, c
+        return None, None
     try:
         from tools import make_golden
         first_out = outcomes_of(1)[0]
-        if not args.override:
-            for name, c in json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.json")))["cases"].items():
-                if (str(c["number"]), c["groups"], c["rounds"]) == (str(args.config), gpg, args.rounds) and c.get("shard", 0) * gpg == first_gid \
-                        and (("shard" in c) == (cfg.groups != gpg)):
-                    case_name = name
-                    verdict = 1.0 if make_golden.canonical_outcome_digest(first_out) == c["outcomes"] else 0.0
+        case_name, c = case_of(first_gid // gpg)
+        if c is not None:
+            verdict = 1.0 if make_golden.canonical_outcome_digest(first_out) == c["outcomes"] else 0.0
     except Exception as e:      # a reporting leg must not take the bench line down with it
         print("bench: golden leg failed on rank %d: %r" % (rank, e), file=sys.stderr)
     verdicts = shard.gather_rows([verdict, float(first_gid // gpg)], device=red_dev if world > 1 else None)
@@ -263,8 +271,7 @@ def main():
             if world == 1:
                 golden = None if case_name is None else {"case": case_name, "outcomes": names[verdict]}
             else:
-                golden = [{"rank": r, "case": "config%s_shard%d_bench_launch" % (args.config, int(row[1])) if row[0] >= 0 else None, "outcomes": names[float(row[0])]}
-                          for r, row in enumerate(verdicts)]
+                golden = [{"rank": r, "case": case_of(int(row[1]))[0] if row[0] >= 0 else None, "outcomes": names[float(row[0])]} for r, row in enumerate(verdicts)]
             # layout floor: event rows in (8 + 16 B, or 40 B + entry terms on wide rows), reply rows out (16 B), the log / commit and persist rows that
             # exist (16 B each, counted on the stream's first launch), the table once per launch (5 + 4 columns of 16 B in, 5 out, run columns
             # and the follower records of leading groups when dirty: bounded here by "all of them")

@@ -97,6 +97,26 @@ def test_bench_with_two_ranks_is_config4_sharded_over_gloo(emulation_library):
     assert d["config"]["groups_per_gpu"] == 256 and d["config"]["groups_total"] == 512
     assert d["config"]["decisions_per_step_per_gpu"] > 0 and d["value"] > 0
     assert d["cpu_baseline"] is None and d["pcie_inclusive_value"] is None          # rank-0-at-N=1 legs only
+    # round 5: EVERY rank checked its first launch against the digest the reference's own code produced for its block of the table
+    assert d["golden"] == [{"rank": 0, "case": "config4_shard0_emulation_launch", "outcomes": "ok"},
+                           {"rank": 1, "case": "config4_shard1_emulation_launch", "outcomes": "ok"}], d["golden"]
+    assert len(lines[0]) > 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("[Gloo]")]      # gloo's connection chatter stays off stdout: ONE line there
+
+
+def test_a_rank_whose_first_launch_misses_the_reference_digest_fails_the_run(emulation_library, tmp_path):
+    """the same two-rank run against a golden file whose case for rank 1 was tampered with: no result line, exit code != 0, the verdicts on stderr"""
+    import json
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.json")))
+    doc["cases"]["config4_shard1_emulation_launch"]["outcomes"] = "0" * 64
+    bad = tmp_path / "tampered.json"
+    bad.write_text(json.dumps(doc))
+    env = dict(os.environ, RG_LIB=emulation_library, RG_SPLIT="1", RG_EMU_WAVES="1", RG_ALLOW_HOST_EMULATION="1", PYTHONPATH=ROOT, OMP_NUM_THREADS="1",
+               RG_GOLDEN_FILE=str(bad), RG_BENCH_ENTRY=os.path.join(EMU, "bench_dry.py"))
+    env.pop("RG_FAST", None)
+    p = subprocess.run([sys.executable, os.path.join(EMU, "bench_dry.py"), "--gpus", "2", "--device", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-1000:]
+    assert "does not reproduce the reference's digest" in p.stderr
 
 
 def test_bench_starts_its_own_ranks_when_no_launcher_does(emulation_library):

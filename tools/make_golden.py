@@ -26,6 +26,9 @@ CASES = [("config2", 2, 1024, 24), ("config3", 3, 2048, 32), ("config5", 5, 2048
 # global group id) of the 1 048 576-group tables of configs 4 and 5; rank r of a multi-GPU run compares its own first launch with case r and the
 # line carries the verdicts. (name, config number, groups, rounds, shard index)
 SHARD_CASES = [("config%d_shard%d_bench_launch" % (number, k), number, 131072, 64, k) for number in (4, 5) for k in range(8)]
+# ... and the same thing small, for the CPU suite's two-rank run of bench.py on the host emulation of the kernels (tests/test_devemu_cpu.py): blocks 0 and 1 of
+# 256 groups x 4 rounds — there the per-rank verdicts, and the non-zero exit on a mismatch, are exercised without a GPU
+SHARD_CASES += [("config4_shard%d_emulation_launch" % k, 4, 256, 4, k) for k in range(2)]
 
 
 def canonical_outcome_digest(out):
