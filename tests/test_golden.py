@@ -18,9 +18,10 @@ GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_digests.js
 # re-deriving them with it is behind RG_RUN_SLOW=1 (two of them — config 4's shard 5, config 5's shard 2 — were re-derived that way in this round's suite runs
 # before the suite was trimmed to stay under ten minutes: profiles/r05_cpu_suite.txt), like round 4's 10.5 M-row replay.
 SHARDS = {n for n, c in GOLDEN.items() if "shard" in c}
-ORACLE_SAMPLE = {"config4_shard7_bench_launch", "config5_shard3_bench_launch"}
-REFERENCE_SAMPLE = set()
-GPU_SAMPLE = {"config4_shard0_bench_launch", "config4_shard6_bench_launch", "config5_shard1_bench_launch", "config5_shard7_bench_launch"}
+TINY = {"config4_shard0_emulation_launch", "config4_shard1_emulation_launch"}      # blocks 0 and 1 of 256 groups x 4 rounds: the emulated two-rank bench run's cases
+ORACLE_SAMPLE = {"config4_shard7_bench_launch", "config5_shard3_bench_launch"} | TINY
+REFERENCE_SAMPLE = set(TINY)
+GPU_SAMPLE = {"config4_shard0_bench_launch", "config4_shard6_bench_launch", "config5_shard1_bench_launch", "config5_shard7_bench_launch"} | TINY
 
 
 def _replay(mk, c):
