@@ -350,7 +350,7 @@ int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outco
  *           array is uploaded every tick; 0 when every AppendEntries row carries RG_HDR_SAME_TERM). All page-locked (rg_host_alloc).
  *   out     as for rg_submit_async_packed (reply dense; logfx / persist lists with counts), page-locked.
  * Same decisions as rg_submit_async_packed on the same rows; launches of one table run in the order they were made, with every other submission
- * (they share the table's stream). Table options and whether the table has index bases are read at creation (set both first). At most one launch of a tick is in flight: rg_tick_launch waits for the previous one. */
+ * (they share the table's stream). Table options and whether the table has index bases are read at creation (set both first). At most one launch of a tick is in flight: rg_tick_launch waits for the previous one. Destroy a tick before its table. */
 typedef struct rg_tick rg_tick_t;
 int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out, rg_tick_t **tick);
 int rg_tick_launch(rg_tick_t *tick);      /* returns at once */
