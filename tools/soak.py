@@ -3,7 +3,7 @@
 protocol, with and without the fast-path tier, through every step kernel in turn: wide rows on the two-wavefront kernel / on the
 single-wavefront kernel, compact rows (rg_submit32: step32_kernel's 32-bit body), compact rows forced onto the 64-bit body, and the last two again with compact
 outcome rows (rg_submit32c).
-usage: python tools/soak.py [seconds=240]"""
+usage: python tools/soak.py [seconds=240] [routes, comma separated: default all six]"""
 import os
 import sys
 import time
@@ -39,6 +39,7 @@ ROUTES = ("split", "compact", "single", "compact-forced-wide", "compact-out32", 
 
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+    routes = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ROUTES       # e.g. compact-out32,compact-out32-forced-wide
     t0 = time.time()
     seed, runs, rows, misses = 1000, 0, 0, 0
     hist = np.zeros(256, dtype=np.int64)
@@ -48,7 +49,7 @@ def main():
         cluster, self_slot = shapes[runs % len(shapes)]
         pre_vote = (runs // len(shapes)) % 2 == 0
         os.environ["RG_FAST"] = "0" if runs % 5 == 4 else "1"
-        route = ROUTES[(runs // 3) % len(ROUTES)]
+        route = routes[(runs // 3) % len(routes)]
         os.environ["RG_SPLIT"] = "0" if route == "single" else "1"
         os.environ["RG_FORCE_WIDE"] = "1" if route.endswith("forced-wide") else "0"
         engine.Table.submit = out32_submit if "out32" in route else (compact_submit if route.startswith("compact") else WIDE_SUBMIT)
