@@ -41,6 +41,10 @@ def test_unfenced_timeouts_are_refused_where_the_table_requires_fences():
     T.fenced_timeouts_case()
 
 
+def test_abi4_misuse_is_reported():
+    T.abi4_misuse_case()
+
+
 def test_multi_round_launch_on_resident_buffers():
     G, P = 256, 5
     st0, batches, outs, _, misses, _ = T._lockstep(G, P, 1, True, 48, 21, allow_miss=False)

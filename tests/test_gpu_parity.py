@@ -282,6 +282,47 @@ def test_unfenced_timeouts_are_refused_where_the_table_requires_fences():
     fenced_timeouts_case()
 
 
+def abi4_misuse_case():
+    """ABI 4's entry points refuse what their header says they refuse, with a message (every check below happens on the host, before any device call)."""
+    import ctypes as C
+    G = 64
+    t = engine.Table(G, 3)
+    L = engine.lib()
+    with pytest.raises(engine.EngineError, match="unknown option"):
+        t.set_option(12345, 1)
+    with pytest.raises(engine.EngineError, match="negative"):
+        t.set_index_base(np.array([5, -1, 7], dtype=np.int64))
+    with pytest.raises(engine.EngineError, match="groups"):
+        t.set_index_base(np.zeros(8, dtype=np.int64), first=G - 4)
+    b = abi.Batch(1, G)
+    b32 = engine.pack32(b)
+    out = abi.Outcome32(G, wide=True)
+    cb, co = b32.as_struct(), out.as_struct()
+    co.wide.logfx = None                                   # two of the three overflow columns
+    assert L.rg_submit32c(t._h, C.byref(cb), C.byref(co), abi.MEM_HOST) < 0 and b"all three or none" in L.rg_last_error(t._h)
+    gid = np.arange(G, dtype=np.uint32)
+    sparse = engine.pack32(abi.Batch(1, G, gid=gid))
+    cs, co = sparse.as_struct(), abi.Outcome32(G, wide=False).as_struct()
+    assert L.rg_submit32c(t._h, C.byref(cs), C.byref(co), abi.MEM_HOST) < 0 and b"dense batches only" in L.rg_last_error(t._h)
+    co = abi.Outcome32(G, wide=False).as_struct()
+    co.persist = None
+    assert L.rg_submit32c(t._h, C.byref(cb), C.byref(co), abi.MEM_HOST) < 0 and b"required" in L.rg_last_error(t._h)
+    h = C.c_void_p()
+    assert L.rg_tick_create(t._h, None, None, C.byref(h)) < 0 and not h.value and b"null batch" in L.rg_last_error(t._h)
+    n = C.c_uint64()
+    assert L.rg_wide_body_workgroups(t._h, None, 0) < 0
+    # the host-side converters refuse missing columns without a table
+    assert L.rg_outcome32_unpack(None, 1, 1, None, None) == -1
+    assert L.rg_batch32_pack_rel(None, None, None, None, None) == -1
+    t.close()
+
+
+def test_abi4_misuse_is_reported(step_kernel_variant):
+    if step_kernel_variant != "split":
+        pytest.skip("host-side checks: once")
+    abi4_misuse_case()
+
+
 def test_api_misuse_is_reported():
     gpu = engine.Table(8, 3)
     with pytest.raises(engine.EngineError):
