@@ -3,7 +3,7 @@ package io.lubricant.consensus.raft;
 import io.lubricant.consensus.raft.command.RaftLog;
 import io.lubricant.consensus.raft.command.storage.RocksEntry;
 import io.lubricant.consensus.raft.support.serial.Serialization;
-import io.lubricant.consensus.raft.transport.RaftResponse;
+import io.lubricant.consensus.raft.RaftResponse;
 import io.lubricant.consensus.raft.transport.event.NodeID;
 
 /**
