@@ -67,7 +67,11 @@ def parse():
     ap.add_argument("--adverse-batches", type=int, default=8, help="launches of the adverse-mix leg (the first two are warm-up)")
     ap.add_argument("--index-base-batches", type=int, default=6, help="launches of the long-lived-groups leg (every log compacted at 2^40, index bases set; the first two are "
                     "warm-up; 0 skips the leg)")
-    ap.add_argument("--tick-batches", type=int, default=100, help="single-round ticks per way of the once-per-tick latency leg (the first ten are warm-up; 0 skips the leg)")
+    ap.add_argument("--tick-batches", type=int, default=310, help="single-round ticks per way of the once-per-tick latency leg (the first ten are warm-up; 0 skips the leg; "
+                    "1010 gives the >= 1000-tick distribution of profiles/r06*_tick_latency_1000.json)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU over a short re-run of the "
+                    "timed leg in child processes: roofline.traffic_measured_in_this_run)")
+    ap.add_argument("--pmc-timeout", type=int, default=150, help="seconds one counter pass may take before it is abandoned (the quoted values stand in)")
     ap.add_argument("--wide-rows", action="store_true", help="stage the batches as rg_batch_t (40 B + 8n per row, 64-bit fields) and decide them with the "
                     "wide-row kernels instead of the default compact rows (rg_batch32_t, 24 B per row) / rg::step32_kernel")
     return ap.parse_args()
@@ -109,6 +113,61 @@ def self_launch(n):
             p.wait()
             rc = rc or (p.returncode or 0)
     sys.exit(0 if rc == 0 else 1)
+
+
+def pmc_passes(args, argv):
+    """-> {"FETCH_SIZE": mean per dispatch of the step kernel, ...} measured by rocprofv3 --pmc over child runs of this script, or {"error": ...}"""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"error": "rocprofv3 is not on PATH"}
+    keep = []
+    skip_next = False
+    for a in argv:                                   # the workload-defining flags travel; steps / warm-up and the legs are the child's own
+        if skip_next:
+            skip_next = False
+            continue
+        if a in ("--steps", "--warmup", "--cpu-batches", "--pcie-batches", "--adverse-batches", "--index-base-batches", "--tick-batches", "--pmc-timeout", "--copy-bytes"):
+            skip_next = True
+            continue
+        if a.split("=")[0] in ("--steps", "--warmup", "--tick-batches", "--index-base-batches") or a in ("--no-cpu-baseline", "--no-pcie", "--no-int64-pass", "--no-adverse",
+                                                                                                       "--no-copy-bw", "--copy-bw", "--no-pmc"):
+            continue
+        keep.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + keep + ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-pcie", "--no-int64-pass", "--no-adverse",
+                                                                  "--index-base-batches", "0", "--tick-batches", "0", "--no-copy-bw", "--no-pmc"]
+    out, t_all = {}, time.time()
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]):
+        d = tempfile.mkdtemp(prefix="rg_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, RG_BENCH_UNDER_PMC="1", TMPDIR="/tmp")
+            p = subprocess.run([exe, "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=args.pmc_timeout)
+            if p.returncode != 0:
+                return dict(out, error="rocprofv3 --pmc %s: exit %d: %s" % (" ".join(counters), p.returncode, (p.stderr or p.stdout)[-300:]))
+            acc = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "")
+                    if "step32_kernel" in name and "wide" not in name:
+                        acc.setdefault(row.get("Counter_Name"), []).append(float(row.get("Counter_Value", 0)))
+            for c in counters:
+                if c not in acc:
+                    return dict(out, error="rocprofv3 --pmc %s: no row for the step kernel" % c)
+                out[c] = sum(acc[c]) / len(acc[c])
+                out[c + "_dispatches"] = len(acc[c])
+        except subprocess.TimeoutExpired:
+            return dict(out, error="rocprofv3 --pmc %s: no result within %d s" % (" ".join(counters), args.pmc_timeout))
+        except Exception as e:
+            return dict(out, error="%s: %s" % (type(e).__name__, str(e)[:300]))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["seconds"] = time.time() - t_all
+    return out
 
 
 def main():
@@ -236,6 +295,35 @@ def main():
                                 device=red_dev if world > 1 else None)
 
     copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
+
+    # ---- per-launch spread: the SAME launches once more — initial state reloaded, the same resident batches in the same order, so every
+    # launch decides what it decided in the timed region and leaves the same outcome rows — each bracketed by its own HIP event pair on the table's stream
+    # (the device is idle between them: a launch's own duration, without the inter-launch gaps the region figure includes). Reported, never `value`.
+    spread = None
+    if rank == 0:
+        try:
+            table.load_state(st0)
+            each = []
+            for i in range(nb):
+                table.timing_begin()
+                table.submit_device(dbatches[i])
+                each.append(table.timing_end())
+            timed_each = np.sort(np.asarray(each[args.warmup:]))
+            spread = {"launches": int(len(timed_each)), "min_ms": float(timed_each[0]), "median_ms": float(timed_each[len(timed_each) // 2]),
+                      "max_ms": float(timed_each[-1]), "mean_ms": float(timed_each.mean()),
+                      "note": "one HIP event pair per launch, device idle in between; the same launches as the timed region (state reloaded, same batches)"}
+            table.sync()
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            spread = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench: per-launch spread leg failed: %r" % (e,), file=sys.stderr)
+
+    # ---- counters measured IN THIS RUN: rocprofv3 --pmc over a short re-run of the timed leg in a child process, one pass per counter
+    # set (FETCH_SIZE; WRITE_SIZE; the SQ instruction counters) — PMC passes only, no trace domain beside them. The child is this script with every other
+    # leg switched off; its step kernel has the same name, shape and library. Skipped (the quoted values of profiles/traffic.json stand in) when rocprofv3
+    # is not on PATH, under --no-pmc, inside such a child, on more than one rank, or when a pass fails or runs out of time.
+    pmc = None
+    if rank == 0 and world == 1 and not args.no_pmc and not args.wide_rows and not os.environ.get("RG_BENCH_UNDER_PMC") and not os.environ.get("RG_ALLOW_HOST_EMULATION"):
+        pmc = pmc_passes(args, sys.argv[1:])
 
     # ---- the stream's FIRST launch against the committed digest of the reference's own run of it (tests/golden/replay_digests.json, made by
     # tools/make_golden.py from oracle/_ref: no oracle in this loop), and what this row / table layout must move per launch -----------------
@@ -558,35 +646,46 @@ def main():
     tick = None
     if rank == 0 and world == 1 and args.tick_batches > 10 and not args.wide_rows and not args.override:
         try:
+            import gc
+
             def lat(us):
                 us = np.sort(np.asarray(us))
-                return {"p50_us": float(us[len(us) // 2]), "p99_us": float(us[min(len(us) - 1, int(len(us) * 0.99))]), "mean_us": float(us.mean()), "ticks": len(us)}
+                q = lambda f: float(us[min(len(us) - 1, int(len(us) * f))])   # noqa: E731
+                return {"p50_us": q(0.5), "p99_us": q(0.99), "p999_us": q(0.999), "max_us": float(us[-1]), "mean_us": float(us.mean()), "ticks": len(us)}
             res = {}
+            tg = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
+            tick_st0 = tg.initial_state()
+            ticks = [tg.next_batch(1) for _ in range(args.tick_batches)]          # ONE list of fresh single-round ticks; every way replays it from the initial state
+            packed = [engine.pack32(b) for b in ticks]
+            cap = max(b.entry_count for b in ticks) + 64
             for way in ("rg_submit_async_packed", "rg_tick_launch"):
-                tg = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
                 tt = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
-                tt.load_state(tg.initial_state())
-                ticks = [tg.next_batch(1) for _ in range(args.tick_batches)]
-                cap = max(b.entry_count for b in ticks) + 64
+                tt.load_state(tick_st0)
                 pb = engine.PackedBatch(tt, ticks[0], entry_cap=cap)
                 tk = engine.Tick(tt, pb) if way == "rg_tick_launch" else None
+                # (round 5's driver run showed ONE 20 ms tick among 90 on the nine-call path, none on the graph: the only thing that path does and the graph
+                #  does not is grow a staging buffer when a tick carries more entry terms than any before it — hipFree + hipMalloc on the tick's path. The
+                #  array's CAPACITY travels now, as the graph has always had it; and the collector is kept out of the timed loop.)
+                pb.c_in.entry_count = cap
                 us = []
-                for i, b in enumerate(ticks):
-                    b32 = engine.pack32(b)
-                    pb.head[:], pb.abcd[:] = b32.head, b32.abcd
-                    pb.entry_terms[:b32.entry_count] = b32.entry_terms[:b32.entry_count]
-                    if tk is None:
-                        pb.c_in.entry_count = b32.entry_count
-                    t1 = time.perf_counter()
-                    if tk is None:
-                        tt.submit_async_packed(pb)
-                        tt.submit_wait()
-                    else:
-                        tk.launch()
-                        tk.wait()
-                    dt = time.perf_counter() - t1
-                    if i >= 10:
-                        us.append(dt * 1e6)
+                gc.collect()
+                gc.disable()
+                try:
+                    for i, b32 in enumerate(packed):
+                        pb.head[:], pb.abcd[:] = b32.head, b32.abcd
+                        pb.entry_terms[:b32.entry_count] = b32.entry_terms[:b32.entry_count]
+                        t1 = time.perf_counter()
+                        if tk is None:
+                            tt.submit_async_packed(pb)
+                            tt.submit_wait()
+                        else:
+                            tk.launch()
+                            tk.wait()
+                        dt = time.perf_counter() - t1
+                        if i >= 10:
+                            us.append(dt * 1e6)
+                finally:
+                    gc.enable()
                 res[way] = lat(us)
                 if tk is not None:
                     tk.close()
@@ -601,8 +700,31 @@ def main():
                         db.free()
                 pb.free()
                 tt.close()
+            # the DEVICE-RESIDENT tick (ABI 5, rg_tick2_*): decisions -> timers -> health -> fired tickets -> send table -> readiness as ONE graph on compact
+            # outcome rows, every large column in HBM; what the device spends per tick, by a HIP event pair around the replays
+            tt = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+            tt.load_state(tick_st0)
+            tt.timers_configure(900, 300, 1)
+            tt.timers_arm(0)
+            t2k = engine.Tick2(tt, 1, entry_cap=cap, expired_cap=gpg, critical_point=1, cool_down_ms=60, device_resident=True)
+            n2 = min(len(packed), 60)
+            for i in range(n2):
+                t2k.refill(packed[i], [300 * (i + 1)])
+                if i == 10:
+                    tt.sync()
+                    t_dev = 0.0
+                if i < 10:
+                    t2k.launch(); t2k.wait()
+                else:
+                    tt.timing_begin()
+                    t2k.launch()
+                    t_dev += tt.timing_end()
+            res["device_us_per_resident_tick"] = t_dev * 1e3 / (n2 - 10)
+            res["resident_tick_steps"] = "step32c -> timers_update32 -> health_update32 -> timers_expired -> replicate -> ready (one hipGraphLaunch)"
+            t2k.close()
+            tt.close()
             tick = dict(res, groups=gpg, rounds_per_tick=1, bytes_up_per_tick=24 * gpg, note="submit -> wait of ONE round over PCIe, page-locked buffers both ways; "
-                        "python call overhead (ctypes, ~2 us per call) included in both ways")
+                        "python call overhead (ctypes, ~2 us per call) included in both ways; gc disabled inside the timed loops")
         except Exception as e:      # a reporting leg must not take the bench line down with it
             tick = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             print("bench: once-per-tick leg failed: %r" % (e,), file=sys.stderr)
@@ -621,7 +743,35 @@ def main():
                     traffic, traffic_src = tr["traffic_bytes_per_launch"] / 1e9, tr["source"]
         except (OSError, KeyError, ValueError):
             pass
+        traffic_here = False
+        if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # measured in THIS run (KB per dispatch; gfx950: FETCH_SIZE counts half of what was fetched — /opt/skills/guides/MI355X_MICROARCH.md, HBM section —
+            # and profiles/r05j_counter_calibration.txt holds the check on kernels of known byte counts)
+            traffic, traffic_src, traffic_here = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0 / 1e9, "this run: FETCH_SIZE x 2 + WRITE_SIZE, separate passes", True
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
+        # the vector-ALU side: instructions the launch issues against what the SIMDs can issue (one wave64 instruction per SIMD per four cycles)
+        valu = None
+        try:
+            props = torch.cuda.get_device_properties(dev)
+            simds = int(props.multi_processor_count) * 4
+            clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+            quoted = None
+            for tr in json.load(open(os.path.join(ROOT, "profiles", "valu.json")))["entries"]:
+                if (tr["config"], tr["groups_per_gpu"], tr["rounds"], tr["kernel"]) == (args.config, gpg, args.rounds, "%s<%d,false>" % ("rg::step32_kernel", F)) \
+                        and not args.override and tr.get("lib_sha16") == engine.library_sha16() and tr.get("outcome_format", "rg_outcome_t") == ("rg_outcome32_t" if compact_out else "rg_outcome_t"):
+                    quoted = tr
+            insts = pmc["SQ_INSTS_VALU"] if pmc and "SQ_INSTS_VALU" in pmc else (quoted["sq_insts_valu_per_launch"] if quoted else None)
+            if insts is not None and avg_kernel_s > 0:
+                peak = simds * clock_hz / 4.0
+                valu = {"insts_per_launch": insts, "per_64_groups_per_round": insts / max(1, (gpg + 63) // 64) / args.rounds,
+                        "achieved_ginst_per_s": insts / avg_kernel_s / 1e9, "peak_ginst_per_s": peak / 1e9, "busy_frac": insts / avg_kernel_s / peak,
+                        "simds": simds, "clock_mhz": clock_hz / 1e6, "peak_basis": "one wave64 vector instruction per SIMD per 4 cycles at the device's maximum clock",
+                        "salu_per_launch": pmc.get("SQ_INSTS_SALU") if pmc else (quoted or {}).get("sq_insts_salu_per_launch"),
+                        "lds_per_launch": pmc.get("SQ_INSTS_LDS") if pmc else (quoted or {}).get("sq_insts_lds_per_launch"),
+                        "measured_in_this_run": bool(pmc and "SQ_INSTS_VALU" in pmc), "lib_sha16": engine.library_sha16(),
+                        "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU" if pmc and "SQ_INSTS_VALU" in pmc else quoted.get("source")}
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            print("bench: valu block failed: %r" % (e,), file=sys.stderr)
         alg_per_launch = alg_bytes / max(args.steps, 1)
         achieved = alg_per_launch / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         moved_bytes = traffic * 1e9 if traffic is not None else floor_bytes
@@ -663,15 +813,19 @@ def main():
                 # and this library build: profiles/traffic.json) over the launch duration measured HERE with HIP events. The byte count is a quotation from
                 # the evidence pass (`traffic_measured_in_this_run`: false), the time is this run's. Without a matching entry the layout estimate stands in
                 # and `frac_basis` says so. Never above 1.
-                "bound": "hbm", "achieved": moved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                # `bound`: what limits the launch at this size is vector-instruction issue, not the memory system: the `valu` block beside
+                # the HBM fraction says how busy the vector ALUs are; achieved / peak / unit / frac stay the HBM figures the contract defines
+                "bound": "valu", "valu": valu, "achieved": moved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": None if moved_gbps is None else moved_gbps / HBM_PEAK_GBPS,
-                "frac_basis": "rocprofv3 PMC bytes of this library build (profiles/traffic.json)" if traffic is not None else
+                "frac_basis": ("rocprofv3 PMC bytes measured in this run" if traffic_here else "rocprofv3 PMC bytes of this library build (profiles/traffic.json)") if traffic is not None else
                               ("layout estimate (no PMC entry for this library build / workload)" if floor_bytes is not None else None),
-                "frac_note": "moved bytes over time: round 5's compact outcome rows move 24 % fewer bytes per launch than round 4's columns (266 -> 203 MB at config 3) in "
-                             "10 % less time, so this fraction FELL (0.45 -> 0.38) while decisions/s rose; traffic is within 6 % of the layout estimate and the kernel is "
-                             "vector-ALU-bound (DESIGN.md section 6). --wide-outcomes reproduces round 4's format." if compact_out else None,
+                "frac_note": "moved bytes over time: compact outcome rows (round 5) move 24 % fewer bytes per launch than round 4's columns (266 -> 203 MB at config 3), "
+                             "so this fraction fell while decisions/s rose; traffic is within 6 % of the layout estimate and the launch is bound by vector-instruction "
+                             "issue (`valu`), not by the memory system (DESIGN.md section 6). --wide-outcomes reproduces round 4's format." if compact_out else None,
                 "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC: %s)" % traffic_src,
-                "traffic_lib_sha16": engine.library_sha16() if traffic is not None else None, "traffic_measured_in_this_run": False,
+                "traffic_lib_sha16": engine.library_sha16() if traffic is not None else None, "traffic_measured_in_this_run": traffic_here,
+                "pmc_passes": pmc,
+                "per_launch": spread,
                 "hbm_bytes_measured": None if traffic is None else traffic * 1e9,
                 "hbm_gbps_measured": None if traffic is None else traffic / avg_kernel_s,
                 "hbm_frac_measured": None if traffic is None else traffic / avg_kernel_s / HBM_PEAK_GBPS,

@@ -57,9 +57,10 @@
 extern "C" {
 #endif
 
-#define RG_ABI_VERSION      4     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
+#define RG_ABI_VERSION      5     /* 2: RG_EV_IS_REQ, RG_EV_TIMEOUT.aux fence, RG_F_TIMER_MUTED, rg_timers_expired_epochs, rg_submit_async(_packed), 48-byte rg_send_head_t
                                      3: rg_submit32 / rg_batch32_pack, RG_HDR_SAME_TERM in rg_batch32_t rows
-                                     4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option; the index base of the compact formats (rg_index_base_set) */
+                                     4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option; the index base of the compact formats (rg_index_base_set)
+                                     5: the device-resident tick on compact outcome rows: rg_timers_update32, rg_health_update32, rg_tick2_*; clusters of up to 15 nodes */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
 #define RG_MAX_CLUSTER      7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
@@ -398,7 +399,8 @@ int64_t rg_batch32_pack_rel(const rg_batch_t *in, const int64_t *index_base, rg_
  * outcome stream shrinks from ~125 MB to ~68 MB.
  *   rg_out32_t      always written.  resp_term: RaftResponse.term, 0 unless RG_F_REPLIED.  flags: as rg_reply_t.flags.  commit_index:
  *                   RaftLog.lastCommitted() AFTER the row, whatever the flags say (rg_logfx_t only has it for rows that carry an effect).
- *                   log_from: as rg_logfx_t.log_from, 0 unless the row carries RG_F_LOG_APPEND / RG_F_LOG_TRUNC or the status RG_NEED_HOST.
+ *                   log_from: as rg_logfx_t.log_from WHERE the row carries RG_F_LOG_APPEND / RG_F_LOG_TRUNC or the status RG_NEED_HOST; UNDEFINED on every
+ *                   other row (the kernel stores it without a select: a raw consumer must test the flags first — rg_outcome32_unpack does).
  *   rg_persist32_t  written iff RG_F_PERSIST (every conversion sets it: RaftMember.<init> persists, member/RaftMember.java:25): the durable
  *                   pair, the role, and the role epoch AFTER the row — the tag for the RPCs the host emits from now on. A row without
  *                   RG_F_PERSIST leaves the group's role epoch where it was.
@@ -406,8 +408,8 @@ int64_t rg_batch32_pack_rel(const rg_batch_t *in, const int64_t *index_base, rg_
  *                   see rg_submit32) puts the full rows of an event whose values do not fit — such a row carries RG_F_WIDE_VALUES and the
  *                   low 32 bits. The columns are not touched otherwise. Without them the full values of such a row are lost to the caller
  *                   (rg_read_state still has the group's state).
- * Same batches, same decisions, same table state as rg_submit32; dense batches only (gid == NULL). rg_timers_update / rg_health_update read
- * rg_reply_t rows: a host that runs the device-side timers unpacks first (or uses rg_submit32). */
+ * Same batches, same decisions, same table state as rg_submit32; dense batches only (gid == NULL). The device-side timers and health statistics
+ * take these rows as they are: rg_timers_update32 / rg_health_update32 (ABI 5), or the whole tick as one graph: rg_tick2_*. */
 typedef struct { int32_t resp_term; uint32_t flags; int32_t commit_index; int32_t log_from; } rg_out32_t;          /* 16 B */
 typedef struct { int32_t term; int32_t voted_for; uint32_t role_epoch; int32_t role; } rg_persist32_t;            /* 16 B */
 typedef struct {
@@ -494,6 +496,12 @@ int rg_timers_expired(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t ca
  * the reference drops it (context/RaftRoutine.java:70). out_epoch: [capacity], same memspace as out_gid. */
 int rg_timers_expired_epochs(rg_table_t *t, int64_t now, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, uint32_t *out_count,
                              int memspace);
+/* The same from COMPACT outcome rows (ABI 5; dense batches, as rg_submit32c): row = the rg_out32_t column, persist32 = the rg_persist32_t column of the
+ * batch just decided, [rounds * groups] each. A compact row names its role epoch only where a conversion happened (rg_persist32_t.role_epoch); the
+ * rows before a batch's first conversion are chained from the epoch the group had after the PREVIOUS batch, which the table remembers per group —
+ * refreshed by rg_load_state, rg_timers_arm and by every rg_timers_update / rg_timers_update32: the timers must see every batch of the table, in
+ * order (they must anyway: a skipped batch loses its RG_F_RESET_TIMER flags). Deadlines are those rg_timers_update makes of the unpacked rows. */
+int rg_timers_update32(rg_table_t *t, uint32_t rounds, const rg_out32_t *row, const rg_persist32_t *persist32, const int64_t *now, int memspace);
 /* arm every group that has no ticket yet (after rg_load_state): role from the table, as rg_timers_update would */
 int rg_timers_arm(rg_table_t *t, int64_t now);
 int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadline);
@@ -511,11 +519,57 @@ int rg_timers_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *deadl
  *                      (0 for non-leaders and for leaders that have not prepared replication). */
 int rg_health_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint32_t *gid, const rg_ev_head_t *head,
                      const rg_reply_t *reply, const int64_t *now, int memspace);
+/* rg_health_update from compact outcome rows (ABI 5; dense): head = the batch's event heads, row = its rg_out32_t column */
+int rg_health_update32(rg_table_t *t, uint32_t rounds, const rg_ev_head_t *head, const rg_out32_t *row, const int64_t *now, int memspace);
 int rg_health_failure(rg_table_t *t, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, int64_t now);
 int rg_ready(rg_table_t *t, int64_t now, int32_t critical_point, int64_t cool_down_ms, uint8_t *ready, int memspace);
 /* request_success / request_failure / recent_failure: [count * (cluster-1)], index g*(P-1)+j like rg_group_state_t peers */
 int rg_health_read(rg_table_t *t, uint32_t first, uint32_t count, int64_t *request_success, int64_t *request_failure,
                    int32_t *recent_failure);
+
+/* ---- THE DEVICE-RESIDENT TICK (ABI 5) --------------------------------------------------------------------------------------------------
+ * "closes the loop leader-step -> follower-step on device". One tick of a node, recorded ONCE as a HIP graph on the table's stream
+ * and replayed with one call:
+ *     rg::step32_kernel (compact rows in, compact outcome rows out: rg_submit32c)                        support/EventLoopGroup.java:32-46
+ *  -> timers_update32   the batch's RESET_TIMER / ROLE_CHANGED / TIMER_MUTED flags into the deadlines     context/RaftRoutine.java:86-130
+ *  -> health_update32   acks that reached statSuccess into requestSuccess / recentFailure                 member/Leadership.java:53-63
+ *  -> timers_expired    the tickets that fired by now[rounds - 1], ascending, with their role epochs      context/RaftRoutine.java:53-77
+ *  -> replicate         what every leader sends to every follower                                          member/Leader.java:142-245
+ *  -> ready             Leader.isReady per group                                                           member/Leader.java:52-64
+ * (the last three are optional: leave their outputs NULL). Nothing is copied: every pointer below must be DEVICE-VISIBLE for the life of the tick —
+ * device memory (rg_dev_alloc) or page-locked host memory (rg_host_alloc, which the device reads and writes over the link) — and is read / written where
+ * it lies, so the caller decides per column what stays in HBM (the rows of a resident replay, the send table a gateway kernel consumes) and what crosses
+ * the link (the expired list, a few counters). The per-round clocks are READ from `now` when the graph runs: refill rows and clocks, launch, wait.
+ * Decisions, deadlines, statistics and send rows are those of the separate calls (tests/test_gpu_parity.py::test_the_device_resident_tick_matches_the_oracle).
+ * The table's options and index bases at creation are part of the recording: rg_tick2_launch refuses (-1) when they have changed since.            */
+typedef struct {
+    /* in */
+    uint32_t              rounds;           /* 1 .. 64; count is the table's group count (dense) */
+    const rg_ev_head_t   *head;             /* [rounds * G] */
+    const rg_ev_quad32_t *abcd;             /* [rounds * G] */
+    const int32_t        *entry_terms;      /* [entry_capacity] or NULL */
+    uint64_t              entry_capacity;
+    const int64_t        *now;              /* [rounds] clock of every round; now[rounds - 1] is "now" for expiry and readiness */
+    const uint8_t        *heartbeat;        /* [G] rg_replicate's per-row flag, or NULL (all 0) */
+    const uint16_t       *in_flight;        /* [(P - 1) * G] or NULL */
+    int32_t               critical_point;   /* rg_ready's availableCriticalPoint / recoveryCoolDownMills */
+    int64_t               cool_down_ms;
+    /* out */
+    rg_out32_t           *row;              /* [rounds * G] */
+    rg_persist32_t       *persist32;        /* [rounds * G] (a row is written iff its flags carry RG_F_PERSIST) */
+    uint32_t             *expired_gid;      /* [expired_capacity] or NULL: no expiry step */
+    uint32_t             *expired_epoch;    /* [expired_capacity] or NULL */
+    uint32_t             *expired_count;    /* [1]: groups that expired (may exceed the capacity: then only the first were listed AND marked fired) */
+    uint32_t              expired_capacity;
+    rg_send_head_t       *send_head;        /* [G] or NULL: no send step */
+    rg_send_t            *send;             /* [(P - 1) * G] */
+    uint8_t              *ready;            /* [G] or NULL */
+} rg_tick2_io_t;
+typedef struct rg_tick2 rg_tick2_t;
+int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick);
+int rg_tick2_launch(rg_tick2_t *tick);      /* asynchronous on the table's stream; a second launch first waits for the one in flight */
+int rg_tick2_wait(rg_tick2_t *tick);
+int rg_tick2_destroy(rg_tick2_t *tick);
 
 /* ---- device memory helpers (so a host without its own HIP binding can keep batches in HBM) --- */
 /* Page-locked host memory for RG_MEM_HOST batches (JNI: wrap it with NewDirectByteBuffer): staging then runs at PCIe

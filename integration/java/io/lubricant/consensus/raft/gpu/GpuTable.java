@@ -6,13 +6,15 @@ import java.nio.ByteBuffer;
  * libraftgpu.so (include/raftgpu.h) as seen from the JVM: one object = one rg_table_t = the raft groups one GPU decides.
  * Every native method is ONE call of the C-ABI (integration/jni/raftgpu_jni.c); buffers are DIRECT ByteBuffers in native byte order laid out
  * exactly as the header says (head 8 B, ab / cd 16 B, abcd 16 B per row; reply / logfx / persist 16 B; rg_out32_t / rg_persist32_t 16 B).
+ * Every buffer is checked by the shim before the library sees its address: a heap (non-direct) or short ByteBuffer is an IllegalArgumentException,
+ * never a native out-of-bounds access, and never a silently "absent" column.
  * A table is not re-entrant: one flusher thread per table, as one ContextLoop thread per context before (support/EventLoopGroup.java:77-80).
  */
 public final class GpuTable implements AutoCloseable {
 
     static { System.loadLibrary("raftgpu_jni"); }
 
-    public static final int ABI = 4;
+    public static final int ABI = 5;
     public static final int OPT_REQUIRE_FENCED_TIMEOUTS = 1;
 
     final long handle;
@@ -65,6 +67,9 @@ public final class GpuTable implements AutoCloseable {
     static native int timersConfigure(long handle, long electionMs, long heartbeatMs, long seed);
     static native int timersArm(long handle, long now);
     static native int timersUpdate(long handle, int rounds, int count, ByteBuffer gid, ByteBuffer reply, ByteBuffer now);
+    /** ABI 5: the same from the compact outcome rows of a dense batch (submit32c's row / persist32 columns), no unpacking in between */
+    static native int timersUpdate32(long handle, int rounds, ByteBuffer row, ByteBuffer persist32, ByteBuffer now);
+    static native int healthUpdate32(long handle, int rounds, ByteBuffer head, ByteBuffer row, ByteBuffer now);
     /** -> number of expired groups (or < 0); the epochs go into the aux field of the RG_EV_TIMEOUT rows */
     static native int timersExpired(long handle, long now, ByteBuffer outGid, ByteBuffer outEpoch, int capacity);
     static native int healthUpdate(long handle, int rounds, int count, ByteBuffer gid, ByteBuffer head, ByteBuffer reply, ByteBuffer now);

@@ -20,6 +20,7 @@
 #include <jni.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "raftgpu.h"
 #include "raftwire.h"
@@ -34,6 +35,32 @@ static void throw_state(JNIEnv *env, const char *msg)
     jclass cls = (*env)->FindClass(env, "java/lang/IllegalStateException");
     if (cls) (*env)->ThrowNew(env, cls, msg ? msg : "libraftgpu");
 }
+
+/* Every buffer that crosses here is checked BEFORE the library sees its address: a heap ByteBuffer has no address — silently reading
+ * that NULL as "column absent" would, e.g., turn a sparse batch into a dense one — and a short one is a native out-of-bounds access inside libraftgpu.
+ * BUF(b, bytes, optional, "name"): the address of direct buffer b, which must hold at least `bytes`; a null b is "absent" only where the C-ABI allows it.
+ * Anything else leaves an IllegalArgumentException pending and sets `bad`: the native method then returns -1 without calling the library. */
+static void *checked(JNIEnv *env, jobject b, jlong need, int optional, const char *what, int *bad)
+{
+    char msg[160];
+    jlong cap = 0;
+    void *p = NULL;
+    if (!b) {
+        if (optional) return NULL;
+        snprintf(msg, sizeof msg, "%s: a direct ByteBuffer of at least %lld bytes is required (got null)", what, (long long)need);
+    } else if (!(p = (*env)->GetDirectBufferAddress(env, b))) {
+        snprintf(msg, sizeof msg, "%s: not a DIRECT ByteBuffer (ByteBuffer.allocateDirect or GpuTable.hostAlloc)", what);
+    } else if ((cap = (*env)->GetDirectBufferCapacity(env, b)) < need) {
+        snprintf(msg, sizeof msg, "%s: capacity %lld, the call needs %lld bytes", what, (long long)cap, (long long)need);
+    } else {
+        return p;
+    }
+    jclass cls = (*env)->FindClass(env, "java/lang/IllegalArgumentException");
+    if (cls) (*env)->ThrowNew(env, cls, msg);
+    *bad = 1;
+    return NULL;
+}
+#define BUF(b, bytes, optional, what) checked(env, (b), (jlong)(bytes), (optional), (what), &bad)
 
 /* ---- GpuTable: life cycle ------------------------------------------------------------------------------------------------------------ */
 
@@ -91,20 +118,37 @@ JNIEXPORT jint JNICALL J(GpuTable, hostFree)(JNIEnv *env, jclass cls, jlong h, j
 /* ---- GpuTable: state (ContextManager.buildContext -> RaftContext.initialize: StableLock.restore, RaftLog.epoch / last) --------------------- */
 
 /* columns: the 24 arrays of rg_group_state_t in declaration order, each a direct ByteBuffer (or null where the struct allows NULL) */
-static int state_columns(JNIEnv *env, jobjectArray columns, rg_group_state_t *s)
+/* bytes per group of every column (runs: per run; peers: per follower): the declaration order of rg_group_state_t */
+static const int state_width[] = {8, 4, 4, 4, 1, 1, 4, 4, 4, 8, 8, 8, 8, 8, 8, 4, 4, /* runs */ 8, 8, /* peers */ 8, 8, 8, 4, 1};
+enum { FIRST_RUN_COLUMN = 17, FIRST_PEER_COLUMN = 19 };
+
+/* loading: the run columns hold sum(run_count) elements (read from the run_count column once ITS size is known); reading: count * RG_TERM_RUNS */
+static int state_columns(JNIEnv *env, jobjectArray columns, rg_group_state_t *s, jlong h, jint count, int loading)
 {
     void **field = (void **)s;
     const jsize n = (jsize)(sizeof(rg_group_state_t) / sizeof(void *));
-    if ((*env)->GetArrayLength(env, columns) != n) return -1;
-    for (jsize i = 0; i < n; i++) field[i] = ADDR((*env)->GetObjectArrayElement(env, columns, i));
-    return 0;
+    int bad = 0;
+    if ((*env)->GetArrayLength(env, columns) != n || count < 0) return -1;
+    const jlong followers = (jlong)rg_table_cluster(TABLE(h)) - 1;
+    jlong runs = (jlong)count * RG_TERM_RUNS;
+    for (jsize i = 0; i < n && !bad; i++) {
+        jlong elems = i < FIRST_RUN_COLUMN ? count : (i < FIRST_PEER_COLUMN ? runs : (jlong)count * followers);
+        field[i] = BUF((*env)->GetObjectArrayElement(env, columns, i), elems * state_width[i], 0, "rg_group_state_t column");
+        if (loading && i == 15 && !bad) {                /* run_count: from here on the run columns' size is known */
+            runs = 0;
+            for (jint g = 0; g < count; g++) runs += ((const uint32_t *)field[15])[g];
+        }
+    }
+    return bad ? -2 : 0;
 }
 
 JNIEXPORT jint JNICALL J(GpuTable, loadState)(JNIEnv *env, jclass cls, jlong h, jint first, jint count, jobjectArray columns)
 {
     (void)cls;
     rg_group_state_t s;
-    if (state_columns(env, columns, &s) != 0) { throw_state(env, "loadState: 24 columns expected (rg_group_state_t)"); return -1; }
+    const int rc = state_columns(env, columns, &s, h, count, 1);
+    if (rc == -1) throw_state(env, "loadState: 24 columns expected (rg_group_state_t)");
+    if (rc != 0) return -1;
     return rg_load_state(TABLE(h), (uint32_t)first, (uint32_t)count, &s);
 }
 
@@ -112,7 +156,9 @@ JNIEXPORT jint JNICALL J(GpuTable, readState)(JNIEnv *env, jclass cls, jlong h, 
 {
     (void)cls;
     rg_group_state_t s;
-    if (state_columns(env, columns, &s) != 0) { throw_state(env, "readState: 24 columns expected (rg_group_state_t)"); return -1; }
+    const int rc = state_columns(env, columns, &s, h, count, 0);
+    if (rc == -1) throw_state(env, "readState: 24 columns expected (rg_group_state_t)");
+    if (rc != 0) return -1;
     return rg_read_state(TABLE(h), (uint32_t)first, (uint32_t)count, &s);
 }
 
@@ -123,22 +169,32 @@ JNIEXPORT jint JNICALL J(GpuTable, submit)(JNIEnv *env, jclass cls, jlong h, jin
                                            jobject entry_terms, jlong entry_count, jobject hint, jobject reply, jobject logfx, jobject persist)
 {
     (void)cls;
+    int bad = 0;
+    const jlong rows = (jlong)rounds * count;
+    if (rounds < 0 || count < 0 || entry_count < 0) { throw_state(env, "submit: negative rounds / count / entry_count"); return -1; }
     rg_batch_t in;
     in.rounds = (uint32_t)rounds; in.count = (uint32_t)count;
-    in.gid = (const uint32_t *)ADDR(gid); in.head = (const rg_ev_head_t *)ADDR(head);
-    in.ab = (const rg_ev_pair_t *)ADDR(ab); in.cd = (const rg_ev_pair_t *)ADDR(cd);
-    in.entry_terms = (const int64_t *)ADDR(entry_terms); in.entry_count = (uint64_t)entry_count;
-    in.hint = (const rg_ev_pair_t *)ADDR(hint);
+    in.gid = (const uint32_t *)BUF(gid, 4 * (jlong)count, 1, "gid"); in.head = (const rg_ev_head_t *)BUF(head, 8 * rows, 0, "head");
+    in.ab = (const rg_ev_pair_t *)BUF(ab, 16 * rows, 0, "ab"); in.cd = (const rg_ev_pair_t *)BUF(cd, 16 * rows, 0, "cd");
+    in.entry_terms = (const int64_t *)BUF(entry_terms, 8 * entry_count, entry_count == 0, "entry_terms"); in.entry_count = (uint64_t)entry_count;
+    in.hint = (const rg_ev_pair_t *)BUF(hint, 16 * rows, 1, "hint");
     rg_outcome_t out;
-    out.reply = (rg_reply_t *)ADDR(reply); out.logfx = (rg_logfx_t *)ADDR(logfx); out.persist = (rg_persist_t *)ADDR(persist);
+    out.reply = (rg_reply_t *)BUF(reply, 16 * rows, 0, "reply"); out.logfx = (rg_logfx_t *)BUF(logfx, 16 * rows, 0, "logfx");
+    out.persist = (rg_persist_t *)BUF(persist, 16 * rows, 0, "persist");
+    if (bad) return -1;
     return rg_submit(TABLE(h), &in, &out, RG_MEM_HOST);
 }
 
-static void batch32(JNIEnv *env, rg_batch32_t *in, jint rounds, jint count, jobject gid, jobject head, jobject abcd, jobject entry_terms, jlong entry_count)
+static int batch32(JNIEnv *env, rg_batch32_t *in, jint rounds, jint count, jobject gid, jobject head, jobject abcd, jobject entry_terms, jlong entry_count)
 {
+    int bad = 0;
+    const jlong rows = (jlong)rounds * count;
+    if (rounds < 0 || count < 0 || entry_count < 0) { throw_state(env, "negative rounds / count / entry_count"); return 1; }
     in->rounds = (uint32_t)rounds; in->count = (uint32_t)count;
-    in->gid = (const uint32_t *)ADDR(gid); in->head = (const rg_ev_head_t *)ADDR(head); in->abcd = (const rg_ev_quad32_t *)ADDR(abcd);
-    in->entry_terms = (const int32_t *)ADDR(entry_terms); in->entry_count = (uint64_t)entry_count;
+    in->gid = (const uint32_t *)BUF(gid, 4 * (jlong)count, 1, "gid"); in->head = (const rg_ev_head_t *)BUF(head, 8 * rows, 0, "head");
+    in->abcd = (const rg_ev_quad32_t *)BUF(abcd, 16 * rows, 0, "abcd");
+    in->entry_terms = (const int32_t *)BUF(entry_terms, 4 * entry_count, entry_count == 0, "entry_terms"); in->entry_count = (uint64_t)entry_count;
+    return bad;
 }
 
 /* compact rows (24 bytes per event), wide outcome columns */
@@ -147,9 +203,12 @@ JNIEXPORT jint JNICALL J(GpuTable, submit32)(JNIEnv *env, jclass cls, jlong h, j
 {
     (void)cls;
     rg_batch32_t in;
-    batch32(env, &in, rounds, count, gid, head, abcd, entry_terms, entry_count);
+    int bad = batch32(env, &in, rounds, count, gid, head, abcd, entry_terms, entry_count);
+    const jlong rows = (jlong)rounds * count;
     rg_outcome_t out;
-    out.reply = (rg_reply_t *)ADDR(reply); out.logfx = (rg_logfx_t *)ADDR(logfx); out.persist = (rg_persist_t *)ADDR(persist);
+    out.reply = (rg_reply_t *)BUF(reply, 16 * rows, 0, "reply"); out.logfx = (rg_logfx_t *)BUF(logfx, 16 * rows, 0, "logfx");
+    out.persist = (rg_persist_t *)BUF(persist, 16 * rows, 0, "persist");
+    if (bad) return -1;
     return rg_submit32(TABLE(h), &in, &out, RG_MEM_HOST);
 }
 
@@ -160,10 +219,13 @@ JNIEXPORT jint JNICALL J(GpuTable, submit32c)(JNIEnv *env, jclass cls, jlong h, 
 {
     (void)cls;
     rg_batch32_t in;
-    batch32(env, &in, rounds, count, NULL, head, abcd, entry_terms, entry_count);
+    int bad = batch32(env, &in, rounds, count, NULL, head, abcd, entry_terms, entry_count);
+    const jlong rows = (jlong)rounds * count;
     rg_outcome32_t out;
-    out.row = (rg_out32_t *)ADDR(row); out.persist = (rg_persist32_t *)ADDR(persist32);
-    out.wide.reply = (rg_reply_t *)ADDR(reply); out.wide.logfx = (rg_logfx_t *)ADDR(logfx); out.wide.persist = (rg_persist_t *)ADDR(persist);
+    out.row = (rg_out32_t *)BUF(row, 16 * rows, 0, "row"); out.persist = (rg_persist32_t *)BUF(persist32, 16 * rows, 0, "persist32");
+    out.wide.reply = (rg_reply_t *)BUF(reply, 16 * rows, 1, "wide reply"); out.wide.logfx = (rg_logfx_t *)BUF(logfx, 16 * rows, 1, "wide logfx");
+    out.wide.persist = (rg_persist_t *)BUF(persist, 16 * rows, 1, "wide persist");
+    if (bad) return -1;
     return rg_submit32c(TABLE(h), &in, &out, RG_MEM_HOST);
 }
 
@@ -172,12 +234,19 @@ JNIEXPORT jint JNICALL J(GpuTable, unpack32)(JNIEnv *env, jclass cls, jint round
                                              jobject wide_logfx, jobject wide_persist, jobject role_epoch, jobject reply, jobject logfx, jobject persist)
 {
     (void)cls;
+    int bad = 0;
+    const jlong rows = (jlong)rounds * count;
+    if (rounds < 0 || count < 0) { throw_state(env, "unpack32: negative rounds / count"); return -1; }
     rg_outcome32_t in;
-    in.row = (rg_out32_t *)ADDR(row); in.persist = (rg_persist32_t *)ADDR(persist32);
-    in.wide.reply = (rg_reply_t *)ADDR(wide_reply); in.wide.logfx = (rg_logfx_t *)ADDR(wide_logfx); in.wide.persist = (rg_persist_t *)ADDR(wide_persist);
+    in.row = (rg_out32_t *)BUF(row, 16 * rows, 0, "row"); in.persist = (rg_persist32_t *)BUF(persist32, 16 * rows, 0, "persist32");
+    in.wide.reply = (rg_reply_t *)BUF(wide_reply, 16 * rows, 1, "wide reply"); in.wide.logfx = (rg_logfx_t *)BUF(wide_logfx, 16 * rows, 1, "wide logfx");
+    in.wide.persist = (rg_persist_t *)BUF(wide_persist, 16 * rows, 1, "wide persist");
     rg_outcome_t out;
-    out.reply = (rg_reply_t *)ADDR(reply); out.logfx = (rg_logfx_t *)ADDR(logfx); out.persist = (rg_persist_t *)ADDR(persist);
-    return rg_outcome32_unpack(&in, (uint32_t)rounds, (uint32_t)count, (uint32_t *)ADDR(role_epoch), &out);
+    out.reply = (rg_reply_t *)BUF(reply, 16 * rows, 0, "reply"); out.logfx = (rg_logfx_t *)BUF(logfx, 16 * rows, 0, "logfx");
+    out.persist = (rg_persist_t *)BUF(persist, 16 * rows, 0, "persist");
+    uint32_t *epochs = (uint32_t *)BUF(role_epoch, 4 * (jlong)count, 0, "role_epoch");
+    if (bad) return -1;
+    return rg_outcome32_unpack(&in, (uint32_t)rounds, (uint32_t)count, epochs, &out);
 }
 
 /* the pipelined host-memory path with compact transfer formats: every buffer from hostAlloc (the device writes the lists into them) */
@@ -187,10 +256,14 @@ JNIEXPORT jint JNICALL J(GpuTable, submitAsyncPacked)(JNIEnv *env, jclass cls, j
 {
     (void)cls;
     rg_batch32_t in;
-    batch32(env, &in, rounds, count, gid, head, abcd, entry_terms, entry_count);
+    int bad = batch32(env, &in, rounds, count, gid, head, abcd, entry_terms, entry_count);
+    const jlong rows = (jlong)rounds * count;
+    if (logfx_cap < 0 || persist_cap < 0) { throw_state(env, "submitAsyncPacked: negative list capacity"); return -1; }
     rg_outcome_packed_t out;
-    out.reply = (rg_reply_t *)ADDR(reply); out.logfx = (rg_logfx_t *)ADDR(logfx); out.persist = (rg_persist_t *)ADDR(persist);
-    out.counts = (uint32_t *)ADDR(counts); out.logfx_cap = (uint32_t)logfx_cap; out.persist_cap = (uint32_t)persist_cap;
+    out.reply = (rg_reply_t *)BUF(reply, 16 * rows, 0, "reply"); out.logfx = (rg_logfx_t *)BUF(logfx, 16 * (jlong)logfx_cap, logfx_cap == 0, "logfx");
+    out.persist = (rg_persist_t *)BUF(persist, 16 * (jlong)persist_cap, persist_cap == 0, "persist");
+    out.counts = (uint32_t *)BUF(counts, 8, 0, "counts"); out.logfx_cap = (uint32_t)logfx_cap; out.persist_cap = (uint32_t)persist_cap;
+    if (bad) return -1;
     return rg_submit_async_packed(TABLE(h), &in, &out);
 }
 
@@ -212,8 +285,16 @@ JNIEXPORT jint JNICALL J(GpuTable, replicate)(JNIEnv *env, jclass cls, jlong h, 
                                               jobject send)
 {
     (void)cls;
-    return rg_replicate(TABLE(h), (uint32_t)count, (const uint32_t *)ADDR(gid), (const uint8_t *)ADDR(heartbeat), (const uint16_t *)ADDR(in_flight),
-                        (rg_send_head_t *)ADDR(head), (rg_send_t *)ADDR(send), RG_MEM_HOST);
+    int bad = 0;
+    const jlong followers = (jlong)rg_table_cluster(TABLE(h)) - 1;
+    if (count < 0) { throw_state(env, "replicate: negative count"); return -1; }
+    const uint32_t *g = (const uint32_t *)BUF(gid, 4 * (jlong)count, 1, "gid");
+    const uint8_t *hb = (const uint8_t *)BUF(heartbeat, count, 1, "heartbeat");
+    const uint16_t *fl = (const uint16_t *)BUF(in_flight, 2 * followers * count, 1, "in_flight");
+    rg_send_head_t *sh = (rg_send_head_t *)BUF(head, 48 * (jlong)count, 0, "head");
+    rg_send_t *ss = (rg_send_t *)BUF(send, 32 * followers * count, 0, "send");
+    if (bad) return -1;
+    return rg_replicate(TABLE(h), (uint32_t)count, g, hb, fl, sh, ss, RG_MEM_HOST);
 }
 
 JNIEXPORT jint JNICALL J(GpuTable, timersConfigure)(JNIEnv *env, jclass cls, jlong h, jlong election_ms, jlong heartbeat_ms, jlong seed)
@@ -231,30 +312,77 @@ JNIEXPORT jint JNICALL J(GpuTable, timersArm)(JNIEnv *env, jclass cls, jlong h, 
 JNIEXPORT jint JNICALL J(GpuTable, timersUpdate)(JNIEnv *env, jclass cls, jlong h, jint rounds, jint count, jobject gid, jobject reply, jobject now)
 {
     (void)cls;
-    return rg_timers_update(TABLE(h), (uint32_t)rounds, (uint32_t)count, (const uint32_t *)ADDR(gid), (const rg_reply_t *)ADDR(reply), (const int64_t *)ADDR(now),
-                            RG_MEM_HOST);
+    int bad = 0;
+    if (rounds < 0 || count < 0) { throw_state(env, "timersUpdate: negative rounds / count"); return -1; }
+    const uint32_t *g = (const uint32_t *)BUF(gid, 4 * (jlong)count, 1, "gid");
+    const rg_reply_t *rep = (const rg_reply_t *)BUF(reply, 16 * (jlong)rounds * count, 0, "reply");
+    const int64_t *clk = (const int64_t *)BUF(now, 8 * (jlong)rounds, 0, "now");
+    if (bad) return -1;
+    return rg_timers_update(TABLE(h), (uint32_t)rounds, (uint32_t)count, g, rep, clk, RG_MEM_HOST);
+}
+
+/* the same from compact outcome rows (ABI 5; dense: rounds * groups rows) */
+JNIEXPORT jint JNICALL J(GpuTable, timersUpdate32)(JNIEnv *env, jclass cls, jlong h, jint rounds, jobject row, jobject persist32, jobject now)
+{
+    (void)cls;
+    int bad = 0;
+    if (rounds < 0) { throw_state(env, "timersUpdate32: negative rounds"); return -1; }
+    const jlong rows = (jlong)rounds * rg_table_groups(TABLE(h));
+    const rg_out32_t *r = (const rg_out32_t *)BUF(row, 16 * rows, 0, "row");
+    const rg_persist32_t *p = (const rg_persist32_t *)BUF(persist32, 16 * rows, 0, "persist32");
+    const int64_t *clk = (const int64_t *)BUF(now, 8 * (jlong)rounds, 0, "now");
+    if (bad) return -1;
+    return rg_timers_update32(TABLE(h), (uint32_t)rounds, r, p, clk, RG_MEM_HOST);
+}
+
+JNIEXPORT jint JNICALL J(GpuTable, healthUpdate32)(JNIEnv *env, jclass cls, jlong h, jint rounds, jobject head, jobject row, jobject now)
+{
+    (void)cls;
+    int bad = 0;
+    if (rounds < 0) { throw_state(env, "healthUpdate32: negative rounds"); return -1; }
+    const jlong rows = (jlong)rounds * rg_table_groups(TABLE(h));
+    const rg_ev_head_t *hd = (const rg_ev_head_t *)BUF(head, 8 * rows, 0, "head");
+    const rg_out32_t *r = (const rg_out32_t *)BUF(row, 16 * rows, 0, "row");
+    const int64_t *clk = (const int64_t *)BUF(now, 8 * (jlong)rounds, 0, "now");
+    if (bad) return -1;
+    return rg_health_update32(TABLE(h), (uint32_t)rounds, hd, r, clk, RG_MEM_HOST);
 }
 
 /* -> number of expired groups; out_gid / out_epoch: int[capacity] direct buffers (the epochs go into the aux of the RG_EV_TIMEOUT rows: the fence) */
 JNIEXPORT jint JNICALL J(GpuTable, timersExpired)(JNIEnv *env, jclass cls, jlong h, jlong now, jobject out_gid, jobject out_epoch, jint capacity)
 {
     (void)cls;
+    int bad = 0;
     uint32_t n = 0;
-    const int rc = rg_timers_expired_epochs(TABLE(h), now, (uint32_t *)ADDR(out_gid), (uint32_t *)ADDR(out_epoch), (uint32_t)capacity, &n, RG_MEM_HOST);
+    if (capacity < 0) { throw_state(env, "timersExpired: negative capacity"); return -1; }
+    uint32_t *g = (uint32_t *)BUF(out_gid, 4 * (jlong)capacity, capacity == 0, "outGid");
+    uint32_t *e = (uint32_t *)BUF(out_epoch, 4 * (jlong)capacity, 1, "outEpoch");
+    if (bad) return -1;
+    const int rc = rg_timers_expired_epochs(TABLE(h), now, g, e, (uint32_t)capacity, &n, RG_MEM_HOST);
     return rc != 0 ? rc : (jint)n;
 }
 
 JNIEXPORT jint JNICALL J(GpuTable, healthUpdate)(JNIEnv *env, jclass cls, jlong h, jint rounds, jint count, jobject gid, jobject head, jobject reply, jobject now)
 {
     (void)cls;
-    return rg_health_update(TABLE(h), (uint32_t)rounds, (uint32_t)count, (const uint32_t *)ADDR(gid), (const rg_ev_head_t *)ADDR(head),
-                            (const rg_reply_t *)ADDR(reply), (const int64_t *)ADDR(now), RG_MEM_HOST);
+    int bad = 0;
+    if (rounds < 0 || count < 0) { throw_state(env, "healthUpdate: negative rounds / count"); return -1; }
+    const jlong rows = (jlong)rounds * count;
+    const uint32_t *g = (const uint32_t *)BUF(gid, 4 * (jlong)count, 1, "gid");
+    const rg_ev_head_t *hd = (const rg_ev_head_t *)BUF(head, 8 * rows, 0, "head");
+    const rg_reply_t *rep = (const rg_reply_t *)BUF(reply, 16 * rows, 0, "reply");
+    const int64_t *clk = (const int64_t *)BUF(now, 8 * (jlong)rounds, 0, "now");
+    if (bad) return -1;
+    return rg_health_update(TABLE(h), (uint32_t)rounds, (uint32_t)count, g, hd, rep, clk, RG_MEM_HOST);
 }
 
 JNIEXPORT jint JNICALL J(GpuTable, ready)(JNIEnv *env, jclass cls, jlong h, jlong now, jint critical_point, jlong cool_down_ms, jobject ready)
 {
     (void)cls;
-    return rg_ready(TABLE(h), now, critical_point, cool_down_ms, (uint8_t *)ADDR(ready), RG_MEM_HOST);
+    int bad = 0;
+    uint8_t *out = (uint8_t *)BUF(ready, (jlong)rg_table_groups(TABLE(h)), 0, "ready");
+    if (bad) return -1;
+    return rg_ready(TABLE(h), now, critical_point, cool_down_ms, out, RG_MEM_HOST);
 }
 
 /* ---- GpuIngress: socket bytes -> the [round][group] batch and back (transport/EventCodec.java:169-335, transport/NettyCluster.java:59-105) ------ */

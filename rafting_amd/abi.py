@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MIN_CLUSTER, MAX_CLUSTER = 2, 7
 TERM_RUNS = 4
 NO_NODE = -1
@@ -111,6 +111,13 @@ class COutcome32(C.Structure):         # rg_outcome32_t
 class COutcomePacked(C.Structure):     # rg_outcome_packed_t
     _fields_ = [("reply", C.c_void_p), ("logfx", C.c_void_p), ("persist", C.c_void_p), ("counts", C.c_void_p),
                 ("logfx_cap", C.c_uint32), ("persist_cap", C.c_uint32)]
+
+
+class CTick2Io(C.Structure):           # rg_tick2_io_t
+    _fields_ = [("rounds", C.c_uint32), ("head", C.c_void_p), ("abcd", C.c_void_p), ("entry_terms", C.c_void_p), ("entry_capacity", C.c_uint64),
+                ("now", C.c_void_p), ("heartbeat", C.c_void_p), ("in_flight", C.c_void_p), ("critical_point", C.c_int32), ("cool_down_ms", C.c_int64),
+                ("row", C.c_void_p), ("persist32", C.c_void_p), ("expired_gid", C.c_void_p), ("expired_epoch", C.c_void_p), ("expired_count", C.c_void_p),
+                ("expired_capacity", C.c_uint32), ("send_head", C.c_void_p), ("send", C.c_void_p), ("ready", C.c_void_p)]
 
 
 _STATE_FIELDS = [

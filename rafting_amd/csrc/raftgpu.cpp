@@ -6,6 +6,7 @@
 // string when no device is present.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -25,7 +26,7 @@ hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32
 hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s);
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
-hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const int64_t *now_mem, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
 hipError_t launch_outcome_count(const rg_reply_t *reply, uint32_t rows, uint32_t *counts, uint32_t *totals, hipStream_t s);
 hipError_t launch_outcome_emit(const rg_reply_t *reply, const I64x2 *logfx, const rg_persist_t *persist, uint32_t rows, const uint32_t *counts,
@@ -70,6 +71,10 @@ struct rg_table {
     double t_total_ms = 0.0;
     hipEvent_t region0 = nullptr, region1 = nullptr;
     int64_t *timer_deadline = nullptr;          // [G] N4
+    uint32_t *timer_epoch = nullptr;            // [G] role epoch after the last batch the timers saw (rg_timers_update32 chains compact rows from it)
+    uint64_t config_gen = 0;                    // bumped by whatever changes what a recorded launch has baked in (options, the first index base)
+    std::vector<struct rg_tick *> ticks;        // live recordings: invalidated when the table goes
+    std::vector<struct rg_tick2 *> ticks2;
     uint32_t *timer_counts = nullptr;           // [waves + 1]: per-wave counts / offsets, last = total
     int64_t election_ms = 900, heartbeat_ms = 300;   // raft1.xml:10-13
     uint64_t timer_seed = 0;
@@ -155,20 +160,30 @@ int rg_table_option(rg_table_t *t, int option, int value)
 {
     if (!t) return -1;
     switch (option) {
-    case RG_OPT_REQUIRE_FENCED_TIMEOUTS: t->require_fence = value != 0; return 0;
+    case RG_OPT_REQUIRE_FENCED_TIMEOUTS:
+        if (t->require_fence != (value != 0)) t->config_gen += 1;       // (a recorded tick has the old value baked in: rg_tick_launch refuses it)
+        t->require_fence = value != 0;
+        return 0;
     default: return fail(t, -1, "rg_table_option: unknown option %d", option);
     }
 }
+
+static void tick_release(struct rg_tick *k);
+static void tick2_release(struct rg_tick2 *k);
 
 int rg_table_destroy(rg_table_t *t)
 {
     if (!t) return 0;
     (void)hipSetDevice(t->device);
     if (t->stream) (void)hipStreamSynchronize(t->stream);
+    // recordings that outlive their table keep no pointer into it: their launch / wait fail with -1, their destroy only frees the handle
+    for (struct rg_tick *k : t->ticks) tick_release(k);
+    for (struct rg_tick2 *k : t->ticks2) tick2_release(k);
+    t->ticks.clear(); t->ticks2.clear();
     void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
                     t->dt.peer_en, t->dt.peer_m, t->dt.ibase, t->wide_bodies, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
-                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline,
+                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline, t->timer_epoch,
                     t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
                     t->health_fail, t->health_recent, t->st_abcd32.ptr, t->st_terms32.ptr, t->st_out32.ptr, t->st_persist32.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
@@ -244,6 +259,8 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     // last group, so the array covers the grid (found by the host emulation: ceil(G/64) + 1 entries were 2 short at G = 300)
     CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 255) / 256 * 4 + 1) * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
+    CREATE_TRY(hipMalloc((void **)&t->timer_epoch, G * sizeof(uint32_t)));
+    CREATE_TRY(hipMemsetAsync(t->timer_epoch, 0, G * sizeof(uint32_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->health_ok, G * F * sizeof(int64_t)));
     CREATE_TRY(hipMalloc((void **)&t->health_fail, G * F * sizeof(int64_t)));
     CREATE_TRY(hipMalloc((void **)&t->health_recent, G * F * sizeof(int32_t)));
@@ -352,6 +369,7 @@ int rg_load_state(rg_table_t *t, uint32_t first, uint32_t count, const rg_group_
         HIP_TRY(t, hipMemcpyAsync(t->dt.peer_m + j * G + first, pm.data() + j * n, n * sizeof(rg::Match), hipMemcpyHostToDevice, st));
     }
     HIP_TRY(t, hipMemsetAsync(t->timer_deadline + first, 0, n * sizeof(int64_t), st));   // loaded groups hold no timer ticket yet
+    HIP_TRY(t, hipMemcpyAsync(t->timer_epoch + first, s->role_epoch, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     for (size_t j = 0; j < F; j++) {                                                       // ... and fresh health statistics
         HIP_TRY(t, hipMemsetAsync(t->health_ok + j * G + first, 0, n * sizeof(int64_t), st));
         HIP_TRY(t, hipMemsetAsync(t->health_fail + j * G + first, 0, n * sizeof(int64_t), st));
@@ -624,19 +642,44 @@ struct rg_tick {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     Staging head, abcd, gid, terms, reply, logfx, persist, counts;
+    uint64_t config_gen = 0;         // the table's at creation: has_bases, require_fence, fast_paths, force_wide are baked into the recorded kernel node
     bool in_flight = false;
 };
+
+// everything a recording holds on the device; afterwards it knows no table (called with the table's device current and its stream idle)
+static void tick_release(struct rg_tick *k)
+{
+    if (k->exec) (void)hipGraphExecDestroy(k->exec);
+    if (k->graph) (void)hipGraphDestroy(k->graph);
+    k->exec = nullptr; k->graph = nullptr;
+    for (Staging *st : {&k->head, &k->abcd, &k->gid, &k->terms, &k->reply, &k->logfx, &k->persist, &k->counts}) {
+        if (st->ptr) (void)hipFree(st->ptr);
+        st->ptr = nullptr; st->cap = 0;
+    }
+    k->t = nullptr;
+}
 
 int rg_tick_destroy(rg_tick_t *k)
 {
     if (!k) return 0;
-    if (k->t) { (void)hipSetDevice(k->t->device); if (k->t->stream) (void)hipStreamSynchronize(k->t->stream); }
-    if (k->exec) (void)hipGraphExecDestroy(k->exec);
-    if (k->graph) (void)hipGraphDestroy(k->graph);
-    for (Staging *st : {&k->head, &k->abcd, &k->gid, &k->terms, &k->reply, &k->logfx, &k->persist, &k->counts})
-        if (st->ptr) (void)hipFree(st->ptr);
+    if (rg_table *t = k->t) {
+        (void)hipSetDevice(t->device);
+        if (t->stream) (void)hipStreamSynchronize(t->stream);
+        t->ticks.erase(std::remove(t->ticks.begin(), t->ticks.end(), k), t->ticks.end());
+        tick_release(k);
+    }
     delete k;
     return 0;
+}
+
+// a buffer a recorded copy replays from / into must be page-locked: a pageable one is either rejected late by the capture with an opaque error, or
+// captured with undefined semantics
+static bool page_locked(const void *p)
+{
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void *>(p), 0) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
 }
 
 int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out, rg_tick_t **tick)
@@ -669,8 +712,12 @@ int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packe
         (void)hipGetLastError();
         return fail(t, -1, "rg_tick_create: counts / logfx / persist must be page-locked memory from rg_host_alloc");
     }
+    if (!page_locked(in->head) || !page_locked(in->abcd) || !page_locked(out->reply) || (in->gid && !page_locked(in->gid)) ||
+        (in->entry_count && !page_locked(in->entry_terms)))
+        return fail(t, -1, "rg_tick_create: head / abcd / gid / entry_terms / reply must be page-locked memory from rg_host_alloc (the recorded copies replay from them)");
     rg_tick *k = new rg_tick();
     k->t = t;
+    k->config_gen = t->config_gen;
     const uint32_t rows = (uint32_t)rows64, waves = (rows + 63u) / 64u;
     const bool sparse = in->gid != nullptr;
     if (reserve(t, k->head, rows64 * sizeof(rg_ev_head_t)) || reserve(t, k->abcd, rows64 * sizeof(rg_ev_quad32_t)) || reserve(t, k->reply, rows64 * sizeof(rg_reply_t)) ||
@@ -705,6 +752,7 @@ int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packe
         rg_tick_destroy(k);
         return fail(t, -2, "rg_tick_create: %s", hipGetErrorString(e));
     }
+    t->ticks.push_back(k);
     *tick = k;
     return 0;
 }
@@ -713,6 +761,8 @@ int rg_tick_launch(rg_tick_t *k)
 {
     if (!k || !k->t) return -1;
     rg_table *t = k->t;
+    if (k->config_gen != t->config_gen)
+        return fail(t, -1, "rg_tick_launch: the table's options or index bases changed after rg_tick_create (they are part of the recording): create the tick again");
     if (bind(t)) return -2;
     if (k->in_flight) { HIP_TRY(t, hipStreamSynchronize(t->stream)); k->in_flight = false; }
     HIP_TRY(t, hipGraphLaunch(k->exec, t->stream));
@@ -721,6 +771,155 @@ int rg_tick_launch(rg_tick_t *k)
 }
 
 int rg_tick_wait(rg_tick_t *k)
+{
+    if (!k || !k->t) return -1;
+    rg_table *t = k->t;
+    HIP_TRY(t, hipSetDevice(t->device));
+    HIP_TRY(t, hipStreamSynchronize(t->stream));
+    k->in_flight = false;
+    return 0;
+}
+
+static rg::TimerParams timer_params(rg_table *t);
+static rg::HealthParams health_params(rg_table *t);
+
+/* the device-resident tick: see include/raftgpu.h */
+struct rg_tick2 {
+    rg_table *t = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t config_gen = 0;
+    bool in_flight = false;
+};
+
+static void tick2_release(struct rg_tick2 *k)
+{
+    if (k->exec) (void)hipGraphExecDestroy(k->exec);
+    if (k->graph) (void)hipGraphDestroy(k->graph);
+    k->exec = nullptr; k->graph = nullptr;
+    k->t = nullptr;
+}
+
+int rg_tick2_destroy(rg_tick2_t *k)
+{
+    if (!k) return 0;
+    if (rg_table *t = k->t) {
+        (void)hipSetDevice(t->device);
+        if (t->stream) (void)hipStreamSynchronize(t->stream);
+        t->ticks2.erase(std::remove(t->ticks2.begin(), t->ticks2.end(), k), t->ticks2.end());
+        tick2_release(k);
+    }
+    delete k;
+    return 0;
+}
+
+// the device's address of memory the caller says is device-visible: page-locked host memory is mapped, device memory is what it is; pageable host
+// memory (which a kernel would fault on) is refused where the runtime can tell
+static int device_visible(rg_table *t, const void *p, const char *what, void **out)
+{
+    *out = nullptr;
+    if (!p) return 0;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess || a.type == hipMemoryTypeUnregistered) {
+        (void)hipGetLastError();
+        return fail(t, -1, "rg_tick2_create: %s is neither device memory (rg_dev_alloc) nor page-locked host memory (rg_host_alloc)", what);
+    }
+    if (a.type == hipMemoryTypeHost) {
+        if (hipHostGetDevicePointer(out, const_cast<void *>(p), 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(t, -1, "rg_tick2_create: %s is host memory the device cannot address", what);
+        }
+        return 0;
+    }
+    *out = const_cast<void *>(p);
+    return 0;
+}
+
+int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick)
+{
+    if (!t) return -1;
+    if (!tick) return fail(t, -1, "rg_tick2_create: tick is NULL");
+    *tick = nullptr;
+    if (!io) return fail(t, -1, "rg_tick2_create: io is NULL");
+    if (io->rounds == 0 || io->rounds > 64) return fail(t, -1, "rg_tick2_create: %u rounds (1 .. 64: one clock per round travels with the tick)", io->rounds);
+    if (!io->head || !io->abcd || !io->now || !io->row || !io->persist32) return fail(t, -1, "rg_tick2_create: head, abcd, now, row and persist32 are required");
+    if (io->entry_capacity && !io->entry_terms) return fail(t, -1, "rg_tick2_create: entry_capacity %llu without entry_terms", (unsigned long long)io->entry_capacity);
+    if (io->expired_gid && (!io->expired_count || io->expired_capacity == 0)) return fail(t, -1, "rg_tick2_create: the expiry step needs expired_count and a capacity");
+    if ((io->send_head == nullptr) != (io->send == nullptr)) return fail(t, -1, "rg_tick2_create: send_head and send come together");
+    rg_batch_t wide{};
+    wide.rounds = io->rounds; wide.count = t->G; wide.head = io->head;
+    wide.ab = wide.cd = reinterpret_cast<const rg_ev_pair_t *>(io->abcd);
+    wide.entry_terms = reinterpret_cast<const int64_t *>(io->entry_terms); wide.entry_count = io->entry_capacity;
+    rg_reply_t dummy_r; rg_logfx_t dummy_l; rg_persist_t dummy_p;
+    const rg_outcome_t shape{&dummy_r, &dummy_l, &dummy_p};
+    if (int rc = check_batch(t, &wide, &shape, false)) return rc;
+    if (bind(t)) return -2;
+    void *d_head, *d_abcd, *d_terms, *d_now, *d_hb, *d_fl, *d_row, *d_per, *d_egid, *d_eep, *d_ecnt, *d_sh, *d_ss, *d_ready;
+    if (device_visible(t, io->head, "head", &d_head) || device_visible(t, io->abcd, "abcd", &d_abcd) || device_visible(t, io->entry_terms, "entry_terms", &d_terms) ||
+        device_visible(t, io->now, "now", &d_now) || device_visible(t, io->heartbeat, "heartbeat", &d_hb) || device_visible(t, io->in_flight, "in_flight", &d_fl) ||
+        device_visible(t, io->row, "row", &d_row) || device_visible(t, io->persist32, "persist32", &d_per) || device_visible(t, io->expired_gid, "expired_gid", &d_egid) ||
+        device_visible(t, io->expired_epoch, "expired_epoch", &d_eep) || device_visible(t, io->expired_count, "expired_count", &d_ecnt) ||
+        device_visible(t, io->send_head, "send_head", &d_sh) || device_visible(t, io->send, "send", &d_ss) || device_visible(t, io->ready, "ready", &d_ready))
+        return -1;
+    rg_tick2 *k = new rg_tick2();
+    k->t = t;
+    k->config_gen = t->config_gen;
+    const uint32_t G = t->G, waves = (G + 63u) / 64u;
+    // the decisions: rg_submit32c on device-visible rows
+    rg::StepParams sp = step_params(t, &wide);
+    sp.head = (const rg_ev_head_t *)d_head; sp.abcd32 = (const rg::I32x4 *)d_abcd;
+    sp.entry_terms32 = io->entry_capacity ? (const int32_t *)d_terms : nullptr;
+    sp.out32 = (rg::I32x4 *)d_row; sp.persist32 = (rg::I32x4 *)d_per;
+    // what the batch did to the timers and to the followers' health, from the compact rows where they lie
+    rg::TimerParams tp = timer_params(t);
+    tp.rounds = io->rounds; tp.count = G; tp.out32 = (const rg::I32x4 *)d_row; tp.persist32 = (const rg::I32x4 *)d_per; tp.now_mem = (const int64_t *)d_now;
+    rg::HealthParams hp = health_params(t);
+    hp.rounds = io->rounds; hp.count = G; hp.head = (const rg_ev_head_t *)d_head; hp.out32 = (const rg::I32x4 *)d_row; hp.now_mem = (const int64_t *)d_now;
+    const int64_t *now_last = (const int64_t *)d_now + (io->rounds - 1);
+    rg::HealthParams rp = health_params(t);
+    rp.now_mem = now_last;
+    rg::ReplicateParams qp{};
+    qp.t = t->dt; qp.count = G; qp.heartbeat = (const uint8_t *)d_hb; qp.in_flight = (const uint16_t *)d_fl; qp.head = (rg_send_head_t *)d_sh; qp.send = (rg_send_t *)d_ss;
+    hipStream_t s = t->stream;
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e == hipSuccess) e = rg::launch_step(sp, (int)t->F, false, 32, s);
+    if (e == hipSuccess) e = rg::launch_timers_update(tp, s);
+    if (e == hipSuccess) e = rg::launch_health_update(hp, s);
+    if (e == hipSuccess && io->expired_gid)
+        e = rg::launch_timers_expired(t->timer_deadline, t->dt.ident, G, 0, now_last, t->timer_counts, (uint32_t *)d_ecnt, (uint32_t *)d_egid, (uint32_t *)d_eep,
+                                      io->expired_capacity, s);
+    if (e == hipSuccess && io->send_head) e = rg::launch_replicate(qp, (int)t->F, s);
+    if (e == hipSuccess && io->ready) e = rg::launch_ready(rp, 0, io->critical_point, io->cool_down_ms, (uint8_t *)d_ready, s);
+    (void)waves;
+    hipGraph_t g = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(s, &g);           // (always: an open capture would poison the stream)
+    k->graph = g;
+    if (e == hipSuccess) e = e2;
+    if (e == hipSuccess) e = hipGraphInstantiate(&k->exec, k->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rg_tick2_destroy(k);
+        return fail(t, -2, "rg_tick2_create: %s", hipGetErrorString(e));
+    }
+    t->ticks2.push_back(k);
+    *tick = k;
+    return 0;
+}
+
+int rg_tick2_launch(rg_tick2_t *k)
+{
+    if (!k || !k->t) return -1;
+    rg_table *t = k->t;
+    if (k->config_gen != t->config_gen)
+        return fail(t, -1, "rg_tick2_launch: the table's options or index bases changed after rg_tick2_create (they are part of the recording): create the tick again");
+    if (bind(t)) return -2;
+    if (k->in_flight) { HIP_TRY(t, hipStreamSynchronize(t->stream)); k->in_flight = false; }
+    HIP_TRY(t, hipGraphLaunch(k->exec, t->stream));
+    k->in_flight = true;
+    return 0;
+}
+
+int rg_tick2_wait(rg_tick2_t *k)
 {
     if (!k || !k->t) return -1;
     rg_table *t = k->t;
@@ -866,7 +1065,8 @@ int rg_index_base_set(rg_table_t *t, uint32_t first, uint32_t count, const int64
     if ((uint64_t)first + count > t->G) return fail(t, -1, "rg_index_base_set: groups [%u, %u) of %u", first, first + count, t->G);
     for (uint32_t i = 0; i < count; i++)
         if (base[i] < 0) return fail(t, -1, "rg_index_base_set: base[%u] = %lld is negative", i, (long long)base[i]);
-    for (uint32_t i = 0; i < count; i++) if (base[i] != 0) t->has_bases = 1;       // (sticky: the kernels read the column from now on)
+    for (uint32_t i = 0; i < count; i++)
+        if (base[i] != 0 && !t->has_bases) { t->has_bases = 1; t->config_gen += 1; }       // (sticky: the kernels read the column from now on; recorded ticks are stale)
     if (count == 0) return 0;
     if (bind(t)) return -2;
     HIP_TRY(t, hipMemcpyAsync(t->dt.ibase + first, base, (size_t)count * sizeof(int64_t), hipMemcpyHostToDevice, t->stream));
@@ -1104,7 +1304,7 @@ int rg_timers_configure(rg_table_t *t, int64_t election_ms, int64_t heartbeat_ms
 static rg::TimerParams timer_params(rg_table *t)
 {
     rg::TimerParams p{};
-    p.deadline = t->timer_deadline; p.ident = t->dt.ident; p.groups = t->G;
+    p.deadline = t->timer_deadline; p.epoch = t->timer_epoch; p.ident = t->dt.ident; p.groups = t->G;
     p.election_ms = t->election_ms; p.heartbeat_ms = t->heartbeat_ms; p.seed = t->timer_seed;
     return p;
 }
@@ -1146,6 +1346,34 @@ int rg_timers_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint3
     return 0;
 }
 
+int rg_timers_update32(rg_table_t *t, uint32_t rounds, const rg_out32_t *row, const rg_persist32_t *persist32, const int64_t *now, int memspace)
+{
+    if (!t) return -1;
+    if (!row || !persist32 || !now || rounds == 0) return fail(t, -1, "rg_timers_update32: row, persist32, now and rounds are required");
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    const uint32_t count = t->G;
+    const size_t rows = (size_t)rounds * count;
+    const rg::I32x4 *d_row = (const rg::I32x4 *)row, *d_per = (const rg::I32x4 *)persist32;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_out32, rows * sizeof(rg_out32_t)) || reserve(t, t->st_persist32, rows * sizeof(rg_persist32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_out32.ptr, row, rows * sizeof(rg_out32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(t, hipMemcpyAsync(t->st_persist32.ptr, persist32, rows * sizeof(rg_persist32_t), hipMemcpyHostToDevice, s));
+        d_row = (const rg::I32x4 *)t->st_out32.ptr; d_per = (const rg::I32x4 *)t->st_persist32.ptr;
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_timers_update32: unknown memspace %d", memspace);
+    }
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 64) {               // <= 64 timestamps travel in the kernel arguments
+        rg::TimerParams p = timer_params(t);
+        p.rounds = rounds - r0 < 64 ? rounds - r0 : 64; p.count = count;
+        p.out32 = d_row + (size_t)r0 * count; p.persist32 = d_per + (size_t)r0 * count;
+        for (uint32_t k = 0; k < p.rounds; k++) p.now[k] = now[r0 + k];
+        HIP_TRY(t, rg::launch_timers_update(p, s));
+    }
+    if (memspace == RG_MEM_HOST) HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
 int rg_timers_arm(rg_table_t *t, int64_t now)
 {
     if (!t) return -1;
@@ -1173,7 +1401,7 @@ int rg_timers_expired_epochs(rg_table_t *t, int64_t now, uint32_t *out_gid, uint
         return fail(t, -1, "rg_timers_expired: unknown memspace %d", memspace);
     }
     const uint32_t waves = (t->G + 63) / 64;
-    HIP_TRY(t, rg::launch_timers_expired(t->timer_deadline, t->dt.ident, t->G, now, t->timer_counts, t->timer_counts + waves, d_out, d_ep, capacity, s));
+    HIP_TRY(t, rg::launch_timers_expired(t->timer_deadline, t->dt.ident, t->G, now, nullptr, t->timer_counts, t->timer_counts + waves, d_out, d_ep, capacity, s));
     uint32_t total = 0;
     HIP_TRY(t, hipMemcpyAsync(&total, t->timer_counts + waves, sizeof total, hipMemcpyDeviceToHost, s));
     HIP_TRY(t, hipStreamSynchronize(s));
@@ -1242,6 +1470,35 @@ int rg_health_update(rg_table_t *t, uint32_t rounds, uint32_t count, const uint3
         rg::HealthParams p = health_params(t);
         p.rounds = rounds - r0 < 64 ? rounds - r0 : 64; p.count = count; p.gid = d_gid;
         p.head = d_head + (size_t)r0 * count; p.reply = d_reply + (size_t)r0 * count;
+        for (uint32_t k = 0; k < p.rounds; k++) p.now[k] = now[r0 + k];
+        HIP_TRY(t, rg::launch_health_update(p, s));
+    }
+    if (memspace == RG_MEM_HOST) HIP_TRY(t, hipStreamSynchronize(s));
+    return 0;
+}
+
+int rg_health_update32(rg_table_t *t, uint32_t rounds, const rg_ev_head_t *head, const rg_out32_t *row, const int64_t *now, int memspace)
+{
+    if (!t) return -1;
+    if (!head || !row || !now || rounds == 0) return fail(t, -1, "rg_health_update32: head, row, now and rounds are required");
+    if (bind(t)) return -2;
+    hipStream_t s = t->stream;
+    const uint32_t count = t->G;
+    const size_t rows = (size_t)rounds * count;
+    const rg_ev_head_t *d_head = head;
+    const rg::I32x4 *d_row = (const rg::I32x4 *)row;
+    if (memspace == RG_MEM_HOST) {
+        if (reserve(t, t->st_head, rows * sizeof(rg_ev_head_t)) || reserve(t, t->st_out32, rows * sizeof(rg_out32_t))) return -2;
+        HIP_TRY(t, hipMemcpyAsync(t->st_head.ptr, head, rows * sizeof(rg_ev_head_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(t, hipMemcpyAsync(t->st_out32.ptr, row, rows * sizeof(rg_out32_t), hipMemcpyHostToDevice, s));
+        d_head = (const rg_ev_head_t *)t->st_head.ptr; d_row = (const rg::I32x4 *)t->st_out32.ptr;
+    } else if (memspace != RG_MEM_DEVICE) {
+        return fail(t, -1, "rg_health_update32: unknown memspace %d", memspace);
+    }
+    for (uint32_t r0 = 0; r0 < rounds; r0 += 64) {
+        rg::HealthParams p = health_params(t);
+        p.rounds = rounds - r0 < 64 ? rounds - r0 : 64; p.count = count;
+        p.head = d_head + (size_t)r0 * count; p.out32 = d_row + (size_t)r0 * count;
         for (uint32_t k = 0; k < p.rounds; k++) p.now[k] = now[r0 + k];
         HIP_TRY(t, rg::launch_health_update(p, s));
     }

@@ -108,11 +108,15 @@ struct ReplicateParams {             // N1: Leader.replicateLog for many groups 
 
 struct TimerParams {                 // N4: RaftRoutine.resetTimer / electionTimeout for many groups (rg_kernels.hip)
     int64_t *deadline;               // [G] 0 = no ticket, -1 = fired (TimerTicket.TIMEOUT), >0 = armed
+    uint32_t *epoch;                 // [G] role epoch of the group after the last batch the timers saw (ABI 5): what a compact outcome row, which
+                                     //     names its role epoch only where a conversion happened, is chained from
     const Ident *ident;              // role / role epoch of the table (arm only)
     uint32_t groups, rounds, count;
     const uint32_t *gid;
     const rg_reply_t *reply;
-    int64_t now[64];                 // per-round timestamps of one update launch (<= 64 rounds per launch)
+    const I32x4 *out32, *persist32;  // compact outcome rows (rg_timers_update32): rg_out32_t / rg_persist32_t, dense
+    const int64_t *now_mem;          // non-null: the per-round timestamps are READ from device-visible memory (a recorded tick is replayed with new clocks)
+    int64_t now[64];                 // else: per-round timestamps of one update launch (<= 64 rounds per launch)
     int64_t election_ms, heartbeat_ms;
     uint64_t seed;
 };
@@ -125,6 +129,8 @@ struct HealthParams {                // N4b: Leadership.State health fields + Le
     const uint32_t *gid;
     const rg_ev_head_t *head;
     const rg_reply_t *reply;
+    const I32x4 *out32;              // compact outcome rows instead of `reply` (rg_health_update32)
+    const int64_t *now_mem;          // as TimerParams.now_mem
     int64_t now[64];
 };
 

@@ -191,27 +191,52 @@ __device__ __forceinline__ int64_t rearm(const TimerParams &p, int64_t d, uint32
     return wadd(now, election_timeout(p.seed, g, role_epoch, now, p.election_ms));
 }
 
+template <class P> __device__ __forceinline__ int64_t now_of(const P &p, uint32_t r) { return p.now_mem ? p.now_mem[r] : p.now[r]; }
+
 __global__ __launch_bounds__(256) void timers_update_kernel(const TimerParams p)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.count) return;
     const uint32_t g = p.gid ? p.gid[i] : i;
     int64_t d = p.deadline[g];
+    uint32_t e = p.epoch[g];
     for (uint32_t r = 0; r < p.rounds; r++) {
         const rg_reply_t rep = p.reply[(size_t)r * p.count + i];
+        e = rep.role_epoch;
         if (rep.flags & RG_F_RESET_TIMER)
             d = rearm(p, d, g, (int)RG_F_ROLE(rep.flags), (rep.flags & RG_F_ROLE_CHANGED) != 0, (rep.flags & RG_F_TIMER_MUTED) != 0,
-                      rep.role_epoch, p.now[r]);
+                      rep.role_epoch, now_of(p, r));
     }
     p.deadline[g] = d;
+    p.epoch[g] = e;
+}
+
+// The same from COMPACT outcome rows (rg_out32_t: flags in .y; rg_persist32_t: the role epoch after a conversion in .z). A row without a
+// conversion keeps the epoch of the row before it; the first rows of a batch keep the epoch the group had after the previous batch: p.epoch.
+__global__ __launch_bounds__(256) void timers_update32_kernel(const TimerParams p)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.count) return;
+    int64_t d = p.deadline[g];
+    uint32_t e = p.epoch[g];
+    for (uint32_t r = 0; r < p.rounds; r++) {
+        const size_t row = (size_t)r * p.count + g;
+        const uint32_t flags = (uint32_t)p.out32[row].y;
+        if (flags & RG_F_PERSIST) e = (uint32_t)p.persist32[row].z;
+        if (flags & RG_F_RESET_TIMER)
+            d = rearm(p, d, g, (int)RG_F_ROLE(flags), (flags & RG_F_ROLE_CHANGED) != 0, (flags & RG_F_TIMER_MUTED) != 0, e, now_of(p, r));
+    }
+    p.deadline[g] = d;
+    p.epoch[g] = e;
 }
 
 __global__ __launch_bounds__(256) void timers_arm_kernel(const TimerParams p)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.groups) return;
-    if (p.deadline[g] != 0) return;
     const Ident id = p.ident[g];
+    p.epoch[g] = id.role_epoch;
+    if (p.deadline[g] != 0) return;
     p.deadline[g] = rearm(p, 0, g, (int)(id.meta & META_ROLE), true, false, id.role_epoch, p.now[0]);
 }
 
@@ -220,8 +245,9 @@ __global__ __launch_bounds__(256) void timers_arm_kernel(const TimerParams p)
 //  2. one block: exclusive prefix sum over the wavefront counts
 //  3. per wavefront: every expired lane writes its gid at offset[wave] + popcount(ballot below its lane) and marks
 //     the ticket fired (electionTimeout's CAS deadline -> TimerTicket.TIMEOUT)
-__global__ __launch_bounds__(256) void timers_count_kernel(const int64_t *deadline, uint32_t groups, int64_t now, uint32_t *counts)
+__global__ __launch_bounds__(256) void timers_count_kernel(const int64_t *deadline, uint32_t groups, int64_t now, const int64_t *now_mem, uint32_t *counts)
 {
+    if (now_mem) now = *now_mem;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t d = g < groups ? deadline[g] : 0;
     const unsigned long long m = __ballot(d > 0 && d <= now);
@@ -248,9 +274,10 @@ __global__ __launch_bounds__(1024) void timers_scan_kernel(uint32_t *counts, uin
     if (tid == 1023) *total = part[1023];
 }
 
-__global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const uint32_t *offsets,
-                                                          uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity)
+__global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const int64_t *now_mem,
+                                                          const uint32_t *offsets, uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity)
 {
+    if (now_mem) now = *now_mem;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t d = g < groups ? deadline[g] : 0;
     const bool exp = d > 0 && d <= now;
@@ -268,7 +295,8 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, con
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s)
 {
     if (p.count == 0) return hipSuccess;
-    hipLaunchKernelGGL(timers_update_kernel, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
+    if (p.out32) hipLaunchKernelGGL(timers_update32_kernel, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
+    else         hipLaunchKernelGGL(timers_update_kernel, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s)
@@ -276,13 +304,15 @@ hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s)
     hipLaunchKernelGGL(timers_arm_kernel, dim3((p.groups + 255) / 256), dim3(256), 0, s, p);
     return hipGetLastError();
 }
-hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, uint32_t *counts, uint32_t *total,
+// now_mem non-null: the clock is read from device-visible memory when the kernels RUN (a recorded tick, rg_tick2); total: where the number of expired
+// groups goes (device memory, or page-locked host memory)
+hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const int64_t *now_mem, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s)
 {
     const uint32_t blocks = (groups + 255) / 256, waves = (groups + 63) / 64;
-    hipLaunchKernelGGL(timers_count_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, counts);
+    hipLaunchKernelGGL(timers_count_kernel, dim3(blocks), dim3(256), 0, s, deadline, groups, now, now_mem, counts);
     hipLaunchKernelGGL(timers_scan_kernel, dim3(1), dim3(1024), 0, s, counts, waves, total);
-    hipLaunchKernelGGL(timers_emit_kernel, dim3(blocks), dim3(256), 0, s, deadline, ident, groups, now, counts, out_gid, out_epoch, capacity);
+    hipLaunchKernelGGL(timers_emit_kernel, dim3(blocks), dim3(256), 0, s, deadline, ident, groups, now, now_mem, counts, out_gid, out_epoch, capacity);
     return hipGetLastError();
 }
 
@@ -295,19 +325,19 @@ __global__ __launch_bounds__(256) void health_update_kernel(const HealthParams p
     const size_t G = p.t.groups;
     for (uint32_t r = 0; r < p.rounds; r++) {
         const size_t row = (size_t)r * p.count + i;
-        const rg_reply_t rep = p.reply[row];
-        if ((rep.flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(rep.flags) == RG_LEADER) {      // new Leader: new State objects
+        const uint32_t flags = p.out32 ? (uint32_t)p.out32[row].y : p.reply[row].flags;      // (rg_out32_t.flags are rg_reply_t.flags)
+        if ((flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(flags) == RG_LEADER) {      // new Leader: new State objects
             for (uint32_t j = 0; j < p.followers; j++) { p.ok[j * G + g] = 0; p.fail[j * G + g] = 0; p.recent[j * G + g] = 0; }
             continue;
         }
-        const uint32_t hdr = p.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(rep.flags);
+        const uint32_t hdr = p.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(flags);
         const bool ack = kind == RG_EV_AE_ACK || kind == RG_EV_IS_ACK;
         // statSuccess ran iff the callback got past the fence and the term check and the row was applied
         const bool reached = st == RG_OK || st == RG_A_MATCH_ROLLBACK || st == RG_NPE_MAJOR_NULL || st == RG_A_COMMIT_ROLLBACK;
-        if (!ack || !reached || (rep.flags & RG_F_ROLE_CHANGED) || slot >= p.followers + 1 || slot == p.self) continue;
+        if (!ack || !reached || (flags & RG_F_ROLE_CHANGED) || slot >= p.followers + 1 || slot == p.self) continue;
         const uint32_t j = slot < p.self ? slot : slot - 1;
-        const int64_t cur = p.ok[j * G + g];
-        if (p.now[r] > cur) p.ok[j * G + g] = p.now[r];                          // increaseMono
+        const int64_t cur = p.ok[j * G + g], now = now_of(p, r);
+        if (now > cur) p.ok[j * G + g] = now;                                    // increaseMono
         p.recent[j * G + g] = 0;
     }
 }
@@ -331,6 +361,7 @@ __global__ __launch_bounds__(256) void health_failure_kernel(const HealthParams 
 // Leader.isReady: ready = 1; for every State that isReady(...): ++ready > followers/2 -> true
 __global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_t now, int32_t critical_point, int64_t cool_down, uint8_t *ready)
 {
+    if (p.now_mem) now = *p.now_mem;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.t.groups) return;
     const Ident id = p.t.ident[g];

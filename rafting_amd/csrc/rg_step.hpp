@@ -708,6 +708,23 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 // outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
 struct Row32 { U32x2 h; I32x4 q; };
 
+// One 16-byte LDS row from four values that live in registers of their own. A ds_write_b128 wants them in four CONSECUTIVE registers, and the outcome rows
+// are made of loop-carried group state (term, votedFor, role, role epoch, commitIndex): each of those is a v_mov per round into the tuple — vector
+// instructions, the one resource this kernel is short of. Two ds_write2_b32 take any four registers.
+__device__ __forceinline__ void store_row(I32x4 *row, int32_t x, int32_t y, int32_t z, int32_t w)
+{
+#ifdef RG_ROW_AS_ONE_STORE          // (the host emulation; A/B builds)
+    *row = I32x4{x, y, z, w};
+#else
+    typedef __attribute__((address_space(3))) int32_t lds_i32;
+    lds_i32 *p = (lds_i32 *)reinterpret_cast<int32_t *>(row);
+    // (four scalar stores are merged back into one ds_write_b128 by the compiler: spelled out. Its wait-count bookkeeping does not see these two operations;
+    //  LDS answers in order, so a wait it computes for an operation of its own can only come out stronger than needed, never weaker — and the hand-over
+    //  barrier drains the queue explicitly: lds_barrier)
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3" : : "v"(p), "v"(x), "v"(y), "v"(z), "v"(w) : "memory");
+#endif
+}
+
 // What the I/O wavefront makes of a compact row for the deciding wavefront of the 32-bit body: {class word, aux, n, header'}. The class word
 // (rg_tier1n.hpp: CW_*) holds every fact about the row that does not depend on the group's state, one bit each, plus the follower index of an
 // ack's responder. Most of it depends on (kind, slot) only — cluster size and own slot are launch constants — and comes from a 256-entry
@@ -968,8 +985,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         // A round that does visit the general handlers writes the rows again afterwards.
         const uint64_t b_open = __builtin_amdgcn_ballot_w64(open);
         const uint32_t slot = r & 1u;
-        sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
-        sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
+        store_row(&sh_o0[slot][lane], out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit);
+        store_row(&sh_o1[slot][lane], out.log_from, g.term, g.voted_for, g.role);
         if (b_open != 0) {
             // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
             const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
@@ -1002,8 +1019,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
                 if (lane == 0) *sh_bail = r + 2u;
                 bailed = true;
             }
-            sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
-            sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
+            store_row(&sh_o0[slot][lane], out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit);
+            store_row(&sh_o1[slot][lane], out.log_from, g.term, g.voted_for, g.role);
         }
         RG_PROBE_MARK(2);
         lds_barrier();

@@ -31,7 +31,7 @@ def exported_symbols():
     """Every entry point include/raftgpu.h declares."""
     return [
         "rg_abi_version", "rg_table_create", "rg_table_destroy", "rg_last_error", "rg_table_groups",
-        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_outcome32_unpack_rel", "rg_index_base_set", "rg_index_base_get", "rg_batch32_pack_rel", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_tick_create", "rg_tick_launch", "rg_tick_wait", "rg_tick_destroy", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
+        "rg_table_cluster", "rg_table_option", "rg_load_state", "rg_read_state", "rg_submit", "rg_submit32", "rg_submit32c", "rg_outcome32_unpack", "rg_outcome32_unpack_rel", "rg_index_base_set", "rg_index_base_get", "rg_batch32_pack_rel", "rg_batch32_pack", "rg_submit_async", "rg_submit_async_packed", "rg_submit_wait", "rg_tick_create", "rg_tick_launch", "rg_tick_wait", "rg_tick_destroy", "rg_tick2_create", "rg_tick2_launch", "rg_tick2_wait", "rg_tick2_destroy", "rg_timers_update32", "rg_health_update32", "rg_sync", "rg_step_kernel", "rg_host_alloc", "rg_host_free", "rg_dev_alloc",
         "rg_dev_free", "rg_copy_to_device", "rg_copy_to_host", "rg_stream", "rg_replicate", "rg_timers_configure", "rg_timers_update",
         "rg_timers_expired", "rg_timers_expired_epochs", "rg_timers_arm", "rg_timers_read", "rg_health_update", "rg_health_failure", "rg_ready", "rg_health_read",
         "rg_timing_enable",
@@ -121,6 +121,12 @@ def lib():
         L.rg_tick_launch.argtypes = [vp]
         L.rg_tick_wait.argtypes = [vp]
         L.rg_tick_destroy.argtypes = [vp]
+        L.rg_tick2_create.argtypes = [vp, C.POINTER(abi.CTick2Io), C.POINTER(vp)]
+        L.rg_tick2_launch.argtypes = [vp]
+        L.rg_tick2_wait.argtypes = [vp]
+        L.rg_tick2_destroy.argtypes = [vp]
+        L.rg_timers_update32.argtypes = [vp, u32, vp, vp, vp, i32]
+        L.rg_health_update32.argtypes = [vp, u32, vp, vp, vp, i32]
         L.rg_replicate.argtypes = [vp, u32, vp, vp, vp, vp, vp, i32]
         L.rg_step_kernel.restype = C.c_char_p
         L.rg_step_kernel.argtypes = [vp, u32]
@@ -315,6 +321,110 @@ class Tick:
         if self._h:
             lib().rg_tick_destroy(self._h)
             self._h = None
+
+
+class Tick2:
+    """The device-resident tick (rg_tick2_create): compact rows in, compact outcome rows out, the batch folded into the timers and the followers' health,
+    the fired tickets listed, the leaders' send table and the readiness gate — ONE HIP graph, replayed with launch() / wait(). Every column lives in
+    page-locked host memory here (the device reads and writes it over the link) so that a test can fill and read it with numpy; a deployment puts what
+    only the device consumes into HBM (rg_dev_alloc).  refill(batch, now[, heartbeat, in_flight]) writes the next tick's rows and clocks."""
+
+    def __init__(self, table, rounds, entry_cap=0, expired_cap=None, send=True, ready=True, critical_point=0, cool_down_ms=0, device_resident=False):
+        G, F = table.groups, table.cluster - 1
+        self.table, self.rounds, self.G, self.F = table, rounds, G, F
+        rows = rounds * G
+        self._pins = []
+        self._devs = []
+
+        def col(dtype, n):
+            a, p = pinned_like(table, np.zeros(max(n, 1), dtype=dtype))
+            self._pins.append(p)
+            return a
+
+        def big(dtype, n):
+            # (device_resident: what only the device reads or writes stays in HBM; the tick is then measured without the link)
+            if not device_resident:
+                return col(dtype, n)
+            b = DeviceBuffer(table, max(n, 1) * np.dtype(dtype).itemsize)
+            self._devs.append(b)
+            return b
+        self.head, self.abcd = big(abi.HEAD_DT, rows), big(abi.QUAD32_DT, rows)
+        self.entry_terms = big(np.int32, entry_cap) if entry_cap else None
+        self.now = col(np.int64, rounds)
+        self.heartbeat, self.in_flight = col(np.uint8, G), col(np.uint16, F * G)
+        self.row, self.persist32 = big(abi.OUT32_DT, rows), big(abi.PERSIST32_DT, rows)
+        cap = G if expired_cap is None else expired_cap
+        self.expired_cap = cap
+        self.expired_gid, self.expired_epoch, self.expired_count = (col(np.uint32, cap), col(np.uint32, cap), col(np.uint32, 1)) if cap else (None, None, None)
+        self.send_head, self.send = (big(abi.SEND_HEAD_DT, G), big(abi.SEND_DT, F * G)) if send else (None, None)
+        self.ready = big(np.uint8, G) if ready else None
+        addr = lambda a: None if a is None else (a.ptr if isinstance(a, DeviceBuffer) else a.ctypes.data)   # noqa: E731
+        io = abi.CTick2Io()
+        io.rounds, io.head, io.abcd, io.entry_terms, io.entry_capacity = rounds, addr(self.head), addr(self.abcd), addr(self.entry_terms), entry_cap
+        io.now, io.heartbeat, io.in_flight = addr(self.now), addr(self.heartbeat), addr(self.in_flight)
+        io.critical_point, io.cool_down_ms = critical_point, cool_down_ms
+        io.row, io.persist32 = addr(self.row), addr(self.persist32)
+        io.expired_gid, io.expired_epoch, io.expired_count, io.expired_capacity = addr(self.expired_gid), addr(self.expired_epoch), addr(self.expired_count), cap
+        io.send_head, io.send, io.ready = addr(self.send_head), addr(self.send), addr(self.ready)
+        self.io = io
+        h = C.c_void_p()
+        table._check(lib().rg_tick2_create(table._h, C.byref(io), C.byref(h)))
+        self._h = h
+
+    def _put(self, dst, src):
+        if isinstance(dst, DeviceBuffer):
+            a = np.ascontiguousarray(src)
+            self.table._check(lib().rg_copy_to_device(self.table._h, dst.ptr, a.ctypes.data, a.nbytes))
+        else:
+            dst[: len(src)] = src
+
+    def _get(self, src, dtype, n):
+        return src.to_host(dtype, n) if isinstance(src, DeviceBuffer) else np.array(src[:n], copy=True)
+
+    def refill(self, batch, now, heartbeat=None, in_flight=None, index_base=None):
+        b32 = batch if isinstance(batch, abi.Batch32) else pack32(batch, index_base)
+        assert (b32.rounds, b32.count) == (self.rounds, self.G) and b32.gid is None and b32.entry_count <= self.io.entry_capacity
+        self._put(self.head, b32.head)
+        self._put(self.abcd, b32.abcd)
+        if b32.entry_count:
+            self._put(self.entry_terms, b32.entry_terms[: b32.entry_count])
+        self.now[:] = np.asarray(now, dtype=np.int64)
+        self.heartbeat[:] = 0 if heartbeat is None else heartbeat
+        self.in_flight[:] = 0 if in_flight is None else np.asarray(in_flight, dtype=np.uint16).reshape(-1)
+
+    def launch(self):
+        self.table._check(lib().rg_tick2_launch(self._h))
+
+    def wait(self):
+        self.table._check(lib().rg_tick2_wait(self._h))
+
+    def outcome32(self):
+        rows = self.rounds * self.G
+        out = abi.Outcome32(rows, wide=False)
+        out.row, out.persist = self._get(self.row, abi.OUT32_DT, rows), self._get(self.persist32, abi.PERSIST32_DT, rows)
+        return out
+
+    def expired(self):
+        """-> (gids, role epochs, total) of the tickets that fired by now[rounds - 1]"""
+        n = int(self.expired_count[0])
+        k = min(n, self.expired_cap)
+        return np.array(self.expired_gid[:k]), np.array(self.expired_epoch[:k]), n
+
+    def sends(self):
+        return self._get(self.send_head, abi.SEND_HEAD_DT, self.G), self._get(self.send, abi.SEND_DT, self.F * self.G).reshape(self.F, self.G).T.copy()
+
+    def readiness(self):
+        return self._get(self.ready, np.uint8, self.G)
+
+    def close(self):
+        if self._h:
+            lib().rg_tick2_destroy(self._h)
+            self._h = None
+        for p in self._pins:
+            p.free()
+        for b in self._devs:
+            b.free()
+        self._pins, self._devs = [], []
 
 
 class DeviceBuffer:
@@ -593,6 +703,19 @@ class Table:
         assert len(now) == batch_rounds and len(reply) == batch_rounds * batch_count
         self._check(lib().rg_timers_update(self._h, batch_rounds, batch_count, None if gid is None else gid.ctypes.data,
                                            reply.ctypes.data, now.ctypes.data, abi.MEM_HOST))
+
+    def timers_update32(self, rounds, out32, now):
+        """rg_timers_update from the COMPACT outcome rows of a dense batch (abi.Outcome32: .row, .persist)"""
+        now = np.ascontiguousarray(now, dtype=np.int64)
+        row, per = np.ascontiguousarray(out32.row), np.ascontiguousarray(out32.persist)
+        assert len(now) == rounds and len(row) == rounds * self.groups == len(per)
+        self._check(lib().rg_timers_update32(self._h, rounds, row.ctypes.data, per.ctypes.data, now.ctypes.data, abi.MEM_HOST))
+
+    def health_update32(self, batch, out32, now):
+        now = np.ascontiguousarray(now, dtype=np.int64)
+        row = np.ascontiguousarray(out32.row)
+        assert batch.gid is None and len(now) == batch.rounds and len(row) == batch.rounds * self.groups
+        self._check(lib().rg_health_update32(self._h, batch.rounds, batch.head.ctypes.data, row.ctypes.data, now.ctypes.data, abi.MEM_HOST))
 
     def timers_arm(self, now):
         self._check(lib().rg_timers_arm(self._h, now))

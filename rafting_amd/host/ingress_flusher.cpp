@@ -24,7 +24,11 @@ IngressFlusher::IngressFlusher(std::vector<rg_table_t *> tables, Ingress &ing, c
     rep_.resize(tables_.size()); lfx_.resize(tables_.size()); per_.resize(tables_.size());
     ing_.retain_bodies(true);
     // the ordering contract of INTEGRATION.md section 1, enforced: a timeout row names the participant whose ticket fired (context/RaftRoutine.java:65-77)
-    for (rg_table_t *t : tables_) rg_table_option(t, RG_OPT_REQUIRE_FENCED_TIMEOUTS, 1);
+    // (this CHANGES the tables for every other user of theirs — an RG_EV_TIMEOUT row with aux == 0 is RG_BAD_EVENT from here on — and is part of what a
+    //  recorded tick bakes in: create rg_tick_* / rg_tick2_* recordings on these tables AFTER the flusher; an older one is refused at its next launch)
+    for (rg_table_t *t : tables_)
+        if (rg_table_option(t, RG_OPT_REQUIRE_FENCED_TIMEOUTS, 1) != 0)
+            throw std::runtime_error(std::string("IngressFlusher: rg_table_option(RG_OPT_REQUIRE_FENCED_TIMEOUTS): ") + rg_last_error(t));
 }
 
 // One applied row -> the host-owned plugins, in the handler's order.

@@ -25,6 +25,8 @@ public:
     // log_of(gid) -> the group's RaftLog; term_of_group[gid] = its currentTerm (kept current from the rows' persist records: a client append
     // creates entries of that term, member/Leader.java:128-140). wide_kernel: decide the batch through rg_submit on an unpacked copy instead
     // of rg_submit32 (tests on the lane-serial emulation of the kernels, which cannot run the compact-row kernel).
+    // NOTE: the constructor turns RG_OPT_REQUIRE_FENCED_TIMEOUTS on for every table it is given (the ordering contract of INTEGRATION.md section 1) and
+    // throws when a table refuses; recordings of the once-per-tick paths (rg_tick_*, rg_tick2_*) on those tables must be created afterwards.
     IngressFlusher(rg_table_t *table, Ingress &ing, const KryoBodyCodec &codec, std::function<raftgpu::host::RaftLog &(uint32_t)> log_of,
                    std::vector<int64_t> term_of_group, raftgpu::host::StableStore *store = nullptr, bool wide_kernel = false);
     // An ingress in front of SEVERAL tables (Ingress's `shards`: block partition, one table per GPU — what support/EventLoopGroup.java:77-80's

@@ -133,6 +133,11 @@ def test_the_once_per_tick_graph_matches_the_oracle():
     T.tick_path_case(G=128, ticks=12)
 
 
+def test_the_device_resident_tick_matches_the_oracle():
+    T.tick2_case(G=128, ticks=14)
+    T.tick2_case(G=64, ticks=6, seed=9, device_resident=True)
+
+
 def test_groups_at_two_to_the_forty_stay_on_the_32_bit_body():
     T.index_base_case(G=192, rounds=24)
     T.index_base_workload_case(groups=320, rounds=12)

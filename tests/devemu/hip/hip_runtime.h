@@ -81,6 +81,7 @@ extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kern
 #define RG_GLOBAL_AS                 /* rg_step.hpp: global-memory pointers made from integers */
 #define RG_OWN_SGPRS(v) ((void)0)
 #define RG_FRESH_VGPR(v) ((void)0)
+#define RG_ROW_AS_ONE_STORE 1        /* rg_step.hpp: store_row() spells two ds_write2_b32 in assembly on the GPU */
 #define __builtin_amdgcn_s_sleep(x) (::hipemu::lane_yield())
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
 #define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */
@@ -113,6 +114,14 @@ static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { const hip
 static inline hipError_t hipHostFree(void *p) { ::hipemu::pinned_remove(p); free(p); return hipSuccess; }
 // page-locked memory is mapped at its own address; anything else is not device-visible (as on the real runtime)
 static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { if (!::hipemu::pinned_has(h)) return hipErrorInvalidValue; *d = h; return hipSuccess; }
+// what kind of memory a pointer is: page-locked ranges are known; everything else on the heap stands for device memory here
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; void *devicePointer; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p)
+{
+    a->type = ::hipemu::pinned_has(p) ? hipMemoryTypeHost : hipMemoryTypeDevice; a->devicePointer = const_cast<void *>(p);
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t)
 {
     if (::hipemu::capture_) { ::hipemu::capture_->push_back([=]() { memmove(d, s, n); }); return hipSuccess; }

@@ -147,6 +147,36 @@ int main(void)
         printf("compact outcome rows through the shim: %u appends, %u conversions, identical to the C-ABI\n", appended, converted);
     }
 
+    /* misuse: a heap ByteBuffer (no direct address), a short buffer, a missing required column — IllegalArgumentException, the library never
+     * sees the address; an optional column may be null */
+    {
+        rg_ev_head_t hd[G]; rg_ev_pair_t xy[G]; rg_reply_t rp[G]; rg_logfx_t lf[G]; rg_persist_t pr[G];
+        memset(hd, 0, sizeof hd); memset(xy, 0, sizeof xy);
+        struct _jobject heap = {K_BUFFER, NULL, (jlong)sizeof hd, 0, 0, 0};            /* GetDirectBufferAddress answers NULL for it */
+        uint32_t gids[G];
+        for (uint32_t g = 0; g < G; g++) gids[g] = g;
+        struct _jobject heap_gid = {K_BUFFER, NULL, (jlong)sizeof gids, 0, 0, 0};
+        thrown[0] = 0;
+        if (J(GpuTable, submit)(env, NULL, h, 1, G, &heap_gid, buf(hd, sizeof hd), buf(xy, sizeof xy), buf(xy, sizeof xy), NULL, 0, NULL, buf(rp, sizeof rp), buf(lf, sizeof lf),
+                                buf(pr, sizeof pr)) != -1 || !strstr(thrown, "gid") || !strstr(thrown, "DIRECT")) { fprintf(stderr, "heap gid accepted: '%s'\n", thrown); return 1; }
+        thrown[0] = 0;
+        if (J(GpuTable, submit)(env, NULL, h, 1, G, NULL, &heap, buf(xy, sizeof xy), buf(xy, sizeof xy), NULL, 0, NULL, buf(rp, sizeof rp), buf(lf, sizeof lf),
+                                buf(pr, sizeof pr)) != -1 || !strstr(thrown, "head")) { fprintf(stderr, "heap head accepted: '%s'\n", thrown); return 1; }
+        thrown[0] = 0;
+        if (J(GpuTable, submit)(env, NULL, h, 1, G, NULL, buf(hd, sizeof hd), buf(xy, sizeof xy), buf(xy, sizeof xy), NULL, 0, NULL, buf(rp, sizeof rp - 16), buf(lf, sizeof lf),
+                                buf(pr, sizeof pr)) != -1 || !strstr(thrown, "reply") || !strstr(thrown, "capacity")) { fprintf(stderr, "short reply accepted: '%s'\n", thrown); return 1; }
+        thrown[0] = 0;
+        if (J(GpuTable, submit)(env, NULL, h, 1, G, NULL, buf(hd, sizeof hd), buf(xy, sizeof xy), NULL, NULL, 0, NULL, buf(rp, sizeof rp), buf(lf, sizeof lf),
+                                buf(pr, sizeof pr)) != -1 || !strstr(thrown, "cd") || !strstr(thrown, "null")) { fprintf(stderr, "missing cd accepted: '%s'\n", thrown); return 1; }
+        jobject short_cols[NCOL];
+        for (int i = 0; i < NCOL; i++) short_cols[i] = cols[i];
+        short_cols[9] = buf(((void **)&st)[9], G * sizes[9] - 8);                       /* elected_term one element short */
+        struct _jobject short_state = {K_ARRAY, 0, 0, NCOL, short_cols, 0};
+        thrown[0] = 0;
+        if (J(GpuTable, readState)(env, NULL, h, 0, G, &short_state) != -1 || !strstr(thrown, "capacity")) { fprintf(stderr, "short state column accepted: '%s'\n", thrown); return 1; }
+        thrown[0] = 0;
+    }
+
     /* page-locked memory as a direct buffer, and back */
     jobject pinned = J(GpuTable, hostAlloc)(env, NULL, h, 4096);
     if (!pinned || pinned->cap != 4096 || !pinned->addr) return 1;

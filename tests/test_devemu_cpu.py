@@ -51,7 +51,10 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
               "roofline", "cpu_baseline", "pcie_inclusive_value"):
         assert k in d, k
     assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "int64"
-    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"]) and d["roofline"]["bound"] == "hbm"
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "valu", "per_launch", "pmc_passes")) <= set(d["roofline"]) and d["roofline"]["bound"] == "valu"
+    pl = d["roofline"]["per_launch"]                                          # round 6: one event pair per launch, the same launches once more
+    assert "error" not in pl and pl["launches"] == 2 and 0 < pl["min_ms"] <= pl["median_ms"] <= pl["max_ms"]
+    assert d["roofline"]["pmc_passes"] is None and d["roofline"]["valu"] is None      # (no counters, no device properties on the emulation)
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     legs = d["pcie_inclusive"]
     assert legs["serial_rg_submit"] > 0 and legs["pipelined_rg_submit_async"] > 0 and legs["pipelined_rg_submit_async_packed"] > 0
@@ -67,6 +70,7 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     tk = d["tick_latency"]                                                      # round 5: the once-per-tick path, both ways
     assert "error" not in tk, tk
     assert tk["rg_tick_launch"]["p50_us"] > 0 and tk["rg_submit_async_packed"]["p99_us"] > 0 and tk["device_us_per_single_round_launch"] > 0
+    assert tk["rg_tick_launch"]["max_us"] >= tk["rg_tick_launch"]["p99_us"] and tk["device_us_per_resident_tick"] > 0      # round 6: the device-resident tick (rg_tick2_*)
     ll = d["long_lived_groups"]                                                 # round 5: groups at 2^40 on the 32-bit body (index bases), checked against the oracle in the run
     assert "error" not in ll, ll
     assert d["value_long_lived_groups"] > 0 and ll["int64_body_workgroups"] == 0 and d["int64_body_workgroups"] == 0 and "bit-identical" in ll["checked"]

@@ -1022,6 +1022,110 @@ def tick_path_case(G=192, P=5, ticks=24, seed=123):
     orc.close()
 
 
+def tick2_case(G=4096, P=5, ticks=40, seed=321, device_resident=False):
+    """The device-resident tick (rg_tick2_*, ABI 5): step32c -> timers_update32 -> health_update32 -> timers_expired -> replicate -> ready as ONE HIP graph,
+    driven by its own timers: the tickets that fire become the TIMEOUT rows (with their role epochs) of the NEXT tick, tick after tick. Every tick is held
+    against the oracle doing the same with separate calls: outcome rows, deadlines, expired lists + epochs, health statistics, send table, readiness."""
+    self_slot = 2 % P
+    st0 = fuzz.random_initial_state(G, P, self_slot, seed)
+    gpu, orc = engine.Table(G, P, self_slot, True), oracle_lib.OracleTable(G, P, self_slot, True)
+    fz = fuzz.Fuzzer(G, P, self_slot, seed, allow_miss=False)
+    for t in (gpu, orc):
+        t.load_state(st0)
+        t.timers_configure(900, 300, 4321)
+        t.timers_arm(10_000)
+    assert np.array_equal(gpu.timers_read(), orc.timers_read())
+    tick = engine.Tick2(gpu, 1, entry_cap=8 * G, expired_cap=G, critical_point=1, cool_down_ms=60, device_resident=device_resident)
+    fired_g, fired_e = np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+    seen_fired = seen_send = repaired = 0
+    rng = np.random.default_rng(seed)
+    for k in range(ticks):
+        now = 10_000 + 150 * k
+        b = abi.Batch(1, G)
+        cur = gpu.read_state()
+        fz.round(cur, b, 0)
+        for g, e in zip(fired_g, fired_e):                  # the tickets that fired at the end of the previous tick: their onTimeout, fenced
+            b.head[int(g)] = (int(abi.hdr_make(abi.EV_TIMEOUT)), int(e))
+        assert abi.batch_fits_32(b)
+        hb = (rng.random(G) < 0.5).astype(np.uint8)
+        fl = rng.integers(0, 24, (G, P - 1)).astype(np.uint16)
+        tick.refill(b, [now], heartbeat=hb, in_flight=fl.T.reshape(-1))
+        tick.launch()
+        tick.wait()
+        got, _ = engine.unpack32(tick.outcome32(), 1, G, cur.role_epoch)
+        # (an ack whose quorum index lies below the cached term runs: the host half of the NEED_HOST protocol, then the repaired rows folded like the others;
+        #  what the graph derived for THOSE groups in this tick — send rows, readiness — was derived before the repair and is not compared)
+        bad = np.flatnonzero(got.status == abi.NEED_HOST)
+        if len(bad):
+            repaired += _resolve_need_host(gpu, orc, b, got, cur)
+            sub = _subset(b, bad, bad.astype(np.uint32))
+            gpu.timers_update(1, len(bad), got.reply[bad], [now], gid=bad.astype(np.uint32))
+            gpu.health_update(sub, got.reply[bad], [now])
+        oo = orc.submit(b, now=[now])
+        compare_outcomes(oo, got, "tick %d" % k)
+        orc.timers_update(1, G, oo.reply, [now])
+        eo, epo, no = orc.timers_expired_epochs(now, capacity=G)
+        eg, epg, ng = tick.expired()
+        assert ng == no and np.array_equal(eg, eo) and np.array_equal(epg, epo), k
+        assert np.array_equal(gpu.timers_read(), orc.timers_read()), k
+        for a, c in zip(gpu.health_read(), orc.health_read()):
+            assert np.array_equal(a, c), k
+        ok = np.ones(G, dtype=bool)
+        ok[bad] = False
+        (hg, sg), (ho, so) = tick.sends(), orc.replicate(heartbeat=hb, in_flight=fl)
+        if len(bad):
+            gpu.replicate(gid=bad.astype(np.uint32), heartbeat=hb[bad], in_flight=fl[bad])     # (prepareReplication of a repaired leader, as the oracle just ran it)
+        for f in ("term", "leader_commit", "epoch_index", "epoch_term", "role_epoch", "is_leader"):
+            assert np.array_equal(hg[f][ok], ho[f][ok]), (k, f)
+        for f in ("prev_index", "prev_term", "last_index", "count", "kind"):
+            assert np.array_equal(sg[f][ok], so[f][ok]), (k, f)
+        assert np.array_equal(tick.readiness()[ok], orc.ready(now, 1, 60)[ok]), k
+        compare_states(orc.read_state(), gpu.read_state(), "tick %d" % k)
+        fired_g, fired_e = eg, epg
+        seen_fired += len(eg)
+        seen_send += int(np.count_nonzero(so["kind"] == abi.SEND_APPEND))
+    assert seen_fired > 0 and seen_send > 0
+    # the separate calls on compact rows give what the wide ones give: one more batch, through rg_submit32c + rg_timers_update32 / rg_health_update32
+    b = abi.Batch(1, G)
+    cur = gpu.read_state()
+    fz.round(cur, b, 0)
+    raw = gpu.submit32c(b)
+    got, _ = engine.unpack32(raw, 1, G, cur.role_epoch)
+    if not np.any(got.status == abi.NEED_HOST):
+        oo = orc.submit(b, now=[99_000])
+        gpu.timers_update32(1, raw, [99_000])
+        gpu.health_update32(b, raw, [99_000])
+        orc.timers_update(1, G, oo.reply, [99_000])
+        assert np.array_equal(gpu.timers_read(), orc.timers_read())
+        for a, c in zip(gpu.health_read(), orc.health_read()):
+            assert np.array_equal(a, c)
+    # a recording is refused once the table's options have moved on ...
+    gpu.set_option(abi.OPT_REQUIRE_FENCED_TIMEOUTS, 1)
+    with pytest.raises(engine.EngineError):
+        tick.launch()
+    tick.close()
+    gpu.close()
+    orc.close()
+    # ... and knows no table once its table is gone: launch / wait answer -1, destroy only frees the handle (ADVICE r5; the same holds for rg_tick_*)
+    small = engine.Table(64, 3, 0, True)
+    orphan = engine.Tick2(small, 1, expired_cap=64)
+    shape = abi.Batch(1, 64)
+    pb = engine.PackedBatch(small, shape)
+    old_tick = engine.Tick(small, pb)
+    small.close()
+    L = engine.lib()
+    assert L.rg_tick2_launch(orphan._h) == -1 and L.rg_tick2_wait(orphan._h) == -1 and L.rg_tick2_destroy(orphan._h) == 0
+    assert L.rg_tick_launch(old_tick._h) == -1 and L.rg_tick_wait(old_tick._h) == -1 and L.rg_tick_destroy(old_tick._h) == 0
+    orphan._h = old_tick._h = None                          # (their page-locked columns went with the table's context: nothing to free through it any more)
+
+
+def test_the_device_resident_tick_matches_the_oracle(step_kernel_variant):
+    if step_kernel_variant != "compact-out32":
+        pytest.skip("one route: the tick always runs the compact-row kernel with compact outcome rows")
+    tick2_case()
+    tick2_case(G=1024, ticks=12, seed=77, device_resident=True)
+
+
 def test_the_once_per_tick_graph_matches_the_oracle(step_kernel_variant):
     if step_kernel_variant != "compact":
         pytest.skip("one route: the tick path always runs the compact-row kernel")
