@@ -234,18 +234,13 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     g.log_dirty = g.log_dirty | app;
     g.peers_dirty = g.peers_dirty | ~fk_n;
     const int32_t cand = (ae_wc < 0) ? ae_x : ack_ct;
-#ifndef RG_ADV_COMMIT_OLD
-    const sw adv_commit = s_lt(commit, cand);                       // markCommitted moved commitIndex (formed from the old value, so that the new one can take its register)
-    g.commit = vmax<int32_t>(commit, cand);
-#else
-    g.commit = vmax<int32_t>(commit, cand);
-    const sw adv_commit = s_lt(commit, g.commit);
-#endif
+    const int32_t new_commit = vmax<int32_t>(commit, cand);
+    g.commit = new_commit;
     uint32_t pw = push_bit(0u, fa_n);
     pw = push_bit(pw, x_ct);
     pw = push_bit(pw, ae_ref);
     pw = push_bit(pw, app);
-    pw = push_bit(pw, adv_commit);
+    pw = push_bit(pw, s_lt(commit, new_commit));
     pw = push_bit(pw, fc_n);
     out.resp = a;
     out.log_from = last + 1;
@@ -253,6 +248,7 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     // that visited the general handlers for each of them would pay a slow round per parked round; their answer for such a row is this one)
     sw done = ~fa_n | ~fk_n | ~fc_n | drop | cw_bit(cw, CW_NONE);
     sw any_drop = drop;
+    uint32_t pw_el = 0u;
 
     // ---- what steady replication does not carry, behind ONE wave-uniform branch -------------------------------------------------------
     // rare: a new term run at the log tail (the first entries of a new leader's term), prepareReplication after a leader's first entry;
@@ -270,10 +266,9 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     if ((b_rare | b_el) != 0) {
         if (b_rare != 0) {
             const bool ae_newrun = (app_ae & x_pl) < 0, fc_newrun = (~fc_n & x_tl) < 0, fc_prepare = (~fc_n & ~prep) < 0;
-            // (out.log_from is the old last + 1; a leader's term did not move above)
-            if (ae_newrun | fc_newrun) g.push_run(out.log_from, ae_newrun ? aux : g.term);
+            if (ae_newrun | fc_newrun) g.push_run(last + 1, ae_newrun ? aux : term);
             if (fc_prepare) {                                           // Leader.prepareReplication after the FIRST new entry: nextIndex = that entry + 1
-                pe.store_prepare(epoch, out.log_from + 1);
+                pe.store_prepare(epoch, last + 2);
                 g.pending = 0;
                 g.prepared = -1; g.peers_dirty = -1;
             }
@@ -282,14 +277,6 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
             // One sub-block per row class, each behind its own ballot, and the conversion tail behind one more: three election rows of four are
             // vote replies that are merely counted (config 3: 1.19 % of the rows, 54 % of the wave-rounds; timeouts 12 %, vote requests 9 %), and a
             // launch ends with its slowest workgroup — the one that meets such a row in 61 of its 64 rounds.
-            // Round 6: this block reads the group AS THE CLASSES ABOVE LEFT IT, not the snapshot taken at the top: a lane in an election class was in none of
-            // them, so for it the two are the same values, and the other lanes compute nothing here that is kept. What it buys: the snapshot's registers die with
-            // the main path's last use, the updated fields can take their place, and the join below needs no copies for them (9 v_mov per round on the path
-            // that does NOT come here — tools/spine.py).
-#ifndef RG_EL_SNAPSHOT            // (A/B builds: the block on the snapshot, as rounds 3-5 had it)
-            const int32_t term = g.term, votes = g.votes, last = g.last, repoch = (int32_t)g.role_epoch;
-            const sw td = g.td;
-#endif
             const int32_t term1 = term + 1;
             const sw is_pv = cw_bit(cw, CW_PV);
             const sw not_f = s_pos(role), not_c = s_ne(role, RG_CANDIDATE), not_l = s_ne(role, RG_LEADER);
@@ -320,7 +307,6 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 conv = conv | (vr_cur & x_Ta) | vr_win | (late_higher & ~s_lt(a, term));
                 el_fast = el_fast | vr_cur | late_higher | late_noop | vote_drop;
                 any_drop = any_drop | vote_drop;
-                g.votes = g.votes + (int32_t)((uint32_t)count >> 31);  // (a counted vote never converts; a converting row sets votes = 1 below)
             }
             // timeouts (aux 0 = whoever is current; context/RaftRoutine.java:70)
             if (b_to != 0) {
@@ -351,12 +337,10 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 reset = reset | pv_judge;
                 conv = conv | rv_new;
                 el_fast = el_fast | vq;
-                out.resp = ((vq & ~rv_new) < 0) ? term : a;             // (only read for the vote requests)
             }
             // RaftRoutine.convertTo + RaftMember.<init> for the lanes in `conv`; what else a row changes beyond the vote count
             const sw lead_prepare = to_lead & ~prep;                    // a new Leader's first tick: Leader.prepareReplication (member/Leader.java:30-50)
-            const uint64_t b_tail = __builtin_amdgcn_ballot_w64((conv | lead_prepare | late_higher) < 0);
-            if (b_tail != 0) {
+            if (__builtin_amdgcn_ballot_w64((conv | lead_prepare | late_higher) < 0) != 0) {
                 const bool m_conv = conv < 0, m_winrv = win_rv < 0;
                 const int32_t new_role = (win_rv < 0) ? RG_LEADER : ((to_c < 0) ? RG_CANDIDATE : RG_FOLLOWER);
                 const int32_t new_term = (to_c < 0) ? term1 : (((win_rv | to_pre) < 0) ? term : a);
@@ -376,25 +360,22 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
                 g.leader = m_conv ? RG_NO_NODE : g.leader;
                 g.prepared = (g.prepared & ~conv) | lead_prepare;
                 g.peers_dirty = g.peers_dirty | lead_prepare;
-                g.recache();                                            // (role, prepared: only a conversion moves the cached words here)
             }
-            // Round 6: a round whose election rows are vote replies that are merely counted, late or dropped — three election rounds of four — has no election
-            // predicate to hand over (every bit below is 0 for every lane), no conversion and nothing to re-cache: it leaves here.
-            if ((b_to | b_vq | b_tail) != 0) {
-                uint32_t pw_el = push_bit(0u, vq);
-                pw_el = push_bit(pw_el, vq_success);
-                pw_el = push_bit(pw_el, reset);
-                pw_el = push_bit(pw_el, conv);
-                pw_el = push_bit(pw_el, to_lead);
-                pw_el = push_bit(pw_el, to_pre);
-                pw_el = push_bit(pw_el, to_c);
-                pw = pw | (pw_el << 6);                                 // (bits 12..6 now, 13..7 after the last push below: `pw` is updated in place, the path that
-            }                                                           //  does not come here pays neither a zero nor a merge for the election half)
+            g.votes = g.votes + (int32_t)((uint32_t)count >> 31);       // (a counted vote never converts)
+            out.resp = ((vq & ~rv_new) < 0) ? term : a;                 // (only read for the vote requests)
+            pw_el = push_bit(0u, vq);
+            pw_el = push_bit(pw_el, vq_success);
+            pw_el = push_bit(pw_el, reset);
+            pw_el = push_bit(pw_el, conv);
+            pw_el = push_bit(pw_el, to_lead);
+            pw_el = push_bit(pw_el, to_pre);
+            pw_el = push_bit(pw_el, to_c);
             done = done | el_fast;
         }
-        if (b_rare != 0) g.recache();
+        g.recache();
     }
-    out.pw = push_bit(pw, any_drop);
+    pw = push_bit(pw, any_drop);
+    out.pw = pw | (pw_el << 7);
     return done;
 }
 

@@ -264,6 +264,30 @@ bool KryoBodyCodec::read_request(Method m, const char *body, size_t len, Request
     return r.ok && r.p == r.end && out.node != RG_NO_NODE;
 }
 
+bool KryoBodyCodec::decode_node_object(const char *bytes, size_t len, Node &out, bool &is_null)
+{
+    In r(bytes, len);
+    is_null = false;
+    const Klass k = r.klass();
+    if (r.ok && k == K_NULL) { is_null = true; return r.p == r.end; }
+    if (!r.ok || k != K_NODE_ID || !r.first_occurrence()) return false;
+    const uint8_t *host; size_t host_len; bool ascii;
+    if (!r.first_occurrence() || !r.string_span(host, host_len, ascii)) return false;
+    out.port = r.varint_zz();
+    out.hostname.assign(reinterpret_cast<const char *>(host), host_len);
+    if (ascii && host_len) out.hostname[host_len - 1] = (char)(out.hostname[host_len - 1] & 0x7F);      // (R3: the last character carries the end mark)
+    return r.ok && r.p == r.end;
+}
+
+void KryoBodyCodec::encode_node_object(const Node *node, std::string &out)
+{
+    Out w(out);
+    if (!node) { w.varint(0); return; }                                            // Kryo.NULL
+    w.class_by_name(N_NODE_ID); w.varint(1);
+    w.varint(1); w.string(node->hostname);
+    w.varint_zz(node->port);
+}
+
 static bool decode_response_general(const char *body, size_t len, Response &out)
 {
     In r(body, len);

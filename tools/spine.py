@@ -26,7 +26,6 @@ def walk(K, hdr, enters):
     ballot is entered. The compiler lays a block out either behind a vccz that skips it or at the target of a vccnz that enters it."""
     labels = {l.split(':')[0]: i for i, l in enumerate(K) if l.startswith('.LBB')}
     i, n, d, ops = hdr, 0, 0, {}
-    vcc_inverted = False
     scc_means_zero = True                        # what SCC = 1 says about the ballot last compared: s_cmp_eq_u64 x, 0 -> "no lane", s_cmp_lg_u64 x, 0 -> "some lane"
     while True:
         if n > 20000 or i >= len(K):
@@ -42,15 +41,12 @@ def walk(K, hdr, enters):
                 scc_means_zero = True
             elif op.startswith('s_cmp_lg') or op.startswith('s_cmp_ne'):
                 scc_means_zero = False
-            elif op == 's_andn2_b64' and re.match(r'\s*s_andn2_b64\s+vcc,\s*exec,', l):
-                vcc_inverted = True              # vcc = exec & ~condition: vccz means "the (wave-uniform) condition holds"
             m = re.search(r'(\.LBB\d+_\d+)', l)
             if op in ('s_cbranch_vccz', 's_cbranch_vccnz', 's_cbranch_scc0', 's_cbranch_scc1'):
                 enter = enters[d] if d < len(enters) else False
                 d += 1
                 if op.startswith('s_cbranch_vcc'):
-                    taken_means_enter = op.endswith('nz') != vcc_inverted
-                    vcc_inverted = False
+                    taken_means_enter = op.endswith('nz')
                 else:                            # (round 5: ballots issued ahead of their branches are tested on the scalar unit: s_cmp + s_cbranch_scc)
                     taken_means_enter = op.endswith('scc1') != scc_means_zero
                 if enter == taken_means_enter:
@@ -68,13 +64,11 @@ def main():
     a, opsa = walk(K, hdr, [])                                   # no {rare, election} block, no general handlers
     # the ballots in program order: {rare | election}, rare, election, then (round 5: one sub-block per row class, each behind its own ballot) vote
     # replies, timeouts, vote requests, the conversion tail; then the general handlers
-    # (round 6: after the conversion tail one more wave-uniform branch: the election half of the predicate word is only assembled when a timeout, a vote
-    #  request or a conversion is in the round)
-    b, opsb = walk(K, hdr, [True, False, True, True, True, True, True, True])       # every class and the conversion tail: the worst round
-    c, _ = walk(K, hdr, [True, False, True, True, False, False, False, False])      # a vote reply that is merely counted: three election rounds of four
-    d, _ = walk(K, hdr, [True, False, True, True, False, False, True, True])        # a vote reply that converts
-    e, _ = walk(K, hdr, [True, False, True, False, True, False, True, True])        # a timeout (always converts or prepares)
-    f, _ = walk(K, hdr, [True, False, True, False, False, True, True, True])        # a vote request that converts
+    b, opsb = walk(K, hdr, [True, False, True, True, True, True, True])       # every class and the conversion tail: the worst round
+    c, _ = walk(K, hdr, [True, False, True, True, False, False, False])       # a vote reply that is merely counted: three election rounds of four
+    d, _ = walk(K, hdr, [True, False, True, True, False, False, True])        # a vote reply that converts
+    e, _ = walk(K, hdr, [True, False, True, False, True, False, True])        # a timeout (always converts or prepares)
+    f, _ = walk(K, hdr, [True, False, True, False, False, True, True])        # a vote request that converts
     # the I/O wavefront's round: the barrier-to-barrier stretches that load a row (two columns) and store up to three (its loop is unrolled by four)
     bars = [i for i, l in enumerate(K) if isinstr(l) and l.split()[0] == 's_barrier']
     ios = []
