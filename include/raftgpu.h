@@ -62,7 +62,10 @@ extern "C" {
                                      4: compact OUTCOME rows (rg_out32_t, rg_submit32c, rg_outcome32_unpack, RG_F_WIDE_VALUES); rg_table_option; the index base of the compact formats (rg_index_base_set)
                                      5: the device-resident tick on compact outcome rows: rg_timers_update32, rg_health_update32, rg_tick2_*; clusters of up to 15 nodes */
 #define RG_MIN_CLUSTER      2     /* P: cluster size incl. self (RaftCluster.size()) */
-#define RG_MAX_CLUSTER      7
+#define RG_MAX_CLUSTER      15    /* (ABI 5; the slot field of a row header is 4 bits. Leadership.majorIndices sorts any number of followers, member/Leadership.java:116-130.)
+                                     Clusters of up to RG_MAX_COMPACT_CLUSTER nodes have every kernel; larger ones are decided by the wide-row kernels only:
+                                     rg_submit / rg_submit_async take them, the compact formats (rg_submit32*, rg_submit_async_packed, rg_tick*) answer -1 */
+#define RG_MAX_COMPACT_CLUSTER 7
 #define RG_TERM_RUNS        4     /* K: cached term runs of the log tail per group */
 #define RG_NO_NODE          (-1)  /* Java null for a RaftCluster.ID */
 

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 ABI_VERSION = 5
-MIN_CLUSTER, MAX_CLUSTER = 2, 7
+MIN_CLUSTER, MAX_CLUSTER, MAX_COMPACT_CLUSTER = 2, 15, 7
 TERM_RUNS = 4
 NO_NODE = -1
 

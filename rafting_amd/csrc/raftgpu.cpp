@@ -25,6 +25,7 @@ hipError_t launch_health_update(const HealthParams &p, hipStream_t s);
 hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32_t *gid, const uint8_t *slot, const uint8_t *flags, hipStream_t s);
 hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s);
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
+hipError_t launch_tick_fold(const TickFoldParams &p, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const int64_t *now_mem, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
@@ -72,6 +73,8 @@ struct rg_table {
     hipEvent_t region0 = nullptr, region1 = nullptr;
     int64_t *timer_deadline = nullptr;          // [G] N4
     uint32_t *timer_epoch = nullptr;            // [G] role epoch after the last batch the timers saw (rg_timers_update32 chains compact rows from it)
+    unsigned long long *tick_masks = nullptr;   // [ceil(G / 256) * 4] expired lanes per wavefront (rg_tick2's folded kernel)
+    uint32_t *tick_ticket = nullptr;            // [1]
     uint64_t config_gen = 0;                    // bumped by whatever changes what a recorded launch has baked in (options, the first index base)
     std::vector<struct rg_tick *> ticks;        // live recordings: invalidated when the table goes
     std::vector<struct rg_tick2 *> ticks2;
@@ -183,7 +186,7 @@ int rg_table_destroy(rg_table_t *t)
     void *cols[] = {t->dt.term_commit, t->dt.epoch, t->dt.window, t->dt.ident, t->dt.elect, t->dt.runs,
                     t->dt.peer_en, t->dt.peer_m, t->dt.ibase, t->wide_bodies, t->counters, t->st_gid.ptr, t->st_head.ptr, t->st_ab.ptr,
                     t->st_cd.ptr, t->st_hint.ptr, t->st_terms.ptr, t->st_reply.ptr, t->st_logfx.ptr,
-                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline, t->timer_epoch,
+                    t->st_persist.ptr, t->st_hb.ptr, t->st_fl.ptr, t->st_sh.ptr, t->st_ss.ptr, t->timer_deadline, t->timer_epoch, t->tick_masks, t->tick_ticket,
                     t->timer_counts, t->st_tgid.ptr, t->st_hgid.ptr, t->st_hslot.ptr, t->st_hflag.ptr, t->st_ready.ptr, t->health_ok,
                     t->health_fail, t->health_recent, t->st_abcd32.ptr, t->st_terms32.ptr, t->st_out32.ptr, t->st_persist32.ptr};
     for (void *c : cols) if (c) (void)hipFree(c);
@@ -259,6 +262,9 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     // last group, so the array covers the grid (found by the host emulation: ceil(G/64) + 1 entries were 2 short at G = 300)
     CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 255) / 256 * 4 + 1) * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
+    CREATE_TRY(hipMalloc((void **)&t->tick_masks, ((G + 255) / 256 * 4) * sizeof(unsigned long long)));
+    CREATE_TRY(hipMalloc((void **)&t->tick_ticket, sizeof(uint32_t)));
+    CREATE_TRY(hipMemsetAsync(t->tick_ticket, 0, sizeof(uint32_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->timer_epoch, G * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_epoch, 0, G * sizeof(uint32_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->health_ok, G * F * sizeof(int64_t)));
@@ -421,7 +427,7 @@ int rg_read_state(rg_table_t *t, uint32_t first, uint32_t count, rg_group_state_
             d->run_start[i * rg::K + k] = k < rc ? runs[(size_t)k * n + i].x : 0;
             d->run_term[i * rg::K + k] = k < rc ? runs[(size_t)k * n + i].y : 0;
         }
-        const uint32_t pend = (meta >> rg::META_PEND_SHIFT) & 0x7Fu;
+        const uint32_t pend = (meta >> rg::META_PEND_SHIFT) & rg::META_PEND_MASK;
         for (size_t j = 0; j < F; j++) {
             d->peer_last_epoch[i * F + j] = en[j * n + i].x;
             d->peer_next_index[i * F + j] = en[j * n + i].y;
@@ -460,6 +466,14 @@ static int launch(rg_table *t, const rg::StepParams &p, bool sparse)
         HIP_TRY(t, hipEventRecord(e1, t->stream));
         t->ev_used += 1;
     }
+    return 0;
+}
+
+// the compact formats belong to clusters of up to RG_MAX_COMPACT_CLUSTER nodes (include/raftgpu.h)
+static int compact_ok(rg_table *t, const char *who)
+{
+    if (t->P > RG_MAX_COMPACT_CLUSTER)
+        return fail(t, -1, "%s: a cluster of %u nodes is decided on wide rows (rg_submit, rg_submit_async); the compact formats end at %d nodes", who, t->P, RG_MAX_COMPACT_CLUSTER);
     return 0;
 }
 
@@ -572,6 +586,7 @@ static int pipeline_ready(rg_table *t)
 int rg_submit_async_packed(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out)
 {
     if (!t) return -1;
+    if (int rc = compact_ok(t, "rg_submit_async_packed")) return rc;
     if (!in || !out) return fail(t, -1, "rg_submit_async_packed: null batch or outcome");
     if (!in->head || !in->abcd || !out->reply || !out->counts || (out->logfx_cap && !out->logfx) || (out->persist_cap && !out->persist))
         return fail(t, -1, "rg_submit_async_packed: head, abcd, reply, counts and every list with a capacity are required");
@@ -685,6 +700,7 @@ static bool page_locked(const void *p)
 int rg_tick_create(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_packed_t *out, rg_tick_t **tick)
 {
     if (!t) return -1;
+    if (int rc = compact_ok(t, "rg_tick_create")) return rc;
     if (!tick) return fail(t, -1, "rg_tick_create: tick is NULL");
     *tick = nullptr;
     if (!in || !out) return fail(t, -1, "rg_tick_create: null batch or outcome");
@@ -838,6 +854,7 @@ static int device_visible(rg_table *t, const void *p, const char *what, void **o
 int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick)
 {
     if (!t) return -1;
+    if (int rc = compact_ok(t, "rg_tick2_create")) return rc;
     if (!tick) return fail(t, -1, "rg_tick2_create: tick is NULL");
     *tick = nullptr;
     if (!io) return fail(t, -1, "rg_tick2_create: io is NULL");
@@ -864,7 +881,7 @@ int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick)
     rg_tick2 *k = new rg_tick2();
     k->t = t;
     k->config_gen = t->config_gen;
-    const uint32_t G = t->G, waves = (G + 63u) / 64u;
+    const uint32_t G = t->G;
     // the decisions: rg_submit32c on device-visible rows
     rg::StepParams sp = step_params(t, &wide);
     sp.head = (const rg_ev_head_t *)d_head; sp.abcd32 = (const rg::I32x4 *)d_abcd;
@@ -883,14 +900,16 @@ int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick)
     hipStream_t s = t->stream;
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e == hipSuccess) e = rg::launch_step(sp, (int)t->F, false, 32, s);
-    if (e == hipSuccess) e = rg::launch_timers_update(tp, s);
-    if (e == hipSuccess) e = rg::launch_health_update(hp, s);
-    if (e == hipSuccess && io->expired_gid)
-        e = rg::launch_timers_expired(t->timer_deadline, t->dt.ident, G, 0, now_last, t->timer_counts, (uint32_t *)d_ecnt, (uint32_t *)d_egid, (uint32_t *)d_eep,
-                                      io->expired_capacity, s);
+    // ONE kernel for what the batch did to the timers and the followers' health and for the list of the tickets that fired (a single-round tick is
+    // launch-bound: rg_kernels.hip, tick_fold_kernel); timer_counts doubles as its per-wavefront masks (64 bits each) + the ticket word
+    rg::TickFoldParams fp{};
+    fp.tp = tp; fp.hp = hp; fp.now_last = now_last;
+    fp.masks = (unsigned long long *)t->tick_masks; fp.ticket = t->tick_ticket;
+    fp.out_gid = (uint32_t *)d_egid; fp.out_epoch = (uint32_t *)d_eep; fp.out_count = (uint32_t *)d_ecnt; fp.capacity = io->expired_capacity;
+    fp.expire = io->expired_gid != nullptr;
+    if (e == hipSuccess) e = rg::launch_tick_fold(fp, s);
     if (e == hipSuccess && io->send_head) e = rg::launch_replicate(qp, (int)t->F, s);
     if (e == hipSuccess && io->ready) e = rg::launch_ready(rp, 0, io->critical_point, io->cool_down_ms, (uint8_t *)d_ready, s);
-    (void)waves;
     hipGraph_t g = nullptr;
     const hipError_t e2 = hipStreamEndCapture(s, &g);           // (always: an open capture would poison the stream)
     k->graph = g;
@@ -997,6 +1016,7 @@ int rg_submit(rg_table_t *t, const rg_batch_t *in, const rg_outcome_t *out, int 
 int rg_submit32(rg_table_t *t, const rg_batch32_t *in, const rg_outcome_t *out, int memspace)
 {
     if (!t) return -1;
+    if (int rc = compact_ok(t, "rg_submit32")) return rc;
     if (!in || !out) return fail(t, -1, "rg_submit32: NULL batch or outcome");
     if (!in->head || !in->abcd) return fail(t, -1, "rg_submit32: head and abcd are required");
     rg_batch_t wide{};                              // the same shape rules as every other submission (rounds, count, gid list, entry bound)
@@ -1102,6 +1122,7 @@ static uint32_t host_index_fields(uint32_t kind)
 int rg_submit32c(rg_table_t *t, const rg_batch32_t *in, const rg_outcome32_t *out, int memspace)
 {
     if (!t) return -1;
+    if (int rc = compact_ok(t, "rg_submit32c")) return rc;
     if (!in || !out) return fail(t, -1, "rg_submit32c: NULL batch or outcome");
     if (!in->head || !in->abcd || !out->row || !out->persist) return fail(t, -1, "rg_submit32c: head, abcd, row and persist are required");
     if (in->gid) return fail(t, -1, "rg_submit32c: dense batches only (gid must be NULL)");

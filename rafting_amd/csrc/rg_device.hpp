@@ -56,6 +56,7 @@ struct alignas(16) Match { int64_t match_index; int32_t rejection; int32_t pad; 
 // meta word: role[1:0] timeoutDetected[2] replPrepared[3] runCount[6:4] pendingInstallation bit per follower [14:8]
 constexpr uint32_t META_ROLE = 3u, META_TD = 1u << 2, META_PREP = 1u << 3;
 constexpr int META_RC_SHIFT = 4, META_PEND_SHIFT = 8;
+constexpr uint32_t META_PEND_MASK = (1u << (RG_MAX_CLUSTER - 1)) - 1u;      // pendingInstallation, one bit per follower (bits 8 .. 21 of meta)
 
 // HBM layout of a table: structure of 16-byte structs, one column per struct kind, so every lane
 // moves 16 B per load/store and a wavefront touches 1 KiB of one column at a time.
@@ -134,6 +135,17 @@ struct HealthParams {                // N4b: Leadership.State health fields + Le
     int64_t now[64];
 };
 
+struct TickFoldParams {              // the device-resident tick's second kernel (rg_tick2: tick_fold_kernel): timers + health + the list of fired tickets
+    TimerParams tp;                  // out32 / persist32 / now_mem set; rounds, count = G
+    HealthParams hp;                 // head / out32 / now_mem set
+    const int64_t *now_last;         // &now[rounds - 1]: the clock of the expiry
+    unsigned long long *masks;       // [waves] which lanes of a wavefront expired (written by every workgroup, read by the last one)
+    uint32_t *ticket;                // [1] workgroups done; the last one to arrive emits the list and puts it back to 0
+    uint32_t *out_gid, *out_epoch, *out_count;
+    uint32_t capacity;
+    int expire;                      // 0: no expiry step
+};
+
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 __device__ __forceinline__ int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
@@ -172,7 +184,7 @@ __device__ __forceinline__ void major_indices(V (&m)[F], V &full, V &major)
         full = m[0]; major = m[1] > m[2] ? m[1] : m[2];
     } else {
 #pragma unroll
-        for (int a = 1; a < F; a++) {                                   // insertion network, F <= 6
+        for (int a = 1; a < F; a++) {                                   // insertion network (any F: clusters of up to 15 nodes)
 #pragma unroll
             for (int b = a; b > 0; b--) cmp_exchange(m[b - 1], m[b]);
         }

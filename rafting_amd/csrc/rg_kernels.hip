@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
 
     const uint32_t limit = hb ? RG_IN_FLIGHT_LIMIT / 10 : RG_IN_FLIGHT_LIMIT;
     const int64_t fetch = hb ? RG_REPLICATE_LIMIT / 2 : RG_REPLICATE_LIMIT;
-    uint32_t pend = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+    uint32_t pend = (id.meta >> META_PEND_SHIFT) & META_PEND_MASK;
     if (leader & !prepared & active) {                // Leader.prepareReplication :30-50
         const int64_t next0 = wadd(has_log ? last : ep.x, 1);
 #pragma unroll
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
             p.t.peer_en[(size_t)j * G + gi] = I64x2{ep.x, next0};
             p.t.peer_m[(size_t)j * G + gi] = Match{0, 0, 0};
         }
-        id.meta = (id.meta & ~(0x7Fu << META_PEND_SHIFT)) | META_PREP;
+        id.meta = (id.meta & ~(META_PEND_MASK << META_PEND_SHIFT)) | META_PREP;
         p.t.ident[gi] = id;
     }
     if (!prepared) pend = 0;
@@ -162,6 +162,9 @@ hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t
     case 4: hipLaunchKernelGGL(replicate_kernel<4>, dim3(blocks), dim3(256), 0, s, p); break;
     case 5: hipLaunchKernelGGL(replicate_kernel<5>, dim3(blocks), dim3(256), 0, s, p); break;
     case 6: hipLaunchKernelGGL(replicate_kernel<6>, dim3(blocks), dim3(256), 0, s, p); break;
+#define RG_REPLICATE_CASE(F_) case F_: hipLaunchKernelGGL(replicate_kernel<F_>, dim3(blocks), dim3(256), 0, s, p); break;
+    RG_REPLICATE_CASE(7) RG_REPLICATE_CASE(8) RG_REPLICATE_CASE(9) RG_REPLICATE_CASE(10) RG_REPLICATE_CASE(11) RG_REPLICATE_CASE(12) RG_REPLICATE_CASE(13) RG_REPLICATE_CASE(14)
+#undef RG_REPLICATE_CASE
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -292,6 +295,98 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, con
     }
 }
 
+// ---- the device-resident tick, folded (rg_tick2) ---------------------------------------------------------------------------------------------
+// A single-round tick over 65 536 groups is launch-bound: every kernel of the chain costs 7-9 us of dispatch whatever it does (measured:
+// eight nodes, 74 us; profiles/r06e_bench_default.json). So what follows the decisions is ONE kernel: per group the batch's flags into the deadline
+// (timers_update32_kernel) and into the followers' statistics (health_update_kernel), then the expiry — every wavefront leaves the ballot of its
+// expired lanes in `masks`, and the LAST workgroup to get there (an acq_rel ticket at agent scope: the masks of the others are visible to it, across
+// XCDs too) scans the per-wavefront counts and writes the list in ascending group order, marking the listed tickets fired — what
+// timers_count / _scan / _emit do in three launches.
+#ifndef RG_AGENT_LOAD               // (the host emulation runs workgroups one after the other on plain memory)
+#define RG_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RG_TICKET_TAKE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+__global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)
+{
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t is_last;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x, G = p.tp.count;
+    const bool active = g < G;
+    int64_t d = 0;
+    if (active) {
+        // RaftRoutine.resetTimer for the rows of this group (timers_update32_kernel)
+        d = p.tp.deadline[g];
+        uint32_t e = p.tp.epoch[g];
+        const size_t GG = p.hp.t.groups;
+        for (uint32_t r = 0; r < p.tp.rounds; r++) {
+            const size_t row = (size_t)r * G + g;
+            const uint32_t flags = (uint32_t)p.tp.out32[row].y;
+            const int64_t now = p.tp.now_mem[r];
+            if (flags & RG_F_PERSIST) e = (uint32_t)p.tp.persist32[row].z;
+            if (flags & RG_F_RESET_TIMER)
+                d = rearm(p.tp, d, g, (int)RG_F_ROLE(flags), (flags & RG_F_ROLE_CHANGED) != 0, (flags & RG_F_TIMER_MUTED) != 0, e, now);
+            // Leadership.State.statSuccess for an ack that was applied (health_update_kernel)
+            if ((flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(flags) == RG_LEADER) {
+                for (uint32_t j = 0; j < p.hp.followers; j++) { p.hp.ok[j * GG + g] = 0; p.hp.fail[j * GG + g] = 0; p.hp.recent[j * GG + g] = 0; }
+                continue;
+            }
+            const uint32_t hdr = p.hp.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(flags);
+            const bool ack = kind == RG_EV_AE_ACK || kind == RG_EV_IS_ACK;
+            const bool reached = st == RG_OK || st == RG_A_MATCH_ROLLBACK || st == RG_NPE_MAJOR_NULL || st == RG_A_COMMIT_ROLLBACK;
+            if (!ack || !reached || (flags & RG_F_ROLE_CHANGED) || slot >= p.hp.followers + 1 || slot == p.hp.self) continue;
+            const uint32_t j = slot < p.hp.self ? slot : slot - 1;
+            if (now > p.hp.ok[j * GG + g]) p.hp.ok[j * GG + g] = now;
+            p.hp.recent[j * GG + g] = 0;
+        }
+        p.tp.deadline[g] = d;
+        p.tp.epoch[g] = e;
+    }
+    if (!p.expire) return;
+    // ---- the fired tickets ------------------------------------------------------------------------------------------------------------
+    const int64_t now = *p.now_last;
+    const unsigned long long m = __ballot(active && d > 0 && d <= now);
+    if ((threadIdx.x & 63u) == 0u) p.masks[g >> 6] = m;
+    __syncthreads();                                                 // (this workgroup's four masks are stored before its ticket is taken)
+    if (threadIdx.x == 0) is_last = RG_TICKET_TAKE(p.ticket) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!is_last) return;
+    const uint32_t waves = gridDim.x * 4u, tid = threadIdx.x;
+    const uint32_t per = (waves + 255u) / 256u, lo = tid * per, hi = lo + per < waves ? lo + per : waves;
+    uint32_t sum = 0;
+    for (uint32_t w = lo; w < hi; w++) sum += (uint32_t)__popcll(RG_AGENT_LOAD(p.masks + w));
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256; off <<= 1) {                   // Hillis-Steele inclusive scan of the 256 partial sums
+        const uint32_t v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t pos = tid ? part[tid - 1] : 0;
+    for (uint32_t w = lo; w < hi; w++) {
+        unsigned long long mw = RG_AGENT_LOAD(p.masks + w);
+        while (mw) {
+            const uint32_t lane = (uint32_t)__builtin_ctzll(mw);
+            mw &= mw - 1;
+            const uint32_t gg = w * 64u + lane;
+            if (pos < p.capacity) {
+                p.out_gid[pos] = gg;
+                if (p.out_epoch) p.out_epoch[pos] = p.tp.ident[gg].role_epoch;
+                p.tp.deadline[gg] = -1;                               // electionTimeout's CAS: deadline -> TimerTicket.TIMEOUT
+            }
+            pos++;
+        }
+    }
+    if (tid == 255) { *p.out_count = part[255]; *p.ticket = 0u; }
+}
+
+hipError_t launch_tick_fold(const TickFoldParams &p, hipStream_t s)
+{
+    if (p.tp.count == 0) return hipSuccess;
+    hipLaunchKernelGGL(tick_fold_kernel, dim3((p.tp.count + 255) / 256), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s)
 {
     if (p.count == 0) return hipSuccess;
@@ -367,7 +462,7 @@ __global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_
     const Ident id = p.t.ident[g];
     uint8_t out = 0;
     if ((id.meta & META_ROLE) == RG_LEADER && (id.meta & META_PREP)) {
-        const uint32_t pend = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+        const uint32_t pend = (id.meta >> META_PEND_SHIFT) & META_PEND_MASK;
         const size_t G = p.t.groups;
         uint32_t n = 1;
         for (uint32_t j = 0; j < p.followers; j++) {

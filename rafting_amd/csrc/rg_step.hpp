@@ -227,7 +227,7 @@ __device__ __forceinline__ void load_group(const DevTable &t, uint32_t gi, Group
     g.role = (int32_t)(id.meta & META_ROLE);
     g.td = (id.meta & META_TD) != 0; g.prepared = (id.meta & META_PREP) != 0;
     g.rc = (int32_t)((id.meta >> META_RC_SHIFT) & 7u);
-    g.pending = (id.meta >> META_PEND_SHIFT) & 0x7Fu;
+    g.pending = (id.meta >> META_PEND_SHIFT) & META_PEND_MASK;
     g.elected_term = el.elected_term; g.elected_epoch = el.elected_epoch; g.votes = el.votes;
     const I64x2 r0 = t.runs[gi], r1 = t.runs[(size_t)G + gi], r2 = t.runs[(size_t)2 * G + gi], r3 = t.runs[(size_t)3 * G + gi];
     g.s0 = r0.x; g.t0 = r0.y; g.s1 = r1.x; g.t1 = r1.y; g.s2 = r2.x; g.t2 = r2.y; g.s3 = r3.x; g.t3 = r3.y;
@@ -496,7 +496,7 @@ __device__ __forceinline__ void lds_barrier()
 // LDS of a two-wavefront workgroup. The 64-bit body and the 32-bit body never run at the same time: one buffer, two layouts. On compact rows
 // (EV32) the 64-bit body's event ring carries five fields instead of eleven (no hint, the entry term is `aux`): 18 KB per workgroup at F = 4 (19 KB with the 32-bit body's tables),
 // eight workgroups per CU instead of six.
-template <int F, bool EV32>
+template <int F, bool EV32, int NO = 2>
 struct SplitLds {
     // 64-bit body
     static constexpr int EVF = EV32 ? (int)EV_D + 1 : (int)EV_FIELDS;
@@ -507,7 +507,7 @@ struct SplitLds {
     static constexpr int MV = (F + 3) / 4;
     static constexpr int NEV = 4;
     static constexpr size_t N_REC = 0, N_MV = N_REC + F * BLOCK * 16, N_EVH = N_MV + MV * BLOCK * 16, N_EVQ = N_EVH + NEV * BLOCK * 16,
-                            N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + 2 * BLOCK * 16, N_BAIL = N_O1 + 2 * BLOCK * 16,
+                            N_O0 = N_EVQ + NEV * BLOCK * 16, N_O1 = N_O0 + NO * BLOCK * 16, N_BAIL = N_O1 + NO * BLOCK * 16,      // (NO outcome slots: 2, or 4 where two rounds share a hand-over)
                             N_LUTC = N_BAIL + 16, N_LUTM = N_LUTC + 256 * 4, N_LUTE = N_LUTM + 128 * 4,      // the I/O wavefront's tables (below)
                             N_BASE = N_LUTE + 128 * 2, N_LUTS = N_BASE + BLOCK * 8,                           // the groups' index bases (the deciding wavefront's; round 5)
                             N_END = N_LUTS + 64 * 4;                                                          // the I/O wavefront's status -> tally table
@@ -541,11 +541,18 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
         // absolute values, so the row's index fields are taken off the base as they are handed over, and put back on it in the rows of OUT32
         int64_t io_base = 0;
         if constexpr (EV32) io_base = (p.has_bases != 0) ? p.t.ibase[SPARSE ? p.gid[ir] : ir] : 0;
+        // (round 6: a wavefront whose 64 bases are all zero — every table that never had one — skips the conversions at both ends behind ONE wave-uniform
+        //  flag, as the 32-bit body does: they were part of what this body lost in round 5, 0.1006 -> 0.1140 ms at config 3)
+        const bool io_rel = EV32 && __builtin_amdgcn_ballot_w64(io_base != 0) != 0;
         auto publish = [&](uint32_t slot, const EventRow &e, const EventTail &t) {
             sh_ev[slot][EV_HEAD][lane] = (uint64_t)decorate<EV32>(p, e, t, false) | ((uint64_t)e.aux << 32);
-            const uint32_t ix = EV32 ? index_fields(RG_HDR_KIND(e.hdr)) : 0u;
-            sh_ev[slot][EV_A][lane] = (uint64_t)((ix & 1u) ? to_abs(e.a, io_base) : e.a); sh_ev[slot][EV_B][lane] = (uint64_t)((ix & 2u) ? to_abs(e.b, io_base) : e.b);
-            sh_ev[slot][EV_C][lane] = (uint64_t)((ix & 4u) ? to_abs(e.c, io_base) : e.c); sh_ev[slot][EV_D][lane] = (uint64_t)((ix & 8u) ? to_abs(e.d, io_base) : e.d);
+            if (io_rel) {
+                const uint32_t ix = index_fields(RG_HDR_KIND(e.hdr));
+                sh_ev[slot][EV_A][lane] = (uint64_t)((ix & 1u) ? to_abs(e.a, io_base) : e.a); sh_ev[slot][EV_B][lane] = (uint64_t)((ix & 2u) ? to_abs(e.b, io_base) : e.b);
+                sh_ev[slot][EV_C][lane] = (uint64_t)((ix & 4u) ? to_abs(e.c, io_base) : e.c); sh_ev[slot][EV_D][lane] = (uint64_t)((ix & 8u) ? to_abs(e.d, io_base) : e.d);
+            } else {
+                sh_ev[slot][EV_A][lane] = (uint64_t)e.a; sh_ev[slot][EV_B][lane] = (uint64_t)e.b; sh_ev[slot][EV_C][lane] = (uint64_t)e.c; sh_ev[slot][EV_D][lane] = (uint64_t)e.d;
+            }
             if constexpr (!EV32) {
                 sh_ev[slot][EV_E0][lane] = (uint64_t)t.e0;
                 sh_ev[slot][EV_HX][lane] = (uint64_t)t.hx; sh_ev[slot][EV_HY][lane] = (uint64_t)t.hy;
@@ -568,7 +575,7 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
             rg_persist_t per;
             per.term = (int64_t)sh_out[slot][OUT_TERM][lane]; per.voted_for = (int32_t)(uint32_t)v; per.role = (int32_t)(uint32_t)(v >> 32);
             if constexpr (OUT32) {
-                const int64_t commit_r = to_rel(lfx.x, io_base), from_r = to_rel(lfx.y, io_base);
+                const int64_t commit_r = io_rel ? to_rel(lfx.x, io_base) : lfx.x, from_r = io_rel ? to_rel(lfx.y, io_base) : lfx.y;
                 const uint64_t bits = (uint64_t)rep.resp_term | (uint64_t)commit_r | (w_lfx ? (uint64_t)from_r : 0ull) | (w_per ? (uint64_t)per.term : 0ull);
                 const bool wide = bits >= (1ull << 31);
                 if (active) {
@@ -708,23 +715,6 @@ __global__ __launch_bounds__(2 * BLOCK) void step_split_kernel(const StepParams 
 // outside [0, 2^30), a state value the general handlers pushed to STATE_LIMIT): nothing of this body's work counts then.
 struct Row32 { U32x2 h; I32x4 q; };
 
-// One 16-byte LDS row from four values that live in registers of their own. A ds_write_b128 wants them in four CONSECUTIVE registers, and the outcome rows
-// are made of loop-carried group state (term, votedFor, role, role epoch, commitIndex): each of those is a v_mov per round into the tuple — vector
-// instructions, the one resource this kernel is short of. Two ds_write2_b32 take any four registers.
-__device__ __forceinline__ void store_row(I32x4 *row, int32_t x, int32_t y, int32_t z, int32_t w)
-{
-#ifdef RG_ROW_AS_ONE_STORE          // (the host emulation; A/B builds)
-    *row = I32x4{x, y, z, w};
-#else
-    typedef __attribute__((address_space(3))) int32_t lds_i32;
-    lds_i32 *p = (lds_i32 *)reinterpret_cast<int32_t *>(row);
-    // (four scalar stores are merged back into one ds_write_b128 by the compiler: spelled out. Its wait-count bookkeeping does not see these two operations;
-    //  LDS answers in order, so a wait it computes for an operation of its own can only come out stronger than needed, never weaker — and the hand-over
-    //  barrier drains the queue explicitly: lds_barrier)
-    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1\n\tds_write2_b32 %0, %3, %4 offset0:2 offset1:3" : : "v"(p), "v"(x), "v"(y), "v"(z), "v"(w) : "memory");
-#endif
-}
-
 // What the I/O wavefront makes of a compact row for the deciding wavefront of the 32-bit body: {class word, aux, n, header'}. The class word
 // (rg_tier1n.hpp: CW_*) holds every fact about the row that does not depend on the group's state, one bit each, plus the follower index of an
 // ack's responder. Most of it depends on (kind, slot) only — cluster size and own slot are launch constants — and comes from a 256-entry
@@ -776,10 +766,15 @@ __device__ __forceinline__ uint32_t expand_by_table(const uint32_t *lutm, const 
 // IOW = 2 (experiment, -DRG_IOW2: launches of at most one workgroup per pair of SIMDs): the I/O work of a workgroup on TWO wavefronts — wave 1 fetches
 // and publishes events, wave 2 retires outcomes and keeps the tallies — so that neither is ever what the deciding wavefront waits for at the
 // barrier; all three meet at the same s_barrier every round.
-template <int F, bool SPARSE, bool OUT32, int IOW = 1>
+// RPB (round 6): ROUNDS PER HAND-OVER. The two wavefronts drain their LDS queues and meet once every RPB rounds instead of once per round: with RPB = 2 the
+// deciding wavefront decides rounds 2i and 2i + 1 back to back while the I/O wavefront publishes events 2i + 2, 2i + 3 and retires outcomes 2i - 2, 2i - 1;
+// the event ring keeps its four slots, the outcome ring gets four (2 * RPB). Half the s_waitcnt lgkmcnt(0) + s_barrier pairs, no instruction added per round.
+template <int F, bool SPARSE, bool OUT32, int IOW = 1, int RPB = 1>
 __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *smem)
 {
-    typedef SplitLds<F, true> L;
+    static_assert(RPB == 1 || (RPB == 2 && IOW == 1), "two rounds per hand-over: the two-wavefront workgroup only");
+    constexpr int NO = 2 * RPB;
+    typedef SplitLds<F, true, NO> L;
     I32x4 *sh_rec = reinterpret_cast<I32x4 *>(smem + L::N_REC);
     int32_t *sh_mv = reinterpret_cast<int32_t *>(smem + L::N_MV);
     I32x4 (*sh_evh)[BLOCK] = reinterpret_cast<I32x4 (*)[BLOCK]>(smem + L::N_EVH);
@@ -847,7 +842,7 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         };
         Tally tally;
         auto retire = [&](uint32_t r, uint32_t hdr) {
-            const uint32_t slot = r & 1u;
+            const uint32_t slot = r & (uint32_t)(NO - 1);
             const uint64_t rb16 = (uint64_t)r * round_rows * 16u;
             const I32x4 o0 = sh_o0[slot][lane], o1 = sh_o1[slot][lane];
             // the deciding wavefront hands over truth values, not flags (rg_tier1n.hpp): the flags, the role field and the "valid iff REPLIED" rule are made here
@@ -896,6 +891,50 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         bool bailed = false;
         uint32_t seen = 0u;                              // the mark as it stood after the previous barrier
         RG_PROBE_BEGIN();
+        if constexpr (RPB == 2) {
+            // Two rounds per hand-over. Step k of the unrolled loop (round r = r0 + k) publishes event r + 2, retires outcome r - 2 — written in the PREVIOUS
+            // pair of rounds, visible since the last barrier — and re-fills its registers with row r + 6; the wavefronts meet after every odd round (and
+            // after an odd last one). hk[i]: header of the newest published row with index = i mod 4 (the tallies need the kind of a retired row): before step
+            // k overwrites hk[(k + 2) & 3] with row r + 2's, it holds row r - 2's.
+            uint32_t hk[4] = {hdr_0, hdr_1, 0u, 0u};
+            for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
+                if ((r0 & 127u) == 124u) tally.spill();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t r = r0 + (uint32_t)k;
+                    if (r >= p.rounds) break;
+                    Row32 &x = buf[(k + 2) & 3];
+                    publish((r + 2u) & 3u, x);
+                    RG_PROBE_MARK(0);
+                    if (r >= 2u) retire(r - 2u, hk[(k + 2) & 3]);
+                    hk[(k + 2) & 3] = x.h.x;
+                    fetch(r + 6u, x);
+                    RG_PROBE_MARK(1);
+                    if ((k & 1) != 0 || r == last_round) {
+                        const uint32_t mark = __builtin_amdgcn_readfirstlane(seen), pair = r >> 1;      // pair `pair - 1` (or an earlier one) left the domain: mark <= pair + 1
+                        if ((mark != 0u) & (mark <= pair + 1u)) { bailed = true; break; }
+                        lds_barrier();
+                        RG_PROBE_MARK(2);
+                        seen = *sh_bail;
+                    }
+                }
+            }
+            if (bailed) return false;
+            { const uint32_t mark = __builtin_amdgcn_readfirstlane(seen); if (mark != 0u) return false; }      // the last pair did
+            for (uint32_t q = p.rounds >= 2u ? p.rounds - 2u : 0u; q < p.rounds; q++) {      // the last pair's outcomes
+                const uint32_t i = q & 3u;
+                retire(q, i == 0u ? hk[0] : (i == 1u ? hk[1] : (i == 2u ? hk[2] : hk[3])));
+            }
+            tally.spill();
+#if defined(RG_PROBE)
+            RG_PROBE_FLUSH(0);
+#elif defined(RG_PROBE_HWID)
+            RG_HWID_END(1);
+#else
+            tally.flush(p, lane, active);
+#endif
+            return true;
+        }
         for (uint32_t r0 = 0; r0 < p.rounds && !bailed; r0 += 4u) {
             if ((r0 & 127u) == 124u) tally.spill();       // (the byte counters of add_packed)
 #pragma unroll
@@ -972,8 +1011,17 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
     lds_barrier();
     if (bailed) return false;
     RG_PROBE_BEGIN();
+#ifdef RG_EVENT_PREFETCH
+    // (experiment, round 6) The event of round r + 1 is in the ring since the barrier of round r - 1: it is READ at the end of round r, ahead of the
+    // drain-and-meet that closes the round, so that its LDS latency is spent inside that wait instead of at the top of the next round.
+    I32x4 h_next = sh_evh[0][lane], q_next = sh_evq[0][lane];
+#endif
     auto round = [&](const uint32_t r) {
+#ifdef RG_EVENT_PREFETCH
+        const I32x4 h = h_next, q = q_next;
+#else
         const I32x4 h = sh_evh[r & 3u][lane], q = sh_evq[r & 3u][lane];
+#endif
         RG_PROBE_MARK(0);
         OutN out;
         const sw done = tier1n<F>(p, g, pe, out, h.x, (uint32_t)h.y, h.z, q.x, q.y, q.z, q.w);
@@ -984,9 +1032,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         // branch is issued (the VALU -> SALU round trip, profiles/r04b_issue_bench.txt), and these stores are independent work to spend that wait on.
         // A round that does visit the general handlers writes the rows again afterwards.
         const uint64_t b_open = __builtin_amdgcn_ballot_w64(open);
-        const uint32_t slot = r & 1u;
-        store_row(&sh_o0[slot][lane], out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit);
-        store_row(&sh_o1[slot][lane], out.log_from, g.term, g.voted_for, g.role);
+        const uint32_t slot = r & (uint32_t)(NO - 1);
+        sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
+        sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
         if (b_open != 0) {
             // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
             const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
@@ -1016,19 +1064,40 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             }
             if (skip) { out.pw = PW_SLOW | ((uint32_t)RG_SKIPPED_AFTER_NEED_HOST << RG_F_STATUS_SHIFT); out.resp = 0; out.log_from = 0; }
             if (__builtin_amdgcn_ballot_w64(bail) != 0) {
-                if (lane == 0) *sh_bail = r + 2u;
+                if (lane == 0) *sh_bail = r / (uint32_t)RPB + 2u;      // (the hand-over this round belongs to, + 2)
                 bailed = true;
             }
-            store_row(&sh_o0[slot][lane], out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit);
-            store_row(&sh_o1[slot][lane], out.log_from, g.term, g.voted_for, g.role);
+            sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
+            sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
         }
         RG_PROBE_MARK(2);
-        lds_barrier();
-        RG_PROBE_MARK(3);
+#ifdef RG_EVENT_PREFETCH
+        h_next = sh_evh[(r + 1u) & 3u][lane]; q_next = sh_evq[(r + 1u) & 3u][lane];
+#endif
+        if constexpr (RPB == 1) {
+            lds_barrier();
+            RG_PROBE_MARK(3);
+        }
     };
+    if constexpr (RPB == 2) {
+        for (uint32_t r = 0; r < p.rounds; r++) {        // (ONE copy of the round's code — the general handlers are inlined in it —, the round counter a scalar)
+            round(r);
+            if (bailed) break;
+            if ((r & 1u) != 0u || r == last_round) {     // the hand-over: after every odd round and after an odd last one (two scalar tests)
+                lds_barrier();
+                RG_PROBE_MARK(3);
+            }
+        }
+        if (bailed) lds_barrier();                       // (the hand-over of the pair that left the domain: the I/O wavefront counts it too)
+    } else {
+#ifdef RG_EVENT_PREFETCH
+    { uint32_t r = 0; do { round(r); r++; } while (!bailed & (r < p.rounds)); }      // (rounds >= 1: the host never launches an empty batch)
+#else
     for (uint32_t r = 0; r < p.rounds; r++) {
         round(r);
         if (bailed) break;
+    }
+#endif
     }
     if (bailed) return false;
     RG_PROBE_FLUSH(4);
@@ -1057,11 +1126,16 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
 // deciding wavefronts per SIMD instead of a pass and a third (round 3's same-box A/B at config 4's shard: 0.1994 -> 0.1307 ms per launch,
 // profiles/r03d_w4_ab.jsonl). Since round 4 the allocator asks for 113 / 112 VGPRs: both variants fit either budget, the two are kept for the
 // bound itself (a change that needs more registers shows up as spills in the second, not as a launch that takes two passes).
+#ifndef RG_ROUNDS_PER_HANDOVER     // 2 = experiment build (round 6): measured SLOWER than a hand-over per round — config 3 0.0659 -> 0.0683 ms, config 2 0.0390 -> 0.0417,
+#define RG_ROUNDS_PER_HANDOVER 1   // same box, same session (profiles/r06g_two_rounds_per_handover_ab.jsonl); bit-exact either way (499 GPU tests, the reference's digest)
+#endif
 template <int F, bool SPARSE, int WAVES, bool OUT32, int IOW = 1>
 __global__ __launch_bounds__((1 + IOW) * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void step32_kernel(const StepParams p)
 {
-    __shared__ alignas(16) unsigned char smem[SplitLds<F, true>::BYTES];
-    if (narrow_body<F, SPARSE, OUT32, IOW>(p, smem)) return;
+    // (the experiment: two rounds per hand-over where four workgroups share a CU — WAVES = 1: launches of up to 65 536 rows, 23 KB of LDS; one where eight do)
+    constexpr int RPB = (WAVES == 1 && IOW == 1) ? RG_ROUNDS_PER_HANDOVER : 1;
+    __shared__ alignas(16) unsigned char smem[SplitLds<F, true, 2 * RPB>::BYTES];
+    if (narrow_body<F, SPARSE, OUT32, IOW, RPB>(p, smem)) return;
     if (threadIdx.x == 0) { RG_NOTE_FALLBACK(); atomicAdd(p.wide_bodies, 1ull); }      // (a workgroup that left the 32-bit domain: rare by design, counted so a host can see it)
     if constexpr (IOW == 2) {
         // the 64-bit body knows two wavefronts: the third only keeps the barriers' count (one to get here, one per staging, one per round)
@@ -1163,6 +1237,18 @@ static hipError_t launch_f(const StepParams &p, bool sparse, int shape, hipStrea
     }
 }
 
+// clusters of 8 .. 15 nodes (ABI 5): the wide-row kernels only — the decision code is generic in F (the quorum select is an insertion network, the
+// follower records live in LDS), the compact-row kernels' LDS budget and class word are not
+template <int F>
+static hipError_t launch_big(const StepParams &p, bool sparse, int shape, hipStream_t s)
+{
+    switch (shape) {
+    case 0:  return launch_split<F>(p, sparse, s);
+    case 64: return launch_single<F>(p, sparse, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_step(const StepParams &p, int followers, bool sparse, int shape, hipStream_t s)
 {
     switch (followers) {
@@ -1172,6 +1258,14 @@ hipError_t launch_step(const StepParams &p, int followers, bool sparse, int shap
     case 3: return launch_f<3>(p, sparse, shape, s);
     case 5: return launch_f<5>(p, sparse, shape, s);
     case 6: return launch_f<6>(p, sparse, shape, s);
+    case 7: return launch_big<7>(p, sparse, shape, s);
+    case 8: return launch_big<8>(p, sparse, shape, s);
+    case 9: return launch_big<9>(p, sparse, shape, s);
+    case 10: return launch_big<10>(p, sparse, shape, s);
+    case 11: return launch_big<11>(p, sparse, shape, s);
+    case 12: return launch_big<12>(p, sparse, shape, s);
+    case 13: return launch_big<13>(p, sparse, shape, s);
+    case 14: return launch_big<14>(p, sparse, shape, s);
 #endif
     case 4: return launch_f<4>(p, sparse, shape, s);
     default: return hipErrorInvalidValue;

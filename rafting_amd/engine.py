@@ -345,13 +345,13 @@ class Tick2:
             # (device_resident: what only the device reads or writes stays in HBM; the tick is then measured without the link)
             if not device_resident:
                 return col(dtype, n)
-            b = DeviceBuffer(table, max(n, 1) * np.dtype(dtype).itemsize)
+            b = DeviceBuffer.from_host(table, np.zeros(max(n, 1), dtype=dtype))
             self._devs.append(b)
             return b
         self.head, self.abcd = big(abi.HEAD_DT, rows), big(abi.QUAD32_DT, rows)
         self.entry_terms = big(np.int32, entry_cap) if entry_cap else None
         self.now = col(np.int64, rounds)
-        self.heartbeat, self.in_flight = col(np.uint8, G), col(np.uint16, F * G)
+        self.heartbeat, self.in_flight = big(np.uint8, G), big(np.uint16, F * G)      # (read by every lane of the send kernel: over the link they cost it tens of microseconds)
         self.row, self.persist32 = big(abi.OUT32_DT, rows), big(abi.PERSIST32_DT, rows)
         cap = G if expired_cap is None else expired_cap
         self.expired_cap = cap
@@ -389,8 +389,10 @@ class Tick2:
         if b32.entry_count:
             self._put(self.entry_terms, b32.entry_terms[: b32.entry_count])
         self.now[:] = np.asarray(now, dtype=np.int64)
-        self.heartbeat[:] = 0 if heartbeat is None else heartbeat
-        self.in_flight[:] = 0 if in_flight is None else np.asarray(in_flight, dtype=np.uint16).reshape(-1)
+        if heartbeat is not None or not isinstance(self.heartbeat, DeviceBuffer):
+            self._put(self.heartbeat, np.zeros(self.G, np.uint8) if heartbeat is None else np.ascontiguousarray(heartbeat, dtype=np.uint8))
+        if in_flight is not None or not isinstance(self.in_flight, DeviceBuffer):
+            self._put(self.in_flight, np.zeros(self.F * self.G, np.uint16) if in_flight is None else np.ascontiguousarray(np.asarray(in_flight, dtype=np.uint16).reshape(-1)))
 
     def launch(self):
         self.table._check(lib().rg_tick2_launch(self._h))

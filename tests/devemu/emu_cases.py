@@ -31,6 +31,11 @@ def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
     assert {abi.OK, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER} <= set(np.flatnonzero(hist).tolist())
 
 
+@pytest.mark.parametrize("cluster,self_slot,seed", [(9, 4, 61), (15, 0, 63)])
+def test_fuzz_lockstep_on_clusters_above_seven_nodes(cluster, self_slot, seed):
+    T._lockstep(64, cluster, self_slot, True, 40, seed, allow_miss=True)
+
+
 def test_fuzz_general_handlers_only(monkeypatch):
     monkeypatch.setenv("RG_FAST", "0")
     _, _, _, hist, _, _ = T._lockstep(192, 5, 0, True, 80, 41, allow_miss=True)

@@ -30,6 +30,14 @@ def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
     assert c[0] > 0 and c[1] > 0 and c[2] > 0
 
 
+def test_fuzz_lockstep_on_an_eleven_node_cluster():
+    """clusters above seven nodes: the two-wavefront wide-row kernel (their follower records fill 25 KB of its LDS at 15 nodes)"""
+    _, _, _, hist, misses, gpu = T._lockstep(64, 11, 10, False, 30, 62, allow_miss=True)
+    assert gpu.step_kernel() == "rg::step_split_kernel" and gpu.counters()[0] > 0
+    with pytest.raises(engine.EngineError, match="wide rows"):
+        gpu.submit32(abi.Batch(1, 64))
+
+
 def test_multi_round_launch_with_exact_counters():
     """ONE 32-round launch of the two-wavefront kernel: outcomes, final state and the I/O wavefront's tallies"""
     G, P = 128, 5

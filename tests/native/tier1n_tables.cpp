@@ -85,7 +85,7 @@ static void class_word_table()
     const uint32_t auxs[] = {0u, 3u, (1u << 30) - 1u, 1u << 30, 0xFFFFFFFFu};
     const uint32_t ns[] = {0u, 1u, 2u, 200u, 201u, RG_MAX_ENTRIES};
     long rows = 0;
-    for (int cluster = 2; cluster <= RG_MAX_CLUSTER; cluster++) for (int self = 0; self < cluster; self += (cluster > 3 ? 2 : 1)) {
+    for (int cluster = 2; cluster <= RG_MAX_COMPACT_CLUSTER; cluster++) for (int self = 0; self < cluster; self += (cluster > 3 ? 2 : 1)) {      // (the class word belongs to the compact-row kernels: clusters of up to 7 nodes)
         StepParams p{};
         p.cluster = cluster; p.self = self;
         std::vector<uint32_t> lutc(256);

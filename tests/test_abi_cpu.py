@@ -74,7 +74,7 @@ def test_argument_validation_needs_no_gpu():
     h = C.c_void_p()
     L = engine.lib()
     assert L.rg_table_create(0, 0, 3, 0, 1, C.byref(h)) == -1
-    assert L.rg_table_create(0, 4, 9, 0, 1, C.byref(h)) == -1
+    assert L.rg_table_create(0, 4, 16, 0, 1, C.byref(h)) == -1                      # (2 .. 15 nodes since ABI 5)
     assert L.rg_table_create(0, 4, 3, 3, 1, C.byref(h)) == -1
     assert b"self_slot" in L.rg_last_error(None)
 

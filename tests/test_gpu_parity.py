@@ -23,7 +23,7 @@ def route_through_compact(monkeypatch, out32=False):
     wide_submit = engine.Table.submit
 
     def submit(self, batch, out=None, fill=0):
-        if batch.hint is None and abi.batch_fits_32(batch):
+        if batch.hint is None and abi.batch_fits_32(batch) and self.cluster <= abi.MAX_COMPACT_CLUSTER:      # (larger clusters: wide rows only, include/raftgpu.h)
             if out32 and batch.gid is None:
                 before = self.read_state()
                 raw = self.submit32c(batch, fill=fill)
@@ -142,6 +142,26 @@ def test_fuzz_lockstep_with_hints(cluster, self_slot, pre_vote, seed):
     assert {abi.OK, abi.A_COMMIT_ROLLBACK, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER} <= seen
     c = gpu.counters()
     assert c[0] > 0 and c[1] > 0 and c[2] > 0
+
+
+@pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(9, 4, True, 61), (11, 10, False, 62), (15, 0, True, 63), (8, 7, True, 64)])
+def test_fuzz_lockstep_on_clusters_above_seven_nodes(step_kernel_variant, cluster, self_slot, pre_vote, seed):
+    """ABI 5: Leadership.majorIndices sorts any number of followers (member/Leadership.java:116-130) and so does the table — clusters of
+    8 .. 15 nodes on the wide-row kernels, the same lockstep differential as the small ones (hints included); the compact formats say no with a message."""
+    if step_kernel_variant not in ("split", "single"):
+        pytest.skip("clusters above %d nodes are decided by the wide-row kernels" % abi.MAX_COMPACT_CLUSTER)
+    _, _, _, hist, misses, gpu = _lockstep(256, cluster, self_slot, pre_vote, 90, seed, allow_miss=True)
+    seen = set(np.flatnonzero(hist).tolist())
+    assert {abi.OK, abi.DROPPED_STALE_ROLE, abi.NOT_LEADER} <= seen
+    c = gpu.counters()
+    assert c[0] > 0 and c[1] > 0 and c[2] > 0 and c[3] > 0
+    b = abi.Batch(1, 256)
+    with pytest.raises(engine.EngineError, match="wide rows"):
+        gpu.submit32(b)
+    with pytest.raises(engine.EngineError, match="wide rows"):
+        gpu.submit32c(b)
+    head, send = gpu.replicate()                          # the send side and the readiness gate take every cluster size
+    assert send.shape == (256, cluster - 1) and gpu.ready(1, 0, 0).shape == (256,)
 
 
 @pytest.mark.parametrize("cluster,self_slot,pre_vote,seed", [(5, 0, True, 41), (3, 2, False, 42)])
@@ -336,7 +356,9 @@ def test_api_misuse_is_reported():
     with pytest.raises(engine.EngineError):
         gpu.load_state(st)
     with pytest.raises(engine.EngineError):
-        engine.Table(8, 9)
+        engine.Table(8, abi.MAX_CLUSTER + 1)                                 # (8 .. 15 nodes are clusters like any other since ABI 5)
+    with pytest.raises(engine.EngineError):
+        engine.Table(8, 1)
 
 
 def test_copy_bandwidth_reports_something_sane():

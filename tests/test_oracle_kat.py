@@ -26,6 +26,8 @@ def test_major_indices_golden_table():
     the majority index (N=2:|o|*|  N=3:|x|o|*|  N=4:|x|o|x|*|  N=5:|x|x|o|x|*|  N=6:|x|x|o|x|x|*|
     N=7:|x|x|x|o|x|x|*|), `[0]` is the index replicated everywhere."""
     table = {1: 0, 2: 1, 3: 1, 4: 2, 5: 2, 6: 3}      # followers -> slot of `o` (0-based, ascending)
+    # beyond the comment table (N = 8 .. 15, ABI 5): the rule under it, `int majorIndex = matchIndices.length / 2` (member/Leadership.java:127)
+    table.update({f: f // 2 for f in range(7, 15)})
     for f, slot in table.items():
         for perm in itertools.islice(itertools.permutations(range(10, 10 + f)), 50):
             full, major = oracle_lib.major_indices(list(perm))
