@@ -37,6 +37,17 @@ def main(src, name):
         doc["entries"] = [x for x in doc["entries"] if key(x) != key(e)] + [e]
         json.dump(doc, open(tpath, "w"), indent=1)
         print("traffic.json:", key(e), "%.1f MB" % (e["traffic_bytes_per_launch"] / 1e6))
+    vent = os.path.join(src, "valu_entry.json")
+    if os.path.exists(vent):
+        e = json.load(open(vent))
+        e["source"] = "profiles/%s_rocprofv3_summary.txt" % name
+        vpath = os.path.join(dst, "valu.json")
+        doc = json.load(open(vpath)) if os.path.exists(vpath) else {"note": "vector (SQ_INSTS_VALU), scalar and LDS instructions per launch of the step kernel from rocprofv3 PMC passes; bench.py "
+                                                                           "quotes an entry in roofline.valu only for the same workload, kernel and library build, and only when its own counter pass did not run", "entries": []}
+        key = lambda x: (x["config"], x["groups_per_gpu"], x["rounds"], x["kernel"], x.get("outcome_format", "rg_outcome_t"))   # noqa: E731
+        doc["entries"] = [x for x in doc["entries"] if key(x) != key(e)] + [e]
+        json.dump(doc, open(vpath, "w"), indent=1)
+        print("valu.json:", key(e), "%.4g VALU" % e["sq_insts_valu_per_launch"])
 
 
 if __name__ == "__main__":

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 evidence pass (run on the GPU box from the repo root): tools/prof_r5.sh <tag>
+# Round-6 evidence pass (round 5's, plus: the default line now carries its own counter passes, per-launch spread and the device-resident tick) (run on the GPU box from the repo root): tools/prof_r6.sh <tag>
 #   1. the default bench line as the driver runs it (every leg: cpu_baseline, PCIe, adverse mix, long-lived groups, tick latency)  -> gpurun_out/bench_<tag>_default.json
 #   2. config 3 (the bench default, 65 536 groups), config 4's and config 5's shard (131 072), config 5 @ 65 536: per workload a bench line, ONE kernel-trace
 #      pass of 24 launches (--stats), a FETCH_SIZE pass and a WRITE_SIZE pass (separate runs, --pmc only); config 3 also the two SQ passes
 #   3. config 2 / 2f (4 096 groups): bench lines only
 #   4. build/membench under the FETCH_SIZE / WRITE_SIZE passes: the calibration of the two counters on kernels of known byte counts
-# Everything lands under gpurun_out/; tools/collect_r5.sh copies what is judged into profiles/.
+# Everything lands under gpurun_out/; tools/collect_r6.sh copies what is judged into profiles/.
 set -u
 TAG=$1
 ROOT=$(pwd)

@@ -54,6 +54,12 @@ def main(out):
                  "lib_sha16": engine.library_sha16(), "source": "profiles/%s" % os.path.basename(out.rstrip("/"))}
         json.dump(entry, open(os.path.join(out, "traffic_entry.json"), "w"), indent=1)
         lines.append("== traffic entry: %.1f MB per launch (fetch x2 + write), lib %s" % (entry["traffic_bytes_per_launch"] / 1e6, entry["lib_sha16"]))
+        if "SQ_INSTS_VALU" in counters:          # round 6: the vector-ALU side, quoted by bench.py's roofline.valu where its own counter pass did not run
+            ventry = {k: entry[k] for k in ("config", "groups_per_gpu", "rounds", "kernel", "outcome_format", "lib_sha16", "source")}
+            ventry.update({"sq_insts_valu_per_launch": counters["SQ_INSTS_VALU"], "sq_insts_salu_per_launch": counters.get("SQ_INSTS_SALU"),
+                           "sq_insts_lds_per_launch": counters.get("SQ_INSTS_LDS"), "sq_waves": counters.get("SQ_WAVES"), "sq_busy_cycles": counters.get("SQ_BUSY_CYCLES")})
+            json.dump(ventry, open(os.path.join(out, "valu_entry.json"), "w"), indent=1)
+            lines.append("== valu entry: %.4g vector instructions per launch" % counters["SQ_INSTS_VALU"])
     text = "\n".join(lines)
     open(os.path.join(out, "summary.txt"), "w").write(text + "\n")
     print(text)
