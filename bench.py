@@ -830,6 +830,7 @@ def main():
                 "traffic": traffic, "traffic_unit": "GB per launch (rocprofv3 PMC: %s)" % traffic_src,
                 "traffic_lib_sha16": engine.library_sha16() if traffic is not None else None, "traffic_measured_in_this_run": traffic_here,
                 "pmc_passes": pmc,
+                "library": os.path.basename(engine.LIB_PATH), "lib_sha16": engine.library_sha16(),      # (same-box A/B records: which build a line is of)
                 "per_launch": spread,
                 "hbm_bytes_measured": None if traffic is None else traffic * 1e9,
                 "hbm_gbps_measured": None if traffic is None else traffic / avg_kernel_s,
