@@ -704,27 +704,41 @@ def main():
                 tt.close()
             # the DEVICE-RESIDENT tick (ABI 5, rg_tick2_*): decisions -> timers -> health -> fired tickets -> send table -> readiness as ONE graph on compact
             # outcome rows, every large column in HBM; what the device spends per tick, by a HIP event pair around the replays
-            tt = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
-            tt.load_state(tick_st0)
-            tt.timers_configure(900, 300, 1)
-            tt.timers_arm(0)
-            t2k = engine.Tick2(tt, 1, entry_cap=cap, expired_cap=gpg, critical_point=1, cool_down_ms=60, device_resident=True)
-            n2 = min(len(packed), 60)
-            for i in range(n2):
-                t2k.refill(packed[i], [300 * (i + 1)])
-                if i == 10:
-                    tt.sync()
-                    t_dev = 0.0
-                if i < 10:
-                    t2k.launch(); t2k.wait()
-                else:
-                    tt.timing_begin()
-                    t2k.launch()
-                    t_dev += tt.timing_end()
-            res["device_us_per_resident_tick"] = t_dev * 1e3 / (n2 - 10)
-            res["resident_tick_steps"] = "step32c -> {timers_update32 + health_update32 + fired tickets, one kernel} -> replicate -> ready (one hipGraphLaunch of four kernel nodes)"
-            t2k.close()
-            tt.close()
+            # The default recording is ONE kernel node (tick_kernel); RG_TICK_NODES=2 / 4 record step + fused tail / the step-by-step form: all three are timed.
+            by_nodes = {}
+            saved_nodes = os.environ.get("RG_TICK_NODES")
+            for nodes in (4, 2, 1):
+                tt = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+                tt.load_state(tick_st0)
+                tt.timers_configure(900, 300, 1)
+                tt.timers_arm(0)
+                os.environ["RG_TICK_NODES"] = str(nodes)
+                try:
+                    t2k = engine.Tick2(tt, 1, entry_cap=cap, expired_cap=gpg, critical_point=1, cool_down_ms=60, device_resident=True)
+                finally:
+                    if saved_nodes is None:
+                        del os.environ["RG_TICK_NODES"]
+                    else:
+                        os.environ["RG_TICK_NODES"] = saved_nodes
+                n2 = min(len(packed), 60)
+                t_dev = 0.0
+                for i in range(n2):
+                    t2k.refill(packed[i], [300 * (i + 1)])
+                    if i == 10:
+                        tt.sync()
+                    if i < 10:
+                        t2k.launch(); t2k.wait()
+                    else:
+                        tt.timing_begin()
+                        t2k.launch()
+                        t_dev += tt.timing_end()
+                by_nodes[str(nodes)] = t_dev * 1e3 / (n2 - 10)
+                t2k.close()
+                tt.close()
+            res["device_us_per_resident_tick"] = by_nodes["1"]
+            res["device_us_per_resident_tick_by_graph_nodes"] = by_nodes
+            res["resident_tick_steps"] = ("decisions (step32c), timers_update32 + health_update32 + fired tickets, replicate, ready — recorded as ONE kernel node (tick_kernel: the workgroup "
+                                          "that decided 64 groups does the rest for them); by_graph_nodes: 2 = step + fused tail, 4 = step, fold, replicate, ready")
             tick = dict(res, groups=gpg, rounds_per_tick=1, bytes_up_per_tick=24 * gpg, note="submit -> wait of ONE round over PCIe, page-locked buffers both ways; "
                         "python call overhead (ctypes, ~2 us per call) included in both ways; gc disabled inside the timed loops")
         except Exception as e:      # a reporting leg must not take the bench line down with it

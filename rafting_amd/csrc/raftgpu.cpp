@@ -26,6 +26,8 @@ hipError_t launch_health_failure(const HealthParams &p, uint32_t n, const uint32
 hipError_t launch_ready(const HealthParams &p, int64_t now, int32_t cp, int64_t cd, uint8_t *ready, hipStream_t s);
 hipError_t launch_timers_update(const TimerParams &p, hipStream_t s);
 hipError_t launch_tick_fold(const TickFoldParams &p, hipStream_t s);
+hipError_t launch_tick_tail(const TickTailParams &p, int followers, hipStream_t s);
+hipError_t launch_tick(const StepParams &p, const TickTailParams &tp, int followers, hipStream_t s);
 hipError_t launch_timers_arm(const TimerParams &p, hipStream_t s);
 hipError_t launch_timers_expired(int64_t *deadline, const Ident *ident, uint32_t groups, int64_t now, const int64_t *now_mem, uint32_t *counts, uint32_t *total,
                                  uint32_t *out_gid, uint32_t *out_epoch, uint32_t capacity, hipStream_t s);
@@ -898,18 +900,33 @@ int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick)
     rg::ReplicateParams qp{};
     qp.t = t->dt; qp.count = G; qp.heartbeat = (const uint8_t *)d_hb; qp.in_flight = (const uint16_t *)d_fl; qp.head = (rg_send_head_t *)d_sh; qp.send = (rg_send_t *)d_ss;
     hipStream_t s = t->stream;
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e == hipSuccess) e = rg::launch_step(sp, (int)t->F, false, 32, s);
-    // ONE kernel for what the batch did to the timers and the followers' health and for the list of the tickets that fired (a single-round tick is
-    // launch-bound: rg_kernels.hip, tick_fold_kernel); timer_counts doubles as its per-wavefront masks (64 bits each) + the ticket word
+    // What follows the decisions — what the batch did to the timers and to the followers' health, the list of the tickets that fired, the leaders' sends, the
+    // readiness column — is one lane per group with same-group dependencies only, and a single-round tick is launch-bound (~14 us per graph node for ~10 us of
+    // work in all at 65 536 groups). So the recording is ONE kernel node: rg_kernels.hip, tick_kernel — the workgroup that decided 64 groups does the rest for
+    // them. RG_TICK_NODES=2 records step + tick_tail_kernel, RG_TICK_NODES=4 the step-by-step form (step, tick_fold, replicate, ready): same-box A/Bs and the
+    // differential tests. timer_counts doubles as the per-wavefront masks of the expiry (64 bits each) + its ticket word.
     rg::TickFoldParams fp{};
     fp.tp = tp; fp.hp = hp; fp.now_last = now_last;
     fp.masks = (unsigned long long *)t->tick_masks; fp.ticket = t->tick_ticket;
     fp.out_gid = (uint32_t *)d_egid; fp.out_epoch = (uint32_t *)d_eep; fp.out_count = (uint32_t *)d_ecnt; fp.capacity = io->expired_capacity;
     fp.expire = io->expired_gid != nullptr;
-    if (e == hipSuccess) e = rg::launch_tick_fold(fp, s);
-    if (e == hipSuccess && io->send_head) e = rg::launch_replicate(qp, (int)t->F, s);
-    if (e == hipSuccess && io->ready) e = rg::launch_ready(rp, 0, io->critical_point, io->cool_down_ms, (uint8_t *)d_ready, s);
+    rg::TickTailParams tt{};
+    tt.fp = fp; tt.qp = qp; tt.rp = rp; tt.critical_point = io->critical_point; tt.cool_down = io->cool_down_ms; tt.ready = (uint8_t *)d_ready;
+    const char *nodes_env = getenv("RG_TICK_NODES");
+    const int nodes = (nodes_env && (nodes_env[0] == '2' || nodes_env[0] == '4')) ? nodes_env[0] - '0' : (sp.force_wide != 0 ? 2 : 1);
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (nodes == 1) {
+        if (e == hipSuccess) e = rg::launch_tick(sp, tt, (int)t->F, s);
+    } else {
+        if (e == hipSuccess) e = rg::launch_step(sp, (int)t->F, false, 32, s);
+        if (nodes == 2) {
+            if (e == hipSuccess) e = rg::launch_tick_tail(tt, (int)t->F, s);
+        } else {
+            if (e == hipSuccess) e = rg::launch_tick_fold(fp, s);
+            if (e == hipSuccess && io->send_head) e = rg::launch_replicate(qp, (int)t->F, s);
+            if (e == hipSuccess && io->ready) e = rg::launch_ready(rp, 0, io->critical_point, io->cool_down_ms, (uint8_t *)d_ready, s);
+        }
+    }
     hipGraph_t g = nullptr;
     const hipError_t e2 = hipStreamEndCapture(s, &g);           // (always: an open capture would poison the stream)
     k->graph = g;

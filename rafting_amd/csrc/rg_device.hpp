@@ -145,6 +145,14 @@ struct TickFoldParams {              // the device-resident tick's second kernel
     uint32_t capacity;
     int expire;                      // 0: no expiry step
 };
+struct TickTailParams {              // everything a recorded tick does after the decisions, one launch (rg_kernels.hip: tick_tail_kernel)
+    TickFoldParams fp;
+    ReplicateParams qp;              // head == nullptr: no send side
+    HealthParams rp;                 // now_mem = &now[rounds - 1]
+    int32_t critical_point;
+    int64_t cool_down;
+    uint8_t *ready;                  // nullptr: no readiness column
+};
 
 __device__ __forceinline__ int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
 __device__ __forceinline__ int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }

@@ -25,12 +25,10 @@ __device__ __forceinline__ void stream_store(uint4 *dst, const uint4 v)
 // Writes: 48 B head + 32 F B sends per row. The outputs are arrays of structs (what the host reads), so a lane's own struct
 // is not a coalesced unit; every wavefront therefore transposes through LDS and stores WHOLE 1 KiB lines, 16 B per lane:
 // three store instructions for the 64 heads, two per follower for the 64 sends of that follower.
+// (the rows of ONE wavefront: i0 = its first row, st = its own 3 KiB of LDS; replicate_kernel and the fused tail of a recorded tick call it)
 template <int F>
-__global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
+__device__ __forceinline__ void replicate_wave(const ReplicateParams &p, uint4 *st, const uint32_t i0, const uint32_t lane)
 {
-    __shared__ uint4 stage[4][3 * 64];                // per wavefront: 64 heads (3 x 16 B) or 64 sends (2 x 16 B)
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t i0 = blockIdx.x * blockDim.x + wave * 64u;      // first row of this wavefront
     const uint32_t i = i0 + lane;
     const bool active = i < p.count;
     const uint32_t ir = active ? i : p.count - 1u;              // lanes past the end shadow the last row; their stores are clipped
@@ -122,7 +120,6 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
     // ---- transposed, line-sized stores -------------------------------------------------------------------------------
     // each wavefront owns its slice of `stage`: LDS operations of one wavefront execute in order, so a wave-level
     // scheduling barrier + lgkmcnt(0) is all the synchronisation the transpose needs (no workgroup barrier)
-    uint4 *st = stage[wave];
     const uint32_t rows_here = p.count > i0 ? (p.count - i0 < 64u ? p.count - i0 : 64u) : 0u;
     {
         const uint4 *hv = reinterpret_cast<const uint4 *>(&h);
@@ -149,6 +146,14 @@ __global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
         }
         wave_lds_sync();
     }
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void replicate_kernel(const ReplicateParams p)
+{
+    __shared__ uint4 stage[4][3 * 64];                // per wavefront: 64 heads (3 x 16 B) or 64 sends (2 x 16 B)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    replicate_wave<F>(p, stage[wave], blockIdx.x * blockDim.x + wave * 64u, lane);
 }
 
 hipError_t launch_replicate(const ReplicateParams &p, int followers, hipStream_t s)
@@ -306,57 +311,60 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, con
 #define RG_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define RG_TICKET_TAKE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
 #endif
-__global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)
+// what the batch did to the timer and the follower statistics of group g (timers_update32_kernel + health_update_kernel); returns the deadline it leaves
+__device__ __forceinline__ int64_t fold_group(const TickFoldParams &p, const uint32_t g)
 {
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t is_last;
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x, G = p.tp.count;
-    const bool active = g < G;
-    int64_t d = 0;
-    if (active) {
-        // RaftRoutine.resetTimer for the rows of this group (timers_update32_kernel)
-        d = p.tp.deadline[g];
-        uint32_t e = p.tp.epoch[g];
-        const size_t GG = p.hp.t.groups;
-        for (uint32_t r = 0; r < p.tp.rounds; r++) {
-            const size_t row = (size_t)r * G + g;
-            const uint32_t flags = (uint32_t)p.tp.out32[row].y;
-            const int64_t now = p.tp.now_mem[r];
-            if (flags & RG_F_PERSIST) e = (uint32_t)p.tp.persist32[row].z;
-            if (flags & RG_F_RESET_TIMER)
-                d = rearm(p.tp, d, g, (int)RG_F_ROLE(flags), (flags & RG_F_ROLE_CHANGED) != 0, (flags & RG_F_TIMER_MUTED) != 0, e, now);
-            // Leadership.State.statSuccess for an ack that was applied (health_update_kernel)
-            if ((flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(flags) == RG_LEADER) {
-                for (uint32_t j = 0; j < p.hp.followers; j++) { p.hp.ok[j * GG + g] = 0; p.hp.fail[j * GG + g] = 0; p.hp.recent[j * GG + g] = 0; }
-                continue;
-            }
-            const uint32_t hdr = p.hp.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(flags);
-            const bool ack = kind == RG_EV_AE_ACK || kind == RG_EV_IS_ACK;
-            const bool reached = st == RG_OK || st == RG_A_MATCH_ROLLBACK || st == RG_NPE_MAJOR_NULL || st == RG_A_COMMIT_ROLLBACK;
-            if (!ack || !reached || (flags & RG_F_ROLE_CHANGED) || slot >= p.hp.followers + 1 || slot == p.hp.self) continue;
-            const uint32_t j = slot < p.hp.self ? slot : slot - 1;
-            if (now > p.hp.ok[j * GG + g]) p.hp.ok[j * GG + g] = now;
-            p.hp.recent[j * GG + g] = 0;
+    const uint32_t G = p.tp.count;
+    // RaftRoutine.resetTimer for the rows of this group (timers_update32_kernel)
+    int64_t d = p.tp.deadline[g];
+    uint32_t e = p.tp.epoch[g];
+    const size_t GG = p.hp.t.groups;
+    for (uint32_t r = 0; r < p.tp.rounds; r++) {
+        const size_t row = (size_t)r * G + g;
+        const uint32_t flags = (uint32_t)p.tp.out32[row].y;
+        const int64_t now = p.tp.now_mem[r];
+        if (flags & RG_F_PERSIST) e = (uint32_t)p.tp.persist32[row].z;
+        if (flags & RG_F_RESET_TIMER)
+            d = rearm(p.tp, d, g, (int)RG_F_ROLE(flags), (flags & RG_F_ROLE_CHANGED) != 0, (flags & RG_F_TIMER_MUTED) != 0, e, now);
+        // Leadership.State.statSuccess for an ack that was applied (health_update_kernel)
+        if ((flags & RG_F_ROLE_CHANGED) && RG_F_ROLE(flags) == RG_LEADER) {
+            for (uint32_t j = 0; j < p.hp.followers; j++) { p.hp.ok[j * GG + g] = 0; p.hp.fail[j * GG + g] = 0; p.hp.recent[j * GG + g] = 0; }
+            continue;
         }
-        p.tp.deadline[g] = d;
-        p.tp.epoch[g] = e;
+        const uint32_t hdr = p.hp.head[row].hdr, kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), st = RG_F_STATUS(flags);
+        const bool ack = kind == RG_EV_AE_ACK || kind == RG_EV_IS_ACK;
+        const bool reached = st == RG_OK || st == RG_A_MATCH_ROLLBACK || st == RG_NPE_MAJOR_NULL || st == RG_A_COMMIT_ROLLBACK;
+        if (!ack || !reached || (flags & RG_F_ROLE_CHANGED) || slot >= p.hp.followers + 1 || slot == p.hp.self) continue;
+        const uint32_t j = slot < p.hp.self ? slot : slot - 1;
+        if (now > p.hp.ok[j * GG + g]) p.hp.ok[j * GG + g] = now;
+        p.hp.recent[j * GG + g] = 0;
     }
-    if (!p.expire) return;
-    // ---- the fired tickets ------------------------------------------------------------------------------------------------------------
+    p.tp.deadline[g] = d;
+    p.tp.epoch[g] = e;
+    return d;
+}
+
+// The fired tickets of the whole table, in ascending gid order, by ONE launch: every wavefront that holds groups leaves its ballot mask in HBM (mask w =
+// groups 64 w .. 64 w + 63), a ticket tells the last workgroup to finish that it is the last, and that workgroup scans the masks. EVERY thread of the grid
+// calls it (the barriers); d = the deadline of the lane's group, `holds` (wave-uniform) = this wavefront has groups at all; `part` = blockDim.x words of LDS
+// (blockDim.x a power of two, at most 256), `is_last` one more.
+__device__ __forceinline__ void expire_tail(const TickFoldParams &p, const int64_t d, const uint32_t mask_index, const bool holds, const bool active,
+                                            const uint32_t nmasks, uint32_t *part, uint32_t *is_last)
+{
     const int64_t now = *p.now_last;
-    const unsigned long long m = __ballot(active && d > 0 && d <= now);
-    if ((threadIdx.x & 63u) == 0u) p.masks[g >> 6] = m;
-    __syncthreads();                                                 // (this workgroup's four masks are stored before its ticket is taken)
-    if (threadIdx.x == 0) is_last = RG_TICKET_TAKE(p.ticket) == gridDim.x - 1u ? 1u : 0u;
+    const unsigned long long m = __ballot(holds && active && d > 0 && d <= now);
+    if (holds && (threadIdx.x & 63u) == 0u) p.masks[mask_index] = m;
+    __syncthreads();                                                 // (this workgroup's masks are stored before its ticket is taken)
+    if (threadIdx.x == 0) *is_last = RG_TICKET_TAKE(p.ticket) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
-    if (!is_last) return;
-    const uint32_t waves = gridDim.x * 4u, tid = threadIdx.x;
-    const uint32_t per = (waves + 255u) / 256u, lo = tid * per, hi = lo + per < waves ? lo + per : waves;
+    if (!*is_last) return;
+    const uint32_t nt = blockDim.x, tid = threadIdx.x;
+    const uint32_t per = (nmasks + nt - 1u) / nt, lo = tid * per < nmasks ? tid * per : nmasks, hi = lo + per < nmasks ? lo + per : nmasks;
     uint32_t sum = 0;
     for (uint32_t w = lo; w < hi; w++) sum += (uint32_t)__popcll(RG_AGENT_LOAD(p.masks + w));
     part[tid] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {                   // Hillis-Steele inclusive scan of the 256 partial sums
+    for (uint32_t off = 1; off < nt; off <<= 1) {                    // Hillis-Steele inclusive scan of the partial sums
         const uint32_t v = tid >= off ? part[tid - off] : 0;
         __syncthreads();
         part[tid] += v;
@@ -377,7 +385,17 @@ __global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)
             pos++;
         }
     }
-    if (tid == 255) { *p.out_count = part[255]; *p.ticket = 0u; }
+    if (tid == nt - 1u) { *p.out_count = part[nt - 1u]; *p.ticket = 0u; }
+}
+
+__global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)
+{
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t is_last;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const bool active = g < p.tp.count;
+    const int64_t d = active ? fold_group(p, g) : 0;
+    if (p.expire) expire_tail(p, d, g >> 6, true, active, gridDim.x * 4u, part, &is_last);
 }
 
 hipError_t launch_tick_fold(const TickFoldParams &p, hipStream_t s)
@@ -454,11 +472,8 @@ __global__ __launch_bounds__(256) void health_failure_kernel(const HealthParams 
 }
 
 // Leader.isReady: ready = 1; for every State that isReady(...): ++ready > followers/2 -> true
-__global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_t now, int32_t critical_point, int64_t cool_down, uint8_t *ready)
+__device__ __forceinline__ uint8_t ready_of(const HealthParams &p, const int64_t now, const int32_t critical_point, const int64_t cool_down, const uint32_t g)
 {
-    if (p.now_mem) now = *p.now_mem;
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= p.t.groups) return;
     const Ident id = p.t.ident[g];
     uint8_t out = 0;
     if ((id.meta & META_ROLE) == RG_LEADER && (id.meta & META_PREP)) {
@@ -474,7 +489,89 @@ __global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_
             if (is_ready && ++n > p.followers / 2) { out = 1; break; }
         }
     }
-    ready[g] = out;
+    return out;
+}
+__global__ __launch_bounds__(256) void ready_kernel(const HealthParams p, int64_t now, int32_t critical_point, int64_t cool_down, uint8_t *ready)
+{
+    if (p.now_mem) now = *p.now_mem;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.t.groups) return;
+    ready[g] = ready_of(p, now, critical_point, cool_down, g);
+}
+
+// ---- the tail of a recorded tick (rg_tick2): timers + health, the leaders' sends, isReady and the fired tickets of every group in ONE launch ------------
+// A single-round tick is launch-bound (four graph nodes: 56 us for ~10 us of work at 65 536 groups), and the three steps after the decisions have the same
+// shape — one lane per group, every group — with only same-group dependencies between them: isReady reads the statistics the fold wrote and the `prepared`
+// mark the send side set, all of the SAME group, i.e. by the same lane, in program order. The ticket of expire_tail comes last (the last workgroup stays).
+template <int F>
+__global__ __launch_bounds__(256) void tick_tail_kernel(const TickTailParams p)
+{
+    __shared__ uint4 stage[4][3 * 64];
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t is_last;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const bool active = g < p.fp.tp.count;
+    const int64_t d = active ? fold_group(p.fp, g) : 0;
+    if (p.qp.head != nullptr) replicate_wave<F>(p.qp, stage[wave], blockIdx.x * 256u + wave * 64u, lane);
+    if (p.ready != nullptr && active) p.ready[g] = ready_of(p.rp, *p.rp.now_mem, p.critical_point, p.cool_down, g);
+    if (p.fp.expire) expire_tail(p.fp, d, g >> 6, true, active, gridDim.x * 4u, part, &is_last);
+}
+// ---- a recorded tick as ONE launch: the decisions of step32_kernel (compact rows, compact outcome rows, dense) and, by the same workgroup for its own 64
+// groups, everything tick_tail_kernel does. What the tail reads was written by THIS workgroup — the outcome rows by its I/O wavefront, the table by its
+// deciding wavefront —, so a workgroup barrier behind `s_waitcnt vmcnt(0)` is all the ordering it needs (the wavefronts of a workgroup share their CU's L1;
+// none of these lines was read before it was written); only the fired-ticket list crosses workgroups, through expire_tail's ticket as before.
+template <int F, int WAVES>
+__global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void tick_kernel(const StepParams p, const TickTailParams tp)
+{
+    __shared__ alignas(16) unsigned char smem[SplitLds<F, true, 2>::BYTES];
+    static_assert(SplitLds<F, true, 2>::BYTES >= 3 * 64 * 16 + (2 * BLOCK + 1) * 4, "the tail's staging rows and scan words reuse the step's LDS");
+    if (!narrow_body<F, false, true, 1, 1>(p, smem)) {
+        if (threadIdx.x == 0) { RG_NOTE_FALLBACK(); atomicAdd(p.wide_bodies, 1ull); }
+        lds_barrier();
+        split_body<F, false, true, true>(p, smem);
+    }
+    __syncthreads();                                         // every store of this workgroup has landed; its LDS is free
+    uint4 *stage = reinterpret_cast<uint4 *>(smem);
+    uint32_t *part = reinterpret_cast<uint32_t *>(smem + 3 * 64 * 16), *is_last = part + 2 * BLOCK;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool holds = __builtin_amdgcn_readfirstlane(threadIdx.x) < (uint32_t)BLOCK;      // the first wavefront: lane = group, as in the step
+    const uint32_t g = blockIdx.x * BLOCK + lane;
+    const bool active = holds && g < tp.fp.tp.count;
+    int64_t d = 0;
+    if (holds) {
+        if (active) d = fold_group(tp.fp, g);
+        if (tp.qp.head != nullptr) replicate_wave<F>(tp.qp, stage, blockIdx.x * BLOCK, lane);
+        if (tp.ready != nullptr && active) tp.ready[g] = ready_of(tp.rp, *tp.rp.now_mem, tp.critical_point, tp.cool_down, g);
+    }
+    if (tp.fp.expire) expire_tail(tp.fp, d, blockIdx.x, holds, active, gridDim.x, part, is_last);
+}
+hipError_t launch_tick(const StepParams &p, const TickTailParams &tp, int followers, hipStream_t s)
+{
+    const uint32_t blocks = (p.count + BLOCK - 1) / BLOCK;
+    if (blocks == 0) return hipSuccess;
+    if (p.count >= (1u << 28) || p.out32 == nullptr || p.force_wide != 0) return hipErrorInvalidValue;
+    const bool many = blocks > 1024u;
+    const dim3 grid(blocks), wg(2 * BLOCK);
+    switch (followers) {
+#define RG_TICK_CASE(F_) case F_: if (many) hipLaunchKernelGGL((tick_kernel<F_, 4>), grid, wg, 0, s, p, tp); else hipLaunchKernelGGL((tick_kernel<F_, 1>), grid, wg, 0, s, p, tp); break;
+    RG_TICK_CASE(1) RG_TICK_CASE(2) RG_TICK_CASE(3) RG_TICK_CASE(4) RG_TICK_CASE(5) RG_TICK_CASE(6)
+#undef RG_TICK_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_tick_tail(const TickTailParams &p, int followers, hipStream_t s)
+{
+    const uint32_t blocks = (p.fp.tp.count + 255) / 256;
+    if (blocks == 0) return hipSuccess;
+    switch (followers) {
+#define RG_TAIL_CASE(F_) case F_: hipLaunchKernelGGL(tick_tail_kernel<F_>, dim3(blocks), dim3(256), 0, s, p); break;
+    RG_TAIL_CASE(1) RG_TAIL_CASE(2) RG_TAIL_CASE(3) RG_TAIL_CASE(4) RG_TAIL_CASE(5) RG_TAIL_CASE(6)
+#undef RG_TAIL_CASE
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_health_update(const HealthParams &p, hipStream_t s)

@@ -144,6 +144,9 @@ def test_the_once_per_tick_graph_matches_the_oracle():
 def test_the_device_resident_tick_matches_the_oracle():
     T.tick2_case(G=128, ticks=14)
     T.tick2_case(G=64, ticks=6, seed=9, device_resident=True)
+    T.tick2_case(G=200, ticks=8, seed=10, nodes=2)
+    T.tick2_case(G=200, ticks=8, seed=11, nodes=4)
+    T.tick2_case(G=200, ticks=8, seed=12, nodes=1)          # (a ragged last workgroup)
 
 
 def test_groups_at_two_to_the_forty_stay_on_the_32_bit_body():

@@ -1044,7 +1044,7 @@ def tick_path_case(G=192, P=5, ticks=24, seed=123):
     orc.close()
 
 
-def tick2_case(G=4096, P=5, ticks=40, seed=321, device_resident=False):
+def tick2_case(G=4096, P=5, ticks=40, seed=321, device_resident=False, nodes=None):
     """The device-resident tick (rg_tick2_*, ABI 5): step32c -> timers_update32 -> health_update32 -> timers_expired -> replicate -> ready as ONE HIP graph,
     driven by its own timers: the tickets that fire become the TIMEOUT rows (with their role epochs) of the NEXT tick, tick after tick. Every tick is held
     against the oracle doing the same with separate calls: outcome rows, deadlines, expired lists + epochs, health statistics, send table, readiness."""
@@ -1057,7 +1057,18 @@ def tick2_case(G=4096, P=5, ticks=40, seed=321, device_resident=False):
         t.timers_configure(900, 300, 4321)
         t.timers_arm(10_000)
     assert np.array_equal(gpu.timers_read(), orc.timers_read())
-    tick = engine.Tick2(gpu, 1, entry_cap=8 * G, expired_cap=G, critical_point=1, cool_down_ms=60, device_resident=device_resident)
+    # (nodes: how the tick is RECORDED — 1 = one kernel (the default), 2 = step + fused tail, 4 = step, fold, replicate, ready; read at rg_tick2_create)
+    saved = os.environ.get("RG_TICK_NODES")
+    if nodes is not None:
+        os.environ["RG_TICK_NODES"] = str(nodes)
+    try:
+        tick = engine.Tick2(gpu, 1, entry_cap=8 * G, expired_cap=G, critical_point=1, cool_down_ms=60, device_resident=device_resident)
+    finally:
+        if nodes is not None:
+            if saved is None:
+                del os.environ["RG_TICK_NODES"]
+            else:
+                os.environ["RG_TICK_NODES"] = saved
     fired_g, fired_e = np.zeros(0, np.uint32), np.zeros(0, np.uint32)
     seen_fired = seen_send = repaired = 0
     rng = np.random.default_rng(seed)
@@ -1144,8 +1155,11 @@ def tick2_case(G=4096, P=5, ticks=40, seed=321, device_resident=False):
 def test_the_device_resident_tick_matches_the_oracle(step_kernel_variant):
     if step_kernel_variant != "compact-out32":
         pytest.skip("one route: the tick always runs the compact-row kernel with compact outcome rows")
-    tick2_case()
+    tick2_case()                                            # (recorded as ONE kernel: tick_kernel)
     tick2_case(G=1024, ticks=12, seed=77, device_resident=True)
+    tick2_case(G=131072 + 64, ticks=6, seed=5, device_resident=True)      # (the 128-VGPR variant; 2 049 workgroups take the expiry's ticket)
+    tick2_case(G=2048, ticks=16, seed=78, nodes=2)          # (step + tick_tail_kernel)
+    tick2_case(G=2048, ticks=16, seed=79, nodes=4)          # (the step-by-step recording)
 
 
 def test_the_once_per_tick_graph_matches_the_oracle(step_kernel_variant):
