@@ -720,22 +720,36 @@ def main():
                         del os.environ["RG_TICK_NODES"]
                     else:
                         os.environ["RG_TICK_NODES"] = saved_nodes
+                # Two readings per recording. `idle`: one event pair around one hipGraphLaunch on an idle stream — what a host that waits for every tick sees; it
+                # contains the host's own submission time (the start event completes at once, the graph's packets arrive tens of microseconds later). `busy`: the same
+                # behind ~80 us of queued work (eight single-round launches of another batch), so that events and graph are all queued while the device is still
+                # busy and the pair brackets DEVICE time only: the tick's kernels and the gaps between its nodes.
                 n2 = min(len(packed), 60)
-                t_dev = 0.0
+                busy_db = engine.DeviceBatch32(tt, ticks[0], compact=True, wide=False)
+                t_idle = t_busy = 0.0
                 for i in range(n2):
                     t2k.refill(packed[i], [300 * (i + 1)])
                     if i == 10:
                         tt.sync()
                     if i < 10:
                         t2k.launch(); t2k.wait()
-                    else:
+                    elif i % 2 == 1:
                         tt.timing_begin()
                         t2k.launch()
-                        t_dev += tt.timing_end()
-                by_nodes[str(nodes)] = t_dev * 1e3 / (n2 - 10)
+                        t_idle += tt.timing_end()
+                    else:
+                        for _ in range(8):
+                            tt.submit_device(busy_db)
+                        tt.timing_begin()
+                        t2k.launch()
+                        t_busy += tt.timing_end()
+                n_idle = len([i for i in range(10, n2) if i % 2 == 1]); n_busy = n2 - 10 - n_idle
+                by_nodes[str(nodes)] = {"device_us": t_busy * 1e3 / max(n_busy, 1), "idle_stream_us": t_idle * 1e3 / n_idle if n_idle else None}
+                busy_db.free()
                 t2k.close()
                 tt.close()
-            res["device_us_per_resident_tick"] = by_nodes["1"]
+            res["device_us_per_resident_tick"] = by_nodes["1"]["device_us"]
+            res["resident_tick_us_on_an_idle_stream"] = by_nodes["1"]["idle_stream_us"]
             res["device_us_per_resident_tick_by_graph_nodes"] = by_nodes
             res["resident_tick_steps"] = ("decisions (step32c), timers_update32 + health_update32 + fired tickets, replicate, ready — recorded as ONE kernel node (tick_kernel: the workgroup "
                                           "that decided 64 groups does the rest for them); by_graph_nodes: 2 = step + fused tail, 4 = step, fold, replicate, ready")

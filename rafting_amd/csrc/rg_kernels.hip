@@ -301,15 +301,22 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, con
 }
 
 // ---- the device-resident tick, folded (rg_tick2) ---------------------------------------------------------------------------------------------
-// A single-round tick over 65 536 groups is launch-bound: every kernel of the chain costs 7-9 us of dispatch whatever it does (measured:
-// eight nodes, 74 us; profiles/r06e_bench_default.json). So what follows the decisions is ONE kernel: per group the batch's flags into the deadline
-// (timers_update32_kernel) and into the followers' statistics (health_update_kernel), then the expiry — every wavefront leaves the ballot of its
-// expired lanes in `masks`, and the LAST workgroup to get there (an acq_rel ticket at agent scope: the masks of the others are visible to it, across
-// XCDs too) scans the per-wavefront counts and writes the list in ascending group order, marking the listed tickets fired — what
+// A single-round tick over 65 536 groups is launch-bound, so what follows the decisions is folded: per group the batch's flags into the deadline
+// (timers_update32_kernel) and into the followers' statistics (health_update_kernel), then the expiry — every wavefront leaves the ballot of its expired
+// lanes in `masks`, and the LAST workgroup to take a ticket scans them and writes the list in ascending group order, marking the listed tickets fired: what
 // timers_count / _scan / _emit do in three launches.
+// What crosses workgroups (and, on this part, XCDs — each with an L2 of its own) does so through AGENT-SCOPE ATOMIC loads and stores only: the masks, and for a
+// lane whose ticket fired its deadline and role epoch. Such a store is written through to the device's coherence point and `s_waitcnt vmcnt(0)` waits for
+// that; such a load does not hit a stale line. So the ticket itself is a RELAXED add behind a drained store queue and no workgroup executes an agent-scope
+// release / acquire — those write back and invalidate the XCD's whole L2, and with one per workgroup the one-kernel tick (1 024 workgroups, each with its
+// outcome rows and table lines dirty in L2) took 84 us against 52 for step + tail (profiles/r06j_bench_tick_recordings_before_fence_fix.json). The owner of a
+// fired ticket also STORES its deadline with an agent-scope atomic, so that no dirty copy of it stays in the owner's L2 to be written back over the -1 the
+// last workgroup puts there.
 #ifndef RG_AGENT_LOAD               // (the host emulation runs workgroups one after the other on plain memory)
 #define RG_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define RG_TICKET_TAKE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+#define RG_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RG_TICKET_TAKE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define RG_DRAIN_STORES() __builtin_amdgcn_s_waitcnt(0)      // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wavefront has reached its scope
 #endif
 // what the batch did to the timer and the follower statistics of group g (timers_update32_kernel + health_update_kernel); returns the deadline it leaves
 __device__ __forceinline__ int64_t fold_group(const TickFoldParams &p, const uint32_t g)
@@ -339,8 +346,16 @@ __device__ __forceinline__ int64_t fold_group(const TickFoldParams &p, const uin
         if (now > p.hp.ok[j * GG + g]) p.hp.ok[j * GG + g] = now;
         p.hp.recent[j * GG + g] = 0;
     }
-    p.tp.deadline[g] = d;
-    p.tp.epoch[g] = e;
+    // (a ticket that fires at the clock of the expiry: deadline and role epoch go where the last workgroup — any workgroup, any XCD — reads them; the epoch is
+    //  the table's own, which this lane's workgroup wrote if the decisions ran in this launch)
+    const bool fired = p.expire && d > 0 && d <= *p.now_last;
+    if (fired) {
+        RG_AGENT_STORE(p.tp.deadline + g, d);
+        RG_AGENT_STORE(p.tp.epoch + g, p.tp.ident[g].role_epoch);
+    } else {
+        p.tp.deadline[g] = d;
+        p.tp.epoch[g] = e;
+    }
     return d;
 }
 
@@ -353,8 +368,9 @@ __device__ __forceinline__ void expire_tail(const TickFoldParams &p, const int64
 {
     const int64_t now = *p.now_last;
     const unsigned long long m = __ballot(holds && active && d > 0 && d <= now);
-    if (holds && (threadIdx.x & 63u) == 0u) p.masks[mask_index] = m;
-    __syncthreads();                                                 // (this workgroup's masks are stored before its ticket is taken)
+    if (holds && (threadIdx.x & 63u) == 0u) RG_AGENT_STORE(p.masks + mask_index, m);
+    RG_DRAIN_STORES();
+    __syncthreads();                                                 // (this workgroup's masks, fired deadlines and epochs have landed before its ticket is taken)
     if (threadIdx.x == 0) *is_last = RG_TICKET_TAKE(p.ticket) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (!*is_last) return;
@@ -379,13 +395,13 @@ __device__ __forceinline__ void expire_tail(const TickFoldParams &p, const int64
             const uint32_t gg = w * 64u + lane;
             if (pos < p.capacity) {
                 p.out_gid[pos] = gg;
-                if (p.out_epoch) p.out_epoch[pos] = p.tp.ident[gg].role_epoch;
-                p.tp.deadline[gg] = -1;                               // electionTimeout's CAS: deadline -> TimerTicket.TIMEOUT
+                if (p.out_epoch) p.out_epoch[pos] = RG_AGENT_LOAD(p.tp.epoch + gg);
+                RG_AGENT_STORE(p.tp.deadline + gg, (int64_t)-1);      // electionTimeout's CAS: deadline -> TimerTicket.TIMEOUT
             }
             pos++;
         }
     }
-    if (tid == nt - 1u) { *p.out_count = part[nt - 1u]; *p.ticket = 0u; }
+    if (tid == nt - 1u) { *p.out_count = part[nt - 1u]; RG_AGENT_STORE(p.ticket, 0u); }
 }
 
 __global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)

@@ -1027,7 +1027,6 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
         const sw done = tier1n<F>(p, g, pe, out, h.x, (uint32_t)h.y, h.z, q.x, q.y, q.z, q.w);
         const bool open = done >= 0;                     // not decided by tier 1: the general handlers — or nothing, for a group blocked after a NEED_HOST
         RG_PROBE_MARK(1);
-        RG_NOTE_SLOW(open & !(blocked & (RG_HDR_KIND((uint32_t)h.w) != RG_EV_NONE)), lane == 0);
         // The outcome rows go to LDS BEFORE the branch on "somebody needs the general handlers": the ballot's scalar result is not there yet when the
         // branch is issued (the VALU -> SALU round trip, profiles/r04b_issue_bench.txt), and these stores are independent work to spend that wait on.
         // A round that does visit the general handlers writes the rows again afterwards.
@@ -1039,7 +1038,11 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
             const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
             const bool skip = open & blocked & (kind != RG_EV_NONE);
-            const bool slow = open & !skip;
+            // tier 1.5 (rg_tier1n.hpp): a new leader's entries over this Follower's uncommitted tail, and the cache miss of a prevLog term, on the 32-bit image
+            bool park;
+            const bool slow = open & !skip & !tier15(g, out, park, open & !skip, h.x, h.y, h.z, q.x, q.y, q.z, q.w);
+            if (park) { blocked = true; g.nallow = -1; g.recache(); }
+            RG_NOTE_SLOW(slow, lane == 0);                  // (the host emulation counts the rows and wave-rounds that reach the general handlers)
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);
             if (slow & !bail) {
                 // the general handlers decide on ABSOLUTE values: the image and the row's index fields are taken off the base, the results put back on it
@@ -1069,6 +1072,8 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             }
             sh_o0[slot][lane] = I32x4{out.resp, (int32_t)out.pw, (int32_t)g.role_epoch, g.commit};
             sh_o1[slot][lane] = I32x4{out.log_from, g.term, g.voted_for, g.role};
+        } else {
+            RG_NOTE_SLOW(false, lane == 0);
         }
         RG_PROBE_MARK(2);
 #ifdef RG_EVENT_PREFETCH

@@ -379,4 +379,58 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
     return done;
 }
 
+// ---- tier 1.5 (round 6): one more row class, decided on the 32-bit image but OFF the main path -------------------------------------------------------
+// An AppendEntries request whose entries OVERWRITE the uncommitted tail of this Follower's newest term run — what a new leader sends a follower that had
+// appended entries of the old one (member/Follower.java:35-88 with RaftLog.conflict / truncate / append, storage/RocksLog.java:131-216): prevLogIndex lies
+// strictly below the tail and inside the newest run (so its term is the tail's term and every overlapped entry has that term too), the carried entries are of
+// ONE other term (the conflict is at the first of them), nothing committed is cut and the commit index does not roll back. Stepper::on_append_entries on that
+// input: [refresh on a higher term or a timed-out Follower], leader = sender, truncate(prev + 1), a new run (prev + 1, entries' term), last = prev + n,
+// mark_committed(min(leaderCommit, last)), reply(term, true). tier1n leaves such a row open (prevLogIndex != last); narrow_body calls this for the open lanes
+// BEFORE it widens the image for the general handlers, and a wave-round whose open rows are all of this class never visits them: config 3 with 0.5 % of such
+// rows spent a general-handler visit on every fourth wave-round (bench.py: value_adverse_mix). A strict special case of the general handlers like every class
+// of tier 1 (test_general_handlers_alone_give_the_same_answers); not on tier1n's instruction path: plain predicates, a divergent branch.
+// The second class is the cache miss itself: an AppendEntries request whose prevLogIndex lies in the log but BELOW the cached term runs. on_append_entries
+// finds that out before it touches anything (its pre-check) and answers RG_NEED_HOST with log_from = the index whose term the host must supply; the group is
+// parked for the rest of the launch (`park`). Deciding that needs four compares, not a widened image and the general handlers.
+// Returns: the lane's row was decided here (state, `out` written).
+__device__ __forceinline__ bool tier15(GroupN &g, OutN &out, bool &park, const bool open, const int32_t cw, const int32_t aux, const int32_t n,
+                                       const int32_t a, const int32_t b, const int32_t c, const int32_t d)
+{
+    {
+        const bool miss = open & (cw_bit(cw, CW_AE) < 0) & (g.stf_n >= 0) & (a >= g.term) & (g.epoch_index < b) & (b <= g.last) & (b < g.s0);
+        if (miss) {
+            out.pw = PW_SLOW | ((uint32_t)RG_NEED_HOST << RG_F_STATUS_SHIFT);
+            out.resp = 0;
+            out.log_from = b;
+        }
+        park = miss;
+        if (__builtin_amdgcn_ballot_w64(open & !miss) == 0) return miss;
+    }
+    const int32_t term = g.term, last = g.last, commit = g.commit, epoch = g.epoch_index, lt = g.lt, top = g.top;
+    const int32_t slot = (int32_t)(((uint32_t)cw >> 5) & 15u);
+    const bool refresh = (term < a) | (g.td < 0);                    // switchTo(Follower, term, lastCandidate)
+    const int32_t new_last = b + n;
+    const int32_t commit_to = vmin<int32_t>(d, new_last);
+    const bool with_commit = epoch < d;                              // leaderCommit > epoch.index
+    const bool ok = open & (cw_bit(cw, CW_AE) < 0) & (g.stf_n >= 0) & (a >= term) & ((g.leader == slot) | refresh) &
+                    (b < last) & (b >= top) & (b > epoch) & (c == lt) & (n >= 1) & (aux != lt) & (b >= commit) & !(with_commit & (commit_to < commit));
+    if (ok) {
+        g.term = a;
+        g.role_epoch = g.role_epoch + (refresh ? 1u : 0u);
+        g.td = 0;
+        g.votes = refresh ? 1 : g.votes;
+        g.leader = slot;
+        g.last = b;                                                  // RaftLog.truncate(prev + 1): the newest run keeps its entries up to prev
+        g.push_run(b + 1, aux);                                      // RaftLog.append: a run of the new term starts right above it
+        g.last = new_last;
+        const int32_t new_commit = with_commit ? vmax<int32_t>(commit, commit_to) : commit;
+        g.commit = new_commit;
+        out.pw = PW_SLOW | RG_F_RESET_TIMER | RG_F_REPLIED | RG_F_SUCCESS | RG_F_LOG_TRUNC | RG_F_LOG_APPEND |
+                 (refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) | ((new_commit > commit) ? RG_F_COMMIT : 0u);
+        out.resp = a;
+        out.log_from = b + 1;
+    }
+    return ok | park;
+}
+
 }  // namespace rg

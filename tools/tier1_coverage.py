@@ -16,8 +16,12 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     L = engine.lib()
     a, b, c = C.c_long(), C.c_long(), C.c_long()
-    for number in (3, 5, 2, "2f"):
-        cfg = workload.config(number, groups)
+    import dataclasses
+    for number in (3, 5, 2, "2f", "adverse"):
+        if number == "adverse":      # bench.py's value_adverse_mix (without the cache misses: they park a group, which is not a general-handler visit per row)
+            cfg = dataclasses.replace(workload.config(3, groups), p_conflict=0.005, p_higher_term=0.01, p_timeout=0.03, p_vote_req=0.008, name="config3 adverse mix")
+        else:
+            cfg = workload.config(number, groups)
         gen = workload.ReplayGenerator(cfg)
         t = engine.Table(cfg.groups, cfg.cluster, cfg.self_slot, cfg.pre_vote)
         t.load_state(gen.initial_state())
