@@ -1038,9 +1038,9 @@ __device__ __forceinline__ bool narrow_body(const StepParams &p, unsigned char *
             // (the header as loaded, KIND_OUT_OF_DOMAIN apart; the general handlers expect the same-term mark where decorate<true> puts it)
             const uint32_t hdr = ((uint32_t)h.w & ~(7u << 9)) | ((((uint32_t)h.w & RG_HDR_SAME_TERM) != 0) ? HDR_SAME_IN : 0u), aux = (uint32_t)h.y, kind = RG_HDR_KIND(hdr);
             const bool skip = open & blocked & (kind != RG_EV_NONE);
-            // tier 1.5 (rg_tier1n.hpp): a new leader's entries over this Follower's uncommitted tail, and the cache miss of a prevLog term, on the 32-bit image
+            // tier 1.5 (rg_tier1n.hpp): four row classes an election or a cache miss leaves behind, decided on the 32-bit image without widening it
             bool park;
-            const bool slow = open & !skip & !tier15(g, out, park, open & !skip, h.x, h.y, h.z, q.x, q.y, q.z, q.w);
+            const bool slow = open & !skip & !tier15<F>(p, g, pe, out, park, open & !skip, h.x, h.y, h.z, q.x, q.y, q.z, q.w);
             if (park) { blocked = true; g.nallow = -1; g.recache(); }
             RG_NOTE_SLOW(slow, lane == 0);                  // (the host emulation counts the rows and wave-rounds that reach the general handlers)
             bool bail = slow & (kind == KIND_OUT_OF_DOMAIN);

@@ -393,9 +393,49 @@ __device__ __forceinline__ sw tier1n(const StepParams &p, GroupN &g, PeersNarrow
 // finds that out before it touches anything (its pre-check) and answers RG_NEED_HOST with log_from = the index whose term the host must supply; the group is
 // parked for the rest of the launch (`park`). Deciding that needs four compares, not a widened image and the general handlers.
 // Returns: the lane's row was decided here (state, `out` written).
-__device__ __forceinline__ bool tier15(GroupN &g, OutN &out, bool &park, const bool open, const int32_t cw, const int32_t aux, const int32_t n,
-                                       const int32_t a, const int32_t b, const int32_t c, const int32_t d)
+// Two more, both of them what an election leaves behind in BASELINE's own streams (config 3: 0.018 % of the rows, but 1.2 % of the wave-rounds — and a launch ends
+// with its slowest workgroup): (i) an AppendEntries ack that REJECTS while nothing of that follower has matched yet (member/Leader.java:218-237 ->
+// Leadership.State.updateIndex, member/Leadership.java:75-114: nextIndex backs off by rejection_step, down to epoch.index + 1; at or below the epoch the
+// follower is marked pending for a snapshot) — tier1n's ack class wants a success or a follower that has matched; (ii) a RequestVote / PreVote of a HIGHER
+// term at a Candidate (member/Candidate.java:90-119: switchTo(Follower, term, candidateId), then the new Follower answers the same request: same term, it has
+// just voted for that candidate -> granted) — tier1n's vote-request class is the Follower's.
+template <int F>
+__device__ __forceinline__ bool tier15(const StepParams &p, GroupN &g, PeersNarrow<F> &pe, OutN &out, bool &park, const bool open, const int32_t cw,
+                                       const int32_t aux, const int32_t n, const int32_t a, const int32_t b, const int32_t c, const int32_t d)
 {
+    bool fixed = false;
+    {
+        const int32_t slot = (int32_t)(((uint32_t)cw >> 5) & 15u);
+        // (i)
+        const uint32_t j = ((uint32_t)cw >> 10) & 7u;
+        const bool nack_shape = open & (cw_bit(cw, CW_ACK) < 0) & (cw_bit(cw, CW_FLAG) >= 0) & (g.stl_n >= 0) & (aux == (int32_t)g.role_epoch) & (a <= g.term);
+        if (nack_shape) {
+            const I32x4 st = pe.rec[j * BLOCK];
+            const bool pend = ((g.pending >> j) & 1u) != 0;
+            if ((st.z == 0) & (b == st.x) & !pend) {                 // nothing matched, same epoch as at send, no snapshot pending
+                const int32_t rej = (int32_t)((uint32_t)st.w + 1u);
+                const int32_t next = vmax<int32_t>(st.y - (int32_t)rejection_step(rej), b + 1);
+                const int32_t s_next = vmin<int32_t>(st.y - 1, next);
+                pe.store_ack(j, st.x, s_next, 0, rej);
+                g.pending = g.pending | ((s_next <= b) ? (1u << j) : 0u);
+                g.peers_dirty = -1;
+                out.pw = PW_SLOW;                                    // no flag, RG_OK
+                out.resp = 0; out.log_from = 0;
+                fixed = true;
+            }
+        }
+        // (ii)
+        const bool cand_vq = open & (cw_bit(cw, CW_VQ) < 0) & (g.nallow >= 0) & (g.role == RG_CANDIDATE) & (g.term < a) & (slot != p.self);
+        if (cand_vq) {
+            g.role = RG_FOLLOWER; g.term = a; g.voted_for = slot;
+            g.role_epoch = g.role_epoch + 1u;
+            g.td = 0; g.leader = RG_NO_NODE; g.votes = 1; g.prepared = 0;
+            g.recache();
+            out.pw = PW_SLOW | RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER | RG_F_REPLIED | RG_F_SUCCESS;
+            out.resp = a; out.log_from = 0;
+            fixed = true;
+        }
+    }
     {
         const bool miss = open & (cw_bit(cw, CW_AE) < 0) & (g.stf_n >= 0) & (a >= g.term) & (g.epoch_index < b) & (b <= g.last) & (b < g.s0);
         if (miss) {
@@ -404,7 +444,8 @@ __device__ __forceinline__ bool tier15(GroupN &g, OutN &out, bool &park, const b
             out.log_from = b;
         }
         park = miss;
-        if (__builtin_amdgcn_ballot_w64(open & !miss) == 0) return miss;
+        fixed = fixed | miss;
+        if (__builtin_amdgcn_ballot_w64(open & !fixed) == 0) return fixed;
     }
     const int32_t term = g.term, last = g.last, commit = g.commit, epoch = g.epoch_index, lt = g.lt, top = g.top;
     const int32_t slot = (int32_t)(((uint32_t)cw >> 5) & 15u);
@@ -430,7 +471,7 @@ __device__ __forceinline__ bool tier15(GroupN &g, OutN &out, bool &park, const b
         out.resp = a;
         out.log_from = b + 1;
     }
-    return ok | park;
+    return ok | fixed;
 }
 
 }  // namespace rg
