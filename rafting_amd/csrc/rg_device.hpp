@@ -1155,4 +1155,76 @@ __device__ __forceinline__ bool tier1(const StepParams &p, GroupT<V> &g, PE &pe,
     return fast_main | el_fast;
 }
 
+// ---- tier 1.5 (round 6), the 64-bit bodies' statement of it (the 32-bit body's is rg_tier1n.hpp: tier15, where the four classes are described) -------------
+// Rows tier 1 leaves open that an election or a cache miss puts into EVERY stream — a rejected ack before the follower's first match, a vote request of a
+// higher term at a Candidate, a new leader's entries over the uncommitted tail of the newest run, an AppendEntries whose prevLogIndex lies below the cached
+// runs (no hint with it) — decided here, each the statements Stepper::run executes on that input, so that a wave-round whose open rows are all of these
+// classes does not run the general handlers. Called for the lanes tier 1 left open (divergent is fine: no wave-level operation inside); `allow` as for tier1.
+template <int F, class V, class PE>
+__device__ __forceinline__ bool tier15w(const StepParams &p, GroupT<V> &g, PE &pe, FxT<V> &fx, bool allow, uint32_t hdr, uint32_t aux, bool hinted,
+                                        V a, V b, V c, V d, V pe0)
+{
+    if (!allow) return false;
+    const uint32_t kind = RG_HDR_KIND(hdr), slot = RG_HDR_SLOT(hdr), n = RG_HDR_N(hdr);
+    const bool flag = RG_HDR_FLAG(hdr) != 0, peer_ok = (hdr & HDR_PEER_OK) != 0;
+    const uint32_t self = (uint32_t)p.self;
+    // a rejected ack while nothing of that follower has matched (on_replicate_ack: updateIndex's back-off)
+    if ((kind == RG_EV_AE_ACK) & peer_ok & !flag & (aux == g.role_epoch) & (g.role == RG_LEADER) & g.prepared & (a <= g.term)) {
+        const uint32_t j = slot < self ? slot : slot - 1u;
+        V s_epoch, s_next, s_match;
+        int32_t s_rej;
+        pe.load_state(j, s_epoch, s_next, s_match, s_rej);
+        const bool pend = ((g.pending >> j) & 1u) != 0;
+        if ((s_match == 0) & (b == s_epoch) & !pend & (c >= 0)) {
+            const int32_t rej = (int32_t)((uint32_t)s_rej + 1u);
+            const V next = vmax<V>((V)(s_next - (V)rejection_step(rej)), vadd<V>(b, 1));
+            const V nn = vmin<V>((V)(s_next - 1), next);
+            pe.store_ack(j, s_epoch, nn, (V)0, rej);
+            g.pending = g.pending | ((nn <= b) ? (1u << j) : 0u);
+            g.peers_dirty = true;
+            fx = FxT<V>{0u, RG_OK, 0, 0};
+            return true;
+        }
+        return false;
+    }
+    // RequestVote / PreVote of a higher term at a Candidate (on_vote_request: switchTo(Follower, term, candidate), then the same-term answer of that Follower)
+    if (((kind == RG_EV_RV_REQ) | (kind == RG_EV_PV_REQ)) & (slot < (uint32_t)p.cluster) & (slot != self) & (g.role == RG_CANDIDATE) & (a > g.term)) {
+        g.role = RG_FOLLOWER; g.term = a; g.voted_for = (int32_t)slot;
+        g.role_epoch += 1u;
+        g.td = false; g.leader = RG_NO_NODE; g.votes = 1; g.prepared = false;
+        fx = FxT<V>{RG_F_PERSIST | RG_F_ROLE_CHANGED | RG_F_RESET_TIMER | RG_F_REPLIED | RG_F_SUCCESS, RG_OK, a, 0};
+        return true;
+    }
+    if (((hdr & HDR_AE_OK) != 0) & (g.role == RG_FOLLOWER) & !g.prepared & (g.rc > 0) & (g.epoch_index < g.last) & (a >= g.term) & (b > g.epoch_index) & (b <= g.last)) {
+        // the cache miss of on_append_entries' pre-check: nothing is touched
+        if (b < g.s0) {
+            if (hinted) return false;
+            fx = FxT<V>{0u, RG_NEED_HOST, 0, b};
+            return true;
+        }
+        // a new leader's entries over the uncommitted tail of the newest run: truncate(prev + 1), a run of the entries' term, commit, reply
+        const V lt = g.lt, commit = g.commit;
+        const bool refresh = (a > g.term) | g.td;
+        const V new_last = vadd<V>(b, (V)n);
+        const V commit_to = vmin<V>(d, new_last);
+        const bool with_commit = d > g.epoch_index;
+        if (((g.leader == (int32_t)slot) | refresh) & (b < g.last) & (b >= g.top) & (c == lt) & (n >= 1u) & (pe0 != lt) & (b >= commit) & !(with_commit & (commit_to < commit))) {
+            g.term = a;
+            g.role_epoch += refresh ? 1u : 0u;
+            g.td = false;
+            g.votes = refresh ? 1 : g.votes;
+            g.leader = (int32_t)slot;
+            g.truncate(vadd<V>(b, 1), (V)0);
+            g.push(vadd<V>(b, 1), pe0);
+            g.last = new_last;
+            const V new_commit = with_commit ? vmax<V>(commit, commit_to) : commit;
+            g.commit = new_commit;
+            fx = FxT<V>{RG_F_RESET_TIMER | RG_F_REPLIED | RG_F_SUCCESS | RG_F_LOG_TRUNC | RG_F_LOG_APPEND | (refresh ? (RG_F_PERSIST | RG_F_ROLE_CHANGED) : 0u) |
+                        ((new_commit > commit) ? RG_F_COMMIT : 0u), RG_OK, a, vadd<V>(b, 1)};
+            return true;
+        }
+    }
+    return false;
+}
+
 }  // namespace rg

@@ -436,9 +436,10 @@ __global__ __launch_bounds__(BLOCK, 1) void step_kernel(const StepParams p)
             const bool skip = blocked & (kind != RG_EV_NONE);
             const uint32_t hdr = decorate<false>(p, cur, cur_t, false);
             const bool done = tier1<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST & !skip, hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, cur_t.e0);
-            const bool slow = !done & !skip;
+            bool slow = !done & !skip;
             if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
             if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+                if (slow) slow = !tier15w<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST, hdr, cur.aux, (RG_HDR_HINT(cur.hdr) != 0) & (p.hint != nullptr), cur.a, cur.b, cur.c, cur.d, cur_t.e0);
                 if (slow) {
                     const Entries en = entries_of<false>(p, cur.hdr, cur.aux, cur_t.e0, cur_t.e1, cur_t.e2, cur_t.e3);
                     st.run(cur.hdr, cur.aux, cur.a, cur.b, cur.c, cur.d, (RG_HDR_HINT(cur.hdr) != 0) & (p.hint != nullptr), cur_t.hx, cur_t.hy, en,
@@ -659,9 +660,10 @@ __device__ __forceinline__ void split_body(const StepParams &p, unsigned char *s
         // tier 1 branches on wavefront ballots: every lane calls it (a lane blocked after a NEED_HOST asks for nothing)
         const bool skip = blocked & (kind != RG_EV_NONE);
         const bool done = tier1<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST & !skip, hdr, aux, a, b, c, d, e0);
-        const bool slow = !done & !skip;
+        bool slow = !done & !skip;
         if (skip) st.fx = Fx{0u, RG_SKIPPED_AFTER_NEED_HOST, 0, 0};
         if (__builtin_amdgcn_ballot_w64(slow) != 0) {
+            if (slow) slow = !tier15w<F, int64_t, PeersWide<F>>(p, g, pe, st.fx, FAST, hdr, aux, EV32 ? false : ((RG_HDR_HINT(hdr) != 0) & (p.hint != nullptr)), a, b, c, d, e0);
             if (slow) {
                 // the general handlers also want the hint and the other prefetched entry terms: read only here
                 int64_t hx = 0, hy = 0, e1 = e0, e2 = e0, e3 = e0;
