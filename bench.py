@@ -720,32 +720,31 @@ def main():
                         del os.environ["RG_TICK_NODES"]
                     else:
                         os.environ["RG_TICK_NODES"] = saved_nodes
-                # Two readings per recording. `idle`: one event pair around one hipGraphLaunch on an idle stream — what a host that waits for every tick sees; it
-                # contains the host's own submission time (the start event completes at once, the graph's packets arrive tens of microseconds later). `busy`: the same
-                # behind ~80 us of queued work (eight single-round launches of another batch), so that events and graph are all queued while the device is still
-                # busy and the pair brackets DEVICE time only: the tick's kernels and the gaps between its nodes.
+                # Two readings per recording. `queued`: ticks launched back to back without a host wait in between (they are ordered on the table's stream), one
+                # event pair around the run — what the DEVICE spends per tick, the way device_us_per_single_round_launch is taken. `idle`: one event pair around one
+                # hipGraphLaunch on an idle stream — what a host that waits for every tick sees: it contains the host's own submission path (the start event
+                # completes at once, the graph's packets arrive tens of microseconds later).
                 n2 = min(len(packed), 60)
-                busy_db = engine.DeviceBatch32(tt, ticks[0], compact=True, wide=False)
-                t_idle = t_busy = 0.0
+                t_idle = 0.0
                 for i in range(n2):
                     t2k.refill(packed[i], [300 * (i + 1)])
                     if i == 10:
                         tt.sync()
                     if i < 10:
                         t2k.launch(); t2k.wait()
-                    elif i % 2 == 1:
+                    else:
                         tt.timing_begin()
                         t2k.launch()
                         t_idle += tt.timing_end()
-                    else:
-                        for _ in range(8):
-                            tt.submit_device(busy_db)
-                        tt.timing_begin()
-                        t2k.launch()
-                        t_busy += tt.timing_end()
-                n_idle = len([i for i in range(10, n2) if i % 2 == 1]); n_busy = n2 - 10 - n_idle
-                by_nodes[str(nodes)] = {"device_us": t_busy * 1e3 / max(n_busy, 1), "idle_stream_us": t_idle * 1e3 / n_idle if n_idle else None}
-                busy_db.free()
+                n_q = 40
+                t2k.refill(packed[0], [300 * (n2 + 1)])
+                tt.sync()
+                tt.timing_begin()
+                for _ in range(n_q):
+                    t2k.launch()
+                t_q = tt.timing_end()
+                t2k.wait()
+                by_nodes[str(nodes)] = {"device_us": t_q * 1e3 / n_q, "idle_stream_us": t_idle * 1e3 / max(n2 - 10, 1)}
                 t2k.close()
                 tt.close()
             res["device_us_per_resident_tick"] = by_nodes["1"]["device_us"]

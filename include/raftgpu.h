@@ -570,7 +570,9 @@ typedef struct {
 } rg_tick2_io_t;
 typedef struct rg_tick2 rg_tick2_t;
 int rg_tick2_create(rg_table_t *t, const rg_tick2_io_t *io, rg_tick2_t **tick);
-int rg_tick2_launch(rg_tick2_t *tick);      /* asynchronous on the table's stream; a second launch first waits for the one in flight */
+int rg_tick2_launch(rg_tick2_t *tick);      /* asynchronous on the table's stream. A launch issued before rg_tick2_wait of the previous one is ORDERED AFTER it
+                                               on that stream and does not wait on the host: with every column in device memory a host can queue ticks whose rows
+                                               another kernel produces; it reads `row`, the lists and `ready` of the LAST tick only after rg_tick2_wait */
 int rg_tick2_wait(rg_tick2_t *tick);
 int rg_tick2_destroy(rg_tick2_t *tick);
 

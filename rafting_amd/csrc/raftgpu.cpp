@@ -75,8 +75,8 @@ struct rg_table {
     hipEvent_t region0 = nullptr, region1 = nullptr;
     int64_t *timer_deadline = nullptr;          // [G] N4
     uint32_t *timer_epoch = nullptr;            // [G] role epoch after the last batch the timers saw (rg_timers_update32 chains compact rows from it)
-    unsigned long long *tick_masks = nullptr;   // [ceil(G / 256) * 4] expired lanes per wavefront (rg_tick2's folded kernel)
-    uint32_t *tick_ticket = nullptr;            // [1]
+    unsigned long long *tick_masks = nullptr;   // [ceil(G / 256) * 4 >= workgroups of any tick kernel] status words of the expiry's look-back (rg_kernels.hip: expire_tail)
+    uint32_t *tick_ticket = nullptr;            // [1] their generation
     uint64_t config_gen = 0;                    // bumped by whatever changes what a recorded launch has baked in (options, the first index base)
     std::vector<struct rg_tick *> ticks;        // live recordings: invalidated when the table goes
     std::vector<struct rg_tick2 *> ticks2;
@@ -265,6 +265,7 @@ int rg_table_create(int device, uint32_t groups, uint32_t cluster, uint32_t self
     CREATE_TRY(hipMalloc((void **)&t->timer_counts, ((G + 255) / 256 * 4 + 1) * sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->timer_deadline, 0, G * sizeof(int64_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->tick_masks, ((G + 255) / 256 * 4) * sizeof(unsigned long long)));
+    CREATE_TRY(hipMemsetAsync(t->tick_masks, 0, ((G + 255) / 256 * 4) * sizeof(unsigned long long), t->stream));      // (status words of the expiry's look-back: state 0 = none)
     CREATE_TRY(hipMalloc((void **)&t->tick_ticket, sizeof(uint32_t)));
     CREATE_TRY(hipMemsetAsync(t->tick_ticket, 0, sizeof(uint32_t), t->stream));
     CREATE_TRY(hipMalloc((void **)&t->timer_epoch, G * sizeof(uint32_t)));
@@ -949,8 +950,7 @@ int rg_tick2_launch(rg_tick2_t *k)
     if (k->config_gen != t->config_gen)
         return fail(t, -1, "rg_tick2_launch: the table's options or index bases changed after rg_tick2_create (they are part of the recording): create the tick again");
     if (bind(t)) return -2;
-    if (k->in_flight) { HIP_TRY(t, hipStreamSynchronize(t->stream)); k->in_flight = false; }
-    HIP_TRY(t, hipGraphLaunch(k->exec, t->stream));
+    HIP_TRY(t, hipGraphLaunch(k->exec, t->stream));             // (a launch behind one in flight is ordered after it on the stream: include/raftgpu.h)
     k->in_flight = true;
     return 0;
 }

@@ -302,21 +302,23 @@ __global__ __launch_bounds__(256) void timers_emit_kernel(int64_t *deadline, con
 
 // ---- the device-resident tick, folded (rg_tick2) ---------------------------------------------------------------------------------------------
 // A single-round tick over 65 536 groups is launch-bound, so what follows the decisions is folded: per group the batch's flags into the deadline
-// (timers_update32_kernel) and into the followers' statistics (health_update_kernel), then the expiry — every wavefront leaves the ballot of its expired
-// lanes in `masks`, and the LAST workgroup to take a ticket scans them and writes the list in ascending group order, marking the listed tickets fired: what
-// timers_count / _scan / _emit do in three launches.
-// What crosses workgroups (and, on this part, XCDs — each with an L2 of its own) does so through AGENT-SCOPE ATOMIC loads and stores only: the masks, and for a
-// lane whose ticket fired its deadline and role epoch. Such a store is written through to the device's coherence point and `s_waitcnt vmcnt(0)` waits for
-// that; such a load does not hit a stale line. So the ticket itself is a RELAXED add behind a drained store queue and no workgroup executes an agent-scope
-// release / acquire — those write back and invalidate the XCD's whole L2, and with one per workgroup the one-kernel tick (1 024 workgroups, each with its
-// outcome rows and table lines dirty in L2) took 84 us against 52 for step + tail (profiles/r06j_bench_tick_recordings_before_fence_fix.json). The owner of a
-// fired ticket also STORES its deadline with an agent-scope atomic, so that no dirty copy of it stays in the owner's L2 to be written back over the -1 the
-// last workgroup puts there.
-#ifndef RG_AGENT_LOAD               // (the host emulation runs workgroups one after the other on plain memory)
+// (timers_update32_kernel) and into the followers' statistics (health_update_kernel), then the expiry: the list of the tickets that fired, in ascending group
+// order — what timers_count / _scan / _emit do in three launches — by a single-pass prefix sum over the workgroups (decoupled look-back): every workgroup
+// counts its fired tickets, publishes the count in its own status word, adds up the words of the workgroups before it until it meets one that already
+// carries an inclusive prefix, publishes its own inclusive prefix, and writes ITS OWN groups at that offset — gid, role epoch, and the -1 in its own
+// deadline column. Nothing but the status words crosses workgroups (and, on this part, XCDs — each with an L2 of its own), and they do so through agent-scope
+// atomic loads and stores: written through to the device's coherence point, never served from a stale line; no workgroup executes an agent-scope release or
+// acquire (those write back and invalidate the XCD's whole L2: with one per workgroup the one-kernel tick took 84 us, profiles/
+// r06j_bench_tick_recordings_before_fence_fix.json), and no workgroup is left to emit the whole list alone (the last-workgroup scan that came next spent
+// 10 us of a 13.6-us kernel walking masks and epochs one load after the other: profiles/r06n_tick_kernel_trace.txt).
+// A status word: state (2 bits: 0 none, 1 the workgroup's own count, 2 inclusive prefix) | generation (30 bits) | value (32 bits). The generation is read
+// from `ticket` and moved on by the LAST workgroup of the grid once its look-back is complete — by then every workgroup has published, hence read it — so the
+// words of the previous launch are simply not of this generation and nothing is ever reset. Workgroups are dispatched in index order, so the ones a
+// workgroup waits for are resident or done (the assumption every single-pass scan makes); the wait is bounded all the same: a launch that runs into the bound
+// reports 0xFFFFFFFF fired tickets instead of hanging.
+#ifndef RG_AGENT_LOAD               // (the host emulation runs workgroups one after the other, in index order, on plain memory)
 #define RG_AGENT_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define RG_AGENT_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define RG_TICKET_TAKE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define RG_DRAIN_STORES() __builtin_amdgcn_s_waitcnt(0)      // vmcnt(0) expcnt(0) lgkmcnt(0): every store of this wavefront has reached its scope
 #endif
 // what the batch did to the timer and the follower statistics of group g (timers_update32_kernel + health_update_kernel); returns the deadline it leaves
 __device__ __forceinline__ int64_t fold_group(const TickFoldParams &p, const uint32_t g)
@@ -346,72 +348,90 @@ __device__ __forceinline__ int64_t fold_group(const TickFoldParams &p, const uin
         if (now > p.hp.ok[j * GG + g]) p.hp.ok[j * GG + g] = now;
         p.hp.recent[j * GG + g] = 0;
     }
-    // (a ticket that fires at the clock of the expiry: deadline and role epoch go where the last workgroup — any workgroup, any XCD — reads them; the epoch is
-    //  the table's own, which this lane's workgroup wrote if the decisions ran in this launch)
-    const bool fired = p.expire && d > 0 && d <= *p.now_last;
-    if (fired) {
-        RG_AGENT_STORE(p.tp.deadline + g, d);
-        RG_AGENT_STORE(p.tp.epoch + g, p.tp.ident[g].role_epoch);
-    } else {
-        p.tp.deadline[g] = d;
-        p.tp.epoch[g] = e;
-    }
+    p.tp.deadline[g] = d;
+    p.tp.epoch[g] = e;
     return d;
 }
 
-// The fired tickets of the whole table, in ascending gid order, by ONE launch: every wavefront that holds groups leaves its ballot mask in HBM (mask w =
-// groups 64 w .. 64 w + 63), a ticket tells the last workgroup to finish that it is the last, and that workgroup scans the masks. EVERY thread of the grid
-// calls it (the barriers); d = the deadline of the lane's group, `holds` (wave-uniform) = this wavefront has groups at all; `part` = blockDim.x words of LDS
-// (blockDim.x a power of two, at most 256), `is_last` one more.
-__device__ __forceinline__ void expire_tail(const TickFoldParams &p, const int64_t d, const uint32_t mask_index, const bool holds, const bool active,
-                                            const uint32_t nmasks, uint32_t *part, uint32_t *is_last)
+// The fired tickets of the whole table, in ascending gid order (see above). EVERY thread of the grid calls it (the barriers); d = the deadline of the lane's
+// group g, `holds` (wave-uniform) = this wavefront has groups at all (lane = group); `part` = at least 136 words of the workgroup's LDS.
+__device__ __forceinline__ void expire_tail(const TickFoldParams &p, const int64_t d, const uint32_t g, const bool holds, const bool active, uint32_t *part)
 {
+    constexpr unsigned long long ST_COUNT = 1ull << 62, ST_PREFIX = 2ull << 62;
+    constexpr uint32_t GEN_MASK = 0x3FFFFFFFu;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int64_t now = *p.now_last;
-    const unsigned long long m = __ballot(holds && active && d > 0 && d <= now);
-    if (holds && (threadIdx.x & 63u) == 0u) RG_AGENT_STORE(p.masks + mask_index, m);
-    RG_DRAIN_STORES();
-    __syncthreads();                                                 // (this workgroup's masks, fired deadlines and epochs have landed before its ticket is taken)
-    if (threadIdx.x == 0) *is_last = RG_TICKET_TAKE(p.ticket) == gridDim.x - 1u ? 1u : 0u;
+    const bool fired = holds && active && d > 0 && d <= now;
+    const unsigned long long m = __ballot(fired);
+    const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    const uint32_t epoch = fired ? p.tp.ident[g].role_epoch : 0u;      // the participant whose ticket fired (RG_EV_TIMEOUT.aux): this workgroup's own group
+    if (lane == 0) part[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    if (!*is_last) return;
-    const uint32_t nt = blockDim.x, tid = threadIdx.x;
-    const uint32_t per = (nmasks + nt - 1u) / nt, lo = tid * per < nmasks ? tid * per : nmasks, hi = lo + per < nmasks ? lo + per : nmasks;
-    uint32_t sum = 0;
-    for (uint32_t w = lo; w < hi; w++) sum += (uint32_t)__popcll(RG_AGENT_LOAD(p.masks + w));
-    part[tid] = sum;
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < nwaves; w++) { const uint32_t c = part[w]; before += w < wave ? c : 0u; total += c; }
     __syncthreads();
-    for (uint32_t off = 1; off < nt; off <<= 1) {                    // Hillis-Steele inclusive scan of the partial sums
-        const uint32_t v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t pos = tid ? part[tid - 1] : 0;
-    for (uint32_t w = lo; w < hi; w++) {
-        unsigned long long mw = RG_AGENT_LOAD(p.masks + w);
-        while (mw) {
-            const uint32_t lane = (uint32_t)__builtin_ctzll(mw);
-            mw &= mw - 1;
-            const uint32_t gg = w * 64u + lane;
-            if (pos < p.capacity) {
-                p.out_gid[pos] = gg;
-                if (p.out_epoch) p.out_epoch[pos] = RG_AGENT_LOAD(p.tp.epoch + gg);
-                RG_AGENT_STORE(p.tp.deadline + gg, (int64_t)-1);      // electionTimeout's CAS: deadline -> TimerTicket.TIMEOUT
+    if (wave == 0) {
+        uint32_t *val = part + 8, *state = part + 72;                  // one look-back window: 64 predecessors
+        const uint32_t gen = RG_AGENT_LOAD(p.ticket) & GEN_MASK;
+        const unsigned long long tag = (unsigned long long)gen << 32;
+        uint32_t excl = 0;
+        bool lost = false;
+        if (blockIdx.x != 0) {
+            if (lane == 0) RG_AGENT_STORE(p.masks + blockIdx.x, ST_COUNT | tag | total);
+            int64_t hi = (int64_t)blockIdx.x - 1;                       // nearest predecessor not added yet
+            for (;;) {
+                const int64_t idx = hi - (int64_t)lane;
+                unsigned long long w = ST_PREFIX | tag;                 // (before workgroup 0: an inclusive prefix of 0)
+                if (idx >= 0) {
+                    uint32_t spins = 0;
+                    for (;;) {
+                        w = RG_AGENT_LOAD(p.masks + idx);
+                        if ((w >> 62) != 0ull && (uint32_t)((w >> 32) & GEN_MASK) == gen) break;
+                        if (++spins > (1u << 20)) { lost = true; w = ST_PREFIX | tag; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                val[lane] = (uint32_t)w; state[lane] = (uint32_t)(w >> 62);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned long long found = __ballot((w >> 62) == 2ull);
+                const uint32_t stop = found ? (uint32_t)__builtin_ctzll(found) : 63u;      // the nearest predecessor that carries an inclusive prefix
+                uint32_t add = 0;
+                for (uint32_t k = 0; k <= stop; k++) add += val[k];    // (every lane walks the window: at most 64 LDS reads, no cross-lane reduction needed)
+                excl += add;
+                __builtin_amdgcn_wave_barrier();
+                if (found) break;
+                hi -= 64;
             }
-            pos++;
+        }
+        lost = __ballot(lost) != 0;
+        if (lane == 0) {
+            RG_AGENT_STORE(p.masks + blockIdx.x, ST_PREFIX | tag | (unsigned long long)(excl + total));
+            part[0] = excl;
+            if (blockIdx.x == gridDim.x - 1u) {
+                *p.out_count = lost ? 0xFFFFFFFFu : excl + total;
+                RG_AGENT_STORE(p.ticket, (gen + 1u) & GEN_MASK);
+            }
         }
     }
-    if (tid == nt - 1u) { *p.out_count = part[nt - 1u]; RG_AGENT_STORE(p.ticket, 0u); }
+    __syncthreads();
+    if (fired) {
+        const uint32_t pos = part[0] + before + rank;
+        if (pos < p.capacity) {
+            p.out_gid[pos] = g;
+            if (p.out_epoch) p.out_epoch[pos] = epoch;
+            p.tp.deadline[g] = -1;                                    // electionTimeout's CAS: deadline -> TimerTicket.TIMEOUT
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void tick_fold_kernel(const TickFoldParams p)
 {
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t is_last;
+    __shared__ uint32_t part[136];
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const bool active = g < p.tp.count;
     const int64_t d = active ? fold_group(p, g) : 0;
-    if (p.expire) expire_tail(p, d, g >> 6, true, active, gridDim.x * 4u, part, &is_last);
+    if (p.expire) expire_tail(p, d, g, true, active, part);
 }
 
 hipError_t launch_tick_fold(const TickFoldParams &p, hipStream_t s)
@@ -523,15 +543,14 @@ template <int F>
 __global__ __launch_bounds__(256) void tick_tail_kernel(const TickTailParams p)
 {
     __shared__ uint4 stage[4][3 * 64];
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t is_last;
+    __shared__ uint32_t part[136];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x * 256u + threadIdx.x;
     const bool active = g < p.fp.tp.count;
     const int64_t d = active ? fold_group(p.fp, g) : 0;
     if (p.qp.head != nullptr) replicate_wave<F>(p.qp, stage[wave], blockIdx.x * 256u + wave * 64u, lane);
     if (p.ready != nullptr && active) p.ready[g] = ready_of(p.rp, *p.rp.now_mem, p.critical_point, p.cool_down, g);
-    if (p.fp.expire) expire_tail(p.fp, d, g >> 6, true, active, gridDim.x * 4u, part, &is_last);
+    if (p.fp.expire) expire_tail(p.fp, d, g, true, active, part);
 }
 // ---- a recorded tick as ONE launch: the decisions of step32_kernel (compact rows, compact outcome rows, dense) and, by the same workgroup for its own 64
 // groups, everything tick_tail_kernel does. What the tail reads was written by THIS workgroup — the outcome rows by its I/O wavefront, the table by its
@@ -541,7 +560,7 @@ template <int F, int WAVES>
 __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void tick_kernel(const StepParams p, const TickTailParams tp)
 {
     __shared__ alignas(16) unsigned char smem[SplitLds<F, true, 2>::BYTES];
-    static_assert(SplitLds<F, true, 2>::BYTES >= 3 * 64 * 16 + (2 * BLOCK + 1) * 4, "the tail's staging rows and scan words reuse the step's LDS");
+    static_assert(SplitLds<F, true, 2>::BYTES >= 3 * 64 * 16 + 136 * 4, "the tail's staging rows and scan words reuse the step's LDS");
     if (!narrow_body<F, false, true, 1, 1>(p, smem)) {
         if (threadIdx.x == 0) { RG_NOTE_FALLBACK(); atomicAdd(p.wide_bodies, 1ull); }
         lds_barrier();
@@ -549,18 +568,25 @@ __global__ __launch_bounds__(2 * BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES
     }
     __syncthreads();                                         // every store of this workgroup has landed; its LDS is free
     uint4 *stage = reinterpret_cast<uint4 *>(smem);
-    uint32_t *part = reinterpret_cast<uint32_t *>(smem + 3 * 64 * 16), *is_last = part + 2 * BLOCK;
+    uint32_t *part = reinterpret_cast<uint32_t *>(smem + 3 * 64 * 16);
+    // Both wavefronts map lane -> group as the step did. The tail is a chain of dependent memory round trips (a row's flags, then what they point at), not
+    // work: the first wavefront folds the outcome rows into timers and health while the second plans the leaders' sends — neither reads what the other
+    // writes —; isReady needs both (the statistics, and the `prepared` mark of a leader that sent for the first time), so it comes after a meeting, on the
+    // second wavefront, while the first is already in the expiry (whose first barrier the second joins when it is done).
     const uint32_t lane = threadIdx.x & 63u;
-    const bool holds = __builtin_amdgcn_readfirstlane(threadIdx.x) < (uint32_t)BLOCK;      // the first wavefront: lane = group, as in the step
+    const bool holds = __builtin_amdgcn_readfirstlane(threadIdx.x) < (uint32_t)BLOCK;
     const uint32_t g = blockIdx.x * BLOCK + lane;
-    const bool active = holds && g < tp.fp.tp.count;
+    const bool in_table = g < tp.fp.tp.count;
+    const bool active = holds && in_table;
     int64_t d = 0;
     if (holds) {
         if (active) d = fold_group(tp.fp, g);
+    } else {
         if (tp.qp.head != nullptr) replicate_wave<F>(tp.qp, stage, blockIdx.x * BLOCK, lane);
-        if (tp.ready != nullptr && active) tp.ready[g] = ready_of(tp.rp, *tp.rp.now_mem, tp.critical_point, tp.cool_down, g);
     }
-    if (tp.fp.expire) expire_tail(tp.fp, d, blockIdx.x, holds, active, gridDim.x, part, is_last);
+    __syncthreads();
+    if (!holds && tp.ready != nullptr && in_table) tp.ready[g] = ready_of(tp.rp, *tp.rp.now_mem, tp.critical_point, tp.cool_down, g);
+    if (tp.fp.expire) expire_tail(tp.fp, d, g, holds, active, part);
 }
 hipError_t launch_tick(const StepParams &p, const TickTailParams &tp, int followers, hipStream_t s)
 {

@@ -83,8 +83,6 @@ extern "C" void rg_emu_note_slow(int slow_row, int wave_round);   // step32_kern
 #define RG_FRESH_VGPR(v) ((void)0)
 #define RG_AGENT_LOAD(p) (*(p))      /* rg_kernels.hip: tick_fold_kernel's cross-workgroup reads (workgroups run one after the other here) */
 #define RG_AGENT_STORE(p, v) (*(p) = (v))
-#define RG_DRAIN_STORES() ((void)0)
-#define RG_TICKET_TAKE(p) __atomic_fetch_add((p), 1u, __ATOMIC_ACQ_REL)
 #define __builtin_amdgcn_s_sleep(x) (::hipemu::lane_yield())
 #define __builtin_amdgcn_s_barrier() (::hipemu::workgroup_barrier(true))
 #define __builtin_amdgcn_wave_barrier() ((void)::hipemu::wave_ballot(true))      /* the lanes of a wavefront meet */
