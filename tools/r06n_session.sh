@@ -1,11 +1,11 @@
 # one gpurun call: kernel trace of the tick leg alone (what the device spends in the kernels of a recorded tick, per recording form)
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_r06p_tick; mkdir -p $OUT
+ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_r06q_tick; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pcie --no-int64-pass --no-adverse --index-base-batches 0 --no-pmc --no-copy-bw --tick-batches 70 > $OUT/bench.json 2> $OUT/bench.err
 cd $ROOT
 python - <<'PY'
 import csv, glob, collections
-f = glob.glob('gpurun_out/prof_r06p_tick/**/t_kernel_trace.csv', recursive=True)[0]
+f = glob.glob('gpurun_out/prof_r06q_tick/**/t_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 dur = collections.defaultdict(list)
