@@ -736,7 +736,7 @@ def main():
                         tt.timing_begin()
                         t2k.launch()
                         t_idle += tt.timing_end()
-                n_q = 40
+                n_q = 4 if os.environ.get("RG_ALLOW_HOST_EMULATION") else 40      # (the CPU suite runs this leg on the host emulation of the kernels)
                 t2k.refill(packed[0], [300 * (n2 + 1)])
                 tt.sync()
                 tt.timing_begin()
