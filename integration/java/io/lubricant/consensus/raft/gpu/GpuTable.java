@@ -74,4 +74,16 @@ public final class GpuTable implements AutoCloseable {
     static native int timersExpired(long handle, long now, ByteBuffer outGid, ByteBuffer outEpoch, int capacity);
     static native int healthUpdate(long handle, int rounds, int count, ByteBuffer gid, ByteBuffer head, ByteBuffer reply, ByteBuffer now);
     static native int ready(long handle, long now, int criticalPoint, long coolDownMs, ByteBuffer ready);
+
+    // ---- the device-resident tick (ABI 5): one recorded launch = decisions, timers, follower health, fired tickets, send table, readiness -------------------
+    /** Every buffer comes from {@link #hostAlloc} (page-locked, device-addressable) and stays bound to the tick until {@link #tick2Destroy}; heartbeat, inFlight,
+     *  the expired* columns, sendHead / send and ready may be null (that step is then not recorded). Refill head / abcd / now, {@link #tick2Launch},
+     *  {@link #tick2Wait}, read row / persist32 / the lists. -> tick handle (0: failed, IllegalStateException carries the reason) */
+    static native long tick2Create(long handle, int rounds, ByteBuffer head, ByteBuffer abcd, ByteBuffer entryTerms, long entryCapacity, ByteBuffer now,
+                                   ByteBuffer heartbeat, ByteBuffer inFlight, int criticalPoint, long coolDownMs, ByteBuffer row, ByteBuffer persist32,
+                                   ByteBuffer expiredGid, ByteBuffer expiredEpoch, ByteBuffer expiredCount, int expiredCapacity, ByteBuffer sendHead,
+                                   ByteBuffer send, ByteBuffer ready);
+    static native int tick2Launch(long tick);
+    static native int tick2Wait(long tick);
+    static native int tick2Destroy(long tick);
 }

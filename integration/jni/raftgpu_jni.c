@@ -21,6 +21,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "raftgpu.h"
 #include "raftwire.h"
@@ -383,6 +384,63 @@ JNIEXPORT jint JNICALL J(GpuTable, ready)(JNIEnv *env, jclass cls, jlong h, jlon
     uint8_t *out = (uint8_t *)BUF(ready, (jlong)rg_table_groups(TABLE(h)), 0, "ready");
     if (bad) return -1;
     return rg_ready(TABLE(h), now, critical_point, cool_down_ms, out, RG_MEM_HOST);
+}
+
+/* ---- the device-resident tick (ABI 5, rg_tick2_*): ONE recorded launch per tick — decisions, RaftRoutine.resetTimer, Leadership.State.statSuccess, the fired
+ * tickets, Leader.replicateLog, Leader.isReady (context/RaftRoutine.java:53-130, member/Leadership.java:28-73, member/Leader.java:52-64,142-245). Every column is
+ * a direct buffer of GpuTable.hostAlloc (page-locked, addressable by the device) and stays bound to the tick until tick2Destroy. -> tick handle, 0 on failure. */
+JNIEXPORT jlong JNICALL J(GpuTable, tick2Create)(JNIEnv *env, jclass cls, jlong h, jint rounds, jobject head, jobject abcd, jobject entry_terms, jlong entry_capacity,
+                                                 jobject now, jobject heartbeat, jobject in_flight, jint critical_point, jlong cool_down_ms, jobject row,
+                                                 jobject persist32, jobject expired_gid, jobject expired_epoch, jobject expired_count, jint expired_capacity,
+                                                 jobject send_head, jobject send, jobject ready)
+{
+    (void)cls;
+    int bad = 0;
+    if (rounds <= 0 || entry_capacity < 0 || expired_capacity < 0) { throw_state(env, "tick2Create: rounds must be positive, capacities not negative"); return 0; }
+    const jlong G = rg_table_groups(TABLE(h)), followers = (jlong)rg_table_cluster(TABLE(h)) - 1, rows = (jlong)rounds * G;
+    rg_tick2_io_t io;
+    memset(&io, 0, sizeof io);
+    io.rounds = (uint32_t)rounds;
+    io.head = (const rg_ev_head_t *)BUF(head, 8 * rows, 0, "head");
+    io.abcd = (const rg_ev_quad32_t *)BUF(abcd, 16 * rows, 0, "abcd");
+    io.entry_terms = (const int32_t *)BUF(entry_terms, 4 * entry_capacity, entry_capacity == 0, "entryTerms");
+    io.entry_capacity = (uint64_t)entry_capacity;
+    io.now = (const int64_t *)BUF(now, 8 * (jlong)rounds, 0, "now");
+    io.heartbeat = (const uint8_t *)BUF(heartbeat, G, 1, "heartbeat");
+    io.in_flight = (const uint16_t *)BUF(in_flight, 2 * followers * G, 1, "inFlight");
+    io.critical_point = critical_point;
+    io.cool_down_ms = cool_down_ms;
+    io.row = (rg_out32_t *)BUF(row, 16 * rows, 0, "row");
+    io.persist32 = (rg_persist32_t *)BUF(persist32, 16 * rows, 0, "persist32");
+    io.expired_gid = (uint32_t *)BUF(expired_gid, 4 * (jlong)expired_capacity, 1, "expiredGid");
+    io.expired_epoch = (uint32_t *)BUF(expired_epoch, 4 * (jlong)expired_capacity, 1, "expiredEpoch");
+    io.expired_count = (uint32_t *)BUF(expired_count, 4, expired_gid == NULL, "expiredCount");
+    io.expired_capacity = (uint32_t)expired_capacity;
+    io.send_head = (rg_send_head_t *)BUF(send_head, 48 * G, 1, "sendHead");
+    io.send = (rg_send_t *)BUF(send, 32 * followers * G, send_head == NULL, "send");
+    io.ready = (uint8_t *)BUF(ready, G, 1, "ready");
+    if (bad) return 0;
+    rg_tick2_t *tick = NULL;
+    if (rg_tick2_create(TABLE(h), &io, &tick) != 0) { throw_state(env, rg_last_error(TABLE(h))); return 0; }
+    return (jlong)(intptr_t)tick;
+}
+
+JNIEXPORT jint JNICALL J(GpuTable, tick2Launch)(JNIEnv *env, jclass cls, jlong tick)
+{
+    (void)env; (void)cls;
+    return rg_tick2_launch((rg_tick2_t *)(intptr_t)tick);
+}
+
+JNIEXPORT jint JNICALL J(GpuTable, tick2Wait)(JNIEnv *env, jclass cls, jlong tick)
+{
+    (void)env; (void)cls;
+    return rg_tick2_wait((rg_tick2_t *)(intptr_t)tick);
+}
+
+JNIEXPORT jint JNICALL J(GpuTable, tick2Destroy)(JNIEnv *env, jclass cls, jlong tick)
+{
+    (void)env; (void)cls;
+    return rg_tick2_destroy((rg_tick2_t *)(intptr_t)tick);
 }
 
 /* ---- GpuIngress: socket bytes -> the [round][group] batch and back (transport/EventCodec.java:169-335, transport/NettyCluster.java:59-105) ------ */

@@ -42,6 +42,11 @@ jint J(GpuTable, readState)(JNIEnv *, jclass, jlong, jint, jint, jobjectArray);
 jint J(GpuTable, submit)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject);
 jint J(GpuTable, submit32c)(JNIEnv *, jclass, jlong, jint, jint, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jobject, jobject);
 jint J(GpuTable, unpack32)(JNIEnv *, jclass, jint, jint, jobject, jobject, jobject, jobject, jobject, jobject, jobject, jobject, jobject);
+jlong J(GpuTable, tick2Create)(JNIEnv *, jclass, jlong, jint, jobject, jobject, jobject, jlong, jobject, jobject, jobject, jint, jlong, jobject, jobject, jobject, jobject,
+                               jobject, jint, jobject, jobject, jobject);
+jint J(GpuTable, tick2Launch)(JNIEnv *, jclass, jlong);
+jint J(GpuTable, tick2Wait)(JNIEnv *, jclass, jlong);
+jint J(GpuTable, tick2Destroy)(JNIEnv *, jclass, jlong);
 
 enum { G = 96, P = 3, NCOL = sizeof(rg_group_state_t) / sizeof(void *) };
 
@@ -145,6 +150,50 @@ int main(void)
         for (uint32_t g = 0; g < G; g++) { appended += (rep_j[g].flags & RG_F_LOG_APPEND) != 0; converted += (rep_j[g].flags & RG_F_ROLE_CHANGED) != 0; }
         if (appended != G / 2 || converted != G / 2) { fprintf(stderr, "compact round: %u appends, %u conversions\n", appended, converted); return 1; }
         printf("compact outcome rows through the shim: %u appends, %u conversions, identical to the C-ABI\n", appended, converted);
+
+        /* the device-resident tick (ABI 5) through the shim and directly: the same rows once more on both tables, timers armed alike; every output column equal */
+        {
+            rg_table_t *tj = (rg_table_t *)(intptr_t)h;
+            if (rg_timers_configure(tj, 900, 300, 7) || rg_timers_configure(direct, 900, 300, 7) || rg_timers_arm(tj, 1000) || rg_timers_arm(direct, 1000)) return 1;
+            enum { NB = 12 };
+            const size_t bytes[NB] = {8 * G, 16 * G, 4 * 2 * G, 8, 16 * G, 16 * G, 4 * G, 4 * G, 4, 48 * G, 32 * (P - 1) * G, G};
+            jobject jb[NB]; void *db[NB];
+            for (int i = 0; i < NB; i++) {
+                jb[i] = J(GpuTable, hostAlloc)(env, NULL, h, (jlong)bytes[i]);
+                if (!jb[i] || rg_host_alloc(direct, bytes[i], &db[i]) != 0) { fprintf(stderr, "hostAlloc %d\n", i); return 1; }
+                memset(jb[i]->addr, 0, bytes[i]); memset(db[i], 0, bytes[i]);
+            }
+            const int64_t clock = 5000;      /* past every armed deadline: tickets fire */
+            for (int side = 0; side < 2; side++) {
+                void **b = side ? db : NULL;
+                memcpy(side ? b[0] : jb[0]->addr, head32, sizeof head32);
+                memcpy(side ? b[1] : jb[1]->addr, abcd, sizeof abcd);
+                memcpy(side ? b[2] : jb[2]->addr, terms32, sizeof terms32);
+                memcpy(side ? b[3] : jb[3]->addr, &clock, 8);
+            }
+            const jlong tk = J(GpuTable, tick2Create)(env, NULL, h, 1, jb[0], jb[1], jb[2], (jlong)(2 * G), jb[3], NULL, NULL, 1, 60, jb[4], jb[5], jb[6], jb[7], jb[8], (jint)G,
+                                                      jb[9], jb[10], jb[11]);
+            rg_tick2_io_t io;
+            memset(&io, 0, sizeof io);
+            io.rounds = 1; io.head = db[0]; io.abcd = db[1]; io.entry_terms = db[2]; io.entry_capacity = 2 * G; io.now = db[3]; io.critical_point = 1; io.cool_down_ms = 60;
+            io.row = db[4]; io.persist32 = db[5]; io.expired_gid = db[6]; io.expired_epoch = db[7]; io.expired_count = db[8]; io.expired_capacity = G;
+            io.send_head = db[9]; io.send = db[10]; io.ready = db[11];
+            rg_tick2_t *td = NULL;
+            if (!tk || rg_tick2_create(direct, &io, &td) != 0) { fprintf(stderr, "tick2Create: %s | %s\n", thrown, rg_last_error(direct)); return 1; }
+            if (J(GpuTable, tick2Launch)(env, NULL, tk) || J(GpuTable, tick2Wait)(env, NULL, tk) || rg_tick2_launch(td) || rg_tick2_wait(td)) { fprintf(stderr, "tick2 launch\n"); return 1; }
+            for (int i = 4; i < NB; i++)
+                if (memcmp(jb[i]->addr, db[i], bytes[i])) { fprintf(stderr, "tick2: output column %d differs\n", i); return 1; }
+            const uint32_t fired = *(uint32_t *)db[8];
+            if (fired == 0 || fired > G) { fprintf(stderr, "tick2: %u fired tickets\n", fired); return 1; }
+            /* a short column is refused before the library sees it */
+            thrown[0] = 0;
+            if (J(GpuTable, tick2Create)(env, NULL, h, 1, jb[0], jb[1], NULL, 0, jb[3], NULL, NULL, 1, 60, jb[8], jb[5], NULL, NULL, NULL, 0, NULL, NULL, NULL) != 0 || !thrown[0]) {
+                fprintf(stderr, "tick2Create took a 4-byte row column\n"); return 1;
+            }
+            if (J(GpuTable, tick2Destroy)(env, NULL, tk) || rg_tick2_destroy(td)) return 1;
+            for (int i = 0; i < NB; i++) { J(GpuTable, hostFree)(env, NULL, h, jb[i]); rg_host_free(direct, db[i]); }
+            printf("the device-resident tick through the shim: %u fired tickets, every output column identical to the C-ABI\n", fired);
+        }
     }
 
     /* misuse: a heap ByteBuffer (no direct address), a short buffer, a missing required column — IllegalArgumentException, the library never

@@ -60,8 +60,9 @@ def test_the_shim_behind_a_fake_jnienv_equals_the_c_abi(tmp_path):
     subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra"] + INC + [os.path.join(ROOT, "tests", "native", "jni_harness.c"), SHIM, emu,
                     "-Wl,--unresolved-symbols=ignore-in-object-files", "-Wl,-rpath," + os.path.dirname(emu), "-lstdc++", "-lpthread", "-o", exe], check=True, timeout=300)
     # wide rows on the lane-serial emulation, then everything again — plus compact rows in / compact outcome rows out / unpack32 — with one OS thread per lane
-    for extra, marker in (({"RG_SPLIT": "0"}, "jni shim ok"), ({"RG_SPLIT": "1", "RG_EMU_WAVES": "1"}, "compact outcome rows through the shim")):
+    for extra, marker in (({"RG_SPLIT": "0"}, "jni shim ok"), ({"RG_SPLIT": "1", "RG_EMU_WAVES": "1"}, "the device-resident tick through the shim")):
         env = dict(os.environ, RG_ALLOW_HOST_EMULATION="1", **extra)
         env.pop("RG_EMU_WAVES", None) if "RG_EMU_WAVES" not in extra else None
         p = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
         assert p.returncode == 0 and "jni shim ok" in p.stdout and marker in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+        assert ("compact outcome rows through the shim" in p.stdout) == ("RG_EMU_WAVES" in extra)
