@@ -262,6 +262,13 @@ def main():
         return outs
 
     # ---- warmup, then EXACTLY `steps` timed steps -------------------------------------------------
+    # The plain-copy yardstick (what a copy kernel reaches on this device in this run) runs FIRST: staging the batches is seconds of host work during
+    # which the device sits idle, and the launches right after an idle spell run slow — measured on one box, alternating runs, the yardstick after the timed
+    # region against before the warm-up: kernel 0.0623 -> 0.0615 ms, ms_per_step 0.0686 - 0.0707 -> 0.0655 - 0.0658 at 10 steps, 0.0649 - 0.0654 -> 0.0630 - 0.0636 at 20
+    # (profiles/r07a_copy_first_ab.jsonl; RG_BENCH_COPY_LAST=1 restores the old order). The timed region itself is what it was: K fresh steps, all of them timed.
+    copy_gbps_early = None
+    if os.environ.get("RG_BENCH_COPY_LAST") != "1" and not args.no_copy_bw:
+        copy_gbps_early = table.copy_bandwidth(args.copy_bytes, 10)
     for i in range(args.warmup):
         table.submit_device(dbatches[i])
     table.sync()
@@ -294,7 +301,7 @@ def main():
     per_gpu = shard.gather_rows([decisions / elapsed_rank, elapsed_rank / args.steps * 1e3, kernel_ms / max(launches, 1), float(dev)],
                                 device=red_dev if world > 1 else None)
 
-    copy_gbps = None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
+    copy_gbps = copy_gbps_early if copy_gbps_early is not None else None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
 
     # ---- per-launch spread: the SAME launches once more — initial state reloaded, the same resident batches in the same order, so every
     # launch decides what it decided in the timed region and leaves the same outcome rows — each bracketed by its own HIP event pair on the table's stream
