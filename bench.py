@@ -532,6 +532,8 @@ def main():
         finally:
             os.environ.pop("RG_FORCE_WIDE", None)
         t2.load_state(st0)
+        if not args.no_copy_bw:
+            t2.copy_bandwidth(args.copy_bytes, 10)          # (the CPU baseline sits in front of this pass: the device out of its idle state first, as in front of the main leg)
         for i in range(args.warmup):
             t2.submit_device(dbatches[i])
         t2.sync()
@@ -570,6 +572,8 @@ def main():
                     aelect += int(np.count_nonzero((kinds >= abi.EV_RV_REQ) & (kinds <= abi.EV_TIMEOUT)))
                     arows += int(np.count_nonzero(kinds))
                 abatches.append(engine.DeviceBatch32(t3, b, compact=compact_out, wide=False))
+            if not args.no_copy_bw:
+                t3.copy_bandwidth(args.copy_bytes, 10)      # (the device out of the idle state the staging left it in, as in front of the main leg)
             for i in range(2):
                 t3.submit_device(abatches[i])
             t3.sync()
@@ -618,6 +622,8 @@ def main():
                 if i >= 2:
                     ldec += workload.batch_stats(b, F)[0]
                 lbatches.append(engine.DeviceBatch32(t4, engine.pack32(b, index_base=lbase), compact=compact_out, wide=False))
+            if not args.no_copy_bw:
+                t4.copy_bandwidth(args.copy_bytes, 10)      # (as in front of the main leg)
             for i in range(2):
                 t4.submit_device(lbatches[i])
             t4.sync()
