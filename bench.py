@@ -268,7 +268,7 @@ def main():
     # (profiles/r07a_copy_first_ab.jsonl; RG_BENCH_COPY_LAST=1 restores the old order). The timed region itself is what it was: K fresh steps, all of them timed.
     copy_gbps_early = None
     if os.environ.get("RG_BENCH_COPY_LAST") != "1" and not args.no_copy_bw:
-        copy_gbps_early = table.copy_bandwidth(args.copy_bytes, 10)
+        copy_gbps_early = table.copy_bandwidth(args.copy_bytes, int(os.environ.get("RG_BENCH_COPY_ITERS", "10")))
     for i in range(args.warmup):
         table.submit_device(dbatches[i])
     table.sync()
