@@ -301,7 +301,13 @@ def main():
     per_gpu = shard.gather_rows([decisions / elapsed_rank, elapsed_rank / args.steps * 1e3, kernel_ms / max(launches, 1), float(dev)],
                                 device=red_dev if world > 1 else None)
 
-    copy_gbps = copy_gbps_early if copy_gbps_early is not None else None if args.no_copy_bw else table.copy_bandwidth(args.copy_bytes, 10)     # the measured-copy yardstick, same run, same device
+    # the measured-copy yardstick, same run, same device (taken in front of the warm-up unless RG_BENCH_COPY_LAST=1)
+    if copy_gbps_early is not None:
+        copy_gbps = copy_gbps_early
+    elif args.no_copy_bw:
+        copy_gbps = None
+    else:
+        copy_gbps = table.copy_bandwidth(args.copy_bytes, 10)
 
     # ---- per-launch spread: the SAME launches once more — initial state reloaded, the same resident batches in the same order, so every
     # launch decides what it decided in the timed region and leaves the same outcome rows — each bracketed by its own HIP event pair on the table's stream
