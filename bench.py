@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--adverse-batches", type=int, default=12, help="launches of the adverse-mix leg (the first two are warm-up)")
     ap.add_argument("--index-base-batches", type=int, default=12, help="launches of the long-lived-groups leg (every log compacted at 2^40, index bases set; the first two are "
                     "warm-up; 0 skips the leg)")
+    ap.add_argument("--long-launch-rounds", type=int, default=256, help="rounds per launch of the long-launch leg (the same configuration handed over in larger batches: the fixed "
+                    "cost of a launch as a share of it; 0 skips the leg)")
+    ap.add_argument("--long-launch-batches", type=int, default=5, help="launches of the long-launch leg (the first is warm-up)")
     ap.add_argument("--tick-batches", type=int, default=310, help="single-round ticks per way of the once-per-tick latency leg (the first ten are warm-up; 0 skips the leg; "
                     "1010 gives the >= 1000-tick distribution of profiles/r06*_tick_latency_1000.json)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU over a short re-run of the "
@@ -131,15 +134,16 @@ def pmc_passes(args, argv):
         if skip_next:
             skip_next = False
             continue
-        if a in ("--steps", "--warmup", "--cpu-batches", "--pcie-batches", "--adverse-batches", "--index-base-batches", "--tick-batches", "--pmc-timeout", "--copy-bytes"):
+        if a in ("--steps", "--warmup", "--cpu-batches", "--pcie-batches", "--adverse-batches", "--index-base-batches", "--tick-batches", "--pmc-timeout", "--copy-bytes", "--long-launch-rounds",
+                 "--long-launch-batches"):
             skip_next = True
             continue
-        if a.split("=")[0] in ("--steps", "--warmup", "--tick-batches", "--index-base-batches") or a in ("--no-cpu-baseline", "--no-pcie", "--no-int64-pass", "--no-adverse",
+        if a.split("=")[0] in ("--steps", "--warmup", "--tick-batches", "--index-base-batches", "--long-launch-rounds", "--long-launch-batches") or a in ("--no-cpu-baseline", "--no-pcie", "--no-int64-pass", "--no-adverse",
                                                                                                        "--no-copy-bw", "--copy-bw", "--no-pmc"):
             continue
         keep.append(a)
     child = [sys.executable, os.path.abspath(__file__)] + keep + ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-pcie", "--no-int64-pass", "--no-adverse",
-                                                                  "--index-base-batches", "0", "--tick-batches", "0", "--no-copy-bw", "--no-pmc"]
+                                                                  "--index-base-batches", "0", "--tick-batches", "0", "--long-launch-rounds", "0", "--no-copy-bw", "--no-pmc"]
     out, t_all = {}, time.time()
     for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"]):
         d = tempfile.mkdtemp(prefix="rg_pmc_", dir="/tmp")
@@ -663,6 +667,42 @@ def main():
             long_lived = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             print("bench: long-lived-groups leg failed: %r" % (e,), file=sys.stderr)
 
+    # ---- the same configuration handed over in LARGER batches: `--long-launch-rounds` rounds per launch instead of `--rounds`. A launch costs 7.5 us whatever its length and ends
+    # with its slowest workgroup (DESIGN.md sections 6, 9); a host that can hand over more rounds at once pays both less often. Reported beside `value`, never as it.
+    long_launch = None
+    if rank == 0 and world == 1 and args.long_launch_rounds > 0 and args.long_launch_batches > 1 and not args.wide_rows and not args.override:
+        try:
+            ggen = workload.ReplayGenerator(cfg, first_gid=first_gid, count=count)
+            t5 = engine.Table(gpg, cfg.cluster, cfg.self_slot, cfg.pre_vote, device=dev)
+            t5.load_state(ggen.initial_state())
+            gbatches, gdec = [], 0
+            for i in range(args.long_launch_batches):
+                b = ggen.next_batch(args.long_launch_rounds)
+                if i >= 1:
+                    gdec += workload.batch_stats(b, F)[0]
+                gbatches.append(engine.DeviceBatch32(t5, b, compact=compact_out, wide=False))
+                del b
+            if not args.no_copy_bw:
+                t5.copy_bandwidth(args.copy_bytes, 10)      # (as in front of the main leg)
+            t5.submit_device(gbatches[0])
+            t5.sync()
+            t5.wide_body_workgroups(reset=True)
+            t5.timing_begin()
+            for i in range(1, args.long_launch_batches):
+                t5.submit_device(gbatches[i])
+            gms = t5.timing_end()
+            t5.sync()
+            n_g = args.long_launch_batches - 1
+            long_launch = {"value": gdec / (gms * 1e-3), "rounds_per_launch": args.long_launch_rounds, "avg_kernel_ms": gms / n_g, "launches": n_g,
+                           "ms_per_%d_rounds" % args.rounds: gms / n_g * args.rounds / args.long_launch_rounds, "int64_body_workgroups": t5.wide_body_workgroups(),
+                           "note": "the same stream and table size in launches of %d rounds instead of %d, by HIP events; not `value`" % (args.long_launch_rounds, args.rounds)}
+            for db in gbatches:
+                db.free()
+            t5.close()
+        except Exception as e:      # a reporting leg must not take the bench line down with it
+            long_launch = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            print("bench: long-launch leg failed: %r" % (e,), file=sys.stderr)
+
     # ---- the once-per-tick path: ONE round per submission, from page-locked host buffers to page-locked host buffers, submit -> wait.
     # Two ways: rg_submit_async_packed (nine runtime calls per tick) and rg_tick_launch (the same chain recorded once as a HIP graph, one call per tick);
     # plus what one single-round launch costs on the device when the rows already lie in HBM. A latency figure, never `value`.
@@ -905,6 +945,8 @@ def main():
             "int64_body_workgroups": wide_wgs,
             "value_long_lived_groups": None if not long_lived or "value" not in long_lived else long_lived["value"],
             "long_lived_groups": long_lived,
+            "value_long_launches": None if not long_launch or "value" not in long_launch else long_launch["value"],
+            "long_launches": long_launch,
             "value_adverse_mix": None if not adverse or "value" not in adverse else adverse["value"],
             "adverse_mix": adverse,
             "golden": golden,

@@ -74,6 +74,8 @@ def test_bench_contract_end_to_end_on_the_emulation(emulation_library):
     ll = d["long_lived_groups"]                                                 # round 5: groups at 2^40 on the 32-bit body (index bases), checked against the oracle in the run
     assert "error" not in ll, ll
     assert d["value_long_lived_groups"] > 0 and ll["int64_body_workgroups"] == 0 and d["int64_body_workgroups"] == 0 and "bit-identical" in ll["checked"]
+    lg = d["long_launches"]                                                     # round 6: the same stream in longer launches, reported beside `value`
+    assert d["value_long_launches"] > 0 and lg["rounds_per_launch"] == 8 and lg["launches"] == 2 and lg["int64_body_workgroups"] == 0
     adv = d["adverse_mix"]                                                      # round 5: the adverse mix as a line of the default run
     assert "error" not in adv, adv
     assert d["value_adverse_mix"] > 0 and adv["need_host_as_expected"] is True and adv["counters"]["need_host"] > 0 and adv["counters"]["asserts"] == 0

@@ -4,7 +4,7 @@
 TAG=$1; shift
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-B="python bench.py --no-cpu-baseline --no-pcie --index-base-batches 0 --tick-batches 0"
+B="python bench.py --no-cpu-baseline --no-pcie --index-base-batches 0 --tick-batches 0 --long-launch-rounds 0"
 line() { python -c "
 import json,sys
 for l in sys.stdin:

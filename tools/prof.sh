@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # (only the timed launches of the default leg may run under the counters: the other legs launch kernels of the same name)
-QUIET="--no-cpu-baseline --no-pcie --no-int64-pass --no-adverse --index-base-batches 0 --tick-batches 0 --no-pmc"
+QUIET="--no-cpu-baseline --no-pcie --no-int64-pass --no-adverse --index-base-batches 0 --tick-batches 0 --long-launch-rounds 0 --no-pmc"
 BENCH="python $ROOT/bench.py $QUIET --steps 4 --warmup 1 $*"
 # the trace pass with TRACE_STEPS launches (default 4; the evidence pass of round 5 uses 20 + 4 warm-up: the first launch of a process is slower)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $ROOT/bench.py $QUIET --steps ${TRACE_STEPS:-4} --warmup ${TRACE_WARMUP:-1} $* > $OUT/trace.log 2>&1

@@ -12,7 +12,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python bench.py --steps 20 --warmup 5 > $OUT/bench_${TAG}_default.json 2> $OUT/bench_${TAG}_default.err
-QUIET="--no-cpu-baseline --no-pcie --no-adverse --index-base-batches 0 --tick-batches 0 --no-pmc"
+QUIET="--no-cpu-baseline --no-pcie --no-adverse --index-base-batches 0 --tick-batches 0 --long-launch-rounds 0 --no-pmc"
 TRACE_STEPS=20 TRACE_WARMUP=4 bash tools/prof.sh $TAG > $OUT/prof_$TAG.log 2>&1
 for spec in "4 131072" "5 131072" "5 65536"; do
   set -- $spec
